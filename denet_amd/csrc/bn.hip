@@ -1,0 +1,313 @@
+// Spatial batch normalisation (+ fused ReLU / residual add) forward and backward for NHWC fp32.
+// Reference: denet/layer/batch_norm.py:50-79 (cuDNN dnn_batch_normalization_train/test, running
+// `mean` and `stdinv`), denet/layer/batch_norm_relu.py:34-54 (in-place ReLU after BN, gradient masked
+// by xn > 0 then cuDNN BN-grad), denet/layer/resnet.py:109-113 (residual add + ReLU).
+//
+// All kernels are HBM-bound. Thread mapping: a thread owns one float4 of channels (c4) and walks
+// rows; LC = gcd(C/4, 256) lanes cover consecutive channels so a wave reads >= 256 contiguous bytes.
+// Per-channel reductions are accumulated in fp64 per thread, combined through LDS, written as
+// per-workgroup partials and finished by a second tiny kernel: deterministic, no atomics.
+#include "common.h"
+
+namespace {
+
+struct BnMap {
+    int LC;      // lanes along channels (float4 units)
+    int RS;      // rows handled concurrently by one workgroup
+    int gx, gy;  // grid
+};
+
+BnMap bn_map(long M, int C) {
+    BnMap m;
+    int c4 = C / 4;
+    int lc = 1;
+    while (lc < 256 && (c4 % (lc * 2)) == 0) lc *= 2;
+    m.LC = lc;
+    m.RS = 256 / lc;
+    m.gx = c4 / lc;
+    long rows_blocks = (M + m.RS - 1) / m.RS;
+    int gy = 2048 / m.gx;
+    if (gy < 1) gy = 1;
+    if (gy > rows_blocks) gy = (int)rows_blocks;
+    m.gy = gy;
+    return m;
+}
+
+// partial[gy][2][C] : sum(x), sum(x*x)
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, long M, int C, int LC,
+                                                               double* __restrict__ partial) {
+    __shared__ double red[256 * 8];
+    const int tid = threadIdx.x;
+    const int cl = tid % LC, rsub = tid / LC, RS = 256 / LC;
+    const int c = (blockIdx.x * LC + cl) * 4;
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    for (long r = (long)blockIdx.y * RS + rsub; r < M; r += (long)gridDim.y * RS) {
+        const f32x4 v = *(const f32x4*)(x + r * C + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double d = (double)v[k];
+            s[k] += d;
+            ss[k] += d * d;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[tid * 8 + k] = s[k];
+        red[tid * 8 + 4 + k] = ss[k];
+    }
+    __syncthreads();
+    if (rsub == 0) {
+        for (int j = 1; j < RS; ++j) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s[k] += red[(j * LC + cl) * 8 + k];
+                ss[k] += red[(j * LC + cl) * 8 + 4 + k];
+            }
+        }
+        double* p = partial + (long)blockIdx.y * 2 * C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            p[c + k] = s[k];
+            p[C + c + k] = ss[k];
+        }
+    }
+}
+
+__global__ void bn_stats_final_kernel(const double* __restrict__ partial, int gy, long M, int C, float eps,
+                                      float momentum, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                      float* __restrict__ run_mean, float* __restrict__ run_stdinv) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0, ss = 0;
+    for (int j = 0; j < gy; ++j) {
+        s += partial[(long)j * 2 * C + c];
+        ss += partial[(long)j * 2 * C + C + c];
+    }
+    const double mean = s / (double)M;
+    double var = ss / (double)M - mean * mean;  // biased variance (cuDNN)
+    if (var < 0) var = 0;
+    const float fmean = (float)mean;
+    const float finv = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = fmean;
+    save_invstd[c] = finv;
+    if (run_mean) {
+        // batch_norm.py:75-76: mean <- m*mean + (1-m)*batch_mean ; stdinv <- m*stdinv + (1-m)*batch_invstd
+        const float om = (float)(1.0 - (double)momentum);
+        run_mean[c] = momentum * run_mean[c] + om * fmean;
+        run_stdinv[c] = momentum * run_stdinv[c] + om * finv;
+    }
+}
+
+// y = relu?( gamma*(x-mean)*invstd + beta (+ res) )
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                       float* __restrict__ y, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, long M, int C, int LC,
+                                                       int relu) {
+    const int tid = threadIdx.x;
+    const int cl = tid % LC, rsub = tid / LC, RS = 256 / LC;
+    const int c = (blockIdx.x * LC + cl) * 4;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sc[k] = gamma[c + k] * invstd[c + k];
+        sh[k] = beta[c + k] - mean[c + k] * sc[k];
+    }
+    for (long r = (long)blockIdx.y * RS + rsub; r < M; r += (long)gridDim.y * RS) {
+        const long o = r * C + c;
+        f32x4 v = *(const f32x4*)(x + o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = fmaf(v[k], sc[k], sh[k]);
+        if (res) v += *(const f32x4*)(res + o);
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        *(f32x4*)(y + o) = v;
+    }
+}
+
+// partial[gy][2][C] : sum(g), sum(g*xhat)  with g = dy * (relu ? y>0 : 1)
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ dy,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, long M, int C, int LC,
+                                                             int relu, double* __restrict__ partial) {
+    __shared__ double red[256 * 8];
+    const int tid = threadIdx.x;
+    const int cl = tid % LC, rsub = tid / LC, RS = 256 / LC;
+    const int c = (blockIdx.x * LC + cl) * 4;
+    float mu[4], is[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mu[k] = mean[c + k];
+        is[k] = invstd[c + k];
+    }
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    for (long r = (long)blockIdx.y * RS + rsub; r < M; r += (long)gridDim.y * RS) {
+        const long o = r * C + c;
+        const f32x4 xv = *(const f32x4*)(x + o);
+        f32x4 g = *(const f32x4*)(dy + o);
+        if (relu) {
+            const f32x4 yv = *(const f32x4*)(y + o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (xv[k] - mu[k]) * is[k];
+            s[k] += (double)g[k];
+            ss[k] += (double)g[k] * (double)xh;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[tid * 8 + k] = s[k];
+        red[tid * 8 + 4 + k] = ss[k];
+    }
+    __syncthreads();
+    if (rsub == 0) {
+        for (int j = 1; j < RS; ++j) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s[k] += red[(j * LC + cl) * 8 + k];
+                ss[k] += red[(j * LC + cl) * 8 + 4 + k];
+            }
+        }
+        double* p = partial + (long)blockIdx.y * 2 * C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            p[c + k] = s[k];
+            p[C + c + k] = ss[k];
+        }
+    }
+}
+
+// dbeta = sum g ; dgamma = sum g*xhat ; coef[0][c] = dbeta/M ; coef[1][c] = dgamma/M
+__global__ void bn_bwd_final_kernel(const double* __restrict__ partial, int gy, long M, int C,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                    float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0, ss = 0;
+    for (int j = 0; j < gy; ++j) {
+        s += partial[(long)j * 2 * C + c];
+        ss += partial[(long)j * 2 * C + C + c];
+    }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)ss;
+    coef[c] = (float)(s / (double)M);
+    coef[C + c] = (float)(ss / (double)M);
+}
+
+// dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) ; optional dres = g
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ dy,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ coef, float* __restrict__ dx,
+                                                           float* __restrict__ dres, long M, int C, int LC, int relu) {
+    const int tid = threadIdx.x;
+    const int cl = tid % LC, rsub = tid / LC, RS = 256 / LC;
+    const int c = (blockIdx.x * LC + cl) * 4;
+    float mu[4], is[4], sc[4], mg[4], mgx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mu[k] = mean[c + k];
+        is[k] = invstd[c + k];
+        sc[k] = gamma[c + k] * is[k];
+        mg[k] = coef[c + k];
+        mgx[k] = coef[C + c + k];
+    }
+    for (long r = (long)blockIdx.y * RS + rsub; r < M; r += (long)gridDim.y * RS) {
+        const long o = r * C + c;
+        const f32x4 xv = *(const f32x4*)(x + o);
+        f32x4 g = *(const f32x4*)(dy + o);
+        if (relu) {
+            const f32x4 yv = *(const f32x4*)(y + o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+        }
+        f32x4 d;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (xv[k] - mu[k]) * is[k];
+            d[k] = sc[k] * (g[k] - mg[k] - xh * mgx[k]);
+        }
+        *(f32x4*)(dx + o) = d;
+        if (dres) *(f32x4*)(dres + o) = g;
+    }
+}
+
+// inference transform: batch_norm.py:50-52 feeds var = (1/stdinv)^2 to cuDNN which adds eps again
+__global__ void bn_test_coef_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_stdinv, int C,
+                                    float eps, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float si = run_stdinv[c];
+    const float var = (1.0f / si) * (1.0f / si);
+    mean_out[c] = run_mean[c];
+    invstd_out[c] = 1.0f / sqrtf(var + eps);
+}
+
+}  // namespace
+
+extern "C" size_t denet_bn_workspace_bytes(long M, int C) {
+    if (C <= 0 || C % 4) return 0;
+    BnMap m = bn_map(M, C);
+    // partials + 2*C floats of coefficients (backward) / test-mode coefficients
+    return (size_t)m.gy * 2 * C * sizeof(double) + (size_t)2 * C * sizeof(float);
+}
+
+extern "C" int denet_bn_fwd_train(const float* x, const float* res, float* y, const float* gamma, const float* beta,
+                                  float* run_mean, float* run_stdinv, float* save_mean, float* save_invstd,
+                                  void* workspace, long M, int C, float momentum, float eps, int relu,
+                                  hipStream_t stream) {
+    DENET_CHECK_ARG(x && y && gamma && beta && save_mean && save_invstd && workspace, "bn_fwd_train: null pointer");
+    DENET_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "bn_fwd_train: bad shape M=%ld C=%d", M, C);
+    BnMap m = bn_map(M, C);
+    double* partial = (double*)workspace;
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, M, C, m.LC, partial);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, partial, m.gy, M, C, eps,
+                       momentum, save_mean, save_invstd, run_mean, run_stdinv);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, res, y, gamma, beta, save_mean,
+                       save_invstd, M, C, m.LC, relu);
+    DENET_CHECK_LAUNCH("bn_fwd_train");
+    return DENET_OK;
+}
+
+extern "C" int denet_bn_fwd_test(const float* x, const float* res, float* y, const float* gamma, const float* beta,
+                                 const float* run_mean, const float* run_stdinv, void* workspace, long M, int C,
+                                 float eps, int relu, hipStream_t stream) {
+    DENET_CHECK_ARG(x && y && gamma && beta && run_mean && run_stdinv && workspace, "bn_fwd_test: null pointer");
+    DENET_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "bn_fwd_test: bad shape M=%ld C=%d", M, C);
+    BnMap m = bn_map(M, C);
+    float* coef = (float*)((double*)workspace + (size_t)m.gy * 2 * C);
+    hipLaunchKernelGGL(bn_test_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, run_mean, run_stdinv, C, eps,
+                       coef, coef + C);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, res, y, gamma, beta, coef, coef + C,
+                       M, C, m.LC, relu);
+    DENET_CHECK_LAUNCH("bn_fwd_test");
+    return DENET_OK;
+}
+
+extern "C" int denet_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma,
+                            const float* save_mean, const float* save_invstd, float* dx, float* dres, float* dgamma,
+                            float* dbeta, void* workspace, long M, int C, int relu, hipStream_t stream) {
+    DENET_CHECK_ARG(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && workspace,
+                    "bn_bwd: null pointer");
+    DENET_CHECK_ARG(!relu || y, "bn_bwd: relu mask needs the forward output");
+    DENET_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "bn_bwd: bad shape M=%ld C=%d", M, C);
+    BnMap m = bn_map(M, C);
+    double* partial = (double*)workspace;
+    float* coef = (float*)(partial + (size_t)m.gy * 2 * C);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, save_mean, save_invstd,
+                       M, C, m.LC, relu, partial);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, partial, m.gy, M, C, dgamma,
+                       dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, gamma, save_mean,
+                       save_invstd, coef, dx, dres, M, C, m.LC, relu);
+    DENET_CHECK_LAUNCH("bn_bwd");
+    return DENET_OK;
+}

@@ -1,0 +1,436 @@
+// Directed-sparse-sampling kernels of the DeNet hot path (NHWC fp32, gfx950).
+//   corner log-softmax + corner NLL cost/gradient   reference denet/layer/denet_corner.py:50-53, 126-134
+//   sparse RoI feature gather (k_sparse_sample)      reference denet/layer/denet_sparse_op.py:42-85 and the
+//                                                    Theano fallback denet/layer/denet_sparse.py:70-96
+//   its gradient (k_sparse_sample_grad, atomicAdd)   reference denet/layer/denet_sparse_op.py:171-212
+//   detection cost/gradient                          reference denet/layer/denet_detect.py:238-313,
+//                                                    denet/common/theano_util.py:27-34
+// This file is compiled with -ffp-contract=off: tap indices must be reproducible bit for bit.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr double LN2 = 0.6931471805599453;
+
+int grid_for(long total) {
+    long b = (total + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// corner map: conv[b,y,x,ci] -> corner_pr[b,k,ci,y,x], k=0: log P(no corner) from logit +x,
+// k=1: log P(corner) from logit -x   (denet_corner.py:52-53: lh = [x, -x], log_softmax(axis=1))
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void corner_fwd_kernel(const float* __restrict__ conv, float* __restrict__ pr, int B,
+                                                         int H, int W, int CP, int Cn) {
+    const long total = (long)B * H * W;
+    const long plane = (long)H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / plane, yx = i - b * plane;
+        for (int ci = 0; ci < Cn; ++ci) {
+            const float x = conv[i * CP + ci];
+            const float mx = fmaxf(x, -x);
+            const float d0 = x - mx, d1 = -x - mx;
+            const float ls = logf(expf(d0) + expf(d1));
+            pr[((b * 2 + 0) * Cn + ci) * plane + yx] = d0 - ls;
+            pr[((b * 2 + 1) * Cn + ci) * plane + yx] = d1 - ls;
+        }
+    }
+}
+
+// cost = -sum(target*logpr)/B/ln2*cost_factor ; dconv[b,y,x,ci] = scale*((t0+t1)(p0-p1) - (t0-t1))
+__global__ __launch_bounds__(256) void corner_loss_kernel(const float* __restrict__ pr, const float* __restrict__ tgt,
+                                                          float* __restrict__ dconv, double* __restrict__ partial,
+                                                          int B, int H, int W, int CP, int Cn, float scale) {
+    __shared__ double red[256];
+    const long total = (long)B * H * W;
+    const long plane = (long)H * W;
+    double acc = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / plane, yx = i - b * plane;
+        for (int ci = 0; ci < Cn; ++ci) {
+            const long o0 = ((b * 2 + 0) * Cn + ci) * plane + yx;
+            const long o1 = ((b * 2 + 1) * Cn + ci) * plane + yx;
+            const float l0 = pr[o0], l1 = pr[o1];
+            const float t0 = tgt[o0], t1 = tgt[o1];
+            acc += (double)t0 * (double)l0 + (double)t1 * (double)l1;
+            if (dconv) {
+                const float p0 = expf(l0), p1 = expf(l1);
+                dconv[i * CP + ci] = scale * ((t0 + t1) * (p0 - p1) - (t0 - t1));
+            }
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// out[slot] = factor * sum(partial[0..n))
+__global__ void finish_sum_kernel(const double* __restrict__ partial, int n, double factor, float* __restrict__ out) {
+    __shared__ double red[256];
+    double acc = 0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = (float)(factor * red[0]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// sparse RoI gather
+// ---------------------------------------------------------------------------------------------
+// tap rule 0 ("theano"): denet_sparse.py:72-84  p = p0 + (i*extent)/(gs-1) ; round half to even
+// tap rule 1 ("cuda")  : denet_sparse_op.py:65-71 p = p0 + i*extent*(1/(gs-1)) ; lroundf (half away)
+__device__ __forceinline__ int tap_index(float p0, float extent, int i, int gs, int size, int rule) {
+    float p;
+    if (rule == 0) {
+        p = p0 + ((float)i * extent) / (float)(gs - 1);
+    } else {
+        const float k = 1.0f / (float)(gs - 1);
+        p = p0 + ((float)i * extent) * k;
+    }
+    float f = p * (float)size;
+    f = fmaxf(0.0f, fminf(f, (float)size - 1.0f));
+    return (rule == 0) ? (int)rintf(f) : (int)lroundf(f);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void sparse_fwd_kernel(const float* __restrict__ fmap, const float* __restrict__ bbox,
+                                                         float* __restrict__ out, int* __restrict__ taps, int H, int W,
+                                                         int CP, int coff, int F, int rois_per_image, int gs, int KP,
+                                                         int rule) {
+    __shared__ int s_cell[256];
+    const int m = blockIdx.x;
+    const int b = m / rois_per_image;
+    const int ntap = gs * gs;
+    const float x0 = bbox[m * 4 + 0], y0 = bbox[m * 4 + 1], x1 = bbox[m * 4 + 2], y1 = bbox[m * 4 + 3];
+    const float bw = x1 - x0, bh = y1 - y0;
+    if ((int)threadIdx.x < ntap) {
+        const int yi = threadIdx.x / gs, xi = threadIdx.x - yi * gs;
+        const int ys = tap_index(y0, bh, yi, gs, H, rule);
+        const int xs = tap_index(x0, bw, xi, gs, W, rule);
+        const int cell = ys * W + xs;
+        s_cell[threadIdx.x] = cell;
+        if (taps) taps[(long)m * ntap + threadIdx.x] = cell;
+    }
+    __syncthreads();
+    float* o = out + (long)m * KP;
+    const float* fb = fmap + (long)b * H * W * CP + coff;
+    if (VEC) {
+        const int F4 = F / 4;
+        for (int idx = threadIdx.x; idx < ntap * F4; idx += 256) {
+            const int tap = idx / F4, f4 = idx - tap * F4;
+            *(f32x4*)(o + (long)idx * 4) = *(const f32x4*)(fb + (long)s_cell[tap] * CP + f4 * 4);
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < ntap * F; idx += 256) {
+            const int tap = idx / F, f = idx - tap * F;
+            o[idx] = fb[(long)s_cell[tap] * CP + f];
+        }
+    }
+    // denet_sparse_op.py:83-84: channel gs*gs*F = box height, +1 = box width; the rest is K padding
+    for (int k = ntap * F + threadIdx.x; k < KP; k += 256)
+        o[k] = (k == ntap * F) ? bh : (k == ntap * F + 1) ? bw : 0.f;
+}
+
+// per image: sort (cell << 15 | tap_slot) ascending in LDS (bitonic, 32768 slots = 128 KiB)
+__global__ __launch_bounds__(1024) void sparse_sort_kernel(const int* __restrict__ taps, unsigned* __restrict__ sorted,
+                                                           int n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned skey[];
+    constexpr int NS = 32768;
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < NS; i += 1024)
+        skey[i] = (i < n) ? (((unsigned)taps[(long)b * n + i] << 15) | (unsigned)i) : 0xFFFFFFFFu;
+    __syncthreads();
+    for (int k = 2; k <= NS; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < NS / 2; t += 1024) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int hi = lo | j;
+                const bool up = ((lo & k) == 0);
+                const unsigned a = skey[lo], c = skey[hi];
+                if ((a > c) == up) {
+                    skey[lo] = c;
+                    skey[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < n; i += 1024) sorted[(long)b * n + i] = skey[i];
+}
+
+__device__ __forceinline__ int lower_bound_u32(const unsigned* a, int n, unsigned v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// one wave per feature-map cell: sums the dy rows of every (roi, tap) that sampled this cell, in the
+// fixed order of the sorted list (deterministic replacement for the reference's atomicAdd scatter)
+__global__ __launch_bounds__(256) void sparse_bwd_kernel(const float* __restrict__ dy,
+                                                         const unsigned* __restrict__ sorted,
+                                                         float* __restrict__ dfmap, int HW, int CP, int coff, int F,
+                                                         int rois_per_image, int ntap, int KP, int zero_from,
+                                                         long ncell_total) {
+    const int lane = threadIdx.x & 63;
+    const long cellg = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cellg >= ncell_total) return;
+    const int b = (int)(cellg / HW);
+    const int cell = (int)(cellg - (long)b * HW);
+    const int n = rois_per_image * ntap;
+    const unsigned* sl = sorted + (long)b * n;
+    const int start = lower_bound_u32(sl, n, (unsigned)cell << 15);
+    const int end = lower_bound_u32(sl, n, (unsigned)(cell + 1) << 15);
+    const int F4 = F / 4;
+    const int epi = 64 / F4;  // entries per iteration
+    const int e = lane / F4, f4 = lane - e * F4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (e < epi) {
+        for (int i = start + e; i < end; i += epi) {
+            const unsigned slot = sl[i] & 0x7FFFu;
+            const int roi = slot / ntap, tap = slot - roi * ntap;
+            acc += *(const f32x4*)(dy + ((long)b * rois_per_image + roi) * KP + (long)tap * F + f4 * 4);
+        }
+    }
+    f32x4 tot = acc;
+    for (int k = 1; k < epi; ++k) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tot[c] += __shfl(acc[c], f4 + k * F4, 64);
+    }
+    float* o = dfmap + cellg * CP;
+    if (lane < F4) *(f32x4*)(o + coff + lane * 4) = tot;
+    // zero the physical padding channels of this cell
+    for (int c = zero_from + lane; c < CP; c += 64) o[c] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// detection cost: one wave per RoI
+//   det_err  = -sum_c t_c*logsoftmax(z)_c / ln(ncls)                       denet_detect.py:257
+//   bbox_err = bbox_factor*valid*sum_k smoothL1(t_k - reg_k)                 denet_detect.py:289-295
+//   cost     = cost_factor*sum(det_err)/B + bbox_factor*sum(bbox_err)/B      denet_detect.py:304-313
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void detect_loss_kernel(const float* __restrict__ logits, const float* __restrict__ det_t,
+                                                          const float* __restrict__ bbox_valid,
+                                                          const float* __restrict__ bbox_t, float* __restrict__ dlogits,
+                                                          double* __restrict__ partial, int M, int CP, int ncls,
+                                                          int nreg, float det_scale, float bbox_factor,
+                                                          float bbox_scale, int bounded_iou,
+                                                          const float* __restrict__ roi_bbox) {
+    __shared__ double red[2][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + wv;
+    double derr = 0, berr = 0;
+    if (m < M) {
+        const float* z = logits + (long)m * CP;
+        float* dz = dlogits ? dlogits + (long)m * CP : nullptr;
+        const float* t = det_t + (long)m * ncls;
+        float mx = -INFINITY;
+        for (int c = lane; c < ncls; c += 64) mx = fmaxf(mx, z[c]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float se = 0.f, tsum = 0.f;
+        for (int c = lane; c < ncls; c += 64) {
+            se += expf(z[c] - mx);
+            tsum += t[c];
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            se += __shfl_xor(se, o, 64);
+            tsum += __shfl_xor(tsum, o, 64);
+        }
+        const float lse = logf(se);
+        const float inv_logn = (float)(1.0 / log((double)ncls));
+        float e = 0.f;
+        for (int c = lane; c < ncls; c += 64) {
+            const float lp = (z[c] - mx) - lse;
+            e += t[c] * lp;
+            if (dz) dz[c] = det_scale * inv_logn * (tsum * expf(lp) - t[c]);
+        }
+        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+        derr = -(double)e * (double)inv_logn;
+        if (nreg > 0) {
+            float sl = 0.f;
+            if (lane < 4) {
+                const float valid = bbox_valid[m];
+                const float* bt = bbox_t + (long)m * 8;
+                const float reg = z[ncls + lane];
+                float d = 0.f, dd_dreg = -1.f;   // d = residual fed to smooth L1 ; dd_dreg = d(d)/d(reg)
+                if (!bounded_iou) {
+                    // Fast R-CNN targets: (tcx-scx)/sw, (tcy-scy)/sh, ln(tw/sw), ln(th/sh)
+                    float tk;
+                    if (lane < 2) tk = (bt[lane] - bt[4 + lane]) / bt[6 + lane];
+                    else tk = logf(bt[lane] / bt[4 + lane]);
+                    d = tk - reg;
+                    dd_dreg = -1.f;
+                } else {
+                    // bounded IoU (denet_detect.py:266-286); prediction decoded from the RoI box
+                    const float* rb = roi_bbox + (long)m * 4;
+                    const float scx = 0.5f * (rb[0] + rb[2]), scy = 0.5f * (rb[1] + rb[3]);
+                    const float sw = rb[2] - rb[0], sh = rb[3] - rb[1];
+                    const float eps = 0.001f;
+                    if (lane < 2) {
+                        const float sc = lane == 0 ? scx : scy, se_ = lane == 0 ? sw : sh;
+                        // predict_x = 0.5*((cx - w/2) + (cx + w/2)) -> cx = reg*extent + centre
+                        const float pc = reg * se_ + sc;
+                        const float dxy = bt[lane] - pc;
+                        const float tw = bt[2 + lane];
+                        if (dxy >= 0.f) {
+                            const float den = tw + dxy + eps;
+                            d = 2.f * dxy / den;
+                            // d/d(dxy) = 2*(tw+eps)/den^2 ; d(dxy)/dreg = -extent
+                            dd_dreg = 2.f * (tw + eps) / (den * den) * (-se_);
+                        } else {
+                            const float den = tw - dxy + eps;
+                            d = -2.f * dxy / den;
+                            dd_dreg = -2.f * (tw + eps) / (den * den) * (-se_);
+                        }
+                    } else {
+                        const float se_ = lane == 2 ? sw : sh;
+                        const float pw = expf(reg) * se_;
+                        const float tw = bt[lane];
+                        const float a = tw / (pw + eps), c2 = pw / (tw + eps);
+                        if (a <= c2) {
+                            d = 1.f - a;
+                            dd_dreg = tw / ((pw + eps) * (pw + eps)) * pw;   // d(1-a)/dpw * dpw/dreg
+                        } else {
+                            d = 1.f - c2;
+                            dd_dreg = -pw / (tw + eps);
+                        }
+                    }
+                }
+                const float ad = fabsf(d);
+                sl = (ad < 1.f) ? 0.5f * d * d : ad - 0.5f;
+                const float dsl = (ad < 1.f) ? d : (d > 0.f ? 1.f : -1.f);
+                if (dz) dz[ncls + lane] = bbox_scale * valid * dsl * dd_dreg;
+                sl *= valid;
+            }
+            for (int o = 2; o > 0; o >>= 1) sl += __shfl_xor(sl, o, 64);
+            berr = (double)bbox_factor * (double)sl;
+        }
+        if (dz) {
+            for (int c = ncls + nreg + lane; c < CP; c += 64) dz[c] = 0.f;
+        }
+    }
+    if (lane == 0) {
+        red[0][wv] = derr;
+        red[1][wv] = berr;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        partial[gridDim.x + blockIdx.x] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+}  // namespace
+
+extern "C" int denet_corner_fwd(const float* conv, float* corner_pr, int B, int H, int W, int CP, int Cn,
+                                hipStream_t stream) {
+    DENET_CHECK_ARG(conv && corner_pr && Cn > 0 && Cn <= CP, "corner_fwd: bad args");
+    hipLaunchKernelGGL(corner_fwd_kernel, dim3(grid_for((long)B * H * W)), dim3(256), 0, stream, conv, corner_pr, B, H,
+                       W, CP, Cn);
+    DENET_CHECK_LAUNCH("corner_fwd");
+    return DENET_OK;
+}
+
+extern "C" size_t denet_loss_workspace_bytes(void) { return (size_t)2 * 8192 * sizeof(double); }
+
+extern "C" int denet_corner_loss(const float* corner_pr, const float* target, float* dconv, float* cost,
+                                 void* workspace, int B, int H, int W, int CP, int Cn, float cost_factor,
+                                 hipStream_t stream) {
+    DENET_CHECK_ARG(corner_pr && target && cost && workspace && Cn > 0, "corner_loss: bad args");
+    int g = grid_for((long)B * H * W);
+    if (g > 1024) g = 1024;
+    const float scale = (float)((double)cost_factor / ((double)B * LN2));
+    hipLaunchKernelGGL(corner_loss_kernel, dim3(g), dim3(256), 0, stream, corner_pr, target, dconv, (double*)workspace,
+                       B, H, W, CP, Cn, scale);
+    hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, stream, (const double*)workspace, g,
+                       -(double)cost_factor / ((double)B * LN2), cost);
+    DENET_CHECK_LAUNCH("corner_loss");
+    return DENET_OK;
+}
+
+extern "C" int denet_sparse_fwd(const float* fmap, const float* bbox, float* out, int* taps, int B, int H, int W,
+                                int CP, int coff, int F, int rois_per_image, int gs, int KP, int tap_rule,
+                                hipStream_t stream) {
+    DENET_CHECK_ARG(fmap && bbox && out, "sparse_fwd: null pointer");
+    DENET_CHECK_ARG(gs >= 2 && gs * gs <= 256, "sparse_fwd: grid size %d unsupported", gs);
+    DENET_CHECK_ARG(coff + F <= CP && KP >= gs * gs * F + 2, "sparse_fwd: channel layout inconsistent");
+    DENET_CHECK_ARG(tap_rule == 0 || tap_rule == 1, "sparse_fwd: tap_rule must be 0 (theano) or 1 (cuda)");
+    const int M = B * rois_per_image;
+    const bool vec = (coff % 4 == 0) && (F % 4 == 0) && (CP % 4 == 0) && (KP % 4 == 0);
+    if (vec)
+        hipLaunchKernelGGL(sparse_fwd_kernel<true>, dim3(M), dim3(256), 0, stream, fmap, bbox, out, taps, H, W, CP, coff,
+                           F, rois_per_image, gs, KP, tap_rule);
+    else
+        hipLaunchKernelGGL(sparse_fwd_kernel<false>, dim3(M), dim3(256), 0, stream, fmap, bbox, out, taps, H, W, CP,
+                           coff, F, rois_per_image, gs, KP, tap_rule);
+    DENET_CHECK_LAUNCH("sparse_fwd");
+    return DENET_OK;
+}
+
+extern "C" int denet_sparse_bwd(const float* dy, const int* taps, unsigned* sorted_ws, float* dfmap, int B, int H,
+                                int W, int CP, int coff, int F, int rois_per_image, int gs, int KP, int zero_from,
+                                hipStream_t stream) {
+    DENET_CHECK_ARG(dy && taps && sorted_ws && dfmap, "sparse_bwd: null pointer");
+    const int ntap = gs * gs;
+    const int n = rois_per_image * ntap;
+    DENET_CHECK_ARG(n <= 32768, "sparse_bwd: %d taps per image exceed the 32768-slot LDS sort", n);
+    DENET_CHECK_ARG(H * W <= (1 << 16), "sparse_bwd: feature map too large for 16-bit cell keys");
+    DENET_CHECK_ARG(F % 4 == 0 && F / 4 <= 64 && coff % 4 == 0 && CP % 4 == 0 && KP % 4 == 0,
+                    "sparse_bwd: F/coff/CP/KP must be multiples of 4 and F <= 256");
+    DENET_CHECK_ARG(zero_from >= coff + F && zero_from <= CP, "sparse_bwd: zero_from out of range");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)sparse_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           32768 * 4);
+        if (e != hipSuccess) {
+            denet_set_error("sparse_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return -(int)e;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sparse_sort_kernel, dim3(B), dim3(1024), 32768 * 4, stream, taps, sorted_ws, n);
+    const long ncell = (long)B * H * W;
+    hipLaunchKernelGGL(sparse_bwd_kernel, dim3((unsigned)((ncell + 3) / 4)), dim3(256), 0, stream, dy, sorted_ws, dfmap,
+                       H * W, CP, coff, F, rois_per_image, ntap, KP, zero_from, ncell);
+    DENET_CHECK_LAUNCH("sparse_bwd");
+    return DENET_OK;
+}
+
+extern "C" int denet_detect_loss(const float* logits, const float* det_target, const float* bbox_valid,
+                                 const float* bbox_target, const float* roi_bbox, float* dlogits, float* costs,
+                                 void* workspace, int M, int batch, int CP, int ncls, int nreg, float cost_factor,
+                                 float bbox_factor, int bounded_iou, hipStream_t stream) {
+    DENET_CHECK_ARG(logits && det_target && costs && workspace, "detect_loss: null pointer");
+    DENET_CHECK_ARG(nreg == 0 || nreg == 4, "detect_loss: nreg must be 0 or 4");
+    DENET_CHECK_ARG(nreg == 0 || (bbox_valid && bbox_target), "detect_loss: bbox targets missing");
+    DENET_CHECK_ARG(!bounded_iou || roi_bbox, "detect_loss: bounded IoU needs the RoI boxes");
+    DENET_CHECK_ARG(ncls + nreg <= CP, "detect_loss: CP too small");
+    const int g = (M + 3) / 4;
+    DENET_CHECK_ARG(g <= 8192, "detect_loss: too many RoIs (%d)", M);
+    const float det_scale = cost_factor / (float)batch;
+    // bbox_factor is applied twice in the reference: get_errors :295 and cost :310
+    const float bbox_scale = bbox_factor * bbox_factor / (float)batch;
+    hipLaunchKernelGGL(detect_loss_kernel, dim3(g), dim3(256), 0, stream, logits, det_target, bbox_valid, bbox_target,
+                       dlogits, (double*)workspace, M, CP, ncls, nreg, det_scale, bbox_factor, bbox_scale, bounded_iou,
+                       roi_bbox);
+    hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, stream, (const double*)workspace, g,
+                       (double)cost_factor / (double)batch, costs);
+    hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, stream, (const double*)workspace + g, g,
+                       (double)bbox_factor / (double)batch, costs + 1);
+    DENET_CHECK_LAUNCH("detect_loss");
+    return DENET_OK;
+}

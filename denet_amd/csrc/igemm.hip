@@ -1,0 +1,521 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): forward, data-gradient and weight-gradient of the
+// DeNet `C` layer (reference: denet/layer/convolution.py:80-83 + tensor.grad model_cnn.py:318, which
+// lower to cuDNN conv fwd / bwd-data / bwd-filter in the reference).
+//
+// Layout (HBM):   activations NHWC fp32, filters KRSC fp32 (already flipped, so the kernel computes a
+//                 correlation; the host converts from the reference's OIHW true-convolution filters).
+// Arithmetic:     v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain), accumulators in registers.
+// Tiling:         one 256-thread workgroup (4 wave64) computes a BM x BN output tile, K is walked in
+//                 chunks of 32; operands are staged global -> VGPR -> LDS (double buffered, one barrier
+//                 per chunk). Two LDS layouts:
+//                   K-inner  [rows][32+4]  read with ds_read_b128 (4 consecutive k per lane-half)
+//                   K-outer  [32][cols]    read with ds_read_b32  (lanes walk the contiguous dim)
+//                 fwd:   A = im2col(x) K-inner,  B = w            K-inner
+//                 dgrad: A = im2col(dy) K-inner, B = w (per tap)  K-outer   (no transposed filter copy)
+//                 wgrad: A = dy^T K-outer,       B = im2col(x)    K-outer   (+ split-K over pixels)
+//                 Inside an 8-wide k block lane-half h consumes k = 4h..4h+3 for both operands, so the
+//                 reduction order is a fixed permutation of k (legal: the sum is over the same terms).
+// Launch:         1-D grid over tiles with an XCD-aware remap (8 XCDs, private L2 each).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;  // padded K-inner row (floats): 144 B rows -> conflict-free ds_read_b128
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
+
+struct IgemmParams {
+    const float* act;   // fwd: x        dgrad: dy       wgrad: x
+    const float* wgt;   // fwd: w(KRSC)  dgrad: w(KRSC)  wgrad: dy
+    float* out;         // fwd: y        dgrad: dx       wgrad: dw or split workspace
+    const float* bias;  // fwd only, [K] or null
+    const float* add;   // fwd/dgrad: tensor of the output's shape added in the epilogue, or null
+    int N, H, W, C;     // x geometry (C = physical channels)
+    int OH, OW, K;      // y geometry (K = physical channels)
+    int R, S, S_real;   // filter taps (S may be padded; taps s >= S_real carry zero weight)
+    int stride, sshift, pad;
+    int M;              // GEMM rows
+    int NC;             // GEMM cols
+    int ksteps;         // number of 32-wide reduction chunks
+    int steps_per_split;
+    int tiles_m, tiles_n;
+    long split_stride;  // wgrad: elements between split slices of the workspace
+    int npix;           // N*OH*OW
+    FastDiv div_row_hw; // fwd/wgrad: OH*OW    dgrad: H*W
+    FastDiv div_row_w;  // fwd/wgrad: OW       dgrad: W
+};
+
+template <int MODE, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+    constexpr bool A_KIN = (MODE != MODE_WGRAD);
+    constexpr bool B_KIN = (MODE == MODE_FWD);
+    constexpr int TM = BM / (32 * WM);
+    constexpr int TN = BN / (32 * WN);
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(TM >= 1 && TN >= 1, "tile too small");
+    constexpr int SZA = A_KIN ? BM * LDK : BK * BM;
+    constexpr int SZB = B_KIN ? BN * LDK : BK * BN;
+    // loader passes (one float4 per thread per pass)
+    constexpr int PA = BM / 32;
+    constexpr int PB = BN / 32;
+    // K-outer thread mapping
+    constexpr int LPR_A = BM / 4, RPP_A = 256 / LPR_A;
+    constexpr int LPR_B = BN / 4, RPP_B = 256 / LPR_B;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;              // [2][SZA]
+    float* sB = smem + 2 * SZA;    // [2][SZB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = bid % p.tiles_n;
+    const int tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    int step_begin = 0, step_end = p.ksteps;
+    if (MODE == MODE_WGRAD) {
+        step_begin = blockIdx.y * p.steps_per_split;
+        step_end = min(p.ksteps, step_begin + p.steps_per_split);
+    }
+    const int nsteps = step_end - step_begin;
+
+    // ---------------- per-thread loader state ----------------
+    const int q8 = tid & 7;        // K-inner: float4 column inside the 32-wide chunk
+    const int row8 = tid >> 3;     // K-inner: row inside a 32-row pass
+    const int qa = tid % LPR_A, kra = tid / LPR_A;   // K-outer A
+    const int qb = tid % LPR_B, krb = tid / LPR_B;   // K-outer B
+
+    int a_off[PA];   // element offsets
+    int a_y[PA];     // fwd: iy0        dgrad: iy+pad
+    int a_x[PA];     // fwd: ix0(+qs)   dgrad: ix+pad
+    int b_off[PB];
+    bool b_ok[PB];
+    int wg_r = 0, wg_s = 0, wg_c = 0;  // wgrad: tap / channel of this thread's B column
+    bool wg_colok = false;
+
+    // uniform reduction cursor (fwd / dgrad): tap (r,s) and channel base c0
+    int cur_r = 0, cur_s = 0, cur_c = 0;
+
+    if (MODE == MODE_FWD) {
+        const int qs = (p.C < 32) ? (4 * q8) / p.C : 0;
+        const int qc = (p.C < 32) ? (4 * q8) % p.C : 4 * q8;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int m = m0 + row8 + 32 * i;
+            if (m < p.M) {
+                const uint32_t n = p.div_row_hw.div(m);
+                const uint32_t rem = m - n * (p.OH * p.OW);
+                const uint32_t oy = p.div_row_w.div(rem);
+                const uint32_t ox = rem - oy * p.OW;
+                a_y[i] = (int)oy * p.stride - p.pad;
+                a_x[i] = (int)ox * p.stride - p.pad + qs;
+                a_off[i] = (((int)n * p.H + a_y[i]) * p.W + a_x[i]) * p.C + qc;
+            } else {
+                a_y[i] = -(1 << 24);
+                a_x[i] = 0;
+                a_off[i] = 0;
+            }
+        }
+        const int kred = p.R * p.S * p.C;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int n = n0 + row8 + 32 * i;
+            b_ok[i] = n < p.K;
+            b_off[i] = n * kred + 4 * q8;
+        }
+    } else if (MODE == MODE_DGRAD) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int m = m0 + row8 + 32 * i;
+            if (m < p.M) {
+                const uint32_t n = p.div_row_hw.div(m);
+                const uint32_t rem = m - n * (p.H * p.W);
+                const uint32_t iy = p.div_row_w.div(rem);
+                const uint32_t ix = rem - iy * p.W;
+                a_y[i] = (int)iy + p.pad;
+                a_x[i] = (int)ix + p.pad;
+                a_off[i] = (int)n * (p.OH * p.OW * p.K) + 4 * q8;
+            } else {
+                a_y[i] = -(1 << 24);
+                a_x[i] = 0;
+                a_off[i] = 0;
+            }
+        }
+        const int rsc = p.R * p.S * p.C;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int col = n0 + 4 * qb;
+            b_ok[i] = col < p.C;
+            b_off[i] = (krb + RPP_B * i) * rsc + col;
+        }
+    } else {  // WGRAD
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            a_off[i] = (kra + RPP_A * i) * p.K + m0 + 4 * qa;
+            a_y[i] = 0;
+            a_x[i] = 0;
+        }
+        const int jg = n0 + 4 * qb;
+        wg_colok = jg < p.NC;
+        const int rs = jg / p.C;
+        wg_c = jg - rs * p.C;
+        wg_r = rs / p.S;
+        wg_s = rs - wg_r * p.S;
+        wg_colok = wg_colok && (wg_s < p.S_real);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            b_ok[i] = wg_colok;
+            b_off[i] = 0;
+        }
+    }
+    const bool wg_rowok = (MODE == MODE_WGRAD) ? (m0 + 4 * qa < p.K) : true;
+
+    f32x4 ra[PA], rb[PB];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // loads the reduction chunk `kc` (absolute chunk index) into ra/rb
+    auto load_chunk = [&](int kc) {
+        if (MODE == MODE_FWD) {
+            const int uoff = (cur_r * p.W + cur_s) * p.C + cur_c;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const bool ok = ((unsigned)(a_y[i] + cur_r) < (unsigned)p.H) &&
+                                ((unsigned)(a_x[i] + cur_s) < (unsigned)p.W);
+                ra[i] = ok ? *(const f32x4*)(p.act + (a_off[i] + uoff)) : zero4;
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                rb[i] = b_ok[i] ? *(const f32x4*)(p.wgt + (b_off[i] + kc * BK)) : zero4;
+            // advance cursor
+            cur_c += BK;
+            if (cur_c >= p.C) {
+                cur_c = 0;
+                cur_s += (p.C < BK) ? (BK / p.C) : 1;
+                if (cur_s >= p.S) {
+                    cur_s = 0;
+                    cur_r += 1;
+                }
+            }
+        } else if (MODE == MODE_DGRAD) {
+            const int smask = p.stride - 1;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const int ty = a_y[i] - cur_r;
+                const int tx = a_x[i] - cur_s;
+                const int oy = ty >> p.sshift;
+                const int ox = tx >> p.sshift;
+                const bool ok = (ty >= 0) && (tx >= 0) && (((ty | tx) & smask) == 0) &&
+                                (oy < p.OH) && (ox < p.OW);
+                ra[i] = ok ? *(const f32x4*)(p.act + (a_off[i] + (oy * p.OW + ox) * p.K + cur_c)) : zero4;
+            }
+            const int uoff = cur_c * (p.R * p.S * p.C) + (cur_r * p.S + cur_s) * p.C;
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                rb[i] = b_ok[i] ? *(const f32x4*)(p.wgt + (b_off[i] + uoff)) : zero4;
+            cur_c += BK;
+            if (cur_c >= p.K) {
+                cur_c = 0;
+                cur_s += 1;
+                if (cur_s >= p.S) {
+                    cur_s = 0;
+                    cur_r += 1;
+                }
+            }
+        } else {
+            const int pix0 = kc * BK;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const int pix = pix0 + kra + RPP_A * i;
+                const bool ok = wg_rowok && (pix < p.npix);
+                ra[i] = ok ? *(const f32x4*)(p.wgt + ((long)pix0 * p.K + a_off[i])) : zero4;
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const int pix = pix0 + krb + RPP_B * i;
+                const uint32_t n = p.div_row_hw.div(pix);
+                const uint32_t rem = pix - n * (p.OH * p.OW);
+                const uint32_t oy = p.div_row_w.div(rem);
+                const uint32_t ox = rem - oy * p.OW;
+                const int iy = (int)oy * p.stride - p.pad + wg_r;
+                const int ix = (int)ox * p.stride - p.pad + wg_s;
+                const bool ok = wg_colok && (pix < p.npix) && ((unsigned)iy < (unsigned)p.H) &&
+                                ((unsigned)ix < (unsigned)p.W);
+                rb[i] = ok ? *(const f32x4*)(p.act + ((((int)n * p.H + iy) * p.W + ix) * p.C + wg_c)) : zero4;
+            }
+        }
+    };
+
+    auto store_chunk = [&](int buf) {
+        float* dA = sA + buf * SZA;
+        float* dB = sB + buf * SZB;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            if (A_KIN)
+                *(f32x4*)(dA + (row8 + 32 * i) * LDK + 4 * q8) = ra[i];
+            else
+                *(f32x4*)(dA + (kra + RPP_A * i) * BM + 4 * qa) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            if (B_KIN)
+                *(f32x4*)(dB + (row8 + 32 * i) * LDK + 4 * q8) = rb[i];
+            else
+                *(f32x4*)(dB + (krb + RPP_B * i) * BN + 4 * qb) = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment base offsets inside the LDS tiles
+    const int fa = A_KIN ? (wm * TM * 32 + li) * LDK + 4 * lh : (4 * lh) * BM + wm * TM * 32 + li;
+    const int fb = B_KIN ? (wn * TN * 32 + li) * LDK + 4 * lh : (4 * lh) * BN + wn * TN * 32 + li;
+
+    auto compute = [&](int buf) {
+        const float* cA = sA + buf * SZA + fa;
+        const float* cB = sB + buf * SZB + fb;
+#pragma unroll
+        for (int kb = 0; kb < BK / 8; ++kb) {
+            float av[TM][4], bv[TN][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (A_KIN) {
+                    const f32x4 t = *(const f32x4*)(cA + i * 32 * LDK + kb * 8);
+                    av[i][0] = t[0]; av[i][1] = t[1]; av[i][2] = t[2]; av[i][3] = t[3];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) av[i][t] = cA[(kb * 8 + t) * BM + i * 32];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (B_KIN) {
+                    const f32x4 t = *(const f32x4*)(cB + j * 32 * LDK + kb * 8);
+                    bv[j][0] = t[0]; bv[j][1] = t[1]; bv[j][2] = t[2]; bv[j][3] = t[3];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) bv[j][t] = cB[(kb * 8 + t) * BN + j * 32];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[j][t], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (nsteps > 0) {
+        // position the uniform cursor at step_begin (only wgrad splits; it has no cursor)
+        load_chunk(step_begin);
+        store_chunk(0);
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            const bool more = (s + 1 < nsteps);
+            if (more) load_chunk(step_begin + s + 1);
+            compute(s & 1);
+            if (more) store_chunk((s + 1) & 1);
+            __syncthreads();
+        }
+    }
+
+    // ---------------- epilogue ----------------
+    float* out = p.out;
+    if (MODE == MODE_WGRAD) out += (long)blockIdx.y * p.split_stride;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + li;
+            if (n >= p.NC) continue;
+            const float bv = (MODE == MODE_FWD && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < p.M) {
+                    const long idx = (long)m * p.NC + n;
+                    float v = acc[i][j][r] + bv;
+                    if (MODE != MODE_WGRAD && p.add) v += p.add[idx];
+                    out[idx] = v;
+                }
+            }
+        }
+    }
+}
+
+// sums the split-K slices of a weight-gradient workspace
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long n4, int splits,
+                                     long stride4) {
+    const f32x4* w4 = (const f32x4*)ws;
+    f32x4* o4 = (f32x4*)out;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 s = w4[i];
+        for (int z = 1; z < splits; ++z) s += w4[i + z * stride4];
+        o4[i] = s;
+    }
+}
+
+template <int MODE, int BM, int BN, int WM, int WN>
+int launch_igemm(const IgemmParams& p, int splits, hipStream_t stream) {
+    constexpr bool A_KIN = (MODE != MODE_WGRAD);
+    constexpr bool B_KIN = (MODE == MODE_FWD);
+    constexpr int SZA = A_KIN ? BM * LDK : BK * BM;
+    constexpr int SZB = B_KIN ? BN * LDK : BK * BN;
+    constexpr size_t lds = 2 * (size_t)(SZA + SZB) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<MODE, BM, BN, WM, WN>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            denet_set_error("igemm: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+            return -(int)e;
+        }
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits, 1);
+    hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN>), grid, dim3(256), lds, stream, p);
+    DENET_CHECK_LAUNCH("igemm");
+    return DENET_OK;
+}
+
+int ilog2_exact(int v) {
+    int s = 0;
+    while ((1 << s) < v) s++;
+    return ((1 << s) == v) ? s : -1;
+}
+
+int check_geom(int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH, int OW) {
+    DENET_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0, "conv: non-positive dimension");
+    DENET_CHECK_ARG(S_real > 0 && S_real <= S, "conv: S_real out of range");
+    DENET_CHECK_ARG(ilog2_exact(stride) >= 0, "conv: stride must be a power of two (got %d)", stride);
+    DENET_CHECK_ARG(pad >= 0, "conv: negative pad");
+    DENET_CHECK_ARG(K % 32 == 0, "conv: physical K (%d) must be a multiple of 32", K);
+    if (C >= 32) {
+        DENET_CHECK_ARG(C % 32 == 0, "conv: physical C (%d) must be a multiple of 32", C);
+    } else {
+        DENET_CHECK_ARG(C == 4 || C == 8 || C == 16, "conv: small C must be 4, 8 or 16 (got %d)", C);
+        DENET_CHECK_ARG((S * C) % 32 == 0, "conv: S*C (%d) must be a multiple of 32 for small C", S * C);
+    }
+    DENET_CHECK_ARG((H + 2 * pad - R) / stride + 1 >= OH && OH > 0, "conv: OH=%d inconsistent", OH);
+    DENET_CHECK_ARG((W + 2 * pad - S_real) / stride + 1 >= OW && OW > 0, "conv: OW=%d inconsistent", OW);
+    DENET_CHECK_ARG((long)N * H * W * C < (1L << 31) && (long)N * OH * OW * K < (1L << 31) &&
+                        (long)K * R * S * C < (1L << 31),
+                    "conv: tensor exceeds 2^31 elements");
+    return DENET_OK;
+}
+
+}  // namespace
+
+extern "C" int denet_conv_fwd(const float* x, const float* w, const float* bias, const float* add, float* y, int N,
+                              int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH,
+                              int OW, hipStream_t stream) {
+    int rc = check_geom(N, H, W, C, K, R, S, S_real, stride, pad, OH, OW);
+    if (rc) return rc;
+    DENET_CHECK_ARG(x && w && y, "conv_fwd: null pointer");
+    IgemmParams p = {};
+    p.act = x; p.wgt = w; p.out = y; p.bias = bias; p.add = add;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K;
+    p.R = R; p.S = S; p.S_real = S_real; p.stride = stride; p.sshift = ilog2_exact(stride); p.pad = pad;
+    p.M = N * OH * OW; p.NC = K; p.ksteps = R * S * C / BK; p.steps_per_split = p.ksteps;
+    p.npix = p.M;
+    p.div_row_hw.init(OH * OW); p.div_row_w.init(OW);
+    if (K >= 128) {
+        p.tiles_m = ceil_div(p.M, 128); p.tiles_n = ceil_div(K, 128);
+        return launch_igemm<MODE_FWD, 128, 128, 2, 2>(p, 1, stream);
+    }
+    p.tiles_m = ceil_div(p.M, 128); p.tiles_n = ceil_div(K, 64);
+    return launch_igemm<MODE_FWD, 128, 64, 2, 2>(p, 1, stream);
+}
+
+extern "C" int denet_conv_dgrad(const float* dy, const float* w, const float* add, float* dx, int N, int H, int W,
+                                int C, int K, int R, int S, int S_real, int stride, int pad, int OH, int OW,
+                                hipStream_t stream) {
+    int rc = check_geom(N, H, W, C, K, R, S, S_real, stride, pad, OH, OW);
+    if (rc) return rc;
+    DENET_CHECK_ARG(dy && w && dx, "conv_dgrad: null pointer");
+    DENET_CHECK_ARG(C >= 32, "conv_dgrad: C < 32 not supported (first layer needs no data gradient)");
+    IgemmParams p = {};
+    p.act = dy; p.wgt = w; p.out = dx; p.bias = nullptr; p.add = add;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K;
+    p.R = R; p.S = S; p.S_real = S_real; p.stride = stride; p.sshift = ilog2_exact(stride); p.pad = pad;
+    p.M = N * H * W; p.NC = C; p.ksteps = R * S * K / BK; p.steps_per_split = p.ksteps;
+    p.npix = N * OH * OW;
+    p.div_row_hw.init(H * W); p.div_row_w.init(W);
+    if (C >= 128) {
+        p.tiles_m = ceil_div(p.M, 128); p.tiles_n = ceil_div(C, 128);
+        return launch_igemm<MODE_DGRAD, 128, 128, 2, 2>(p, 1, stream);
+    }
+    p.tiles_m = ceil_div(p.M, 128); p.tiles_n = ceil_div(C, 64);
+    return launch_igemm<MODE_DGRAD, 128, 64, 2, 2>(p, 1, stream);
+}
+
+extern "C" size_t denet_conv_wgrad_workspace_bytes(int N, int C, int K, int R, int S, int OH, int OW) {
+    // upper bound used by the launcher below: at most 64 split slices
+    return (size_t)64 * K * R * S * C * sizeof(float);
+}
+
+extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes,
+                                int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad,
+                                int OH, int OW, hipStream_t stream) {
+    int rc = check_geom(N, H, W, C, K, R, S, S_real, stride, pad, OH, OW);
+    if (rc) return rc;
+    DENET_CHECK_ARG(x && dy && dw, "conv_wgrad: null pointer");
+    IgemmParams p = {};
+    p.act = x; p.wgt = dy; p.bias = nullptr; p.add = nullptr;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K;
+    p.R = R; p.S = S; p.S_real = S_real; p.stride = stride; p.sshift = ilog2_exact(stride); p.pad = pad;
+    p.M = K; p.NC = R * S * C; p.npix = N * OH * OW;
+    p.ksteps = ceil_div(p.npix, BK);
+    p.div_row_hw.init(OH * OW); p.div_row_w.init(OW);
+    const bool big_m = (K >= 128);
+    const int bm = big_m ? 128 : 64;
+    p.tiles_m = ceil_div(K, bm); p.tiles_n = ceil_div(p.NC, 128);
+    const long wsize = (long)K * p.NC;
+    p.split_stride = wsize;
+    // split the pixel reduction so that the grid fills the chip (>= ~1024 workgroups), keeping
+    // at least 8 chunks per slice; bounded by the caller's workspace
+    int tiles = p.tiles_m * p.tiles_n;
+    int splits = ceil_div(1024, tiles);
+    splits = splits < 1 ? 1 : splits;
+    if (splits > p.ksteps / 8) splits = p.ksteps / 8;
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+    size_t max_by_ws = workspace ? workspace_bytes / ((size_t)wsize * sizeof(float)) : 0;
+    if ((size_t)splits > max_by_ws) splits = (int)max_by_ws;
+    if (splits <= 1) {
+        splits = 1;
+        p.out = dw;
+    } else {
+        p.out = workspace;
+    }
+    p.steps_per_split = ceil_div(p.ksteps, splits);
+    splits = ceil_div(p.ksteps, p.steps_per_split);
+    if (big_m)
+        rc = launch_igemm<MODE_WGRAD, 128, 128, 2, 2>(p, splits, stream);
+    else
+        rc = launch_igemm<MODE_WGRAD, 64, 128, 2, 2>(p, splits, stream);
+    if (rc) return rc;
+    if (splits > 1) {
+        DENET_CHECK_ARG(wsize % 4 == 0, "conv_wgrad: weight size not a multiple of 4");
+        long n4 = wsize / 4;
+        int blocks = (int)((n4 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, dw, n4, splits, n4);
+        DENET_CHECK_LAUNCH("splitk_reduce");
+    }
+    return DENET_OK;
+}

@@ -1,0 +1,456 @@
+// GPU corner selection + RoI proposal: the MI355X counterpart of the reference's host C++
+// `build_samples` (denet/layer/denet_sparse.cc:489-557 run_build_samples, :321-471 search_corners,
+// :271-308 get_sample, :474-487 get_local_max), which the reference runs on CPU threads between two
+// halves of the device step (denet/layer/denet_sparse.py:117-145).
+//
+// Pipeline (all on `stream`, no host round trip):
+//   1. corner_select: one workgroup per (image, corner type). Threshold (+ optional local-max test)
+//      over the log-probability plane in raster order; survivors are compacted with wave ballots and
+//      a prefix sum over the wave counts, which preserves the reference's raster order. If more than
+//      max_corners survive the list is bitonic-sorted in LDS by (logpr desc, raster asc) and truncated
+//      (reference: std::partial_sort by logpr). Also emits a membership bitmap per corner type.
+//   2. three histogram passes (12+12+8 bits) over the score keys of all TLxBR and TRxBL pairs: an exact
+//      32-bit radix select of the sample_count-th best candidate. Pairs are enumerated on the fly; the
+//      reference's unordered_map de-duplication reduces to an O(1) test (a TRxBL box is a duplicate
+//      iff its TL and BR corners are both selected), because the two passes cannot repeat a box
+//      internally.
+//   3. collect + final bitonic sort by (key asc, generation index asc), emit integer boxes and |d|.
+// Score key: pr = 1/(1+exp(|pr_f - pr_t|)) is strictly decreasing in |d|, so candidates are ranked by
+// the fp32 bit pattern of |d| (ascending); the fp32 sums are evaluated in the reference's order, so
+// the key is bit-identical to the reference's. The final pr is evaluated on the host by
+// denet_samples_finish_host with the same libm expression as the reference (denet_sparse.cc:306).
+// Compiled with -ffp-contract=off.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int TIE_CAP = 4096;   // extra slots for candidates tying with the threshold key
+constexpr int NBLK_PAIR = 64;   // workgroups per image for the pair passes
+
+struct ImgState {
+    unsigned prefix;   // key bits fixed so far
+    unsigned need;     // how many more candidates are needed from the current bin
+    unsigned done;     // 1: every candidate is selected (total <= sample_count)
+    unsigned nless;    // collected candidates with key < T
+    unsigned ntie;     // collected candidates with key == T
+    unsigned total;    // number of candidates
+    unsigned pad0, pad1;
+};
+
+__device__ __forceinline__ bool corner_before(float va, unsigned pa, float vb, unsigned pb) {
+    return (va > vb) || (va == vb && pa < pb);
+}
+
+// max over [y-l, y+l) x [x-l, x+l) clipped to [0,H-1) x [0,W-1): upper bounds EXCLUSIVE and clipped to
+// size-1 exactly as denet_sparse.cc:474-487
+__device__ __forceinline__ float local_max_at(const float* plane, int H, int W, int y, int x, int l) {
+    const int x0 = max(0, x - l), y0 = max(0, y - l);
+    const int x1 = min(W - 1, x + l), y1 = min(H - 1, y + l);
+    float m = -100000.f;
+    for (int yy = y0; yy < y1; ++yy)
+        for (int xx = x0; xx < x1; ++xx) m = fmaxf(m, plane[yy * W + xx]);
+    return m;
+}
+
+__global__ __launch_bounds__(1024) void corner_select_kernel(const float* __restrict__ pr, int* __restrict__ corners,
+                                                             int* __restrict__ ncorner, unsigned* __restrict__ bitmap,
+                                                             int Cn, int H, int W, float thr, int max_corners,
+                                                             int local_max, int NP) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* sval = (float*)smem_raw;              // [NP]
+    unsigned* spos = (unsigned*)(sval + NP);     // [NP]
+    unsigned* sbits = spos + NP;                 // [HW/32 rounded up]
+    __shared__ int sh_w[16];
+    const int b = blockIdx.x, ci = blockIdx.y;
+    const int HW = H * W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* plane = pr + ((long)(b * 2 + 1) * Cn + ci) * HW;
+    const int nwords = (HW + 31) / 32;
+    for (int i = tid; i < nwords; i += 1024) sbits[i] = 0u;
+
+    int base = 0;
+    for (int chunk = 0; chunk < HW; chunk += 1024) {
+        const int cell = chunk + tid;
+        const bool valid = cell < HW;
+        const float v = valid ? plane[cell] : 0.f;
+        bool pred = valid && (v > thr);
+        if (pred && local_max > 0) {
+            const int y = cell / W, x = cell - y * W;
+            if (v < local_max_at(plane, H, W, y, x, local_max)) pred = false;
+        }
+        const unsigned long long mask = __ballot(pred);
+        const int wofs = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) sh_w[wave] = __popcll(mask);
+        __syncthreads();
+        int wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int c = sh_w[w];
+            if (w < wave) wbase += c;
+            total += c;
+        }
+        if (pred) {
+            const int idx = base + wbase + wofs;
+            sval[idx] = v;
+            spos[idx] = (unsigned)cell;
+        }
+        base += total;
+        __syncthreads();
+    }
+    int n = base;
+    if (n > max_corners) {
+        int np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        for (int i = n + tid; i < np2; i += 1024) {
+            sval[i] = -INFINITY;
+            spos[i] = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        for (int k = 2; k <= np2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < np2 / 2; t += 1024) {
+                    const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int hi = lo | j;
+                    const bool up = ((lo & k) == 0);
+                    const float va = sval[lo], vb = sval[hi];
+                    const unsigned pa = spos[lo], pb = spos[hi];
+                    // ascending position in the "before" order: swap when hi should come before lo
+                    const bool hi_first = corner_before(vb, pb, va, pa);
+                    if (hi_first == up) {
+                        sval[lo] = vb; sval[hi] = va;
+                        spos[lo] = pb; spos[hi] = pa;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        n = max_corners;
+    }
+    int* cl = corners + ((long)b * Cn + ci) * max_corners;
+    for (int i = tid; i < n; i += 1024) {
+        const unsigned p = spos[i];
+        cl[i] = (int)p;
+        atomicOr(&sbits[p >> 5], 1u << (p & 31));
+    }
+    __syncthreads();
+    unsigned* bm = bitmap + ((long)b * Cn + ci) * nwords;
+    for (int i = tid; i < nwords; i += 1024) bm[i] = sbits[i];
+    if (tid == 0) ncorner[b * Cn + ci] = n;
+}
+
+struct PairCtx {
+    const float* pr;        // [B,2,Cn,H,W]
+    const int* corners;     // [B,Cn,max_corners]
+    const int* ncorner;     // [B,Cn]
+    const unsigned* bitmap; // [B,Cn,nwords]
+    int Cn, H, W, max_corners, nwords;
+};
+
+// enumerates the candidates of image b assigned to this thread and calls f(key, gen, x0, y0, x1, y1)
+template <class F>
+__device__ __forceinline__ void for_each_candidate(const PairCtx& c, int b, F&& f) {
+    const int HW = c.H * c.W;
+    const int* nc = c.ncorner + b * c.Cn;
+    const int nTL = nc[0], nTR = nc[1], nBL = nc[2], nBR = nc[3];
+    const int* cTL = c.corners + ((long)b * c.Cn + 0) * c.max_corners;
+    const int* cTR = c.corners + ((long)b * c.Cn + 1) * c.max_corners;
+    const int* cBL = c.corners + ((long)b * c.Cn + 2) * c.max_corners;
+    const int* cBR = c.corners + ((long)b * c.Cn + 3) * c.max_corners;
+    const unsigned* bTL = c.bitmap + ((long)b * c.Cn + 0) * c.nwords;
+    const unsigned* bBR = c.bitmap + ((long)b * c.Cn + 3) * c.nwords;
+    const float* pf = c.pr + (long)(b * 2 + 0) * c.Cn * HW;
+    const float* pt = c.pr + (long)(b * 2 + 1) * c.Cn * HW;
+    const unsigned P0 = (unsigned)nTL * (unsigned)nBR, P1 = (unsigned)nTR * (unsigned)nBL;
+    const unsigned total = P0 + P1;
+    for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
+        int x0, y0, x1, y1;
+        if (p < P0) {
+            const unsigned i = p / (unsigned)nBR, j = p - i * (unsigned)nBR;
+            const int tl = cTL[i], br = cBR[j];
+            y0 = tl / c.W; x0 = tl - y0 * c.W;
+            y1 = br / c.W; x1 = br - y1 * c.W;
+            if (x1 <= x0 || y1 <= y0) continue;
+        } else {
+            const unsigned q = p - P0;
+            const unsigned i = q / (unsigned)nBL, j = q - i * (unsigned)nBL;
+            const int tr = cTR[i], bl = cBL[j];
+            y0 = tr / c.W; x1 = tr - y0 * c.W;
+            y1 = bl / c.W; x0 = bl - y1 * c.W;
+            if (x1 <= x0 || y1 <= y0) continue;
+            // already produced by the TLxBR pass?
+            const int ptl = y0 * c.W + x0, pbr = y1 * c.W + x1;
+            if (((bTL[ptl >> 5] >> (ptl & 31)) & 1u) && ((bBR[pbr >> 5] >> (pbr & 31)) & 1u)) continue;
+        }
+        // denet_sparse.cc:276-294: sequential fp32 sums in the order TL, TR, BL, BR
+        float sf = 0.f, st = 0.f;
+        sf += pf[0 * HW + y0 * c.W + x0];
+        sf += pf[1 * HW + y0 * c.W + x1];
+        sf += pf[2 * HW + y1 * c.W + x0];
+        sf += pf[3 * HW + y1 * c.W + x1];
+        st += pt[0 * HW + y0 * c.W + x0];
+        st += pt[1 * HW + y0 * c.W + x1];
+        st += pt[2 * HW + y1 * c.W + x0];
+        st += pt[3 * HW + y1 * c.W + x1];
+        const unsigned key = __float_as_uint(fabsf(sf - st));
+        f(key, p, x0, y0, x1, y1);
+    }
+}
+
+// LEVEL 0: bin = key >> 20 ; LEVEL 1: (key>>20)==prefix>>20, bin = (key>>8)&0xFFF ; LEVEL 2: bin = key&0xFF
+template <int LEVEL>
+__global__ __launch_bounds__(256) void pair_hist_kernel(PairCtx c, const ImgState* __restrict__ state,
+                                                        unsigned* __restrict__ hist) {
+    __shared__ unsigned sh[4096];
+    const int b = blockIdx.y;
+    const ImgState st = state[b];
+    if (LEVEL > 0 && st.done) return;
+    for (int i = threadIdx.x; i < 4096; i += 256) sh[i] = 0u;
+    __syncthreads();
+    const unsigned prefix = st.prefix;
+    for_each_candidate(c, b, [&](unsigned key, unsigned, int, int, int, int) {
+        if (LEVEL == 0) {
+            atomicAdd(&sh[key >> 20], 1u);
+        } else if (LEVEL == 1) {
+            if ((key >> 20) == (prefix >> 20)) atomicAdd(&sh[(key >> 8) & 0xFFFu], 1u);
+        } else {
+            if ((key >> 8) == (prefix >> 8)) atomicAdd(&sh[key & 0xFFu], 1u);
+        }
+    });
+    __syncthreads();
+    unsigned* h = hist + (long)b * 4096;
+    for (int i = threadIdx.x; i < 4096; i += 256)
+        if (sh[i]) atomicAdd(&h[i], sh[i]);
+}
+
+template <int LEVEL>
+__global__ void pair_pick_kernel(ImgState* __restrict__ state, unsigned* __restrict__ hist, int sample_count, int B) {
+    // one thread per image: a 4096-bin scan is tiny
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    ImgState st = state[b];
+    unsigned* h = hist + (long)b * 4096;
+    const int nbins = (LEVEL == 2) ? 256 : 4096;
+    if (LEVEL == 0) {
+        unsigned total = 0;
+        for (int i = 0; i < 4096; ++i) total += h[i];
+        st.total = total;
+        st.need = (unsigned)sample_count;
+        st.prefix = 0;
+        st.done = (total <= (unsigned)sample_count) ? 1u : 0u;
+        if (st.done) st.prefix = 0xFFFFFFFFu;
+    }
+    if (!st.done) {
+        unsigned cum = 0;
+        int sel = nbins - 1;
+        for (int i = 0; i < nbins; ++i) {
+            if (cum + h[i] >= st.need) {
+                sel = i;
+                break;
+            }
+            cum += h[i];
+        }
+        st.need -= cum;
+        if (LEVEL == 0) st.prefix = (unsigned)sel << 20;
+        else if (LEVEL == 1) st.prefix |= (unsigned)sel << 8;
+        else st.prefix |= (unsigned)sel;
+    }
+    for (int i = 0; i < nbins; ++i) h[i] = 0u;
+    state[b] = st;
+}
+
+struct Cand {
+    unsigned key, gen, box;   // box = x0 | y0<<8 | x1<<16 | y1<<24
+};
+
+__global__ __launch_bounds__(256) void pair_collect_kernel(PairCtx c, ImgState* __restrict__ state,
+                                                           Cand* __restrict__ cand, int sample_count) {
+    const int b = blockIdx.y;
+    const unsigned T = state[b].prefix;
+    const bool all = state[b].done != 0;
+    Cand* out = cand + (long)b * (sample_count + TIE_CAP);
+    for_each_candidate(c, b, [&](unsigned key, unsigned gen, int x0, int y0, int x1, int y1) {
+        Cand e;
+        e.key = key;
+        e.gen = gen;
+        e.box = (unsigned)x0 | ((unsigned)y0 << 8) | ((unsigned)x1 << 16) | ((unsigned)y1 << 24);
+        if (all || key < T) {
+            const unsigned slot = atomicAdd(&state[b].nless, 1u);
+            if (slot < (unsigned)sample_count) out[slot] = e;
+        } else if (key == T) {
+            const unsigned slot = atomicAdd(&state[b].ntie, 1u);
+            if (slot < (unsigned)TIE_CAP) out[sample_count + slot] = e;
+        }
+    });
+}
+
+__device__ __forceinline__ bool cand_before(const Cand& a, const Cand& b) {
+    return (a.key < b.key) || (a.key == b.key && a.gen < b.gen);
+}
+
+// sorts the collected candidates by (key, gen) and writes the first sample_count
+__global__ __launch_bounds__(1024) void pair_finalize_kernel(const ImgState* __restrict__ state,
+                                                             const Cand* __restrict__ cand, int sample_count,
+                                                             int* __restrict__ out_box, float* __restrict__ out_absd,
+                                                             int* __restrict__ out_count, int NP) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Cand* s = (Cand*)smem_raw;  // [NP]
+    const int b = blockIdx.x;
+    const ImgState st = state[b];
+    const int nless = min((int)st.nless, sample_count);
+    const int ntie = min((int)st.ntie, TIE_CAP);
+    const Cand* in = cand + (long)b * (sample_count + TIE_CAP);
+    const int n = nless + ntie;
+    for (int i = threadIdx.x; i < NP; i += 1024) {
+        Cand e;
+        if (i < nless) e = in[i];
+        else if (i < n) e = in[sample_count + (i - nless)];
+        else { e.key = 0xFFFFFFFFu; e.gen = 0xFFFFFFFFu; e.box = 0; }
+        s[i] = e;
+    }
+    __syncthreads();
+    for (int k = 2; k <= NP; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < NP / 2; t += 1024) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int hi = lo | j;
+                const bool up = ((lo & k) == 0);
+                const Cand a = s[lo], c2 = s[hi];
+                if (cand_before(c2, a) == up) {
+                    s[lo] = c2;
+                    s[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int nout = min(n, sample_count);
+    for (int i = threadIdx.x; i < sample_count; i += 1024) {
+        int* ob = out_box + ((long)b * sample_count + i) * 4;
+        if (i < nout) {
+            const Cand e = s[i];
+            ob[0] = e.box & 0xFF; ob[1] = (e.box >> 8) & 0xFF; ob[2] = (e.box >> 16) & 0xFF; ob[3] = (e.box >> 24) & 0xFF;
+            out_absd[(long)b * sample_count + i] = __uint_as_float(e.key);
+        } else {
+            ob[0] = ob[1] = ob[2] = ob[3] = 0;
+            out_absd[(long)b * sample_count + i] = 0.f;
+        }
+    }
+    if (threadIdx.x == 0) out_count[b] = nout;
+}
+
+struct WsLayout {
+    size_t corners, ncorner, bitmap, hist, state, cand, total;
+    int nwords;
+};
+
+WsLayout ws_layout(int B, int Cn, int H, int W, int max_corners, int sample_count) {
+    WsLayout l;
+    l.nwords = (H * W + 31) / 32;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    l.corners = take((size_t)B * Cn * max_corners * sizeof(int));
+    l.ncorner = take((size_t)B * Cn * sizeof(int));
+    l.bitmap = take((size_t)B * Cn * l.nwords * sizeof(unsigned));
+    l.hist = take((size_t)B * 4096 * sizeof(unsigned));
+    l.state = take((size_t)B * sizeof(ImgState));
+    l.cand = take((size_t)B * (sample_count + TIE_CAP) * sizeof(Cand));
+    l.total = o;
+    return l;
+}
+
+}  // namespace
+
+extern "C" size_t denet_build_samples_workspace_bytes(int B, int Cn, int H, int W, int max_corners, int sample_count) {
+    if (B <= 0 || Cn <= 0 || H <= 0 || W <= 0 || max_corners <= 0 || sample_count <= 0) return 0;
+    return ws_layout(B, Cn, H, W, max_corners, sample_count).total;
+}
+
+extern "C" int denet_build_samples(const float* corner_pr, int* out_box, float* out_absd, int* out_count,
+                                   void* workspace, size_t workspace_bytes, int B, int Cn, int H, int W,
+                                   float corner_threshold, int sample_count, int max_corners, int local_max,
+                                   hipStream_t stream) {
+    DENET_CHECK_ARG(corner_pr && out_box && out_absd && out_count && workspace, "build_samples: null pointer");
+    DENET_CHECK_ARG(Cn == 4, "build_samples: only the 4-corner variant runs on the GPU (Cn=%d)", Cn);
+    DENET_CHECK_ARG(H > 0 && W > 0 && H <= 256 && W <= 256 && H * W <= 16384, "build_samples: map %dx%d unsupported", H, W);
+    DENET_CHECK_ARG(max_corners > 0 && max_corners <= 1024, "build_samples: max_corners must be in 1..1024");
+    DENET_CHECK_ARG(sample_count > 0 && sample_count <= 4096, "build_samples: sample_count must be in 1..4096");
+    DENET_CHECK_ARG(local_max >= 0, "build_samples: negative local_max");
+    const WsLayout l = ws_layout(B, Cn, H, W, max_corners, sample_count);
+    DENET_CHECK_ARG(workspace_bytes >= l.total, "build_samples: workspace too small (%zu < %zu)", workspace_bytes, l.total);
+    char* ws = (char*)workspace;
+    int* corners = (int*)(ws + l.corners);
+    int* ncorner = (int*)(ws + l.ncorner);
+    unsigned* bitmap = (unsigned*)(ws + l.bitmap);
+    unsigned* hist = (unsigned*)(ws + l.hist);
+    ImgState* state = (ImgState*)(ws + l.state);
+    Cand* cand = (Cand*)(ws + l.cand);
+    // denet_sparse.cc:503: float threshold = std::log(corner_threshold)
+    const float thr = logf(corner_threshold);
+
+    hipError_t e = hipMemsetAsync(ws + l.hist, 0, l.cand - l.hist, stream);   // hist + state
+    if (e != hipSuccess) {
+        denet_set_error("build_samples: hipMemsetAsync: %s", hipGetErrorString(e));
+        return -(int)e;
+    }
+    int NP = 1;
+    while (NP < H * W) NP <<= 1;
+    const size_t lds1 = (size_t)NP * 8 + (size_t)l.nwords * 4;
+    static size_t lds1_set = 0, lds2_set = 0;
+    if (lds1 > lds1_set) {
+        e = hipFuncSetAttribute((const void*)corner_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        if (e != hipSuccess) { denet_set_error("build_samples: LDS attr: %s", hipGetErrorString(e)); return -(int)e; }
+        lds1_set = lds1;
+    }
+    hipLaunchKernelGGL(corner_select_kernel, dim3(B, Cn), dim3(1024), lds1, stream, corner_pr, corners, ncorner, bitmap,
+                       Cn, H, W, thr, max_corners, local_max, NP);
+    PairCtx c;
+    c.pr = corner_pr; c.corners = corners; c.ncorner = ncorner; c.bitmap = bitmap;
+    c.Cn = Cn; c.H = H; c.W = W; c.max_corners = max_corners; c.nwords = l.nwords;
+    const dim3 pg(NBLK_PAIR, B), pickg((B + 63) / 64);
+    hipLaunchKernelGGL(pair_hist_kernel<0>, pg, dim3(256), 0, stream, c, state, hist);
+    hipLaunchKernelGGL(pair_pick_kernel<0>, pickg, dim3(64), 0, stream, state, hist, sample_count, B);
+    hipLaunchKernelGGL(pair_hist_kernel<1>, pg, dim3(256), 0, stream, c, state, hist);
+    hipLaunchKernelGGL(pair_pick_kernel<1>, pickg, dim3(64), 0, stream, state, hist, sample_count, B);
+    hipLaunchKernelGGL(pair_hist_kernel<2>, pg, dim3(256), 0, stream, c, state, hist);
+    hipLaunchKernelGGL(pair_pick_kernel<2>, pickg, dim3(64), 0, stream, state, hist, sample_count, B);
+    hipLaunchKernelGGL(pair_collect_kernel, pg, dim3(256), 0, stream, c, state, cand, sample_count);
+    int NP2 = 1;
+    while (NP2 < sample_count + TIE_CAP) NP2 <<= 1;
+    const size_t lds2 = (size_t)NP2 * sizeof(Cand);
+    if (lds2 > lds2_set) {
+        e = hipFuncSetAttribute((const void*)pair_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) { denet_set_error("build_samples: LDS attr: %s", hipGetErrorString(e)); return -(int)e; }
+        lds2_set = lds2;
+    }
+    hipLaunchKernelGGL(pair_finalize_kernel, dim3(B), dim3(1024), lds2, stream, state, cand, sample_count, out_box,
+                       out_absd, out_count, NP2);
+    DENET_CHECK_LAUNCH("build_samples");
+    return DENET_OK;
+}
+
+// Host epilogue: turns the integer boxes + |d| of denet_build_samples (copied to the host) into the
+// reference's sample tuples (pr, x0, y0, x1, y1) with the reference's exact host arithmetic
+// (denet_sparse.cc:306-307): pr = (float)(1.0 / (1.0 + std::exp(fabs(d)))) with the fp32 exp overload,
+// box = ((double)x0/W, (double)y0/H, (double)(x1+1)/W, (double)(y1+1)/H) rounded to fp32.
+extern "C" int denet_samples_finish_host(const int* box_host, const float* absd_host, const int* count_host, int B,
+                                         int sample_count, int H, int W, float* samples_host) {
+    DENET_CHECK_ARG(box_host && absd_host && count_host && samples_host, "samples_finish_host: null pointer");
+    for (int b = 0; b < B; ++b) {
+        for (int i = 0; i < sample_count; ++i) {
+            float* s = samples_host + ((long)b * sample_count + i) * 5;
+            if (i < count_host[b]) {
+                const int* bx = box_host + ((long)b * sample_count + i) * 4;
+                const float d = absd_host[(long)b * sample_count + i];
+                s[0] = (float)(1.0 / (1.0 + (double)expf(d)));
+                s[1] = (float)((double)bx[0] / W);
+                s[2] = (float)((double)bx[1] / H);
+                s[3] = (float)((double)(bx[2] + 1) / W);
+                s[4] = (float)((double)(bx[3] + 1) / H);
+            } else {
+                s[0] = s[1] = s[2] = s[3] = s[4] = 0.f;
+            }
+        }
+    }
+    return DENET_OK;
+}

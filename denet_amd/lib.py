@@ -1,0 +1,96 @@
+"""ctypes binding of libdenet_hip.so (include/denet_hip.h).
+
+This is the only door from the Python host side to the HIP kernels: plain pointers, sizes and a stream.
+There is deliberately NO fallback: if the library is missing or a call fails the caller gets an exception.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdenet_hip.so")
+
+P = ctypes.c_void_p
+I = ctypes.c_int
+L = ctypes.c_long
+F = ctypes.c_float
+Z = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/denet_hip.h declaration by declaration
+SIGNATURES = {
+    "denet_last_error": (ctypes.c_char_p, []),
+    "denet_abi_version": (I, []),
+    "denet_device_info": (I, [I, P, P, P, I]),
+    "denet_conv_fwd": (I, [P, P, P, P, P] + [I] * 12 + [P]),
+    "denet_conv_dgrad": (I, [P, P, P, P] + [I] * 12 + [P]),
+    "denet_conv_wgrad_workspace_bytes": (Z, [I] * 7),
+    "denet_conv_wgrad": (I, [P, P, P, P, Z] + [I] * 12 + [P]),
+    "denet_bn_workspace_bytes": (Z, [L, I]),
+    "denet_bn_fwd_train": (I, [P] * 10 + [L, I, F, F, I, P]),
+    "denet_bn_fwd_test": (I, [P] * 8 + [L, I, F, I, P]),
+    "denet_bn_bwd": (I, [P] * 11 + [L, I, I, P]),
+    "denet_maxpool_fwd": (I, [P, P, P] + [I] * 9 + [P]),
+    "denet_maxpool_bwd": (I, [P, P, P] + [I] * 9 + [P]),
+    "denet_avgpool_fwd": (I, [P, P] + [I] * 9 + [P]),
+    "denet_avgpool_bwd": (I, [P, P] + [I] * 9 + [P]),
+    "denet_pool_inv_fwd": (I, [P, P] + [I] * 6 + [P]),
+    "denet_pool_inv_bwd": (I, [P, P] + [I] * 6 + [P]),
+    "denet_nchw_to_nhwc": (I, [P, P] + [I] * 5 + [P]),
+    "denet_nhwc_to_nchw": (I, [P, P] + [I] * 5 + [P]),
+    "denet_add": (I, [P, P, P, L, I, P]),
+    "denet_relu_fwd": (I, [P, P, L, P]),
+    "denet_relu_bwd": (I, [P, P, P, L, P]),
+    "denet_colsum_workspace_bytes": (Z, [L, I]),
+    "denet_colsum": (I, [P, P, P, L, I, P]),
+    "denet_solver_step": (I, [P, P, P, L, L, F, F, I, F, F, I, P]),
+    "denet_scale": (I, [P, L, F, P]),
+    "denet_corner_fwd": (I, [P, P] + [I] * 5 + [P]),
+    "denet_loss_workspace_bytes": (Z, []),
+    "denet_corner_loss": (I, [P] * 5 + [I] * 5 + [F, P]),
+    "denet_sparse_fwd": (I, [P, P, P, P] + [I] * 10 + [P]),
+    "denet_sparse_bwd": (I, [P, P, P, P] + [I] * 10 + [P]),
+    "denet_detect_loss": (I, [P] * 8 + [I] * 5 + [F, F, I, P]),
+    "denet_build_samples_workspace_bytes": (Z, [I] * 6),
+    "denet_build_samples": (I, [P, P, P, P, P, Z] + [I] * 4 + [F, I, I, I, P]),
+    "denet_samples_finish_host": (I, [P, P, P, I, I, I, I, P]),
+}
+
+
+class DenetHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads the library (once). Raises if it has not been built: there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DenetHipError(
+            "libdenet_hip.so is missing (%s): run `python -m denet_amd.build` / __graft_entry__.build() first. "
+            "The DeNet hot path has no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().denet_last_error().decode("utf-8", "replace")
+        raise DenetHipError("%s failed (rc=%d): %s" % (what or "denet call", rc, msg))
+
+
+def ptr(t):
+    """device (or host) pointer of a torch tensor / None"""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,272 @@
+"""Thin host wrappers: torch tensors (storage only) -> C-ABI calls of libdenet_hip.so.
+
+Tensors are NHWC fp32, contiguous, on the current HIP device. No torch arithmetic happens here; every
+function enqueues hand-written HIP kernels on the current torch stream and returns.
+"""
+import torch
+
+from . import lib as _lib
+from .lib import check, ptr, stream_ptr
+
+
+def _L():
+    return _lib.load()
+
+
+def empty(*shape, dtype=torch.float32):
+    return torch.empty(*shape, dtype=dtype, device="cuda")
+
+
+class Workspace:
+    """Grow-only scratch buffers shared by all kernels of one stream (conv split-K slices, BN partials, ...)."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, name, nbytes):
+        nbytes = int(nbytes)
+        buf = self.bufs.get(name)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device="cuda")
+            self.bufs[name] = buf
+        return buf
+
+
+WS = Workspace()
+WGRAD_WS_BYTES = 512 << 20
+
+
+def conv_geom(x_shape, w_shape, stride, pad, s_real=None):
+    N, H, W, C = x_shape
+    K, R, S, Cw = w_shape
+    assert Cw == C, (x_shape, w_shape)
+    s_real = S if s_real is None else s_real
+    OH = (H + 2 * pad - R) // stride + 1
+    OW = (W + 2 * pad - s_real) // stride + 1
+    return N, H, W, C, K, R, S, s_real, stride, pad, OH, OW
+
+
+def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None):
+    g = conv_geom(x.shape, w.shape, stride, pad, s_real)
+    N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
+    y = out if out is not None else empty(N, OH, OW, K)
+    check(_L().denet_conv_fwd(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), *g, stream_ptr()), "conv_fwd")
+    return y
+
+
+def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None):
+    g = conv_geom(x_shape, w.shape, stride, pad, s_real)
+    assert tuple(dy.shape) == (g[0], g[10], g[11], g[4]), (dy.shape, g)
+    dx = out if out is not None else empty(*x_shape)
+    check(_L().denet_conv_dgrad(ptr(dy), ptr(w), ptr(add), ptr(dx), *g, stream_ptr()), "conv_dgrad")
+    return dx
+
+
+def conv_wgrad(x, dy, w_shape, stride=1, pad=0, s_real=None, out=None):
+    g = conv_geom(x.shape, w_shape, stride, pad, s_real)
+    assert tuple(dy.shape) == (g[0], g[10], g[11], g[4]), (dy.shape, g)
+    dw = out if out is not None else empty(*w_shape)
+    ws = WS.get("wgrad", WGRAD_WS_BYTES)
+    check(_L().denet_conv_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel(), *g, stream_ptr()), "conv_wgrad")
+    return dw
+
+
+def _bn_ws(M, C):
+    return WS.get("bn", _L().denet_bn_workspace_bytes(M, C))
+
+
+def bn_fwd_train(x, gamma, beta, run_mean, run_stdinv, momentum=0.9, eps=1e-5, relu=False, res=None, out=None):
+    C = x.shape[-1]
+    M = x.numel() // C
+    y = out if out is not None else torch.empty_like(x)
+    save_mean, save_invstd = empty(C), empty(C)
+    check(_L().denet_bn_fwd_train(ptr(x), ptr(res), ptr(y), ptr(gamma), ptr(beta), ptr(run_mean), ptr(run_stdinv),
+                                  ptr(save_mean), ptr(save_invstd), ptr(_bn_ws(M, C)), M, C, momentum, eps,
+                                  int(relu), stream_ptr()), "bn_fwd_train")
+    return y, save_mean, save_invstd
+
+
+def bn_fwd_test(x, gamma, beta, run_mean, run_stdinv, eps=1e-5, relu=False, res=None, out=None):
+    C = x.shape[-1]
+    M = x.numel() // C
+    y = out if out is not None else torch.empty_like(x)
+    check(_L().denet_bn_fwd_test(ptr(x), ptr(res), ptr(y), ptr(gamma), ptr(beta), ptr(run_mean), ptr(run_stdinv),
+                                 ptr(_bn_ws(M, C)), M, C, eps, int(relu), stream_ptr()), "bn_fwd_test")
+    return y
+
+
+def bn_bwd(x, y, dy, gamma, save_mean, save_invstd, relu=False, want_dres=False, dgamma=None, dbeta=None, dx=None):
+    C = x.shape[-1]
+    M = x.numel() // C
+    dx = dx if dx is not None else torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    dgamma = dgamma if dgamma is not None else empty(C)
+    dbeta = dbeta if dbeta is not None else empty(C)
+    check(_L().denet_bn_bwd(ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(save_mean), ptr(save_invstd), ptr(dx), ptr(dres),
+                            ptr(dgamma), ptr(dbeta), ptr(_bn_ws(M, C)), M, C, int(relu), stream_ptr()), "bn_bwd")
+    return dx, dres, dgamma, dbeta
+
+
+def maxpool_fwd(x, k, stride, pad):
+    N, H, W, C = x.shape
+    OH = (H + 2 * pad - k) // stride + 1
+    OW = (W + 2 * pad - k) // stride + 1
+    y = empty(N, OH, OW, C)
+    arg = torch.empty((N, OH, OW, C), dtype=torch.uint8, device="cuda")
+    check(_L().denet_maxpool_fwd(ptr(x), ptr(y), ptr(arg), N, H, W, C, OH, OW, k, stride, pad, stream_ptr()),
+          "maxpool_fwd")
+    return y, arg
+
+
+def maxpool_bwd(dy, arg, x_shape, k, stride, pad):
+    N, H, W, C = x_shape
+    OH, OW = dy.shape[1], dy.shape[2]
+    dx = empty(*x_shape)
+    check(_L().denet_maxpool_bwd(ptr(dy), ptr(arg), ptr(dx), N, H, W, C, OH, OW, k, stride, pad, stream_ptr()),
+          "maxpool_bwd")
+    return dx
+
+
+def avgpool_fwd(x, k, stride, pad):
+    N, H, W, C = x.shape
+    OH = (H + 2 * pad - k) // stride + 1
+    OW = (W + 2 * pad - k) // stride + 1
+    y = empty(N, OH, OW, C)
+    check(_L().denet_avgpool_fwd(ptr(x), ptr(y), N, H, W, C, OH, OW, k, stride, pad, stream_ptr()), "avgpool_fwd")
+    return y
+
+
+def avgpool_bwd(dy, x_shape, k, stride, pad):
+    N, H, W, C = x_shape
+    dx = empty(*x_shape)
+    check(_L().denet_avgpool_bwd(ptr(dy), ptr(dx), N, H, W, C, dy.shape[1], dy.shape[2], k, stride, pad,
+                                 stream_ptr()), "avgpool_bwd")
+    return dx
+
+
+def pool_inv_fwd(x, fy, fx):
+    N, H, W, C = x.shape
+    y = empty(N, H * fy, W * fx, C)
+    check(_L().denet_pool_inv_fwd(ptr(x), ptr(y), N, H, W, C, fy, fx, stream_ptr()), "pool_inv_fwd")
+    return y
+
+
+def pool_inv_bwd(dy, fy, fx):
+    N, OH, OW, C = dy.shape
+    dx = empty(N, OH // fy, OW // fx, C)
+    check(_L().denet_pool_inv_bwd(ptr(dy), ptr(dx), N, OH // fy, OW // fx, C, fy, fx, stream_ptr()), "pool_inv_bwd")
+    return dx
+
+
+def nchw_to_nhwc(x, cp):
+    N, C, H, W = x.shape
+    y = empty(N, H, W, cp)
+    check(_L().denet_nchw_to_nhwc(ptr(x), ptr(y), N, C, H, W, cp, stream_ptr()), "nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x, c):
+    N, H, W, CP = x.shape
+    y = empty(N, c, H, W)
+    check(_L().denet_nhwc_to_nchw(ptr(x), ptr(y), N, c, H, W, CP, stream_ptr()), "nhwc_to_nchw")
+    return y
+
+
+def add(a, b, relu=False, out=None):
+    y = out if out is not None else torch.empty_like(a)
+    check(_L().denet_add(ptr(a), ptr(b), ptr(y), a.numel(), int(relu), stream_ptr()), "add")
+    return y
+
+
+def relu_fwd(x):
+    y = torch.empty_like(x)
+    check(_L().denet_relu_fwd(ptr(x), ptr(y), x.numel(), stream_ptr()), "relu_fwd")
+    return y
+
+
+def relu_bwd(y, dy):
+    dx = torch.empty_like(dy)
+    check(_L().denet_relu_bwd(ptr(y), ptr(dy), ptr(dx), y.numel(), stream_ptr()), "relu_bwd")
+    return dx
+
+
+def colsum(x, out=None):
+    C = x.shape[-1]
+    M = x.numel() // C
+    out = out if out is not None else empty(C)
+    ws = WS.get("colsum", _L().denet_colsum_workspace_bytes(M, C))
+    check(_L().denet_colsum(ptr(x), ptr(out), ptr(ws), M, C, stream_ptr()), "colsum")
+    return out
+
+
+def solver_step(params, moments, grads, n_decay, lr, momentum, iteration, decay, mode, grad_scale=1.0):
+    check(_L().denet_solver_step(ptr(params), ptr(moments), ptr(grads), params.numel(), int(n_decay), lr, momentum,
+                                 int(iteration), decay, grad_scale, int(mode), stream_ptr()), "solver_step")
+
+
+def corner_fwd(conv, cn):
+    B, H, W, CP = conv.shape
+    pr = empty(B, 2, cn, H, W)
+    check(_L().denet_corner_fwd(ptr(conv), ptr(pr), B, H, W, CP, cn, stream_ptr()), "corner_fwd")
+    return pr
+
+
+def _loss_ws():
+    return WS.get("loss", _L().denet_loss_workspace_bytes())
+
+
+def corner_loss(corner_pr, target, dconv, cost_out, cost_factor):
+    B, _, cn, H, W = corner_pr.shape
+    CP = dconv.shape[-1] if dconv is not None else 0
+    check(_L().denet_corner_loss(ptr(corner_pr), ptr(target), ptr(dconv), ptr(cost_out), ptr(_loss_ws()), B, H, W, CP,
+                                 cn, cost_factor, stream_ptr()), "corner_loss")
+
+
+def sparse_fwd(fmap, bbox, coff, F, rois_per_image, gs, kp, tap_rule=0):
+    B, H, W, CP = fmap.shape
+    M = B * rois_per_image
+    out = empty(M, kp)
+    taps = torch.empty((M, gs * gs), dtype=torch.int32, device="cuda")
+    check(_L().denet_sparse_fwd(ptr(fmap), ptr(bbox), ptr(out), ptr(taps), B, H, W, CP, coff, F, rois_per_image, gs,
+                                kp, tap_rule, stream_ptr()), "sparse_fwd")
+    return out, taps
+
+
+def sparse_bwd(dy, taps, dfmap, coff, F, rois_per_image, gs, zero_from):
+    B, H, W, CP = dfmap.shape
+    kp = dy.shape[-1]
+    ws = WS.get("sparse_sort", B * rois_per_image * gs * gs * 4)
+    check(_L().denet_sparse_bwd(ptr(dy), ptr(taps), ptr(ws), ptr(dfmap), B, H, W, CP, coff, F, rois_per_image, gs, kp,
+                                zero_from, stream_ptr()), "sparse_bwd")
+    return dfmap
+
+
+def detect_loss(logits, det_target, bbox_valid, bbox_target, roi_bbox, dlogits, costs, batch, ncls, nreg,
+                cost_factor, bbox_factor, bounded_iou=False):
+    M, CP = logits.shape
+    check(_L().denet_detect_loss(ptr(logits), ptr(det_target), ptr(bbox_valid), ptr(bbox_target), ptr(roi_bbox),
+                                 ptr(dlogits), ptr(costs), ptr(_loss_ws()), M, batch, CP, ncls, nreg, cost_factor,
+                                 bbox_factor, int(bounded_iou), stream_ptr()), "detect_loss")
+
+
+def build_samples(corner_pr, corner_threshold, sample_count, max_corners=1024, local_max=0):
+    """Device part of build_samples: returns (box int32 [B,S,4], absd fp32 [B,S], count int32 [B]) on device."""
+    B, _, cn, H, W = corner_pr.shape
+    nbytes = _L().denet_build_samples_workspace_bytes(B, cn, H, W, max_corners, sample_count)
+    ws = WS.get("samples", nbytes)
+    box = torch.empty((B, sample_count, 4), dtype=torch.int32, device="cuda")
+    absd = empty(B, sample_count)
+    count = torch.empty((B,), dtype=torch.int32, device="cuda")
+    check(_L().denet_build_samples(ptr(corner_pr), ptr(box), ptr(absd), ptr(count), ptr(ws), ws.numel(), B, cn, H, W,
+                                   corner_threshold, sample_count, max_corners, local_max, stream_ptr()),
+          "build_samples")
+    return box, absd, count
+
+
+def samples_finish_host(box, absd, count, H, W):
+    """Host epilogue (libm expf, double box arithmetic exactly as the reference). CPU tensors in, CPU tensor out."""
+    B, S, _ = box.shape
+    out = torch.empty((B, S, 5), dtype=torch.float32)
+    check(_L().denet_samples_finish_host(box.data_ptr(), absd.data_ptr(), count.data_ptr(), B, S, H, W,
+                                         out.data_ptr()), "samples_finish_host")
+    return out

@@ -1,0 +1,143 @@
+/*
+ * denet_hip.h — C ABI of libdenet_hip.so, the MI355X (gfx950) implementation of the DeNet training hot path.
+ *
+ * Every entry point replaces one device-side operation that the reference (lachlants/denet) reaches through
+ * Theano GpuOps / cuDNN, or one host-side C++ function it loads through common.import_c. The reference
+ * interface each function stands in for is cited as `denet/...:line`.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the parameter name ends in `_host`;
+ *   - activations are NHWC fp32 with a *physical* channel count (multiple of 32 for convolution operands,
+ *     4 for the network input), filters are KRSC fp32 holding the already flipped (correlation) taps;
+ *   - functions enqueue work on `stream` and return immediately: they never allocate, never synchronise;
+ *   - return value 0 = ok, DENET_ERR_ARG (-1000) = rejected arguments, other negative = -(hipError_t);
+ *     denet_last_error() returns a thread-local description of the last failure;
+ *   - buffers are owned by the caller; `workspace` sizes come from the matching *_workspace_bytes().
+ */
+#ifndef DENET_HIP_H
+#define DENET_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define DENET_ERR_ARG (-1000)
+#define DENET_TAP_THEANO 0 /* denet/layer/denet_sparse.py:72-84  (i*extent)/(gs-1), round half to even */
+#define DENET_TAP_CUDA 1   /* denet/layer/denet_sparse_op.py:65-71 i*extent*(1/(gs-1)), lroundf           */
+#define DENET_SOLVER_SGD 0      /* denet/model/model_cnn.py:282-287 */
+#define DENET_SOLVER_NESTEROV 1 /* denet/model/model_cnn.py:289-294 ("torch" == "nesterov") */
+
+/* ---- runtime ---------------------------------------------------------------------------------------- */
+const char* denet_last_error(void);
+int denet_abi_version(void);
+int denet_device_info(int device, int* cu_count, int* clock_khz, char* arch, int arch_len);
+
+/* ---- convolution  (denet/layer/convolution.py:80-83 -> cuDNN conv fwd; model_cnn.py:318 tensor.grad ->
+ *      cuDNN bwd-data / bwd-filter).  x:[N,H,W,C]  w:[K,R,S,C]  y:[N,OH,OW,K]; `S` may be padded beyond the
+ *      real tap count S_real when C < 32 (first layer: C=4, S=8, S_real=7); `add` (optional, shape of the
+ *      output) is summed in the epilogue: residual / skip accumulation without an extra pass.          */
+int denet_conv_fwd(const float* x, const float* w, const float* bias, const float* add, float* y, int N, int H, int W,
+                   int C, int K, int R, int S, int S_real, int stride, int pad, int OH, int OW, hipStream_t stream);
+int denet_conv_dgrad(const float* dy, const float* w, const float* add, float* dx, int N, int H, int W, int C, int K,
+                     int R, int S, int S_real, int stride, int pad, int OH, int OW, hipStream_t stream);
+size_t denet_conv_wgrad_workspace_bytes(int N, int C, int K, int R, int S, int OH, int OW);
+int denet_conv_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes, int N,
+                     int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH, int OW,
+                     hipStream_t stream);
+
+/* ---- batch norm (+ReLU, +residual)  (denet/layer/batch_norm.py:50-79 dnn_batch_normalization_train/test,
+ *      denet/layer/batch_norm_relu.py:34-54 BatchNormReluOp + grad, denet/layer/resnet.py:109-113).
+ *      x,y,res,dy,dx,dres: [M,C] (M = N*H*W).  run_mean/run_stdinv are updated in place (momentum form of
+ *      batch_norm.py:75-76; the running statistic is the INVERSE standard deviation).                    */
+size_t denet_bn_workspace_bytes(long M, int C);
+int denet_bn_fwd_train(const float* x, const float* res, float* y, const float* gamma, const float* beta,
+                       float* run_mean, float* run_stdinv, float* save_mean, float* save_invstd, void* workspace,
+                       long M, int C, float momentum, float eps, int relu, hipStream_t stream);
+int denet_bn_fwd_test(const float* x, const float* res, float* y, const float* gamma, const float* beta,
+                      const float* run_mean, const float* run_stdinv, void* workspace, long M, int C, float eps,
+                      int relu, hipStream_t stream);
+int denet_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* save_mean,
+                 const float* save_invstd, float* dx, float* dres, float* dgamma, float* dbeta, void* workspace, long M,
+                 int C, int relu, hipStream_t stream);
+
+/* ---- pooling  (denet/layer/pool.py:28-40 dnn_pool max / average_inc_pad;
+ *      denet/layer/pool_inv_op.py:38-63 k_pool_inv, :144-169 k_pool_inv_grad)                             */
+int denet_maxpool_fwd(const float* x, float* y, unsigned char* argmax, int N, int H, int W, int C, int OH, int OW,
+                      int k, int stride, int pad, hipStream_t stream);
+int denet_maxpool_bwd(const float* dy, const unsigned char* argmax, float* dx, int N, int H, int W, int C, int OH,
+                      int OW, int k, int stride, int pad, hipStream_t stream);
+int denet_avgpool_fwd(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, int k, int stride, int pad,
+                      hipStream_t stream);
+int denet_avgpool_bwd(const float* dy, float* dx, int N, int H, int W, int C, int OH, int OW, int k, int stride,
+                      int pad, hipStream_t stream);
+int denet_pool_inv_fwd(const float* x, float* y, int N, int H, int W, int C, int fy, int fx, hipStream_t stream);
+int denet_pool_inv_bwd(const float* dy, float* dx, int N, int H, int W, int C, int fy, int fx, hipStream_t stream);
+
+/* ---- element-wise / boundary helpers
+ *      layout conversion of the NCHW batches handed to ModelCNN.train_step (denet/model/model_cnn.py:407),
+ *      residual / skip add (denet/layer/skip.py:81-86), `A` relu (denet/layer/activation.py:31-34),
+ *      conv-bias gradient, solver update (denet/model/model_cnn.py:282-294, 321-331).                    */
+int denet_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int CP, hipStream_t stream);
+int denet_nhwc_to_nchw(const float* x, float* y, int N, int C, int H, int W, int CP, hipStream_t stream);
+int denet_add(const float* a, const float* b, float* y, long n, int relu, hipStream_t stream);
+int denet_relu_fwd(const float* x, float* y, long n, hipStream_t stream);
+int denet_relu_bwd(const float* y, const float* dy, float* dx, long n, hipStream_t stream);
+size_t denet_colsum_workspace_bytes(long M, int C);
+int denet_colsum(const float* x, float* out, void* workspace, long M, int C, hipStream_t stream);
+int denet_solver_step(float* params, float* moments, const float* grads, long n, long n_decay, float lr,
+                      float momentum, int iteration, float decay, float grad_scale, int mode, hipStream_t stream);
+int denet_scale(float* x, long n, float s, hipStream_t stream);
+
+/* ---- DeNet corner map  (denet/layer/denet_corner.py:50-53 log_softmax([x,-x]); :126-134 cost)
+ *      conv:[B,H,W,CP] (first Cn channels are corner logits)  corner_pr/target:[B,2,Cn,H,W] (the reference's
+ *      own layout, it is what build_samples consumes).  cost[0] receives cost_factor*corner_cost.         */
+int denet_corner_fwd(const float* conv, float* corner_pr, int B, int H, int W, int CP, int Cn, hipStream_t stream);
+size_t denet_loss_workspace_bytes(void);
+int denet_corner_loss(const float* corner_pr, const float* target, float* dconv, float* cost, void* workspace, int B,
+                      int H, int W, int CP, int Cn, float cost_factor, hipStream_t stream);
+
+/* ---- sparse RoI feature sampling  (denet/layer/denet_sparse_op.py:42-85 k_sparse_sample<gs>, :171-212
+ *      k_sparse_sample_grad<gs>; Theano fallback denet/layer/denet_sparse.py:70-96)
+ *      fmap:[B,H,W,CP] channels [coff,coff+F) are sampled; bbox:[B*rois,4] normalised x0,y0,x1,y1;
+ *      out:[B*rois,KP] = gs*gs*F features, box height, box width, zero padding; taps:[B*rois,gs*gs] receives
+ *      the sampled cell index ys*W+xs (bit-exact parity surface).  The gradient is a deterministic segmented
+ *      sum (LDS bitonic sort of the taps per image) instead of the reference's atomicAdd scatter.         */
+int denet_sparse_fwd(const float* fmap, const float* bbox, float* out, int* taps, int B, int H, int W, int CP,
+                     int coff, int F, int rois_per_image, int gs, int KP, int tap_rule, hipStream_t stream);
+int denet_sparse_bwd(const float* dy, const int* taps, unsigned* sorted_ws, float* dfmap, int B, int H, int W, int CP,
+                     int coff, int F, int rois_per_image, int gs, int KP, int zero_from, hipStream_t stream);
+
+/* ---- detection cost  (denet/layer/denet_detect.py:238-313 get_errors/cost; theano_util.py:27-34)
+ *      logits:[M,CP] (ncls class logits then nreg box regressors); det_target:[M,ncls]; bbox_valid:[M];
+ *      bbox_target:[M,8] = target cx,cy,w,h, sample cx,cy,w,h; costs[0] = DET cost, costs[1] = BBOX cost.  */
+int denet_detect_loss(const float* logits, const float* det_target, const float* bbox_valid, const float* bbox_target,
+                      const float* roi_bbox, float* dlogits, float* costs, void* workspace, int M, int batch, int CP,
+                      int ncls, int nreg, float cost_factor, float bbox_factor, int bounded_iou, hipStream_t stream);
+
+/* ---- corner selection + RoI proposal  (denet/layer/denet_sparse.cc:489-557 run_build_samples, :321-471
+ *      search_corners, :271-308 get_sample; Python-facing wrapper build_samples :559-668, which the reference
+ *      calls on the HOST with a D2H copy of the corner map, denet/layer/denet_sparse.py:129-139).
+ *      corner_pr:[B,2,4,H,W] device. Per image the best `sample_count` candidate boxes, ranked exactly like
+ *      the reference (score descending == |pr_f-pr_t| ascending; equal scores ordered by generation index):
+ *        out_box:[B,sample_count,4] int32 corner cells x0,y0,x1,y1;  out_absd:[B,sample_count] fp32 |pr_f-pr_t|;
+ *        out_count:[B].
+ *      denet_samples_finish_host converts HOST copies of these into the reference's tuples
+ *      (pr, x0/W, y0/H, (x1+1)/W, (y1+1)/H) with the reference's own host arithmetic (denet_sparse.cc:306-307);
+ *      samples_host:[B,sample_count,5].  cluster_threshold < 1 (apply_cluster) is not provided.            */
+size_t denet_build_samples_workspace_bytes(int B, int Cn, int H, int W, int max_corners, int sample_count);
+int denet_build_samples(const float* corner_pr, int* out_box, float* out_absd, int* out_count, void* workspace,
+                        size_t workspace_bytes, int B, int Cn, int H, int W, float corner_threshold, int sample_count,
+                        int max_corners, int local_max, hipStream_t stream);
+int denet_samples_finish_host(const int* box_host, const float* absd_host, const int* count_host, int B,
+                              int sample_count, int H, int W, float* samples_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DENET_HIP_H */

@@ -1,0 +1,399 @@
+"""GPU parity of the individual HIP kernels against plain torch fp32 references of the same op.
+(The end-to-end / layer-level parity against the oracle lives in test_parity_gpu.py.)"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(t):  # NCHW -> NHWC contiguous
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def _close(a, b, rtol=1e-3, atol=None):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    if atol is None:
+        atol = 1e-4 * float(b.abs().max()) + 1e-7
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    assert not bad.any(), "max err %.3e (tol %.3e), %d/%d bad" % (float(err.max()), float(tol.min()), int(bad.sum()), bad.numel())
+
+
+CONV_CASES = [
+    # N, H, W, C, K, R, stride, pad
+    (2, 16, 16, 64, 64, 3, 1, 1),
+    (2, 16, 16, 64, 128, 3, 2, 1),
+    (2, 16, 16, 128, 256, 1, 2, 0),
+    (1, 12, 12, 128, 128, 3, 1, 1),     # M not a multiple of 128
+    (2, 8, 8, 256, 96, 1, 1, 0),        # K not a multiple of the N tile
+    (3, 24, 24, 32, 160, 3, 1, 1),
+    (2, 10, 14, 64, 64, 3, 1, 1),       # non-square
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(hip, case):
+    from denet_amd import ops
+    N, H, W, C, K, R, stride, pad = case
+    g = torch.Generator(device="cpu").manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, C, H, W, generator=g).cuda()
+    w = (torch.randn(K, C, R, R, generator=g) * 0.1).cuda()
+    bias = torch.randn(K, generator=g).cuda()
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    y_ref = Fn.conv2d(x, w, bias, stride=stride, padding=pad)
+    dy = torch.randn(y_ref.shape, generator=g).cuda()
+    y_ref.backward(dy)
+
+    xn, wn = _nhwc(x.detach()), w.detach().permute(0, 2, 3, 1).contiguous()
+    y = ops.conv_fwd(xn, wn, bias=bias, stride=stride, pad=pad)
+    _close(_nchw(y), y_ref)
+    dyn = _nhwc(dy)
+    dx = ops.conv_dgrad(dyn, wn, tuple(xn.shape), stride=stride, pad=pad)
+    _close(_nchw(dx), x.grad)
+    dw = ops.conv_wgrad(xn, dyn, tuple(wn.shape), stride=stride, pad=pad)
+    _close(dw.permute(0, 3, 1, 2), w.grad)
+    # epilogue add
+    addt = torch.randn(y.shape, generator=g).cuda()
+    y2 = ops.conv_fwd(xn, wn, bias=bias, add=addt, stride=stride, pad=pad)
+    _close(y2, y + addt)
+    addx = torch.randn(xn.shape, generator=g).cuda()
+    dx2 = ops.conv_dgrad(dyn, wn, tuple(xn.shape), add=addx, stride=stride, pad=pad)
+    _close(dx2, dx + addx)
+
+
+def test_conv_stem_small_c(hip):
+    """7x7/2 stem: C=3 padded to 4, S padded 7->8 (zero tap); wgrad must leave the padded tap at 0."""
+    from denet_amd import ops
+    g = torch.Generator().manual_seed(5)
+    N, H, W, K = 2, 32, 32, 64
+    x = torch.rand(N, 3, H, W, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(K, 3, 7, 7, generator=g) * 0.1).cuda().requires_grad_(True)
+    bias = torch.randn(K, generator=g).cuda()
+    y_ref = Fn.conv2d(x, w, bias, stride=2, padding=3)
+    dy = torch.randn(y_ref.shape, generator=g).cuda()
+    y_ref.backward(dy)
+    xn = ops.nchw_to_nhwc(x.detach().contiguous(), 4)
+    wn = torch.zeros(K, 7, 8, 4).cuda()
+    wn[:, :, :7, :3] = w.detach().permute(0, 2, 3, 1)
+    y = ops.conv_fwd(xn, wn, bias=bias, stride=2, pad=3, s_real=7)
+    _close(_nchw(y), y_ref)
+    dw = ops.conv_wgrad(xn, _nhwc(dy), tuple(wn.shape), stride=2, pad=3, s_real=7)
+    _close(dw[:, :, :7, :3].permute(0, 3, 1, 2), w.grad)
+    assert float(dw[:, :, 7, :].abs().max()) == 0.0
+    assert float(dw[:, :, :, 3].abs().max()) == 0.0
+
+
+def test_conv_is_mfma_exact_order_free(hip):
+    """A = I check with an asymmetric filter (catches transposed fragments)."""
+    from denet_amd import ops
+    C = K = 64
+    x = torch.zeros(1, 8, 16, C).cuda()
+    for c in range(C):
+        x[0, c % 8, c % 16, c] = 1.0 + c
+    w = torch.arange(K * C, dtype=torch.float32).reshape(K, 1, 1, C).cuda() / 100.0
+    y = ops.conv_fwd(x, w)
+    ref = torch.einsum("nhwc,kc->nhwk", x, w[:, 0, 0, :])
+    _close(y, ref, rtol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(4, 16, 16, 64), (2, 8, 8, 1536), (3, 5, 7, 768), (2, 32, 32, 128)])
+@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
+def test_bn_fwd_bwd(hip, shape, relu, res):
+    from denet_amd import ops
+    g = torch.Generator().manual_seed(11)
+    N, H, W, C = shape
+    x = (torch.randn(shape, generator=g) * 2 + 0.5).cuda().requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda().requires_grad_(True)
+    beta = torch.randn(C, generator=g).cuda().requires_grad_(True)
+    r = torch.randn(shape, generator=g).cuda().requires_grad_(True) if res else None
+    rm, rs = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    eps = 1e-5
+    xf = x.reshape(-1, C)
+    mean = xf.mean(0)
+    var = xf.var(0, unbiased=False)
+    inv = 1.0 / torch.sqrt(var + eps)
+    yr = (x - mean) * inv * gamma + beta
+    if res:
+        yr = yr + r
+    if relu:
+        yr = torch.relu(yr)
+    dy = torch.randn(shape, generator=g).cuda()
+    yr.backward(dy)
+
+    y, sm, si = ops.bn_fwd_train(x.detach(), gamma.detach(), beta.detach(), rm, rs, 0.9, eps, relu=relu,
+                                 res=r.detach() if res else None)
+    _close(y, yr)
+    _close(sm, mean)
+    _close(si, inv)
+    _close(rm, 0.1 * mean)
+    _close(rs, 0.9 + 0.1 * inv)
+    dx, dres, dgamma, dbeta = ops.bn_bwd(x.detach(), y, dy, gamma.detach(), sm, si, relu=relu, want_dres=res)
+    _close(dx, x.grad, rtol=2e-3)
+    _close(dgamma, gamma.grad, rtol=2e-3)
+    _close(dbeta, beta.grad, rtol=2e-3)
+    if res:
+        _close(dres, r.grad)
+
+
+def test_bn_known_answer(hip):
+    """Reference's own KAT (denet/layer/batch_norm.py:131-154): x~U(0,1) (64,128,32,32), running stdinv mean
+    = 0.9 + 0.1/sqrt(1/12 + 1e-5) = 1.24641, running mean = 0.1*mean(x), output mean 0 / std 1."""
+    from denet_amd import ops
+    rng = np.random.RandomState(1002)
+    x = torch.from_numpy(rng.uniform(0.0, 1.0, (64, 128, 32, 32)).astype(np.float32)).cuda()
+    xn = ops.nchw_to_nhwc(x, 128)
+    C = 128
+    rm, rs = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    y, _, _ = ops.bn_fwd_train(xn, torch.ones(C).cuda(), torch.zeros(C).cuda(), rm, rs, 0.9, 1e-5)
+    eps = 1e-4
+    assert abs(float(y.mean())) < eps and abs(float(y.std()) - 1.0) < eps
+    assert abs(float(rm.mean()) - float(x.mean()) * 0.1) < eps
+    assert abs(float(rs.mean()) - 1.24641) < eps
+
+
+def test_bn_test_mode_double_eps(hip):
+    from denet_amd import ops
+    g = torch.Generator().manual_seed(3)
+    C = 64
+    x = torch.randn(2, 4, 4, C, generator=g).cuda()
+    gamma, beta = torch.rand(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    rm, rs = torch.randn(C, generator=g).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    y = ops.bn_fwd_test(x, gamma, beta, rm, rs, eps=1e-5, relu=True)
+    var = (1.0 / rs) ** 2
+    ref = torch.relu((x - rm) / torch.sqrt(var + 1e-5) * gamma + beta)
+    _close(y, ref)
+
+
+@pytest.mark.parametrize("k,s,p", [(3, 2, 1), (2, 2, 0), (3, 1, 1)])
+def test_maxpool(hip, k, s, p):
+    from denet_amd import ops
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 64, 18, 22, generator=g).cuda().requires_grad_(True)
+    yr = Fn.max_pool2d(x, k, s, p)
+    dy = torch.randn(yr.shape, generator=g).cuda()
+    yr.backward(dy)
+    y, arg = ops.maxpool_fwd(_nhwc(x.detach()), k, s, p)
+    assert torch.equal(_nchw(y), yr)
+    dx = ops.maxpool_bwd(_nhwc(dy), arg, (2, 18, 22, 64), k, s, p)
+    _close(_nchw(dx), x.grad, rtol=1e-5)
+
+
+@pytest.mark.parametrize("k,s,p", [(8, 8, 0), (7, 7, 0), (3, 2, 1)])
+def test_avgpool(hip, k, s, p):
+    from denet_amd import ops
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 64, 16, 16, generator=g).cuda().requires_grad_(True)
+    yr = Fn.avg_pool2d(x, k, s, p, count_include_pad=True)
+    dy = torch.randn(yr.shape, generator=g).cuda()
+    yr.backward(dy)
+    y = ops.avgpool_fwd(_nhwc(x.detach()), k, s, p)
+    _close(_nchw(y), yr, rtol=1e-5)
+    dx = ops.avgpool_bwd(_nhwc(dy), (2, 16, 16, 64), k, s, p)
+    _close(_nchw(dx), x.grad, rtol=1e-5)
+
+
+def test_pool_inv(hip):
+    """Differential design of the reference's own check (denet/layer/pool_inv.py:43-88): op vs double repeat."""
+    from denet_amd import ops
+    rng = np.random.RandomState(1)
+    x = torch.from_numpy(rng.uniform(-5, 5, (4, 64, 4, 4)).astype(np.float32)).cuda()
+    y = ops.pool_inv_fwd(_nhwc(x), 2, 2)
+    ref = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    assert torch.equal(_nchw(y), ref)
+    dy = torch.from_numpy(rng.uniform(-1, 1, (4, 64, 8, 8)).astype(np.float32)).cuda()
+    dx = ops.pool_inv_bwd(_nhwc(dy), 2, 2)
+    ref = dy.reshape(4, 64, 4, 2, 4, 2).sum(dim=(3, 5))
+    _close(_nchw(dx), ref, rtol=1e-6)
+
+
+def test_elementwise_and_solver(hip):
+    from denet_amd import ops
+    g = torch.Generator().manual_seed(9)
+    a, b = torch.randn(1024, generator=g).cuda(), torch.randn(1024, generator=g).cuda()
+    assert torch.equal(ops.add(a, b), a + b)
+    assert torch.equal(ops.add(a, b, relu=True), torch.relu(a + b))
+    y = ops.relu_fwd(a)
+    assert torch.equal(y, torch.relu(a))
+    assert torch.equal(ops.relu_bwd(y, b), b * (y > 0))
+    m = torch.randn(300, 96, generator=g).cuda()
+    _close(ops.colsum(m), m.sum(0), rtol=1e-5)
+    for mode in (0, 1):
+        for it in (0, 3):
+            p = torch.randn(1000, generator=g).cuda()
+            mom = torch.randn(1000, generator=g).cuda()
+            gr = torch.randn(1000, generator=g).cuda()
+            p0, m0 = p.clone(), mom.clone()
+            ops.solver_step(p, mom, gr, 600, 0.1, 0.9, it, 1e-2, mode)
+            gg = gr.clone()
+            gg[:600] += 1e-2 * p0[:600]
+            rho = 0.9 if it > 0 else 0.0
+            if mode == 1:
+                mr = rho * m0 + gg
+                pr = p0 - 0.1 * (gg + 0.9 * mr)
+            else:
+                mr = rho * m0 + (1 - rho) * gg
+                pr = p0 - 0.1 * mr
+            _close(mom, mr, rtol=1e-5)
+            _close(p, pr, rtol=1e-5)
+
+
+def test_corner_fwd_loss(hip):
+    from denet_amd import ops
+    g = torch.Generator().manual_seed(10)
+    B, H, W, CP, Cn = 3, 16, 16, 128, 4
+    conv = (torch.randn(B, H, W, CP, generator=g) * 3).cuda().requires_grad_(True)
+    x = conv[..., :Cn].permute(0, 3, 1, 2)
+    lh = torch.stack([x, -x], dim=1)
+    pr_ref = torch.log_softmax(lh, dim=1)
+    tgt = torch.rand(B, 2, Cn, H, W, generator=g).cuda() / (H * W * Cn)
+    cost_ref = 100.0 * (-(tgt * pr_ref).sum(dim=(1, 2, 3, 4)).mean() / np.log(2))
+    cost_ref.backward()
+    pr = ops.corner_fwd(conv.detach(), Cn)
+    _close(pr, pr_ref, rtol=1e-5, atol=1e-6)
+    dconv = torch.zeros(B, H, W, CP).cuda()
+    cost = torch.zeros(1).cuda()
+    ops.corner_loss(pr, tgt, dconv, cost, 100.0)
+    _close(cost, cost_ref.reshape(1), rtol=1e-5)
+    _close(dconv, conv.grad, rtol=1e-4)
+
+
+def _sparse_ref(fmap_nchw, bbox, gs, rule):
+    """numpy restatement of the two tap formulas (denet_sparse.py:72-84 / denet_sparse_op.py:65-71)."""
+    B, Fc, H, W = fmap_nchw.shape
+    M = bbox.shape[0]
+    rois = M // B
+    out = np.zeros((M, gs * gs * Fc + 2), np.float32)
+    taps = np.zeros((M, gs * gs), np.int32)
+    f32 = np.float32
+    for m in range(M):
+        b = m // rois
+        x0, y0, x1, y1 = [f32(v) for v in bbox[m]]
+        bw, bh = f32(x1 - x0), f32(y1 - y0)
+
+        def tap(p0, ext, i, size):
+            if rule == 0:
+                p = f32(p0 + f32(f32(f32(i) * ext) / f32(gs - 1)))
+            else:
+                k = f32(f32(1.0) / f32(gs - 1))
+                p = f32(p0 + f32(f32(f32(i) * ext) * k))
+            f = f32(p * f32(size))
+            f = max(f32(0.0), min(f, f32(size - 1)))
+            if rule == 0:
+                return int(np.rint(f))
+            return int(np.floor(f + f32(0.5))) if f >= 0 else int(np.ceil(f - f32(0.5)))
+
+        for yi in range(gs):
+            ys = tap(y0, bh, yi, H)
+            for xi in range(gs):
+                xs = tap(x0, bw, xi, W)
+                t = yi * gs + xi
+                taps[m, t] = ys * W + xs
+                out[m, t * Fc:(t + 1) * Fc] = fmap_nchw[b, :, ys, xs]
+        out[m, gs * gs * Fc] = bh
+        out[m, gs * gs * Fc + 1] = bw
+    return out, taps
+
+
+@pytest.mark.parametrize("rule", [0, 1])
+def test_sparse_fwd_bwd(hip, rule):
+    from denet_amd import ops
+    rng = np.random.RandomState(1)
+    B, Fc, H, W, sn, gs = 3, 32, 16, 16, 6, 7
+    CP, coff = 64, 4
+    rois = sn * sn
+    M = B * rois
+    fm = rng.uniform(-5, 5, (B, Fc, H, W)).astype(np.float32)
+    bbox = np.zeros((M, 4), np.float32)
+    for m in range(M):
+        x0, y0 = rng.uniform(0, 1), rng.uniform(0, 1)
+        bbox[m] = (x0, y0, rng.uniform(x0, 1), rng.uniform(y0, 1))
+    # detector-style boxes on the cell lattice: exact .5 taps exercise the rounding rule
+    for m in range(0, M, 3):
+        c = rng.randint(0, W, 4)
+        bbox[m] = (min(c[0], c[2]) / W, min(c[1], c[3]) / H, (max(c[0], c[2]) + 1) / W, (max(c[1], c[3]) + 1) / H)
+    ref, taps_ref = _sparse_ref(fm, bbox, gs, rule)
+    fmap = torch.zeros(B, H, W, CP).cuda()
+    fmap[..., coff:coff + Fc] = torch.from_numpy(fm).cuda().permute(0, 2, 3, 1)
+    KP = ((gs * gs * Fc + 2 + 31) // 32) * 32
+    out, taps = ops.sparse_fwd(fmap, torch.from_numpy(bbox).cuda(), coff, Fc, rois, gs, KP, rule)
+    assert np.array_equal(taps.cpu().numpy(), taps_ref)            # bit-exact indices
+    assert np.array_equal(out[:, :gs * gs * Fc + 2].cpu().numpy(), ref)   # pure copy -> bit-exact values
+    assert float(out[:, gs * gs * Fc + 2:].abs().max()) == 0.0
+    # gradient: scatter-add of dy back to the sampled cells
+    dy = rng.uniform(-1, 1, (M, KP)).astype(np.float32)
+    dref = np.zeros((B, H * W, Fc), np.float64)
+    for m in range(M):
+        for t in range(gs * gs):
+            dref[m // rois, taps_ref[m, t]] += dy[m, t * Fc:(t + 1) * Fc]
+    dfmap = torch.full((B, H, W, CP), 7.0).cuda()
+    ops.sparse_bwd(torch.from_numpy(dy).cuda(), taps, dfmap, coff, Fc, rois, gs, coff + Fc)
+    got = dfmap.cpu().numpy().reshape(B, H * W, CP)
+    np.testing.assert_allclose(got[:, :, coff:coff + Fc], dref, rtol=1e-4, atol=1e-5)
+    assert np.all(got[:, :, coff + Fc:] == 0.0)
+    assert np.all(got[:, :, :coff] == 7.0)      # corner-logit channels are owned by corner_loss
+    # determinism
+    dfmap2 = torch.zeros(B, H, W, CP).cuda()
+    ops.sparse_bwd(torch.from_numpy(dy).cuda(), taps, dfmap2, coff, Fc, rois, gs, coff + Fc)
+    assert torch.equal(dfmap2[..., coff:], dfmap[..., coff:])
+
+
+@pytest.mark.parametrize("bounded", [False, True])
+def test_detect_loss(hip, bounded):
+    from denet_amd import ops
+    g = torch.Generator().manual_seed(12)
+    B, rois, ncls, CP = 2, 36, 81, 96
+    M = B * rois
+    logits = torch.randn(M, CP, generator=g).cuda().requires_grad_(True)
+    t = torch.zeros(M, ncls)
+    cls = torch.randint(0, ncls, (M,), generator=g)
+    t[torch.arange(M), cls] = 1.0
+    t[::5, 3] = 1.0
+    t = (t / t.sum(1, keepdim=True) / rois).cuda()
+    valid = ((torch.rand(M, generator=g) > 0.5).float() / rois).cuda()
+    roi = torch.rand(M, 4, generator=g)
+    roi[:, 2:] = roi[:, :2] + 0.05 + roi[:, 2:] * 0.5
+    tb = torch.rand(M, 4, generator=g)
+    tb[:, 2:] = tb[:, :2] + 0.05 + tb[:, 2:] * 0.5
+    def cxcywh(bx):
+        return torch.stack([0.5 * (bx[:, 0] + bx[:, 2]), 0.5 * (bx[:, 1] + bx[:, 3]), bx[:, 2] - bx[:, 0], bx[:, 3] - bx[:, 1]], 1)
+    bt = torch.cat([cxcywh(tb), cxcywh(roi)], 1).cuda()
+    roi = roi.cuda()
+    cost_factor, bbox_factor = 1.0, 2.0
+    lp = torch.log_softmax(logits[:, :ncls], 1)
+    det_err = -(t * lp).sum(1) / np.log(ncls)
+    reg = logits[:, ncls:ncls + 4]
+    if not bounded:
+        tt = torch.stack([(bt[:, 0] - bt[:, 4]) / bt[:, 6], (bt[:, 1] - bt[:, 5]) / bt[:, 7],
+                          torch.log(bt[:, 2] / bt[:, 6]), torch.log(bt[:, 3] / bt[:, 7])], 1)
+        d = tt - reg
+    else:
+        scx, scy = 0.5 * (roi[:, 0] + roi[:, 2]), 0.5 * (roi[:, 1] + roi[:, 3])
+        sw, sh = roi[:, 2] - roi[:, 0], roi[:, 3] - roi[:, 1]
+        pcx, pcy = reg[:, 0] * sw + scx, reg[:, 1] * sh + scy
+        pw, ph = torch.exp(reg[:, 2]) * sw, torch.exp(reg[:, 3]) * sh
+        dx, dyv = bt[:, 0] - pcx, bt[:, 1] - pcy
+        e = 0.001
+        cx = torch.where(dx >= 0, 2 * dx / (bt[:, 2] + dx + e), -2 * dx / (bt[:, 2] - dx + e))
+        cy = torch.where(dyv >= 0, 2 * dyv / (bt[:, 3] + dyv + e), -2 * dyv / (bt[:, 3] - dyv + e))
+        cw = 1.0 - torch.minimum(bt[:, 2] / (pw + e), pw / (bt[:, 2] + e))
+        ch = 1.0 - torch.minimum(bt[:, 3] / (ph + e), ph / (bt[:, 3] + e))
+        d = torch.stack([cx, cy, cw, ch], 1)
+    sl1 = torch.where(d.abs() < 1, 0.5 * d * d, d.abs() - 0.5)
+    bbox_err = bbox_factor * valid * sl1.sum(1)
+    c_det = cost_factor * det_err.sum() / B
+    c_bbox = bbox_factor * bbox_err.sum() / B
+    (c_det + c_bbox).backward()
+    dl = torch.full((M, CP), 5.0).cuda()
+    costs = torch.zeros(2).cuda()
+    ops.detect_loss(logits.detach(), t, valid, bt, roi, dl, costs, B, ncls, 4, cost_factor, bbox_factor, bounded)
+    _close(costs, torch.stack([c_det, c_bbox]).detach(), rtol=1e-4)
+    _close(dl, logits.grad, rtol=2e-3, atol=1e-7)
