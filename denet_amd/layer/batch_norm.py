@@ -1,0 +1,126 @@
+"""`BN` layer — spatial batch normalisation. Mirrors denet/layer/batch_norm.py (BatchNormLayer :12-129):
+cuDNN batch statistics (biased variance, eps inside the sqrt), running `mean` and running INVERSE standard
+deviation `stdinv` with momentum (:75-76), gamma/beta reported as biases (no L2 decay, :106-107), and the
+test-time path that feeds var = 1/stdinv^2 to cuDNN which adds eps a second time (:50-52)."""
+import numpy
+
+from . import AbstractLayer, Act, Param, get_train
+from .. import ops
+
+
+class BatchNormLayer(AbstractLayer):
+    type_name = "batchnorm"
+    fused_relu = False
+
+    def __init__(self, layers, momentum=0.9, eps=1e-5, renorm_max_r=1.0, renorm_max_d=0.0, renorm_max_it=10,
+                 json_param={}):
+        super().__init__(layer_index=len(layers))
+        self.input = layers[-1].output
+        self.input_shape = layers[-1].output_shape
+        self.enabled = json_param.get("enabled", True)
+        self.momentum = json_param.get("momentum", momentum)
+        self.renorm_max_r = json_param.get("renormMaxR", renorm_max_r)
+        self.renorm_max_d = json_param.get("renormMaxD", renorm_max_d)
+        self.renorm_max_it = json_param.get("renormMaxIt", renorm_max_it)
+        self.eps = json_param.get("eps", eps)
+        self.output_shape = self.input_shape
+        if self.enabled:
+            assert self.input.cp == self.input_shape[1], "batch norm needs an unpadded channel count (multiple of 32)"
+            c = self.input_shape[1]
+            self.omega = Param(numpy.ones((c,)), "bn omega")
+            self.beta = Param(numpy.zeros((c,)), "bn beta")
+            self.mean = Param(numpy.zeros((c,)), "bn mean")
+            self.stdinv = Param(numpy.ones((c,)), "bn std inv")
+            self.output = Act(self.output_shape, self.input.cp, "bn%i" % self.layer_index)
+        else:
+            self.output = self.input
+        self._save = None
+
+    @staticmethod
+    def parse_desc(layers, name, tags, params):
+        if name != "BN":
+            return False
+        layers.append(BatchNormLayer(layers, params.get(0, 0.9), params.get(1, 1e-5), params.get(2, 1),
+                                     params.get(3, 0), params.get(4, 0)))
+        return True
+
+    def params(self):
+        return [self.omega, self.beta, self.mean, self.stdinv] if self.enabled else []
+
+    def updates(self, cost=None):
+        return [self.mean, self.stdinv] if self.enabled else []
+
+    def biases(self):
+        return [self.omega, self.beta] if self.enabled else []
+
+    def all_params(self):
+        return [self.omega, self.beta] if self.enabled else []
+
+    def export_json(self):
+        json = super().export_json()
+        json.update({"momentum": self.momentum,
+                     "eps": self.eps,
+                     "mean": self.mean.get_value() if self.enabled else None,
+                     "std": self.stdinv.get_value() if self.enabled else None,
+                     "gamma": self.omega.get_value() if self.enabled else None,
+                     "bias": self.beta.get_value() if self.enabled else None,
+                     "renormMaxR": self.renorm_max_r,
+                     "renormMaxD": self.renorm_max_d,
+                     "renormMaxIt": self.renorm_max_it,
+                     "enabled": self.enabled})
+        return json
+
+    def import_json(self, json_param):
+        if self.enabled:
+            self.omega.set_value(numpy.asarray(json_param["gamma"], dtype=numpy.float32))
+            self.beta.set_value(numpy.asarray(json_param["bias"], dtype=numpy.float32))
+            self.mean.set_value(numpy.asarray(json_param["mean"], dtype=numpy.float32))
+            self.stdinv.set_value(numpy.asarray(json_param["std"], dtype=numpy.float32))
+
+    # ---- execution ----
+    def forward(self, ctx, res=None, relu=None, out_act=None):
+        """res / relu / out_act let ResnetLayer fuse the residual add + ReLU into the normalisation pass"""
+        if not self.enabled:
+            return
+        relu = self.fused_relu if relu is None else relu
+        out_act = self.output if out_act is None else out_act
+        x = self.input.data
+        if get_train():
+            y, sm, si = ops.bn_fwd_train(x, self.omega.dev, self.beta.dev, self.mean.dev, self.stdinv.dev,
+                                         self.momentum, self.eps, relu=relu, res=res)
+            self._save = (sm, si, relu, out_act)
+        else:
+            y = ops.bn_fwd_test(x, self.omega.dev, self.beta.dev, self.mean.dev, self.stdinv.dev, self.eps, relu=relu,
+                                res=res)
+        out_act.data = y
+
+    def backward(self, ctx, want_dres=False):
+        if not self.enabled:
+            return None
+        sm, si, relu, out_act = self._save
+        dx, dres, _, _ = ops.bn_bwd(self.input.data, out_act.data, out_act.grad, self.omega.dev, sm, si, relu=relu,
+                                    want_dres=want_dres, dgamma=self.omega.grad, dbeta=self.beta.grad)
+        self.input.add_grad(dx)
+        return dres
+
+
+def test():
+    """The reference's known-answer test (denet/layer/batch_norm.py:131-154), runnable on a GPU box."""
+    from . import InitialLayer, set_train
+    import torch
+    numpy.random.seed(1002)
+    eps = 1e-4
+    input_shape = (64, 128, 32, 32)
+    bn = BatchNormLayer([InitialLayer(Act(input_shape), input_shape)])
+    for p in bn.params():
+        p.dev = torch.from_numpy(p.to_dev_layout()).cuda()
+    x = numpy.random.uniform(0.0, 1.0, input_shape).astype(numpy.float32)
+    bn.input.data = ops.nchw_to_nhwc(torch.from_numpy(x).cuda(), 128)
+    set_train(True)
+    bn.forward(None)
+    y = bn.output.data
+    x_mean = bn.mean.get_value()
+    x_std = bn.stdinv.get_value()
+    if abs(float(y.mean())) > eps or abs(float(y.std()) - 1.0) > eps or abs(x_mean.mean() - x.mean() * 0.1) > eps \
+            or abs(x_std.mean() - 1.24641) > eps:
+        raise Exception("Batchnorm failed test! ", float(y.mean()), float(y.std()), x_mean.mean(), x_std.mean())

@@ -1,0 +1,157 @@
+"""`C` layer — 2-D convolution. Mirrors denet/layer/convolution.py (ConvLayer :10-136, parse_desc :99-112,
+export/import_json :114-136). The reference lowers to Theano `conv2d` (a TRUE convolution: flipped filters,
+convolution.py:80-83) and cuDNN; here forward / data-gradient / weight-gradient are the MFMA implicit-GEMM
+kernels of csrc/igemm.hip, the filters being stored flipped in KRSC layout on the device (layer.Param)."""
+import math
+
+import numpy
+
+from . import AbstractLayer, Act, Param, round_up
+from .. import ops
+
+
+def conv_padding(border_mode, k):
+    """symmetric zero padding implied by a Theano border mode for a k-wide filter"""
+    if border_mode == "valid":
+        return 0
+    if border_mode == "full":
+        return k - 1
+    if border_mode == "half":
+        return k // 2
+    if border_mode == "same":
+        if k % 2 == 0:
+            raise NotImplementedError("border_mode 'same' with an even filter needs asymmetric padding")
+        return (k - 1) // 2
+    if isinstance(border_mode, (tuple, list)):
+        assert border_mode[0] == border_mode[1], "only symmetric padding is supported"
+        return int(border_mode[0])
+    if isinstance(border_mode, int):  # includes False == 0 (denet_corner.py:39)
+        return int(border_mode)
+    raise Exception("Unknown border mode: " + str(border_mode))
+
+
+class ConvLayer(AbstractLayer):
+    type_name = "conv"
+
+    def __init__(self, layers, filter_shape=None, filter_stride=(1, 1), use_bias=False, border_mode="half",
+                 wb="he-backward", json_param={}):
+        super().__init__(layer_index=len(layers))
+        self.input = layers[-1].output
+        self.input_shape = layers[-1].output_shape
+
+        self.border_mode = json_param.get("border", border_mode)
+        if isinstance(self.border_mode, list):
+            self.border_mode = tuple(self.border_mode)
+        self.filter_shape = tuple(json_param.get("shape", filter_shape))
+        self.stride = tuple(json_param.get("stride", filter_stride))
+        self.use_bias = json_param.get("useBias", use_bias)
+        self.size = (self.filter_shape[2], self.filter_shape[3])
+        self.enabled = json_param.get("enabled", True)
+
+        fs = self.filter_shape
+        # weight initialisation bound (convolution.py:31-40)
+        if type(wb) is float or type(wb) is int:
+            self.w_bound = float(wb)
+        elif "he-forward" in wb:
+            self.w_bound = math.sqrt(2.0 / (fs[2] * fs[3] * fs[1]))
+        elif "he-backward" in wb:
+            self.w_bound = math.sqrt(2.0 / (fs[2] * fs[3] * fs[0]))
+        elif "xavier-forward" in wb:
+            self.w_bound = math.sqrt(1.0 / (fs[2] * fs[3] * fs[1]))
+        elif "xavier-backward" in wb:
+            self.w_bound = math.sqrt(1.0 / (fs[2] * fs[3] * fs[0]))
+        else:
+            raise Exception("Unknown weight initialisation: " + str(wb))
+
+        # same numpy.random call sequence as the reference (convolution.py:42-48)
+        if self.w_bound > 0:
+            if type(wb) is str and "uniform" in wb:
+                w = numpy.random.uniform(-self.w_bound, self.w_bound, size=fs)
+            else:
+                w = numpy.random.normal(0.0, self.w_bound, size=fs)
+        else:
+            w = numpy.zeros(shape=fs)
+
+        assert fs[1] == self.input_shape[1], "filter channels %i != input channels %i" % (fs[1], self.input_shape[1])
+        assert self.stride[0] == self.stride[1], "only square strides are supported"
+        assert fs[2] == fs[3], "only square filters are supported"
+        self.pad = conv_padding(self.border_mode, fs[2])
+        if self.border_mode == "same":
+            assert self.stride == (1, 1)
+
+        # device geometry: physical channels, padded taps for the small-C first layer
+        self.cp = self.input.cp
+        self.kp = round_up(fs[0], 32)
+        self.s_pad = fs[3] if self.cp >= 32 else round_up(fs[3], 32 // self.cp)
+        self.omega = Param(w, "conv omega", "conv", (self.kp, fs[2], self.s_pad, self.cp), s_real=fs[3])
+        if self.use_bias:
+            self.beta = Param(numpy.zeros((fs[0],)), "conv beta", "vector", (self.kp,))
+
+        # output shape (convolution.py:55-74)
+        oh = int(math.ceil((self.input_shape[-2] + 2 * self.pad - fs[2] + 1) / self.stride[0]))
+        ow = int(math.ceil((self.input_shape[-1] + 2 * self.pad - fs[3] + 1) / self.stride[1]))
+        self.output_shape = (self.input_shape[0], fs[0], oh, ow)
+        self.output = Act(self.output_shape, self.kp, "conv%i" % self.layer_index)
+
+    @staticmethod
+    def parse_desc(layers, name, tags, params):
+        if name != "C":
+            return False
+        use_bias = bool("B" in tags)
+        if bool("X" in tags):
+            filter_shape = (params.get(0), layers[-1].output_shape[1], params.get(1), params.get(2))
+            filter_stride = (params.get(3, 1), params.get(4, 1))
+        else:
+            filter_shape = (params.get(0), layers[-1].output_shape[1], params.get(1, 1), params.get(1, 1))
+            filter_stride = (params.get(2, 1), params.get(2, 1))
+        layers.append(ConvLayer(layers, filter_shape, filter_stride, use_bias, params["borderMode"], params["wb"]))
+        return True
+
+    def weights(self):
+        return super().weights() + ([self.omega] if self.enabled else [])
+
+    def biases(self):
+        return super().biases() + ([self.beta] if self.use_bias and self.enabled else [])
+
+    def all_params(self):
+        """every array of the layer, trained or frozen (device packing)"""
+        return [self.omega] + ([self.beta] if self.use_bias else [])
+
+    def import_json(self, json_param):
+        super().import_json(json_param)
+        if self.use_bias:
+            self.beta.set_value(numpy.asarray(json_param["bias"], dtype=numpy.float32))
+        self.omega.set_value(numpy.asarray(json_param["weight"], dtype=numpy.float32))
+
+    def export_json(self):
+        json = super().export_json()
+        json.update({"shape": self.filter_shape,
+                     "stride": self.stride,
+                     "border": self.border_mode,
+                     "enabled": self.enabled,
+                     "useBias": self.use_bias,
+                     "bias": self.beta.get_value() if self.use_bias else None,
+                     "weight": self.omega.get_value()})
+        return json
+
+    # ---- execution ----
+    def _w(self):
+        return self.omega.dev.view(self.omega.dev_shape)
+
+    def forward(self, ctx, add=None):
+        x = self.input.data
+        self.output.data = ops.conv_fwd(x, self._w(), bias=self.beta.dev if self.use_bias else None, add=add,
+                                        stride=self.stride[0], pad=self.pad, s_real=self.filter_shape[3])
+
+    def backward(self, ctx):
+        dy = self.output.grad
+        x = self.input.data
+        st, pad, sr = self.stride[0], self.pad, self.filter_shape[3]
+        if self.enabled and self.omega.grad is not None:
+            ops.conv_wgrad(x, dy, self.omega.dev_shape, stride=st, pad=pad, s_real=sr,
+                           out=self.omega.grad.view(self.omega.dev_shape))
+            if self.use_bias:
+                ops.colsum(dy.view(-1, self.kp), out=self.beta.grad)
+        if getattr(self.input, "requires_grad", True):
+            self.input.grad = ops.conv_dgrad(dy, self._w(), tuple(x.shape), add=self.input.grad, stride=st, pad=pad,
+                                             s_real=sr)

@@ -1,0 +1,136 @@
+"""`DNC` — DeNet corner layer. Mirrors denet/layer/denet_corner.py (DeNetCornerLayer :17-134): a 1x1 convolution
+producing `corner_num` corner logits + `sample_feat` sampling features (:39), corner rows zero-initialised with
+bias +5 (:41-47), corner_pr = log_softmax([x,-x]) over a new axis (:50-53), host-side corner target rasteriser
+(get_target :81-123) and the corner NLL cost (:126-134). The layer passes its input through."""
+import math
+
+import numpy
+
+from . import AbstractLayer, InitialLayer
+from .convolution import ConvLayer
+from .. import ops
+
+
+class DeNetCornerLayer(AbstractLayer):
+    type_name = "denet-corner"
+
+    def __init__(self, layers, sample_feat=512, cost_factor=1, dropout=0.0, use_center=False, json_param={}):
+        super().__init__(layer_index=len(layers))
+        self.input = layers[-1].output
+        self.input_shape = layers[-1].output_shape
+        self.output = layers[-1].output
+        self.output_shape = layers[-1].output_shape
+        self.batch_size, self.features, self.height, self.width = self.input_shape
+
+        self.sample_feat = json_param.get("sampleFeat", sample_feat)
+        self.cost_factor = json_param.get("costFactor", cost_factor)
+        self.use_center = json_param.get("useCenter", use_center)
+        self.dropout = json_param.get("dropout", dropout)
+
+        self.corner_num = 5 if self.use_center else 4
+        self.layers = [InitialLayer(self.input, self.input_shape)]
+        self.layers.append(ConvLayer(self.layers, (self.corner_num + self.sample_feat, self.features, 1, 1), (1, 1), True, False))
+
+        conv = self.layers[-1]
+        omega = conv.omega.get_value()
+        omega[:self.corner_num, :, :, :] = 0.0
+        conv.omega.set_value(omega)
+        beta = conv.beta.get_value()
+        beta[:self.corner_num] = 5.0
+        conv.beta.set_value(beta)
+
+        self.corner_shape = (self.batch_size, 2, self.corner_num, self.height, self.width)
+        self.sample_shape = (self.batch_size, self.sample_feat, self.height, self.width)
+        # device state of the current step
+        self.corner_pr = None      # [B,2,Cn,H,W] log-probabilities (reference layout)
+        self.dconv = None          # gradient w.r.t. the conv output, filled by the corner cost and the RoI gather
+        self._target = None
+        self.sample_shared = None  # inference: sampling features kept from get_samples (denet_sparse.py:122)
+
+    @staticmethod
+    def parse_desc(layers, name, tags, params):
+        if name != "DNC":
+            return False
+        layers.append(DeNetCornerLayer(layers, params.get(0, 512), params.get(1, 1.0), params.get(2, 0.0), "C" in tags))
+        return True
+
+    def export_json(self):
+        json = super().export_json()
+        json.update({"sampleFeat": self.sample_feat, "useCenter": self.use_center, "costFactor": self.cost_factor,
+                     "dropout": self.dropout})
+        return json
+
+    def get_target(self, model, samples, metas):
+        corner_pr = numpy.zeros(self.corner_shape, dtype=numpy.float32)
+        for b, meta in enumerate(metas):
+            for bbox in meta["bbox"]:
+                x0 = int(round(bbox[0] * self.width))
+                y0 = int(round(bbox[1] * self.height))
+                x1 = max(x0, int(round(bbox[2] * self.width)) - 1)
+                y1 = max(y0, int(round(bbox[3] * self.height)) - 1)
+                x0_valid = (x0 >= 0 and x0 < self.width)
+                y0_valid = (y0 >= 0 and y0 < self.height)
+                x1_valid = (x1 >= 0 and x1 < self.width)
+                y1_valid = (y1 >= 0 and y1 < self.height)
+                if x0_valid and y0_valid:
+                    corner_pr[b, 1, 0, y0, x0] = 1.0
+                if x1_valid and y0_valid:
+                    corner_pr[b, 1, 1, y0, x1] = 1.0
+                if x0_valid and y1_valid:
+                    corner_pr[b, 1, 2, y1, x0] = 1.0
+                if x1_valid and y1_valid:
+                    corner_pr[b, 1, 3, y1, x1] = 1.0
+                if self.use_center:
+                    cx = int(round((bbox[0] + bbox[2]) * 0.5 * self.width))
+                    cy = int(round((bbox[1] + bbox[3]) * 0.5 * self.height))
+                    if cx >= 0 and cx < self.width and cy >= 0 and cy < self.height:
+                        corner_pr[b, 1, 4, cy, cx] = 1.0
+
+        corner_pr[:, 0, :, :, :] = 1.0 - corner_pr[:, 1, :, :, :]
+        corner_pr /= self.width * self.height * self.corner_num
+        if self.dropout > 0.0:
+            mask = numpy.random.binomial(1, 1.0 - self.dropout, (self.corner_shape[0], self.corner_shape[2],
+                                                                 self.corner_shape[3], self.corner_shape[4])).astype(numpy.float32)
+            corner_pr *= mask[:, None, :, :, :] / (1.0 - self.dropout)
+        return numpy.array([], dtype=numpy.int64), corner_pr.flatten()
+
+    def cost(self, yt_index, yt_value):
+        return True
+
+    # ---- execution ----
+    @property
+    def conv(self):
+        return self.layers[-1]
+
+    def set_target(self, ctx, yt_index, yt_value):
+        import torch
+        self._target = torch.from_numpy(numpy.ascontiguousarray(yt_value, dtype=numpy.float32)).cuda(non_blocking=True)
+
+    def forward(self, ctx):
+        self.conv.forward(ctx)
+        self.corner_pr = ops.corner_fwd(self.conv.output.data, self.corner_num)
+        self.dconv = None
+
+    def sample_map(self):
+        """(tensor, channel offset, F): the sampling features live in channels [Cn, Cn+F) of the conv output"""
+        return self.conv.output.data, self.corner_num, self.sample_feat
+
+    def alloc_dconv(self, zero):
+        import torch
+        if self.dconv is None:
+            shape = self.conv.output.data.shape
+            self.dconv = torch.zeros(shape, device="cuda") if zero else ops.empty(*shape)
+        return self.dconv
+
+    def loss_backward(self, ctx, cost_out, want_grad=True):
+        dconv = None
+        if want_grad:
+            # if no RoI gather follows, the sampling / padding channels carry no gradient: start from zeros
+            dconv = self.alloc_dconv(zero=not ctx.has_sparse)
+        ops.corner_loss(self.corner_pr, self._target, dconv, cost_out, float(self.cost_factor))
+
+    def backward(self, ctx):
+        if self.dconv is None:
+            return
+        self.conv.output.grad = self.dconv
+        self.conv.backward(ctx)

@@ -1,0 +1,395 @@
+"""ModelCNN — model-description parser, graph builder and trainer of the DeNet hot path.
+
+Mirrors denet/model/model_cnn.py of the reference: build_layer / build (:122-157, the `TYPE.TAGS[a,b,..]`
+mini-language), export_json / import_json (:159-203, `.mdl.gz` version 3), build_train_func (:205-405: cost
+collection, L2 decay on weights only, sgd / torch==nesterov solvers, BN running-stat updates), train_step
+(:407-445: get_target on every layer in order, then the device step; returns (cost, [per-layer costs])).
+
+The Theano function compilation is replaced by a static executor: layers are run in order (forward), the cost
+layers seed the gradients, layers are run in reverse (backward), gradients are (optionally) all-reduced over
+RCCL and one fused solver kernel updates the flat parameter buffer. Every arithmetic step is a HIP kernel
+reached through the C-ABI (denet_amd/ops.py); torch provides device memory, streams and the process group.
+"""
+import getpass
+import math
+import random
+import time
+
+import numpy
+
+from .. import common
+from .. import layer as layer_mod
+from ..common import json_util
+from ..layer import Act, InitialLayer, round_up
+from ..layer.layer_types import layer_types
+
+SOLVER_MODES = {"sgd": 0, "torch": 1, "nesterov": 1}
+
+
+def load_from_json(json_obj, batch_size=32, layer_range=None):
+    model = ModelCNN()
+    model.batch_size = batch_size
+    model.import_json(json_obj, layer_range)
+    return model
+
+
+def load_from_file(fname, batch_size=32, layer_range=None):
+    model = load_from_json(json_util.json_from_gz(fname), batch_size, layer_range)
+    model.fname = fname
+    return model
+
+
+def save_to_file(model, fname, compresslevel=9):
+    json_util.json_to_gz(fname, model.export_json(), compresslevel)
+
+
+def initialize(args, data_shape, class_labels, class_num):
+    """model from CLI arguments (model_cnn.py:46-77)"""
+    if args.model is None:
+        model = ModelCNN()
+        model.batch_size = args.batch_size
+        model.class_labels = class_labels
+        model.class_num = class_num
+        try:
+            n = int(args.border_mode)
+            border_mode = (n, n)
+        except ValueError:
+            border_mode = args.border_mode
+        model.build(args.model_desc, data_shape, args.activation, border_mode, list(args.weight_init))
+    else:
+        model = load_from_file(args.model, args.batch_size)
+        model.class_labels = class_labels
+        model.class_num = class_num
+        assert tuple(data_shape) == tuple(model.data_shape), "Mismatching data shapes in .mdl and data"
+    model.skip_layer_updates = getattr(args, "skip_layer_updates", [])
+    return model
+
+
+def walk_layers(layers):
+    """every layer and nested sub-layer, depth first, each object once"""
+    seen, out = set(), []
+
+    def rec(l):
+        if id(l) in seen:
+            return
+        seen.add(id(l))
+        out.append(l)
+        for s in getattr(l, "layers", []):
+            rec(s)
+
+    for l in layers:
+        rec(l)
+    return out
+
+
+class StepContext:
+    def __init__(self, model):
+        self.model = model
+        self.has_sparse = any(l.type_name == "denet-sparse" for l in model.layers)
+
+
+class ModelCNN:
+    def __init__(self):
+        self.batch_size = 0
+        self.iteration = 0
+        self.class_labels = None
+        self.data_shape = None
+        self.class_num = 0
+        self.rng_seed = random.randint(1, 9999)
+        self.gradient_clip = 0.0
+        self.skip_layer_updates = []
+        self.bias_decay = False
+        self.layers = []
+        self.func = {}
+        self.input = None
+        self.dist = None           # denet_amd.multi.DataParallel or None
+        self._packed = False
+        self.timing = {}
+
+    # ---------------------------------------------------------------- construction
+    def get_input_shape(self):
+        assert self.data_shape is not None, "Data shape hasn't been set!"
+        return tuple([self.batch_size] + list(self.data_shape))
+
+    def get_output_shape(self):
+        return self.layers[-1].output_shape
+
+    def get_parameter_num(self):
+        n = 0
+        for layer in self.layers:
+            for param in layer.params():
+                n += param.value.size
+        return n
+
+    def _make_input(self):
+        shape = self.get_input_shape()
+        cp = 4 if shape[1] <= 4 else round_up(shape[1], 32)
+        act = Act(shape, cp, "input")
+        act.requires_grad = False
+        self.input = act
+        return act
+
+    def build_layer(self, layer_desc, layers, activation, border_mode, wb):
+        p_start = layer_desc.find("[")
+        p_end = layer_desc.find("]")
+        layer_params = {"classNum": self.class_num, "activation": activation, "borderMode": border_mode, "wb": wb}
+        if p_start > 0 and p_end > p_start:
+            layer_type = layer_desc[:p_start]
+            for i, p in enumerate(layer_desc[(p_start + 1):p_end].split(",")):
+                layer_params[i] = common.convert_num(p)
+        else:
+            layer_type = layer_desc
+        t_index = layer_type.find(".")
+        if t_index > 0:
+            layer_tags = layer_type[(t_index + 1):]
+            layer_type = layer_type[:t_index]
+        else:
+            layer_tags = ""
+        for layer in layer_types:
+            if layer.parse_desc(layers, layer_type, layer_tags, layer_params):
+                return
+        raise Exception("Invalid layer - type: ", layer_type, "tags:", layer_tags, "params:", layer_params)
+
+    def build(self, model_desc, data_shape, activation="relu", border_mode="valid", weight_init="he-forward"):
+        if isinstance(model_desc, str):
+            model_desc = model_desc.split()
+        if isinstance(weight_init, str):
+            weight_init = [weight_init]
+        self.model_desc = " ".join(model_desc)
+        self.data_shape = tuple(data_shape)
+        self.layers = [InitialLayer(self._make_input(), self.get_input_shape())]
+        for i, layer_desc in enumerate(model_desc):
+            wb = weight_init[min(len(weight_init) - 1, i)]
+            self.build_layer(layer_desc, self.layers, activation, border_mode, wb)
+        self._packed = False
+
+    def export_json(self):
+        from time import gmtime, strftime
+        json_layers = [self.layers[index].export_json() for index in range(1, len(self.layers))]
+        json_obj = {"classifierType": "CNN",
+                    "classLabels": self.class_labels,
+                    "classNum": self.class_num,
+                    "dataShape": self.data_shape,
+                    "date": strftime("%Y-%m-%d %H:%M:%S", gmtime()),
+                    "user": getpass.getuser()}
+        json_obj.update({"version": 3, "layers": json_layers})
+        return json_obj
+
+    def import_json(self, json_obj, layer_range=None):
+        self.func = {}
+        if json_obj.get("version", 0) == 0:
+            raise Exception("Old format model file detected, no compatibility!")
+        self.class_labels = json_obj["classLabels"]
+        if "imageSize" in json_obj and "imageMode" in json_obj:
+            width, height = json_obj["imageSize"][0], json_obj["imageSize"][1]
+            image_mode = json_obj.get("imageMode", "RGB")
+            self.data_shape = ({"RGB": 3, "L": 1}[image_mode], width, height)
+        elif "dataShape" in json_obj:
+            self.data_shape = tuple(json_obj["dataShape"])
+        else:
+            assert False, "Bad mdl file, Cannot determine input data shape!"
+        assert json_obj.get("imageBorder", 0) == 0
+        self.class_num = json_obj.get("classNum", len(self.class_labels) if self.class_labels else 0)
+        self.layers = layer_mod.import_json(json_obj["layers"], self._make_input(), self.get_input_shape(), layer_range)
+        self._packed = False
+
+    # ---------------------------------------------------------------- device state
+    def pack_device(self):
+        """allocate the flat device buffers (parameters, gradients, momentum, BN statistics) and hand each
+        Param its views; layout = [weights (layer order) | biases (layer order) | frozen]"""
+        import torch
+        weights, biases = [], []
+        for layer in self.layers:
+            weights += layer.weights()
+            biases += layer.biases()
+        trainable = set(id(p) for p in weights + biases)
+        frozen, stats = [], []
+        for l in walk_layers(self.layers):
+            for p in getattr(l, "all_params", lambda: [])():
+                if id(p) not in trainable and all(p is not q for q in frozen):
+                    frozen.append(p)
+        for layer in self.layers:
+            stats += layer.updates(None)
+        order = weights + biases + frozen
+
+        def align(n):
+            return round_up(n, 64)
+
+        total = sum(align(p.dev_size) for p in order)
+        self.P = torch.zeros(total, device="cuda")
+        self.G = torch.zeros(total, device="cuda")
+        self.M = torch.zeros(total, device="cuda")
+        host = numpy.zeros(total, dtype=numpy.float32)
+        off = 0
+        self.param_ranges = {}
+        for p in order:
+            n = p.dev_size
+            host[off:off + n] = p.to_dev_layout().reshape(-1)
+            p.dev = self.P[off:off + n]
+            if id(p) in trainable:
+                p.grad = self.G[off:off + n]
+                p.mom = self.M[off:off + n]
+            self.param_ranges[id(p)] = (off, off + n)
+            off += align(n)
+        self.P.copy_(torch.from_numpy(host))
+        self.n_weights = sum(align(p.dev_size) for p in weights)
+        self.n_trainable = sum(align(p.dev_size) for p in weights + biases)
+        # per top-level layer range inside the weights region (for bucketed all-reduce)
+        self.layer_weight_range = []
+        for layer in self.layers:
+            ws = layer.weights()
+            if ws:
+                self.layer_weight_range.append((layer, self.param_ranges[id(ws[0])][0],
+                                                align(self.param_ranges[id(ws[-1])][1])))
+        stotal = sum(align(p.dev_size) for p in stats)
+        self.S = torch.zeros(max(stotal, 1), device="cuda")
+        shost = numpy.zeros(max(stotal, 1), dtype=numpy.float32)
+        off = 0
+        for p in stats:
+            n = p.dev_size
+            shost[off:off + n] = p.to_dev_layout().reshape(-1)
+            p.dev = self.S[off:off + n]
+            off += align(n)
+        self.S.copy_(torch.from_numpy(shost))
+        self.acts = []
+        seen = set()
+        for l in walk_layers(self.layers):
+            for a in (l.input, l.output):
+                if isinstance(a, Act) and id(a) not in seen:
+                    seen.add(id(a))
+                    self.acts.append(a)
+        self.cost_buf = torch.zeros(16, device="cuda")
+        self._packed = True
+
+    def build_train_func(self, solver_mode="sgd", cost_factors=[], use_acc_mode=False, skip_build=False):
+        if solver_mode not in SOLVER_MODES:
+            raise NotImplementedError("solver '%s' is outside the hot path (sgd, torch, nesterov are provided)" % solver_mode)
+        if use_acc_mode:
+            raise NotImplementedError("--use-acc-mode is outside the hot path")
+        self.solver_mode = solver_mode
+        self.cost_layers = []
+        self.cost_layer_names = []
+        for layer in self.layers:
+            if layer.cost(None, None) is not None:
+                self.cost_layers.append(layer)
+                self.cost_layer_names.append(layer.type_name)
+        self.cost_factors = [1.0] * len(self.cost_layers) if len(cost_factors) == 0 else [float(c) for c in cost_factors]
+        assert len(self.cost_factors) == len(self.cost_layers), \
+            "Different number of cost factors (%i) and cost layers (%i)" % (len(self.cost_factors), len(self.cost_layers))
+        assert len(self.cost_layers) <= 8
+        if self.gradient_clip > 0.0:
+            raise NotImplementedError("gradient clipping is outside the hot path")
+        self.use_split_mode = False   # split points are identities here (288 GB of HBM)
+        if not skip_build:
+            self.pack_device()
+        self.func["train_step"] = self._device_step
+
+    # ---------------------------------------------------------------- execution
+    def _upload_input(self, data_x):
+        import torch
+        from .. import ops
+        if isinstance(data_x, torch.Tensor):
+            x = data_x if data_x.is_cuda else data_x.cuda(non_blocking=True)
+        else:
+            x = torch.from_numpy(numpy.ascontiguousarray(data_x, dtype=numpy.float32)).cuda(non_blocking=True)
+        assert tuple(x.shape) == self.get_input_shape(), (tuple(x.shape), self.get_input_shape())
+        self.input.data = ops.nchw_to_nhwc(x.contiguous(), self.input.cp)
+
+    def forward(self, data_x, data_m=None, train=True):
+        """runs the layers in order; in training mode get_target of layer i is called right before its forward
+        (so DNS sees the corner map of this very pass and DND sees the edited RoI list)"""
+        layer_mod.set_train(train)
+        if not self._packed:
+            self.pack_device()
+        for a in self.acts:
+            a.grad = None
+        self._upload_input(data_x)
+        ctx = StepContext(self)
+        for layer in self.layers[1:]:
+            if train and data_m is not None:
+                target = layer.get_target(self, data_x, data_m)
+                if target is not None:
+                    layer.set_target(ctx, target[0], target[1])
+            layer.forward(ctx)
+        return ctx
+
+    def backward(self, ctx):
+        """cost layers seed the gradients, then the reverse sweep; all-reduce buckets are launched as soon as the
+        last layer of a bucket has produced its weight gradient"""
+        import torch
+        from .. import ops
+        for i, layer in enumerate(self.cost_layers):
+            layer.loss_backward(ctx, self.cost_buf[2 * i:2 * i + 2])
+            if self.cost_factors[i] != 1.0:
+                g = layer.dconv if layer.type_name == "denet-corner" else (
+                    layer.conv.output.grad if hasattr(layer, "conv") else layer.input.grad)
+                ops._L().denet_scale(g.data_ptr(), g.numel(), float(self.cost_factors[i]), ops.stream_ptr())
+        dist = self.dist
+        if dist is not None:
+            dist.begin_step(self)
+        for layer in reversed(self.layers[1:]):
+            layer.backward(ctx)
+            if dist is not None:
+                dist.layer_done(self, layer)
+        if dist is not None:
+            dist.finish_step(self)
+
+    def _device_step(self, epoch, it, learn_rate, momentum, decay, data_x, data_m, fetch_cost=True):
+        from .. import ops
+        ctx = self.forward(data_x, data_m, train=True)
+        self.backward(ctx)
+        scale = 1.0 / self.dist.world_size if self.dist is not None else 1.0
+        n_decay = self.n_trainable if self.bias_decay else self.n_weights
+        ops.solver_step(self.P[:self.n_trainable], self.M[:self.n_trainable], self.G[:self.n_trainable], n_decay,
+                        float(learn_rate), float(momentum[0]), it, float(decay), SOLVER_MODES[self.solver_mode], scale)
+        if not fetch_cost:
+            return None
+        costs = self.cost_buf[:2 * len(self.cost_layers)].cpu().numpy().reshape(-1, 2)
+        layer_costs = []
+        for i, layer in enumerate(self.cost_layers):
+            c = float(costs[i, 0]) + (float(costs[i, 1]) if layer.type_name == "denet-detect" else 0.0)
+            layer_costs.append(c)
+        total = sum(f * c for f, c in zip(self.cost_factors, layer_costs))
+        self.last_cost_terms = costs
+        return [total] + layer_costs
+
+    def train_step(self, data_x, data_m, epoch, it, learning_rate, momentum, decay, fetch_cost=True):
+        """same signature and return value as the reference (model_cnn.py:407-445)"""
+        layer_mod.set_iteration(it)
+        layer_mod.set_epoch(epoch)
+        momentum = numpy.array(momentum, dtype=numpy.float32).reshape(-1)
+        costs = self.func["train_step"](epoch, it, learning_rate, momentum, decay, data_x, data_m, fetch_cost)
+        if costs is None:
+            return None, []
+        return costs[0], costs[1:]
+
+    def train_epoch(self, dataset, epoch, learning_rate, momentum=[0, 1, 0], decay=0.0, solver_mode="sgd"):
+        dataset_x, dataset_m, dataset_size = dataset.export(self.batch_size)
+        index_num = math.ceil(dataset_size / self.batch_size)
+        total_cost = 0
+        for index in range(index_num):
+            data_x = dataset_x[index * self.batch_size:(index + 1) * self.batch_size]
+            data_m = dataset_m[index * self.batch_size:(index + 1) * self.batch_size]
+            cost, _ = self.train_step(data_x, data_m, epoch, self.iteration, learning_rate, momentum, decay)
+            if math.isnan(cost):
+                raise Exception("ERROR: Cost is NaN")
+            total_cost += cost
+            self.iteration += 1
+        return total_cost
+
+    def predict_output_step(self, data_x):
+        """inference forward (BN in test mode); returns the last layer's output as a numpy array in the reference's
+        NCHW convention (class probabilities for a regression head)"""
+        from .. import ops
+        self.forward(data_x, None, train=False)
+        last = self.layers[-1]
+        out = last.output.data
+        if last.type_name == "regression":
+            # regression.py:44-50: output = exp(log_softmax(x)); B x C values, evaluated on the host
+            B, C = last.output_shape
+            logits = out.view(B, last.input.cp).cpu().numpy()[:, :C].astype(numpy.float32)
+            xdev = logits - logits.max(axis=1, keepdims=True)
+            return numpy.exp(xdev - numpy.log(numpy.exp(xdev).sum(axis=1, keepdims=True)))
+        if out.dim() == 4:
+            return ops.nhwc_to_nchw(out, last.output_shape[1]).cpu().numpy()
+        return out.cpu().numpy()

@@ -1,0 +1,113 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, RCCL all-reduce over xGMI.
+
+The reference's only parallelism is host-side PARAMETER AVERAGING: every worker copies all update targets
+(parameters, momentum, BN running statistics) to host shared memory, the parent averages them with numpy and the
+workers copy them back (denet/model/train_multi.py:96-145, denet/multi/shared.py:105-119,155-165,
+denet/multi/worker.py:89-93). For the linear solvers (sgd, torch/nesterov) with identical initial state and
+batch_size_factor=1 that equals: average the GRADIENTS, update once, and average the BN running statistics —
+which is what this module does with `torch.distributed` (backend "nccl" is RCCL on ROCm):
+
+  * gradients live in one flat buffer [weights in layer order | biases]; the weight region is cut into buckets
+    of >= bucket_bytes; the all-reduce of a bucket is issued (async, on RCCL's stream) as soon as the backward
+    sweep has passed the first layer of that bucket, so it overlaps the remaining backward kernels;
+  * the 1/N of the mean is folded into the solver kernel (grad_scale), no extra pass over the gradients;
+  * BN running mean / stdinv (a few thousand floats) are averaged after the step, like shared.py does.
+"""
+import os
+
+
+class DataParallel:
+    def __init__(self, backend=None, bucket_bytes=32 << 20, scale_fn=None, init=True):
+        import torch
+        import torch.distributed as dist
+        self.dist = dist
+        self.bucket_bytes = int(bucket_bytes)
+        if init and not dist.is_initialized():
+            if backend is None:
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            if backend == "nccl":
+                torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            dist.init_process_group(backend=backend)
+        self.backend = dist.get_backend()
+        self.world_size = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.scale_fn = scale_fn
+        self._buckets = None
+        self._pending = []
+
+    # ---- setup -------------------------------------------------------------------------------------------
+    def broadcast_state(self, model):
+        """identical initial state on every rank (reference: model_write of the shared state to every worker,
+        train_multi.py:102, shared.py:90-92)"""
+        self.dist.broadcast(model.P, src=0)
+        self.dist.broadcast(model.M, src=0)
+        self.dist.broadcast(model.S, src=0)
+
+    def make_buckets(self, layer_weight_range):
+        """layer_weight_range: [(layer, lo, hi)] in layer order. Returns [(lo, hi, trigger_layer)]: contiguous
+        slices of the weight region, built from the LAST layer backwards; a bucket is complete once the backward
+        sweep has finished `trigger_layer` (its lowest-index layer)."""
+        buckets = []
+        cur_hi = None
+        cur_lo = None
+        trigger = None
+        min_elems = max(1, self.bucket_bytes // 4)
+        for layer, lo, hi in reversed(layer_weight_range):
+            if cur_hi is None:
+                cur_hi = hi
+            cur_lo = lo
+            trigger = layer
+            if cur_hi - cur_lo >= min_elems:
+                buckets.append((cur_lo, cur_hi, trigger))
+                cur_hi = None
+        if cur_hi is not None:
+            buckets.append((cur_lo, cur_hi, trigger))
+        return buckets
+
+    # ---- per step ----------------------------------------------------------------------------------------
+    def begin_step(self, model):
+        if self._buckets is None:
+            self._buckets = self.make_buckets(model.layer_weight_range)
+            self._trigger = {}
+            for lo, hi, layer in self._buckets:
+                self._trigger[id(layer)] = (lo, hi)
+        self._pending = []
+
+    def layer_done(self, model, layer):
+        r = self._trigger.get(id(layer))
+        if r is not None and self.world_size > 1:
+            lo, hi = r
+            self._pending.append(self.dist.all_reduce(model.G[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True))
+
+    def finish_step(self, model):
+        if self.world_size > 1:
+            d = self.dist
+            if model.n_trainable > model.n_weights:
+                self._pending.append(d.all_reduce(model.G[model.n_weights:model.n_trainable], op=d.ReduceOp.SUM,
+                                                  async_op=True))
+            self._pending.append(d.all_reduce(model.S, op=d.ReduceOp.SUM, async_op=True))
+            for w in self._pending:
+                w.wait()
+            self._scale(model.S, 1.0 / self.world_size)
+        self._pending = []
+
+    def _scale(self, t, s):
+        if self.scale_fn is not None:
+            self.scale_fn(t, s)
+        else:
+            from .. import ops
+            ops.check(ops._L().denet_scale(t.data_ptr(), t.numel(), float(s), ops.stream_ptr()), "scale")
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def max_over_ranks(self, value):
+        """max of a python float over all ranks (bench timing)"""
+        import torch
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+        if self.world_size > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
