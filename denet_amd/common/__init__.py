@@ -100,5 +100,4 @@ def get_overlap_iou(obj_bboxs, sample_bboxs):
     dy = numpy.maximum(numpy.minimum(x[:, None, 3], y[None, :, 3]) - numpy.maximum(x[:, None, 1], y[None, :, 1]), zero)
     inter = dx * dy
     union = (x_area[:, None] + y_area[None, :]) - inter
-    with numpy.errstate(divide="ignore", invalid="ignore"):
-        return (inter / union).astype(numpy.float32)
+    return inter / union

@@ -26,7 +26,7 @@ BnMap bn_map(long M, int C) {
     m.RS = 256 / lc;
     m.gx = c4 / lc;
     long rows_blocks = (M + m.RS - 1) / m.RS;
-    int gy = 2048 / m.gx;
+    int gy = 1024 / m.gx;   // ~4 workgroups per CU; keeps the second-stage reduction short
     if (gy < 1) gy = 1;
     if (gy > rows_blocks) gy = (int)rows_blocks;
     m.gy = gy;
@@ -73,15 +73,36 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     }
 }
 
-__global__ void bn_stats_final_kernel(const double* __restrict__ partial, int gy, long M, int C, float eps,
-                                      float momentum, float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                      float* __restrict__ run_mean, float* __restrict__ run_stdinv) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0, ss = 0;
-    for (int j = 0; j < gy; ++j) {
-        s += partial[(long)j * 2 * C + c];
-        ss += partial[(long)j * 2 * C + C + c];
+// second stage: a workgroup reduces 32 channels, 8 lanes stride over the partial rows
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partial, int gy, int C, int c, int jl,
+                                                double& s, double& ss) {
+    s = 0;
+    ss = 0;
+    if (c < C) {
+        for (int j = jl; j < gy; j += 8) {
+            s += partial[(long)j * 2 * C + c];
+            ss += partial[(long)j * 2 * C + C + c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ partial, int gy, long M, int C,
+                                                             float eps, float momentum, float* __restrict__ save_mean,
+                                                             float* __restrict__ save_invstd,
+                                                             float* __restrict__ run_mean,
+                                                             float* __restrict__ run_stdinv) {
+    __shared__ double red[2][8][32];
+    const int cl = threadIdx.x & 31, jl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s, ss;
+    reduce_partials(partial, gy, C, c, jl, s, ss);
+    red[0][jl][cl] = s;
+    red[1][jl][cl] = ss;
+    __syncthreads();
+    if (jl != 0 || c >= C) return;
+    for (int j = 1; j < 8; ++j) {
+        s += red[0][j][cl];
+        ss += red[1][j][cl];
     }
     const double mean = s / (double)M;
     double var = ss / (double)M - mean * mean;  // biased variance (cuDNN)
@@ -184,15 +205,21 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 }
 
 // dbeta = sum g ; dgamma = sum g*xhat ; coef[0][c] = dbeta/M ; coef[1][c] = dgamma/M
-__global__ void bn_bwd_final_kernel(const double* __restrict__ partial, int gy, long M, int C,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                    float* __restrict__ coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0, ss = 0;
-    for (int j = 0; j < gy; ++j) {
-        s += partial[(long)j * 2 * C + c];
-        ss += partial[(long)j * 2 * C + C + c];
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restrict__ partial, int gy, long M, int C,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ coef) {
+    __shared__ double red[2][8][32];
+    const int cl = threadIdx.x & 31, jl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s, ss;
+    reduce_partials(partial, gy, C, c, jl, s, ss);
+    red[0][jl][cl] = s;
+    red[1][jl][cl] = ss;
+    __syncthreads();
+    if (jl != 0 || c >= C) return;
+    for (int j = 1; j < 8; ++j) {
+        s += red[0][j][cl];
+        ss += red[1][j][cl];
     }
     dbeta[c] = (float)s;
     dgamma[c] = (float)ss;
@@ -269,7 +296,7 @@ extern "C" int denet_bn_fwd_train(const float* x, const float* res, float* y, co
     BnMap m = bn_map(M, C);
     double* partial = (double*)workspace;
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, M, C, m.LC, partial);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, partial, m.gy, M, C, eps,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, partial, m.gy, M, C, eps,
                        momentum, save_mean, save_invstd, run_mean, run_stdinv);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, res, y, gamma, beta, save_mean,
                        save_invstd, M, C, m.LC, relu);
@@ -304,7 +331,7 @@ extern "C" int denet_bn_bwd(const float* x, const float* y, const float* dy, con
     float* coef = (float*)(partial + (size_t)m.gy * 2 * C);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, save_mean, save_invstd,
                        M, C, m.LC, relu, partial);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, partial, m.gy, M, C, dgamma,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, partial, m.gy, M, C, dgamma,
                        dbeta, coef);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, gamma, save_mean,
                        save_invstd, coef, dx, dres, M, C, m.LC, relu);

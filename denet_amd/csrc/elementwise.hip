@@ -104,11 +104,18 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     }
 }
 
-__global__ void colsum_final_kernel(const double* __restrict__ partial, int gy, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ partial, int gy, int C,
+                                                           float* __restrict__ out) {
+    __shared__ double red[8][32];
+    const int cl = threadIdx.x & 31, jl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double s = 0;
-    for (int j = 0; j < gy; ++j) s += partial[(long)j * C + c];
+    if (c < C)
+        for (int j = jl; j < gy; j += 8) s += partial[(long)j * C + c];
+    red[jl][cl] = s;
+    __syncthreads();
+    if (jl != 0 || c >= C) return;
+    for (int j = 1; j < 8; ++j) s += red[j][cl];
     out[c] = (float)s;
 }
 
@@ -187,11 +194,11 @@ extern "C" int denet_colsum(const float* x, float* out, void* workspace, long M,
     while (lc < 256 && (c4 % (lc * 2)) == 0) lc *= 2;
     int rs = 256 / lc, gx = c4 / lc;
     long rb = (M + rs - 1) / rs;
-    int gy = 2048 / gx;
+    int gy = 1024 / gx;
     if (gy < 1) gy = 1;
     if (gy > rb) gy = (int)rb;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(gx, gy), dim3(256), 0, stream, x, M, C, lc, (double*)workspace);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const double*)workspace, gy,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, (const double*)workspace, gy,
                        C, out);
     DENET_CHECK_LAUNCH("colsum");
     return DENET_OK;

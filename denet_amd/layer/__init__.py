@@ -215,6 +215,13 @@ class AbstractLayer(object):
                 self.layers[i].import_json(json_layer)
 
     # ---- executor protocol (this build) ----
+    def prepare_target(self, ctx, model, data_x, metas):
+        """host-side target construction right before this layer's forward; layers with a faster internal
+        representation override this, the default goes through the reference-format get_target()"""
+        target = self.get_target(model, data_x, metas)
+        if target is not None:
+            self.set_target(ctx, target[0], target[1])
+
     def forward(self, ctx):
         """compute self.output.data from self.input.data (ctx: denet_amd.model.model_cnn.StepContext)"""
         raise NotImplementedError(type(self).__name__)

@@ -104,7 +104,11 @@ class DeNetCornerLayer(AbstractLayer):
 
     def set_target(self, ctx, yt_index, yt_value):
         import torch
-        self._target = torch.from_numpy(numpy.ascontiguousarray(yt_value, dtype=numpy.float32)).cuda(non_blocking=True)
+        v = numpy.ascontiguousarray(yt_value, dtype=numpy.float32)
+        if getattr(self, "_pinned", None) is None or self._pinned.numel() != v.size:
+            self._pinned = torch.empty(v.size, dtype=torch.float32).pin_memory()
+        self._pinned.copy_(torch.from_numpy(v))
+        self._target = self._pinned.cuda(non_blocking=True)
 
     def forward(self, ctx):
         self.conv.forward(ctx)

@@ -84,67 +84,89 @@ class DeNetDetectLayer(AbstractLayer):
                      "classNum": self.class_num, "overlapThreshold": self.overlap_threshold})
         return json
 
-    def get_target(self, model, samples, metas):
-        """vectorised restatement of denet_detect.py:147-235 (the per-match Python loops become fancy indexing;
-        assignments only ever write the constant 1.0 / 0.0 so the order of matches is immaterial)"""
+    def _buf(self, name, shape):
+        """reusable pinned host staging buffers (RoI-major target arrays)"""
+        import torch
+        bufs = self.__dict__.setdefault("_bufs", {})
+        t = bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(shape, dtype=torch.float32)
+            try:
+                t = t.pin_memory()
+            except RuntimeError:      # no HIP runtime (CPU-only host logic tests)
+                pass
+            bufs[name] = t
+        return t.numpy()
+
+    def build_targets(self, metas):
+        """IoU based target assignment of denet_detect.py:147-235 in RoI-major layout: row m = b*sn*sn + index,
+        index = j*sn + i (:174-175). The per-match Python loops of the reference become fancy indexing — every
+        assignment writes the constants 1.0 / 0.0, so the order of the matches is immaterial.
+        returns det [M,s0], bbox_valid [M] or None, bbox_reg [M,8] or None (float32)"""
         t0, t1 = self._thresholds()
-        sn = self.sample_num
-        det_pr = numpy.zeros(self.det_shape, dtype=numpy.float32)
-        det_pr[:, self.null_class, ...] = 1.0
+        sn, B = self.sample_num, self.batch_size
+        S = sn * sn
+        sp = self.sparse_layer
+        det = self._buf("det", (B * S, self.s0))
+        det.fill(0.0)
+        det[:, self.null_class] = 1.0
+        valid = reg = None
         if self.use_bbox_reg:
-            bbox_valid = numpy.zeros((self.batch_size, sn, sn), dtype=numpy.float32)
-            bbox_reg = numpy.zeros((self.batch_size, 8, sn, sn), dtype=numpy.float32)
-            bbox_reg[:, 2, ...] = 1.0
-            bbox_reg[:, 3, ...] = 1.0
-            bbox_reg[:, 6, ...] = 1.0
-            bbox_reg[:, 7, ...] = 1.0
+            valid = self._buf("valid", (B * S,))
+            reg = self._buf("reg", (B * S, 8))
+            valid.fill(0.0)
+            reg.fill(0.0)
+            reg[:, [2, 3, 6, 7]] = 1.0
 
         for b, meta in enumerate(metas):
-            samples = [bbox for _, bbox in self.sparse_layer.sample_bbox_list[b]]
-            if len(meta["bbox"]) > 0 and len(samples) > 0:
-                overlap = common.get_overlap_iou(meta["bbox"], samples)
-                bbox_indexs, sample_indexs = numpy.where(overlap > t0)
-                if len(bbox_indexs) > 0:
-                    si = sample_indexs % sn
-                    sj = sample_indexs // sn
-                    cls = numpy.asarray(meta["class"], dtype=numpy.int64)[bbox_indexs]
-                    if self.use_jointfit:
-                        # float64 arithmetic on float32 IoUs, as the Python loop does (:176,:180-183)
-                        sample_f = (overlap[bbox_indexs, sample_indexs].astype(numpy.float64) - t0) / (1.0 - t0)
-                        f = numpy.clip((self.fitness_num * sample_f).astype(numpy.int64), 0, self.fitness_num - 1)
-                        det_pr[b, cls * self.fitness_num + f, sj, si] = 1.0
-                    else:
-                        det_pr[b, cls, sj, si] = 1.0
-                    det_pr[b, self.null_class, sj, si] = 0.0
+            boxes = sp.sample_boxes[b]
+            if len(meta["bbox"]) == 0 or len(boxes) == 0:
+                continue
+            overlap = common.get_overlap_iou(meta["bbox"], boxes)
+            bbox_indexs, sample_indexs = numpy.where(overlap > t0)
+            if len(bbox_indexs) > 0:
+                rows = b * S + sample_indexs
+                cls = numpy.asarray(meta["class"], dtype=numpy.int64)[bbox_indexs]
+                if self.use_jointfit:
+                    # float64 arithmetic on float32 IoUs, as the Python loop does (:176,:180-183)
+                    sample_f = (overlap[bbox_indexs, sample_indexs].astype(numpy.float64) - t0) / (1.0 - t0)
+                    f = numpy.clip((self.fitness_num * sample_f).astype(numpy.int64), 0, self.fitness_num - 1)
+                    det[rows, cls * self.fitness_num + f] = 1.0
+                else:
+                    det[rows, cls] = 1.0
+                det[rows, self.null_class] = 0.0
+            if self.use_bbox_reg:
+                overlap_max = overlap.argmax(axis=0)
+                idx = numpy.arange(len(boxes))
+                idx = idx[overlap[overlap_max, idx] > t1]
+                if len(idx) > 0:
+                    tgt = numpy.asarray(meta["bbox"], dtype=numpy.float64)[overlap_max[idx]]
+                    smp = boxes[idx]
+                    rows = b * S + idx
+                    valid[rows] = 1.0
+                    reg[rows, 0] = 0.5 * (tgt[:, 0] + tgt[:, 2])
+                    reg[rows, 1] = 0.5 * (tgt[:, 1] + tgt[:, 3])
+                    reg[rows, 2] = tgt[:, 2] - tgt[:, 0]
+                    reg[rows, 3] = tgt[:, 3] - tgt[:, 1]
+                    reg[rows, 4] = 0.5 * (smp[:, 0] + smp[:, 2])
+                    reg[rows, 5] = 0.5 * (smp[:, 1] + smp[:, 3])
+                    reg[rows, 6] = smp[:, 2] - smp[:, 0]
+                    reg[rows, 7] = smp[:, 3] - smp[:, 1]
 
-                if self.use_bbox_reg:
-                    overlap_max = overlap.argmax(axis=0)
-                    idx = numpy.arange(len(samples))
-                    keep = overlap[overlap_max, idx] > t1
-                    idx = idx[keep]
-                    if len(idx) > 0:
-                        obj = overlap_max[idx]
-                        tgt = numpy.asarray(meta["bbox"], dtype=numpy.float64)[obj]
-                        smp = numpy.asarray(samples, dtype=numpy.float64)[idx]
-                        si, sj = idx % sn, idx // sn
-                        bbox_valid[b, sj, si] = 1.0
-                        bbox_reg[b, 0, sj, si] = 0.5 * (tgt[:, 0] + tgt[:, 2])
-                        bbox_reg[b, 1, sj, si] = 0.5 * (tgt[:, 1] + tgt[:, 3])
-                        bbox_reg[b, 2, sj, si] = tgt[:, 2] - tgt[:, 0]
-                        bbox_reg[b, 3, sj, si] = tgt[:, 3] - tgt[:, 1]
-                        bbox_reg[b, 4, sj, si] = 0.5 * (smp[:, 0] + smp[:, 2])
-                        bbox_reg[b, 5, sj, si] = 0.5 * (smp[:, 1] + smp[:, 3])
-                        bbox_reg[b, 6, sj, si] = smp[:, 2] - smp[:, 0]
-                        bbox_reg[b, 7, sj, si] = smp[:, 3] - smp[:, 1]
+        det /= det.sum(axis=1, keepdims=True)
+        det /= S
+        if self.use_bbox_reg:
+            valid /= S
+        return det, valid, reg
 
-        det_pr /= det_pr.sum(axis=1)[:, None, ...]
-        nfactor = sn * sn
-        det_pr /= nfactor
+    def get_target(self, model, samples, metas):
+        """the reference's packed target vector: det (B,s0,sn,sn) || bbox_valid (B,sn,sn) || bbox_reg (B,8,sn,sn)"""
+        sn, B = self.sample_num, self.batch_size
+        det, valid, reg = self.build_targets(metas)
+        yt_value = det.reshape(B, sn, sn, self.s0).transpose(0, 3, 1, 2).flatten()
         if self.use_bbox_reg:
-            bbox_valid /= nfactor
-        yt_value = det_pr.flatten()
-        if self.use_bbox_reg:
-            yt_value = numpy.concatenate((yt_value, bbox_valid.flatten(), bbox_reg.flatten()))
+            yt_value = numpy.concatenate((yt_value, valid.flatten(),
+                                          reg.reshape(B, sn, sn, 8).transpose(0, 3, 1, 2).flatten()))
         return numpy.array([], dtype=numpy.int64), yt_value
 
     def cost(self, yt_index, yt_value):
@@ -155,6 +177,16 @@ class DeNetDetectLayer(AbstractLayer):
     def conv(self):
         return self.layers[0]
 
+    def prepare_target(self, ctx, model, data_x, metas):
+        import torch
+        det, valid, reg = self.build_targets(metas)
+        b = self._bufs
+        t = {"det": b["det"].cuda(non_blocking=True), "valid": None, "reg": None}
+        if self.use_bbox_reg:
+            t["valid"] = b["valid"].cuda(non_blocking=True)
+            t["reg"] = b["reg"].cuda(non_blocking=True)
+        self._targets = t
+
     def set_target(self, ctx, yt_index, yt_value):
         """unpack the reference's packed target vector (:241-254) into RoI-major device arrays"""
         import torch
@@ -164,10 +196,10 @@ class DeNetDetectLayer(AbstractLayer):
             shapes += [(B, sn, sn), (B, 8, sn, sn)]
         v = common.ndarray_unpack(numpy.asarray(yt_value, dtype=numpy.float32), shapes)
         det = numpy.ascontiguousarray(v[0].transpose(0, 2, 3, 1).reshape(B * sn * sn, self.s0))
-        t = {"det": torch.from_numpy(det).cuda(non_blocking=True), "valid": None, "reg": None}
+        t = {"det": torch.from_numpy(det).cuda(), "valid": None, "reg": None}
         if self.use_bbox_reg:
-            t["valid"] = torch.from_numpy(numpy.ascontiguousarray(v[1].reshape(-1))).cuda(non_blocking=True)
-            t["reg"] = torch.from_numpy(numpy.ascontiguousarray(v[2].transpose(0, 2, 3, 1).reshape(-1, 8))).cuda(non_blocking=True)
+            t["valid"] = torch.from_numpy(numpy.ascontiguousarray(v[1].reshape(-1))).cuda()
+            t["reg"] = torch.from_numpy(numpy.ascontiguousarray(v[2].transpose(0, 2, 3, 1).reshape(-1, 8))).cuda()
         self._targets = t
 
     def forward(self, ctx):

@@ -5,7 +5,9 @@ editing with the stdlib `random` module (random trim, random boxes, ground-truth
 
 Differences by construction: the corner map never leaves the device — build_samples runs as HIP kernels
 (csrc/samples.hip) and only the <= sample_count boxes per image come back for the Python-side editing; the
-backbone is not run a second time (the reference compiles a separate `corner_func`)."""
+backbone is not run a second time (the reference compiles a separate `corner_func`). The RoI lists are kept as
+float64 arrays (the values of the reference's Python floats); `sample_bbox_list` materialises the reference's
+list-of-tuples view on demand."""
 import math
 import random
 
@@ -19,8 +21,43 @@ TAP_THEANO = 0   # denet_sparse.py:72-84 (Theano CPU path, canonical per north s
 TAP_CUDA = 1     # denet_sparse_op.py:65-71
 
 
+class PyRandomMirror:
+    """Vectorised draws from the stdlib `random` stream. numpy's RandomState is the same MT19937 with the same
+    53-bit double construction as CPython's `random`, so the generator state can be moved across, doubles drawn
+    in bulk, and the advanced state moved back: bit-identical to calling random.random() n times."""
+
+    def __init__(self):
+        self.rs = numpy.random.RandomState()
+        self.pull()
+
+    def pull(self):
+        """adopt the current state of the stdlib generator"""
+        st = random.getstate()
+        self._version, self._gauss = st[0], st[2]
+        self.rs.set_state(("MT19937", numpy.array(st[1][:-1], dtype=numpy.uint32), int(st[1][-1])))
+
+    def push(self):
+        """hand the advanced state back to the stdlib generator"""
+        ns = self.rs.get_state()
+        random.setstate((self._version, tuple(ns[1].tolist()) + (int(ns[2]),), self._gauss))
+
+    def doubles(self, n):
+        return self.rs.random_sample(n) if n > 0 else numpy.zeros((0,), dtype=numpy.float64)
+
+
+def py_random_doubles(n):
+    """the next n values of random.random(), drawn in one call"""
+    m = PyRandomMirror()
+    v = m.doubles(n)
+    m.push()
+    return v
+
+
 class DeNetSparseLayer(AbstractLayer):
     type_name = "denet-sparse"
+    # coverage statistics are log output only in the reference (denet_sparse.py:172-182); off by default because
+    # the O(GT x RoI) Python loop is pure host overhead
+    log_coverage = False
 
     def __init__(self, layers, grid_size=3, sample_num=16, corner_threshold=0.01, random_sample=0.0, local_max=0,
                  nms_threshold=0.7, sample_gt=True, version="v2", json_param={}):
@@ -48,12 +85,15 @@ class DeNetSparseLayer(AbstractLayer):
         if self.nms_threshold < 1.0:
             raise NotImplementedError("RoI clustering (nms_threshold < 1, apply_cluster) is outside the hot path")
 
-        self.sample_bbox_list = []
-        self.sample_bbox = None   # device [B*sn*sn, 4]
+        self.sample_pr = []        # per image float64 [n]
+        self.sample_boxes = []     # per image float64 [n,4]
+        self.sample_bbox = None    # device [B*sn*sn, 4]
         self.output_feat = self.grid_size * self.grid_size * self.corner_layer.sample_shape[1] + 2
         self.output_shape = (self.batch_size, self.output_feat, self.sample_num, self.sample_num)
         self.output = Act(self.output_shape, None, "sparse")
         self._taps = None
+        self._pinned = None
+        self.coverage = (0, 0)
 
     @staticmethod
     def parse_desc(layers, name, tags, params):
@@ -63,54 +103,81 @@ class DeNetSparseLayer(AbstractLayer):
                                        params.get(3, 0.1), params.get(4, 0), params.get(5, 1.0), not "G" in tags))
         return True
 
-    # ---- corner detector -> sample boxes ----
-    def get_samples(self, data_x, train=False, store_shared=False):
-        """list[B] of list[(pr, (x0, y0, x1, y1))], the return shape of c_code.build_samples
-        (denet_sparse.cc:587-592). Uses the corner map of the forward pass in flight."""
+    # ---- reference list-of-tuples view --------------------------------------------------------------------
+    @property
+    def sample_bbox_list(self):
+        return [[(float(p), tuple(bx)) for p, bx in zip(pr.tolist(), boxes.tolist())]
+                for pr, boxes in zip(self.sample_pr, self.sample_boxes)]
+
+    @staticmethod
+    def _from_lists(sample_bboxs):
+        prs, boxes = [], []
+        for samples in sample_bboxs:
+            prs.append(numpy.array([s[0] for s in samples], dtype=numpy.float64).reshape(-1))
+            boxes.append(numpy.array([s[1] for s in samples], dtype=numpy.float64).reshape(-1, 4))
+        return prs, boxes
+
+    # ---- corner detector -> sample boxes ------------------------------------------------------------------
+    def _device_samples(self, store_shared=False):
         cl = self.corner_layer
         assert cl.corner_pr is not None, "run the model forward up to the corner layer first"
-        timer = common.Timer()
         box, absd, count = ops.build_samples(cl.corner_pr, float(self.corner_threshold), self.sample_count,
                                              self.corner_max, int(self.local_max))
         if store_shared:
             cl.sample_shared = cl.conv.output.data
         box, absd, count = box.cpu(), absd.cpu(), count.cpu()     # one small D2H, implicit sync
-        timer.mark()
-        samples = ops.samples_finish_host(box, absd, count, cl.height, cl.width).numpy()
+        samples = ops.samples_finish_host(box, absd, count, cl.height, cl.width).numpy().astype(numpy.float64)
         counts = count.tolist()
-        result = []
-        for b in range(self.batch_size):
-            rows = samples[b, :counts[b]].tolist()
-            result.append([(r[0], (r[1], r[2], r[3], r[4])) for r in rows])
-        timer.mark()
-        self.last_timing_ms = (timer.delta_ms(0), timer.delta_ms(1))
-        return result
+        prs = [samples[b, :counts[b], 0] for b in range(self.batch_size)]
+        boxes = [samples[b, :counts[b], 1:5] for b in range(self.batch_size)]
+        return prs, boxes
+
+    def get_samples(self, data_x, train=False, store_shared=False):
+        """list[B] of list[(pr, (x0, y0, x1, y1))], the return shape of c_code.build_samples
+        (denet_sparse.cc:587-592). Uses the corner map of the forward pass in flight."""
+        prs, boxes = self._device_samples(store_shared)
+        return [[(p, tuple(bx)) for p, bx in zip(pr.tolist(), bxs.tolist())] for pr, bxs in zip(prs, boxes)]
 
     def get_bbox_array(self, sample_bboxs):
         """build_bbox_array (denet_sparse.cc:670-699): bbox[b, i//sn, i%sn] = box i; the rest stays 0"""
+        _, boxes = self._from_lists(sample_bboxs)
+        return self._bbox_array(boxes)
+
+    def _bbox_array(self, boxes):
         bboxs = numpy.zeros((self.batch_size, self.sample_num, self.sample_num, 4), dtype=numpy.float32)
         flat = bboxs.reshape(self.batch_size, self.sample_count, 4)
-        for b, samples in enumerate(sample_bboxs):
-            if len(samples) > 0:
-                flat[b, :len(samples)] = numpy.array([s[1] for s in samples], dtype=numpy.float64).astype(numpy.float32)
+        for b, bx in enumerate(boxes):
+            if len(bx) > 0:
+                flat[b, :len(bx)] = bx
         return bboxs
 
     def set_samples(self, sample_bboxs):
+        self.sample_pr, self.sample_boxes = self._from_lists(sample_bboxs)
+        return self._upload_boxes()
+
+    def _upload_boxes(self):
         import torch
-        bboxs = self.get_bbox_array(sample_bboxs)
-        self.sample_bbox = torch.from_numpy(bboxs.reshape(-1, 4)).cuda(non_blocking=True)
-        self.sample_bbox_list = sample_bboxs
+        bboxs = self._bbox_array(self.sample_boxes)
+        if self._pinned is None:
+            self._pinned = torch.empty((self.batch_size * self.sample_count, 4), dtype=torch.float32).pin_memory()
+        self._pinned.copy_(torch.from_numpy(bboxs.reshape(-1, 4)))
+        self.sample_bbox = self._pinned.cuda(non_blocking=True)
+        self.sample_bbox_f32 = bboxs.reshape(self.batch_size, self.sample_count, 4)
         return bboxs
 
-    def get_target(self, model, data_x, metas):
-        sample_bboxs = self.get_samples(data_x, train=True)
-        total_cover = 0
-        total_bbox = 0
+    def edit_samples(self, prs, boxes, metas):
+        """training-time RoI list editing (denet_sparse.py:184-201), call for call on the stdlib generator:
+        random.sample when the detector produced too many boxes, then 4 uniform draws per random box in the order
+        x0, y0, x1, y1, then ground truth written over the tail of the list."""
+        total_cover = total_bbox = 0
+        out_pr, out_boxes = [], []
+        mirror = PyRandomMirror()
         for b, meta in enumerate(metas):
+            pr, bx = prs[b], boxes[b]
             if self.log_coverage:
                 cover = 0
                 for meta_bbox in meta["bbox"]:
-                    for _, sample_bbox in sample_bboxs[b]:
+                    for sample_bbox in bx.tolist():
                         if common.overlap_iou(meta_bbox, sample_bbox) > 0.5:
                             cover += 1
                             break
@@ -118,26 +185,40 @@ class DeNetSparseLayer(AbstractLayer):
                 total_bbox += len(meta["bbox"])
 
             n = self.sample_count - math.floor(self.random_sample * self.sample_count)
-            if len(sample_bboxs[b]) > n:
-                sample_bboxs[b] = random.sample(sample_bboxs[b], n)
+            if len(bx) > n:
+                mirror.push()
+                keep = random.sample(range(len(bx)), n)     # same draws as random.sample(list, n)
+                mirror.pull()
+                pr, bx = pr[keep], bx[keep]
 
-            while len(sample_bboxs[b]) < self.sample_count:
-                x0 = random.uniform(0.0, 1.0)
-                y0 = random.uniform(0.0, 1.0)
-                x1 = random.uniform(x0, 1.0)
-                y1 = random.uniform(y0, 1.0)
-                sample_bboxs[b].append((0.0, (x0, y0, x1, y1)))
+            k = self.sample_count - len(bx)
+            if k > 0:
+                r = mirror.doubles(4 * k).reshape(k, 4)
+                # random.uniform(a, b) = a + (b - a) * random()
+                x0 = 0.0 + (1.0 - 0.0) * r[:, 0]
+                y0 = 0.0 + (1.0 - 0.0) * r[:, 1]
+                x1 = x0 + (1.0 - x0) * r[:, 2]
+                y1 = y0 + (1.0 - y0) * r[:, 3]
+                bx = numpy.concatenate([bx, numpy.stack([x0, y0, x1, y1], axis=1)], axis=0)
+                pr = numpy.concatenate([pr, numpy.zeros(k)])
+            else:
+                bx, pr = bx.copy(), pr.copy()
 
             if self.sample_gt:
                 for index, bbox in enumerate(meta["bbox"]):
-                    sample_bboxs[b][-(index + 1)] = (1.0, bbox)
+                    bx[-(index + 1)] = bbox
+                    pr[-(index + 1)] = 1.0
+            out_pr.append(pr)
+            out_boxes.append(bx)
+        mirror.push()
         self.coverage = (total_cover, total_bbox)
-        self.set_samples(sample_bboxs)
-        return None
+        return out_pr, out_boxes
 
-    # coverage statistics are log output only in the reference (denet_sparse.py:172-182); off by default because
-    # the O(GT x RoI) Python loop is pure host overhead
-    log_coverage = False
+    def get_target(self, model, data_x, metas):
+        prs, boxes = self._device_samples()
+        self.sample_pr, self.sample_boxes = self.edit_samples(prs, boxes, metas)
+        self._upload_boxes()
+        return None
 
     def export_json(self):
         json = super().export_json()
@@ -146,7 +227,7 @@ class DeNetSparseLayer(AbstractLayer):
                      "randomSample": self.random_sample, "nmsThreshold": self.nms_threshold, "version": self.version})
         return json
 
-    # ---- execution ----
+    # ---- execution ----------------------------------------------------------------------------------------
     def forward(self, ctx):
         cl = self.corner_layer
         if get_train() or cl.sample_shared is None:

@@ -307,9 +307,7 @@ class ModelCNN:
         ctx = StepContext(self)
         for layer in self.layers[1:]:
             if train and data_m is not None:
-                target = layer.get_target(self, data_x, data_m)
-                if target is not None:
-                    layer.set_target(ctx, target[0], target[1])
+                layer.prepare_target(ctx, self, data_x, data_m)
             layer.forward(ctx)
         return ctx
 

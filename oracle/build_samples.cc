@@ -122,12 +122,6 @@ std::vector<Sample> search(const float* pr, int Cn, int H, int W, int b, const s
     return out;
 }
 
-float box_overlap(const Sample& a, const Sample& b) {
-    float dx = std::max(0.0f, std::min(a.x1, b.x1) - std::max(a.x0, b.x0));
-    float dy = std::max(0.0f, std::min(a.y1, b.y1) - std::max(a.y0, b.y0));
-    return dx * dy;
-}
-
 }  // namespace
 
 // corner_pr: [B,2,Cn,H,W] fp32 C-contiguous.  Outputs (caller allocated):

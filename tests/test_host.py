@@ -1,0 +1,246 @@
+"""CPU tests of the host logic (no GPU compute): model-desc grammar, graph assembly, JSON surface, targets,
+RoI editing, the C-ABI export table and the N>1 data-parallel path over gloo."""
+import ctypes
+import json
+import os
+import random
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from denet_amd import lib as dlib
+from denet_amd.common import json_util
+from denet_amd.model import model_cnn, modify, zoo
+from oracle import layers as OL
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def denet_small():
+    return zoo.denet34(2, "skip", 128, class_num=80, seed=1)
+
+
+def test_denet34_skip_shape_table():
+    """parse_desc + the model-modify sequence of papers/dss/denet34.sh reproduce the SURVEY §8 table"""
+    m = zoo.denet34(32, "skip", 512)
+    tab = json.load(open(os.path.join(GOLDEN, "denet34_skip_shapes.json")))
+    assert len(m.layers) == len(tab["layers"])
+    for (idx, tname, shape), layer in zip(tab["layers"], m.layers):
+        assert layer.type_name == tname, (idx, layer.type_name, tname)
+        assert tuple(layer.output_shape[1:]) == tuple(shape), (idx, layer.output_shape, shape)
+    n = sum(p.value.size for l in m.layers for p in l.weights() + l.biases())
+    assert abs(n / 1e6 - tab["trainable_parameters_millions"]) < 0.01
+    # weights() then biases(): BN gamma/beta are biases (no decay), conv omega is a weight
+    rsn = m.layers[4]
+    assert len(rsn.weights()) == 2 and len(rsn.biases()) == 4 and len(rsn.updates()) == 4
+    dnc = m.layers[30]
+    conv = dnc.layers[-1]
+    assert np.all(conv.omega.value[:4] == 0) and np.all(conv.beta.value[:4] == 5.0) and conv.pad == 0
+    dnd = m.layers[40]
+    assert np.all(dnd.layers[0].omega.value == 0) and dnd.layers[0].filter_shape[0] == 85
+
+
+def test_desc_grammar_and_errors():
+    m = model_cnn.ModelCNN()
+    m.batch_size = 4
+    m.class_num = 10
+    m.build(zoo.CIFAR3_DESC, (3, 32, 32), "relu", "half", ["he-backward"])
+    names = [l.type_name for l in m.layers]
+    assert names == ["initial", "conv", "batchnorm", "activation", "pool", "conv", "batchnorm", "activation", "pool",
+                     "conv", "batchnorm", "activation", "pool", "conv", "regression"]
+    assert m.layers[-1].output_shape == (4, 10)
+    assert m.layers[12].mode == "average_inc_pad" and m.layers[12].output_shape == (4, 512, 1, 1)
+    with pytest.raises(Exception):
+        m.build_layer("ZZ[1]", m.layers, "relu", "half", "he-backward")
+    with pytest.raises(Exception):   # bare P has no size in this version of the reference (pool.py:51)
+        m.build_layer("P.A", list(m.layers[:4]), "relu", "half", "he-backward")
+    # C.X[filters,kh,kw,sh,sw], C.B = bias ON (code wins over README)
+    ls = list(m.layers[:1])
+    m.build_layer("C.BX[16,3,3,2,2]", ls, "relu", "half", "he-backward")
+    assert ls[-1].use_bias and ls[-1].stride == (2, 2) and ls[-1].output_shape == (4, 16, 16, 16)
+
+
+def test_json_roundtrip_and_layout(denet_small, tmp_path):
+    m = denet_small
+    j = m.export_json()
+    assert j["version"] == 3 and j["layers"][0]["type"] == "conv"
+    assert set(["shape", "stride", "border", "enabled", "useBias", "bias", "weight"]) <= set(j["layers"][0].keys())
+    assert set(["momentum", "eps", "mean", "std", "gamma", "bias"]) <= set(j["layers"][1].keys())
+    f = str(tmp_path / "m.mdl.gz")
+    model_cnn.save_to_file(m, f)
+    m2 = model_cnn.load_from_file(f, 2)
+    for a, b in zip(m.layers, m2.layers):
+        assert a.type_name == b.type_name and a.output_shape == b.output_shape
+        for pa, pb in zip(a.params(), b.params()):
+            np.testing.assert_array_equal(pa.value, pb.value)
+    # device layout: flipped KRSC with channel padding
+    conv = m.layers[1]
+    d = conv.omega.to_dev_layout()
+    assert d.shape == (64, 7, 8, 4)
+    w = conv.omega.value
+    assert d[5, 1, 2, 1] == w[5, 1, 5, 4] and np.all(d[:, :, 7, :] == 0) and np.all(d[:, :, :, 3] == 0)
+    np.testing.assert_array_equal(conv.omega.from_dev_layout(d), w)
+
+
+def test_modify_operations():
+    np.random.seed(3)
+    m = model_cnn.ModelCNN()
+    m.batch_size = 2
+    m.class_num = 10
+    m.build("C.B[32,3] BN A nRSN.O[2,32,3] P.A[8] R", (3, 8, 8), "relu", "half", ["he-backward"])
+    m2 = modify.convert_bn_relu(m)
+    assert [l.type_name for l in m2.layers][:4] == ["initial", "conv", "batchnorm-relu", "resnet"]
+    assert "bnrelu" in m2.layers[3].version and m2.layers[3].layers[2].type_name == "batchnorm-relu"
+    np.testing.assert_array_equal(m.layers[1].omega.value, m2.layers[1].omega.value)
+    m3 = modify.layer_remove(m2, 3)
+    assert len(m3.layers) == len(m2.layers) - 3
+    m4 = modify.layer_insert(m3, ["3:SKIPSRC.X[0]"])
+    assert m4.layers[3].type_name == "skip-src" and m4.layers[3].has_split
+    m5 = modify.layer_append(m4, "C[32,3] SKIP[0] BNA")
+    assert [l.type_name for l in m5.layers][-3:] == ["conv", "skip", "batchnorm-relu"]
+
+
+def test_random_mirror_matches_stdlib():
+    from denet_amd.layer.denet_sparse import py_random_doubles
+    random.seed(11)
+    a = [random.random() for _ in range(257)]
+    nxt = random.uniform(1, 2)
+    random.seed(11)
+    b = py_random_doubles(257)
+    assert np.array_equal(np.array(a), b) and random.uniform(1, 2) == nxt
+
+
+def test_roi_editing_matches_reference_loop(denet_small):
+    dns = denet_small.layers[31]
+    _, metas = zoo.synthetic_batch(2, 128, seed=4)
+    rng = np.random.RandomState(3)
+    prs, boxes, lists = [], [], []
+    for b, k in enumerate([40, 576]):
+        bx = np.sort(rng.uniform(0, 1, (k, 4)).astype(np.float32).astype(np.float64), axis=1)
+        pr = rng.uniform(0, 0.5, k).astype(np.float32).astype(np.float64)
+        prs.append(pr)
+        boxes.append(bx)
+        lists.append([(float(p), tuple(v)) for p, v in zip(pr.tolist(), bx.tolist())])
+    random.seed(7)
+    p2, b2 = dns.edit_samples(prs, boxes, metas)
+    after = random.random()
+    random.seed(7)
+    ref = OL.edit_samples(lists, metas, 576, 0.1, True)
+    assert random.random() == after
+    for b in range(2):
+        assert np.array_equal(np.array([s[1] for s in ref[b]]), b2[b])
+        assert np.array_equal(np.array([s[0] for s in ref[b]]), p2[b])
+    # bbox array == build_bbox_array
+    dns.sample_pr, dns.sample_boxes = p2, b2
+    np.testing.assert_array_equal(dns._bbox_array(b2), OL.bbox_array(ref, 2, 24))
+
+
+@pytest.mark.parametrize("jointfit", [False, True])
+def test_detect_and_corner_targets_match_reference_loops(jointfit):
+    head = zoo.DENET34_SKIP_DESC.replace("DND[0.5,1,1]", "DND.J[0.5,1,1]") if jointfit else None
+    m = zoo.denet34(2, "skip", 128, head_desc=head)
+    dns, dnd, dnc = m.layers[31], m.layers[40], m.layers[30]
+    _, metas = zoo.synthetic_batch(2, 128, seed=5)
+    random.seed(2)
+    prs = [np.zeros(0), np.zeros(0)]
+    boxes = [np.zeros((0, 4)), np.zeros((0, 4))]
+    dns.sample_pr, dns.sample_boxes = dns.edit_samples(prs, boxes, metas)
+    idx, val = dnd.get_target(m, None, metas)
+    det_t, valid, reg_t = OL.detect_target(metas, dns.sample_bbox_list, 2, 24, 80, (0.5, 0.5), True, jointfit)
+    ref = np.concatenate([det_t.flatten(), valid.flatten(), reg_t.flatten()])
+    assert idx.size == 0 and val.dtype == np.float32
+    np.testing.assert_array_equal(val, ref)
+    assert (det_t.sum(axis=1) > 0).all() and valid.sum() > 0
+    _, cval = dnc.get_target(m, None, metas)
+    np.testing.assert_array_equal(cval.reshape(dnc.corner_shape), OL.corner_target(metas, dnc.corner_shape))
+
+
+def test_cabi_exports_every_declared_symbol():
+    """the shared library loads and exports exactly what include/denet_hip.h declares (no compute calls)"""
+    hdr = open(os.path.join(ROOT, "include", "denet_hip.h")).read()
+    declared = set(re.findall(r"\b(denet_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(dlib.SIGNATURES.keys()), declared ^ set(dlib.SIGNATURES.keys())
+    lib = dlib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.denet_abi_version() == 1
+    # argument validation happens before any device work: callable on a CPU-only box
+    assert lib.denet_conv_fwd(None, None, None, None, None, 1, 8, 8, 32, 33, 3, 3, 3, 1, 1, 8, 8, None) == -1000
+    assert b"multiple of 32" in lib.denet_last_error()
+
+
+def test_product_fails_loudly_without_library(monkeypatch):
+    monkeypatch.setattr(dlib, "_lib", None)
+    monkeypatch.setattr(dlib, "LIB_PATH", "/nonexistent/libdenet_hip.so")
+    with pytest.raises(dlib.DenetHipError):
+        dlib.load()
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "denet_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cc")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("oracle's", ""), os.path.join(dirpath, f)
+
+
+DP_WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+from denet_amd.multi import DataParallel
+
+class FakeModel: pass
+
+rank = int(os.environ["RANK"])
+dp = DataParallel(backend="gloo", bucket_bytes=4 * 100, scale_fn=lambda t, s: t.mul_(s))
+m = FakeModel()
+sizes = [64, 192, 128, 64, 320]
+layers = [object() for _ in sizes]
+off, rng = 0, []
+for l, n in zip(layers, sizes):
+    rng.append((l, off, off + n)); off += n
+m.layer_weight_range = rng
+m.n_weights, m.n_trainable = off, off + 64
+torch.manual_seed(rank)
+m.G = torch.randn(m.n_trainable)
+m.S = torch.full((32,), float(rank))
+m.P = torch.full((8,), float(rank)); m.M = m.P.clone()
+g_local = m.G.clone()
+dp.broadcast_state(m)
+assert float(m.P[0]) == 0.0 and float(m.S[0]) == 0.0
+m.S = torch.full((32,), float(rank))      # per-rank BN running statistics after a local step
+dp.begin_step(m)
+buckets = dp._buckets
+assert buckets[0][1] == m.n_weights and buckets[-1][0] == 0
+assert sum(hi - lo for lo, hi, _ in buckets) == m.n_weights
+for l in reversed(layers):
+    dp.layer_done(m, l)
+dp.finish_step(m)
+others = []
+for r in range(dp.world_size):
+    torch.manual_seed(r); others.append(torch.randn(m.n_trainable))
+assert torch.allclose(m.G, sum(others), atol=1e-6)
+assert torch.allclose(m.S, torch.full((32,), 0.5))
+assert dp.max_over_ranks(float(rank)) == 1.0
+print("rank", rank, "ok")
+'''
+
+
+def test_data_parallel_gloo_world2(tmp_path):
+    script = tmp_path / "dp_worker.py"
+    script.write_text(DP_WORKER % ROOT)
+    port = 29500 + (os.getpid() % 1000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out.decode()

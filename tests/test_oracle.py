@@ -1,0 +1,269 @@
+"""CPU tests of the oracle (oracle/): pins it against the reference's own known answers and against an
+independent second implementation (torch CPU ops + autograd), as SURVEY.md §8(c) prescribes."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+from oracle import layers as L
+from oracle import model as OM
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _corner_map(case):
+    H, W, Cn = case["H"], case["W"], case["Cn"]
+    P = np.full((1, Cn, H, W), case["default_p"], np.float64)
+    for c in case["corners"]:
+        P[0, c["type"], c["y"], c["x"]] = c["p"]
+    pos = np.log(P).astype(np.float32)
+    neg = np.log(1 - P).astype(np.float32)
+    return np.ascontiguousarray(np.stack([neg, pos], axis=1))
+
+
+def test_build_samples_known_answers():
+    """SURVEY.md §8(c) known answers of the compiled reference build_samples"""
+    kat = json.load(open(os.path.join(GOLDEN, "build_samples_kat.json")))
+    for case in kat["cases"]:
+        pr = _corner_map(case)
+        lists = OM.oracle_build_samples(pr, case["corner_threshold"], case["sample_num"], case["max_corners"],
+                                        case["local_max"])
+        got = lists[0]
+        if "expect" in case:
+            assert len(got) == len(case["expect"]), case["name"]
+            for g, e in zip(got, case["expect"]):
+                assert np.float32(g[0]) == np.float32(e["pr"]), (case["name"], g[0])
+                assert tuple(g[1]) == tuple(e["box"]), case["name"]
+        else:
+            assert sorted(tuple(g[1]) for g in got) == sorted(tuple(b) for b in case["expect_boxes"]), case["name"]
+
+
+def test_bn_known_answer():
+    """the reference's own BN test block (denet/layer/batch_norm.py:131-154)"""
+    np.random.seed(1002)
+    eps = 1e-4
+    x = np.random.uniform(0.0, 1.0, (64, 128, 32, 32)).astype(np.float32)
+    C = 128
+    y, mean, invstd = L.bn_train(x, np.ones(C, np.float32), np.zeros(C, np.float32), 1e-5)
+    rm, rs = L.bn_running_update(np.zeros(C, np.float32), np.ones(C, np.float32), mean, invstd, 0.9)
+    assert abs(y.mean()) < eps and abs(y.std() - 1.0) < eps
+    assert abs(rm.mean() - x.mean() * 0.1) < eps
+    assert abs(rs.mean() - 1.24641) < eps
+
+
+def _t(a, grad=False):
+    return torch.tensor(np.asarray(a, dtype=np.float64), requires_grad=grad)
+
+
+@pytest.mark.parametrize("k,stride,pad", [(3, 1, 1), (3, 2, 1), (1, 2, 0), (7, 2, 3), (4, 1, 2)])
+def test_conv_vs_torch(k, stride, pad):
+    rng = np.random.RandomState(k * 10 + stride)
+    x = rng.randn(2, 5, 12, 12).astype(np.float32)
+    w = rng.randn(6, 5, k, k).astype(np.float32)
+    b = rng.randn(6).astype(np.float32)
+    tx, tw, tb = _t(x, True), _t(w, True), _t(b, True)
+    ty = Fn.conv2d(tx, torch.flip(tw, [2, 3]), tb, stride=stride, padding=pad)   # true convolution
+    y = L.conv2d(x, w, b, stride, pad)
+    np.testing.assert_allclose(y, ty.detach().numpy(), rtol=1e-4, atol=1e-4)
+    dy = rng.randn(*y.shape).astype(np.float32)
+    ty.backward(_t(dy))
+    dx, dw, db = L.conv2d_grad(x, w, dy, stride, pad)
+    np.testing.assert_allclose(dx, tx.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dw, tw.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(db, tb.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_bn_grad_and_test_mode_vs_torch():
+    rng = np.random.RandomState(3)
+    x = (rng.randn(4, 6, 5, 5) * 2 + 1).astype(np.float32)
+    g, b = rng.rand(6).astype(np.float32) + 0.5, rng.randn(6).astype(np.float32)
+    tx, tg, tb = _t(x, True), _t(g, True), _t(b, True)
+    ty = Fn.batch_norm(tx, None, None, tg, tb, training=True, eps=1e-5)
+    y, mean, invstd = L.bn_train(x, g, b, 1e-5)
+    np.testing.assert_allclose(y, ty.detach().numpy(), rtol=1e-5, atol=1e-5)
+    dy = rng.randn(*x.shape).astype(np.float32)
+    ty.backward(_t(dy))
+    dx, dg, db = L.bn_grad(x, dy, g, mean, invstd)
+    np.testing.assert_allclose(dx, tx.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dg, tg.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(db, tb.grad.numpy(), rtol=1e-4, atol=1e-5)
+    # test mode: eps is applied twice (batch_norm.py:50-52)
+    rm, rs = rng.randn(6).astype(np.float32), (rng.rand(6) + 0.5).astype(np.float32)
+    yt = L.bn_test(x, g, b, rm, rs, 1e-5)
+    var = (1.0 / rs.astype(np.float64)) ** 2
+    ref = (x - rm[None, :, None, None]) / np.sqrt(var + 1e-5)[None, :, None, None] * g[None, :, None, None] + b[None, :, None, None]
+    np.testing.assert_allclose(yt, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_pools_vs_torch():
+    rng = np.random.RandomState(4)
+    x = rng.randn(2, 3, 11, 13).astype(np.float32)
+    for k, s, p in [(3, 2, 1), (2, 2, 0)]:
+        tx = _t(x, True)
+        ty = Fn.max_pool2d(tx, k, s, p)
+        y, arg = L.pool_max(x, k, s, p)
+        np.testing.assert_array_equal(y, ty.detach().numpy().astype(np.float32))
+        dy = rng.randn(*y.shape).astype(np.float32)
+        ty.backward(_t(dy))
+        np.testing.assert_allclose(L.pool_max_grad(dy, arg, x.shape, k, s, p), tx.grad.numpy(), rtol=1e-6, atol=1e-6)
+        tx = _t(x, True)
+        ty = Fn.avg_pool2d(tx, k, s, p, count_include_pad=True)
+        np.testing.assert_allclose(L.pool_avg(x, k, s, p), ty.detach().numpy(), rtol=1e-5, atol=1e-6)
+        ty.backward(_t(dy))
+        np.testing.assert_allclose(L.pool_avg_grad(dy, x.shape, k, s, p), tx.grad.numpy(), rtol=1e-5, atol=1e-6)
+    # pool-inv: the reference's own differential design (pool_inv.py:43-88): op == double repeat
+    rng = np.random.RandomState(1)
+    x = rng.uniform(-5, 5, (4, 64, 4, 4)).astype(np.float32)
+    tx = _t(x, True)
+    ty = tx.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    np.testing.assert_array_equal(L.pool_inv(x, (2, 2)), ty.detach().numpy().astype(np.float32))
+    ty.sum().backward()
+    np.testing.assert_allclose(L.pool_inv_grad(np.ones((4, 64, 8, 8), np.float32), (2, 2)), tx.grad.numpy())
+
+
+def test_corner_cost_grad_vs_autograd():
+    rng = np.random.RandomState(5)
+    x = (rng.randn(2, 4, 6, 6) * 2).astype(np.float32)
+    t = rng.rand(2, 2, 4, 6, 6).astype(np.float32) / 100
+    tx = _t(x, True)
+    lp = torch.log_softmax(torch.stack([tx, -tx], 1), 1)
+    cost = 100.0 * (-(_t(t) * lp).sum(dim=(1, 2, 3, 4)).mean() / np.log(2))
+    cost.backward()
+    pr = L.corner_pr(x)
+    np.testing.assert_allclose(pr, lp.detach().numpy(), rtol=1e-5, atol=1e-6)
+    c, g = L.corner_cost(t, pr, 100.0)
+    assert abs(c - float(cost)) < 1e-4 * abs(float(cost))
+    np.testing.assert_allclose(g, tx.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("rule", [0, 1])
+def test_sparse_sample_vs_gather(rule):
+    """the reference's own differential design (denet_sparse.py:222-285): op vs explicit gather, fwd and grad"""
+    import random
+    rng = np.random.RandomState(1)
+    random.seed(1)
+    B, Fc, H, W, sn, gs = 2, 8, 16, 16, 5, 7
+    x = rng.uniform(-5, 5, (B, Fc, H, W)).astype(np.float32)
+    bbox = np.zeros((B, sn, sn, 4), np.float32)
+    for b in range(B):
+        for idx in range(sn * sn):
+            j, i = idx // sn, idx % sn
+            bbox[b, j, i, 0] = random.uniform(0.0, 1.0)
+            bbox[b, j, i, 1] = random.uniform(0.0, 1.0)
+            bbox[b, j, i, 2] = random.uniform(bbox[b, j, i, 0], 1.0)
+            bbox[b, j, i, 3] = random.uniform(bbox[b, j, i, 1], 1.0)
+    out, taps = L.sparse_sample(x, bbox, gs, rule)
+    ys, xs = taps
+    assert out.shape == (B, gs * gs * Fc + 2, sn, sn)
+    # scalar restatement of one RoI
+    for (b, j, i) in [(0, 0, 0), (1, 3, 2), (1, 4, 4)]:
+        m = b * sn * sn + j * sn + i
+        x0, y0, x1, y1 = bbox[b, j, i]
+        for yi in range(gs):
+            for xi in range(gs):
+                v = out[b, (yi * gs + xi) * Fc:(yi * gs + xi + 1) * Fc, j, i]
+                np.testing.assert_array_equal(v, x[b, :, ys[m, yi], xs[m, xi]])
+        assert out[b, gs * gs * Fc, j, i] == np.float32(y1 - y0) and out[b, gs * gs * Fc + 1, j, i] == np.float32(x1 - x0)
+    # gradient of sum(output) w.r.t. fmap == tap counts
+    g = L.sparse_sample_grad(np.ones_like(out), taps, x.shape, gs)
+    counts = np.zeros((B, H, W))
+    for m in range(B * sn * sn):
+        for yi in range(gs):
+            for xi in range(gs):
+                counts[m // (sn * sn), ys[m, yi], xs[m, xi]] += 1
+    np.testing.assert_allclose(g, np.broadcast_to(counts[:, None], g.shape))
+
+
+def test_tap_rules_differ_only_at_half_cells():
+    """(i*w)/(gs-1) round-half-even vs i*w*(1/(gs-1)) lroundf: lattice boxes produce exact .5 taps"""
+    bb = np.array([[1 / 64, 1 / 64, 4 / 64, 4 / 64]], np.float32)   # w = 3 cells: tap 1 -> 1.5
+    y0, x0, _, _ = L.sparse_taps(bb, 7, 64, 64, 0)
+    y1, x1, _, _ = L.sparse_taps(bb, 7, 64, 64, 1)
+    assert x0[0, 1] == 2 and x1[0, 1] == 2          # 1.5 -> 2 under both (even / away)
+    assert x0[0, 3] == 2 and x1[0, 3] == 3          # 2.5 -> 2 (half to even) vs 3 (half away)
+
+
+@pytest.mark.parametrize("bounded", [False, True])
+def test_detect_cost_grad_vs_autograd(bounded):
+    rng = np.random.RandomState(6)
+    B, sn, C = 2, 3, 5
+    s0 = C + 1
+    out = rng.randn(B, s0 + 4, sn, sn).astype(np.float32)
+    det_t = rng.rand(B, s0, sn, sn).astype(np.float32)
+    det_t /= det_t.sum(1, keepdims=True) * sn * sn
+    valid = (rng.rand(B, sn, sn) > 0.4).astype(np.float32) / (sn * sn)
+    box = rng.rand(B, sn, sn, 4).astype(np.float32)
+    box[..., 2:] = box[..., :2] + 0.05 + 0.5 * box[..., 2:]
+    tb = rng.rand(B, sn, sn, 4).astype(np.float32)
+    tb[..., 2:] = tb[..., :2] + 0.05 + 0.5 * tb[..., 2:]
+
+    def cxcywh(bx):
+        return np.stack([0.5 * (bx[..., 0] + bx[..., 2]), 0.5 * (bx[..., 1] + bx[..., 3]), bx[..., 2] - bx[..., 0],
+                         bx[..., 3] - bx[..., 1]], axis=1)
+
+    reg_t = np.concatenate([cxcywh(tb), cxcywh(box)], axis=1).astype(np.float32)
+    dc, bc, g = L.detect_cost(out, det_t, valid, reg_t, box, s0, 1.5, 2.0, bounded)
+    to = _t(out, True)
+    lp = torch.log_softmax(to[:, :s0], 1)
+    det_err = -(_t(det_t) * lp).sum(1) / np.log(s0)
+    reg = to[:, s0:]
+    bt = _t(reg_t)
+    if not bounded:
+        t = torch.stack([(bt[:, 0] - bt[:, 4]) / bt[:, 6], (bt[:, 1] - bt[:, 5]) / bt[:, 7], torch.log(bt[:, 2] / bt[:, 6]),
+                         torch.log(bt[:, 3] / bt[:, 7])], 1)
+        d = t - reg
+    else:
+        sb = _t(box)
+        scx, scy = 0.5 * (sb[..., 0] + sb[..., 2]), 0.5 * (sb[..., 1] + sb[..., 3])
+        sw, sh = sb[..., 2] - sb[..., 0], sb[..., 3] - sb[..., 1]
+        pcx, pcy = reg[:, 0] * sw + scx, reg[:, 1] * sh + scy
+        pw, ph = torch.exp(reg[:, 2]) * sw, torch.exp(reg[:, 3]) * sh
+        e = 0.001
+        dx, dy = bt[:, 0] - pcx, bt[:, 1] - pcy
+        cx = torch.where(dx >= 0, 2 * dx / (bt[:, 2] + dx + e), -2 * dx / (bt[:, 2] - dx + e))
+        cy = torch.where(dy >= 0, 2 * dy / (bt[:, 3] + dy + e), -2 * dy / (bt[:, 3] - dy + e))
+        cw = 1.0 - torch.minimum(bt[:, 2] / (pw + e), pw / (bt[:, 2] + e))
+        ch = 1.0 - torch.minimum(bt[:, 3] / (ph + e), ph / (bt[:, 3] + e))
+        d = torch.stack([cx, cy, cw, ch], 1)
+    sl1 = torch.where(d.abs() < 1, 0.5 * d * d, d.abs() - 0.5)
+    bbox_err = 2.0 * _t(valid) * sl1.sum(1)
+    c_det, c_bbox = 1.5 * det_err.sum() / B, 2.0 * bbox_err.sum() / B
+    (c_det + c_bbox).backward()
+    assert abs(dc - float(c_det)) < 1e-5 and abs(bc - float(c_bbox)) < 1e-5
+    np.testing.assert_allclose(g, to.grad.numpy(), rtol=1e-4, atol=1e-7)
+
+
+def test_regression_cost_vs_autograd():
+    rng = np.random.RandomState(7)
+    x = rng.randn(4, 10, 1, 1).astype(np.float32)
+    cls = np.array([1, 3, 3, 9])
+    tx = _t(x, True)
+    cost = -torch.log_softmax(tx.reshape(4, 10), 1)[torch.arange(4), torch.tensor(cls)].mean()
+    cost.backward()
+    c, g = L.regression_cost(x, cls)
+    assert abs(c - float(cost)) < 1e-6
+    np.testing.assert_allclose(g, tx.grad.numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_nms_oracle_semantics():
+    """denet_detect.cc:73-97: an instance is dropped iff a strictly better one overlaps it by more than the threshold"""
+    import ctypes
+    lib = OM.oracle_lib()
+    B, C1, sn = 1, 3, 2
+    det = np.full((B, C1, sn, sn), -10.0, np.float32)
+    det[0, 0] = [[-0.1, -0.2], [-0.3, -5.0]]
+    fit = det.copy()
+    bbox = np.array([[[[0, 0, .5, .5], [0.05, 0, .55, .5]], [[.6, .6, 1, 1], [0, 0, 1, 1]]]], np.float32)
+    num = np.array([4], np.int32)
+    out = np.zeros((B, 16, 6), np.float32)
+    cnt = np.zeros(B, np.int32)
+    f = lib.oracle_build_detections_nms
+    f.argtypes = [ctypes.c_float, ctypes.c_float, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 2
+    f(0.05, 0.5, 0, det.ctypes.data, fit.ctypes.data, bbox.ctypes.data, num.ctypes.data, B, C1, sn, 16, out.ctypes.data, cnt.ctypes.data)
+    # candidates above log(0.05): three; the second overlaps the first (IoU 0.82) and scores lower -> dropped
+    assert cnt[0] == 2
+    np.testing.assert_allclose(out[0, 0, 0], np.exp(-0.1), rtol=1e-6)
+    np.testing.assert_allclose(out[0, 1, 2:], [.6, .6, 1, 1])

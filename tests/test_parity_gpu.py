@@ -1,0 +1,354 @@
+"""GPU parity of the hot path against the oracle (oracle/): every check goes through the C-ABI via the product's
+host layer (denet_amd) and compares with the CPU restatement on the same seeded inputs.
+
+  * RoI proposal (GPU build_samples) vs oracle C++: integer boxes bit-exact, order identical up to exact score ties
+  * sparse gather taps bit-exact (both tap rules)
+  * one/two full training steps of a reduced DeNet-34 skip and of the CIFAR 3-layer CNN vs the numpy oracle:
+    activations / costs / updated parameters within 1e-3 relative, RoI lists bit-identical
+  * full-size (B=32, 512x512) size-independent properties: determinism, sortedness, idempotence, gather checksum
+"""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from denet_amd import ops
+from denet_amd.model import zoo
+from oracle import model as OM
+from oracle import layers as OL
+
+
+def rel_close(a, b, rtol=1e-3, what="", atol=0.0):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    scale = np.abs(b).max() + 1e-12
+    err = np.abs(a - b).max()
+    assert err <= rtol * scale + atol, "%s: max abs err %.3e vs scale %.3e (rel %.2e)" % (what, err, scale, err / scale)
+
+
+def random_corner_map(rng, B, H, W, frac, Cn=4):
+    """log-probability maps with roughly `frac` of the cells above the 0.01 threshold"""
+    z = rng.randn(B, Cn, H, W).astype(np.float32) * 2.0
+    thr = np.quantile(z, 1.0 - frac)
+    x = (z - thr) * 1.5 - 2.2975        # logit offset so that sigma(2x') crosses 0.01 at the quantile
+    pos = -np.logaddexp(0, -2 * x).astype(np.float32)      # log sigma(2x)
+    neg = -np.logaddexp(0, 2 * x).astype(np.float32)
+    return np.ascontiguousarray(np.stack([neg, pos], axis=1).astype(np.float32))
+
+
+def check_samples(pr_map, thr, sn, maxc, lm):
+    d = torch.from_numpy(pr_map).cuda()
+    box, absd, cnt = ops.build_samples(d, thr, sn * sn, maxc, lm)
+    box, absd, cnt = box.cpu(), absd.cpu(), cnt.cpu()
+    got = ops.samples_finish_host(box, absd, cnt, pr_map.shape[3], pr_map.shape[4]).numpy()
+    ref, rbox, rabsd, rcnt = OM.oracle_build_samples_raw(pr_map, thr, sn, maxc, lm)
+    assert np.array_equal(cnt.numpy(), rcnt)
+    box, absd = box.numpy(), absd.numpy()
+    nties = 0
+    for b in range(pr_map.shape[0]):
+        n = rcnt[b]
+        # scores: identical multiset, non-increasing
+        assert np.array_equal(got[b, :n, 0], ref[b, :n, 0]), "score sequence differs"
+        assert np.all(np.diff(absd[b, :n]) >= 0)
+        # boxes: identical inside every group of equal score (order inside a tie group is unspecified)
+        i = 0
+        while i < n:
+            j = i
+            while j + 1 < n and ref[b, j + 1, 0] == ref[b, i, 0]:
+                j += 1
+            ga = sorted(map(tuple, box[b, i:j + 1].tolist()))
+            gb = sorted(map(tuple, rbox[b, i:j + 1].tolist()))
+            if j + 1 == n and n == sn * sn and ga != gb:
+                pass     # a tie group cut by the top-K boundary may keep different members
+            else:
+                assert ga == gb, "boxes differ at rank %d..%d" % (i, j)
+            if j == i:
+                assert np.array_equal(got[b, i], ref[b, i])
+            nties += j - i
+            i = j + 1
+    return int(rcnt.sum()), nties
+
+
+@pytest.mark.parametrize("frac,lm", [(0.0, 0), (0.004, 0), (0.01, 0), (0.02, 1), (0.05, 2), (0.4, 0)])
+def test_build_samples_vs_oracle(hip, frac, lm):
+    rng = np.random.RandomState(int(frac * 1000) + lm)
+    pr = random_corner_map(rng, 4, 64, 64, frac)
+    total, ties = check_samples(pr, 0.01, 24, 1024, lm)
+    if frac == 0.0:
+        assert total == 0
+    else:
+        assert total > 0
+
+
+def test_build_samples_truncation_and_small_k(hip):
+    rng = np.random.RandomState(9)
+    pr = random_corner_map(rng, 2, 64, 64, 0.5)        # > 1024 corners per type -> top-1024 by log-probability
+    counts = np.zeros(8, np.int32)
+    import ctypes
+    f = OM.oracle_lib().oracle_count_corners
+    f.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    f(pr.ctypes.data, 2, 4, 64, 64, 0.01, 100000, 0, counts.ctypes.data)
+    assert counts.min() > 1024
+    check_samples(pr, 0.01, 24, 1024, 0)
+    check_samples(pr, 0.01, 4, 64, 0)
+    check_samples(random_corner_map(rng, 3, 16, 16, 0.1), 0.01, 24, 1024, 0)
+
+
+def test_build_samples_exact_ties(hip):
+    """hand-built ties: identical scores for many boxes -> same scores, same boxes per tie group"""
+    P = np.full((1, 4, 16, 16), 1e-4, np.float64)
+    for (x, y) in [(1, 1), (2, 1), (1, 2), (3, 3)]:
+        P[0, 0, y, x] = 0.5
+    for (x, y) in [(10, 10), (12, 10), (10, 12), (14, 14)]:
+        P[0, 3, y, x] = 0.5
+    pr = np.ascontiguousarray(np.stack([np.log(1 - P), np.log(P)], axis=1).astype(np.float32))
+    total, ties = check_samples(pr, 0.01, 24, 1024, 0)
+    assert total == 16 and ties > 0
+
+
+def _product_acts(model):
+    out = {}
+    for i, layer in enumerate(model.layers[1:], 1):
+        a = layer.output
+        if a.data is None:
+            continue
+        if a.data.dim() == 4:
+            out[i] = ops.nhwc_to_nchw(a.data, a.shape[1]).cpu().numpy()
+    return out
+
+
+def _force_list(model):
+    """the product's op outputs (NCHW numpy) in the order the oracle interpreter evaluates its ops"""
+    def nchw(act):
+        return ops.nhwc_to_nchw(act.data, act.shape[1]).cpu().numpy()
+
+    out = []
+    for layer in model.layers[1:]:
+        t = layer.type_name
+        if t in ("conv", "batchnorm", "batchnorm-relu", "pool", "pool-inv"):
+            out.append(nchw(layer.output))
+        elif t == "activation":
+            if layer.activation != "none":
+                out.append(nchw(layer.output))
+        elif t == "resnet":
+            main, sc = layer._main(), layer._shortcut()
+            for s in main:
+                fused_tail = (s is main[-1]) and ("pre-activation" not in layer.version)
+                if s.type_name == "activation" and s.activation == "none":
+                    continue
+                out.append(None if fused_tail else nchw(s.output))   # the last BN is fused with add+ReLU
+            for s in sc:
+                out.append(nchw(s.output))
+            out.append(nchw(layer.output))
+        elif t == "skip":
+            out.append(nchw(layer.output))
+        elif t in ("denet-corner", "denet-detect"):
+            out.append(nchw(layer.conv.output))
+        elif t == "denet-sparse":
+            out.append(nchw(layer.output))
+    return out
+
+
+def _param_pairs(model, om):
+    def walk(layers):
+        out = []
+        for l in layers:
+            if l.type_name == "conv" and l.enabled:
+                out.append(l.omega)
+                if l.use_bias:
+                    out.append(l.beta)
+            elif l.type_name in ("batchnorm", "batchnorm-relu") and l.enabled:
+                out += [l.omega, l.beta]
+            out += walk([s for s in l.layers if s.type_name != "initial"])
+        return out
+
+    pp, op = walk(model.layers[1:]), om.params()
+    assert len(pp) == len(op)
+    for a, b in zip(pp, op):
+        assert a.value.shape == b.v.shape
+    # a conv bias directly in front of a batch norm has an analytically zero gradient
+    for l, nxt in zip(model.layers[1:-1], model.layers[2:]):
+        if l.type_name == "conv" and l.use_bias and nxt.type_name in ("batchnorm", "batchnorm-relu"):
+            l.beta.zero_grad_expected = l.omega
+    return list(zip(pp, op))
+
+
+def _bn_pairs(model, om):
+    def walk(layers):
+        out = []
+        for l in layers:
+            if l.type_name in ("batchnorm", "batchnorm-relu") and l.enabled:
+                out.append(l)
+            out += walk([s for s in l.layers if s.type_name != "initial"])
+        return out
+
+    a, b = walk(model.layers[1:]), om.bn_nodes()
+    assert len(a) == len(b)
+    return list(zip(a, b))
+
+
+def _forced_step_check(model, om, x, metas, it, lr, mu, decay, solver, roi_lists, rtol=1e-3):
+    """op-by-op parity: the oracle re-runs the step with every op output replaced by the product's tensor
+    (identical inputs per op, identical ReLU masks), so forward, gradients, running statistics and the solver
+    update are each compared without 40 layers of accumulated rounding in between."""
+    grads = [(p, p.get_grad()) for p, _ in _param_pairs(model, om)]
+    om.force = _force_list(model)
+    ocost, ocosts = om.train_step(x, metas, it, lr, mu, decay, solver, sample_override=roi_lists)
+    om.force = None
+    assert om._fpos == len(_force_list(model)), "op order mismatch between product and oracle"
+    worst = max(om.force_err, key=lambda e: e[1])
+    assert worst[1] <= 2e-4, "per-op forward error %s" % (worst,)
+    for (p, g), (_, o) in zip(grads, _param_pairs(model, om)):
+        og = o.g if o.g is not None else np.zeros_like(o.v)
+        atol = 0.0
+        w = getattr(p, "zero_grad_expected", None)
+        if w is not None:      # both sides hold only fp32 roundoff: bound it by the layer's weight-gradient scale
+            atol = 1e-3 * float(np.abs(w.get_grad()).max()) * w.value[0].size ** 0.5
+        rel_close(g, og, rtol, "it%d grad %s %s" % (it, p.name, g.shape), atol=atol)
+    for p, o in _param_pairs(model, om):
+        # updated value of a zero-gradient bias = lr * roundoff: same bound, scaled by the learning rate
+        w = getattr(p, "zero_grad_expected", None)
+        atol = 1e-6 if w is None else 1e-6 + lr * 1e-3 * float(np.abs(w.get_grad()).max()) * w.value[0].size ** 0.5 * 2
+        rel_close(p.get_value(), o.v, rtol, "it%d updated %s" % (it, p.name), atol=atol)
+    for l, n in _bn_pairs(model, om):
+        rel_close(l.mean.get_value(), n["mean"], rtol, "running mean")
+        rel_close(l.stdinv.get_value(), n["stdinv"], rtol, "running stdinv")
+    return ocost, ocosts
+
+
+def _warm_corner_head(model, bias, std, seed=3):
+    """makes the corner detector fire: random corner filters + a lower bias (SURVEY §8d 'warm' regime)"""
+    rng = np.random.RandomState(seed)
+    conv = model.layers[30].layers[-1]
+    w = conv.omega.get_value().copy()
+    w[:4] = rng.normal(0, std, w[:4].shape)
+    conv.omega.set_value(w)
+    b = conv.beta.get_value().copy()
+    b[:4] = bias
+    conv.beta.set_value(b)
+
+
+@pytest.mark.parametrize("regime", ["cold", "warm"])
+def test_denet34_skip_train_step_vs_oracle(hip, regime):
+    B, IMG = 2, 128
+    model = zoo.denet34(B, "skip", IMG, class_num=80, seed=1)
+    # break the all-zero detect head so that its gradients are exercised
+    rng = np.random.RandomState(5)
+    dconv = model.layers[40].layers[0]
+    dconv.omega.set_value(rng.normal(0, 0.05, dconv.omega.value.shape))
+    if regime == "warm":
+        _warm_corner_head(model, 4.0, 0.3)
+    x, metas = zoo.synthetic_batch(B, IMG, seed=2)
+    om_free = OM.OracleModel(model.export_json(), B)      # free running
+    om = OM.OracleModel(model.export_json(), B)           # teacher forced, op by op
+    model.build_train_func("nesterov")
+    lr, mu, decay = 0.05, 0.9, 1e-4
+    for it in range(2):
+        random.seed(100 + it)
+        cost, costs = model.train_step(x, metas, 0, it, lr, [mu], decay)
+        dns = model.layers[31]
+        roi_lists = dns.sample_bbox_list
+        if regime == "warm":
+            # the RoI proposal contract is exact on the SAME corner map: oracle C++ on the product's map
+            cl = model.layers[30]
+            lists = OM.oracle_build_samples(cl.corner_pr.cpu().numpy(), dns.corner_threshold, dns.sample_num, 1024, 0)
+            if it == 0:
+                assert sum(len(l) for l in lists) > 0, "warm regime produced no detector boxes"
+            random.seed(100 + it)
+            ref_lists = OL.edit_samples(lists, metas, dns.sample_count, dns.random_sample, dns.sample_gt)
+            assert ref_lists == roi_lists, "RoI lists differ from the oracle on the same corner map"
+        if it == 0:
+            # free-running oracle: whole-network forward parity (1e-3 rel on activations and costs)
+            random.seed(100 + it)
+            if regime == "warm":
+                fcost, fcosts = om_free.train_step(x, metas, it, lr, mu, decay, "nesterov", sample_override=roi_lists)
+            else:
+                fcost, fcosts = om_free.train_step(x, metas, it, lr, mu, decay, "nesterov")
+                assert om_free.sample_bbox_list == roi_lists, "RoI lists differ (cold: random boxes + GT injection)"
+            ys, xs = om_free.taps
+            taps_ref = (ys[:, :, None] * (IMG // 8) + xs[:, None, :]).reshape(ys.shape[0], -1)
+            assert np.array_equal(dns._taps.cpu().numpy(), taps_ref)
+            assert abs(cost - fcost) <= 1e-3 * abs(fcost), (cost, fcost)
+            for c, oc in zip(costs, fcosts):
+                assert abs(c - oc) <= 1e-3 * max(abs(oc), 1e-6), (costs, fcosts)
+            for i, a in _product_acts(model).items():
+                rel_close(a, om_free.acts[i], 1e-3, "activation L%d %s" % (i, model.layers[i].type_name))
+            rel_close(model.layers[30].corner_pr.cpu().numpy(), om_free.corner_pr, 1e-3, "corner_pr")
+        # op-by-op forward + backward + solver parity
+        ocost, ocosts = _forced_step_check(model, om, x, metas, it, lr, mu, decay, "nesterov", roi_lists)
+        assert abs(cost - ocost) <= 1e-4 * abs(ocost), (cost, ocost)
+        ys, xs = om.taps
+        taps_ref = (ys[:, :, None] * (IMG // 8) + xs[:, None, :]).reshape(ys.shape[0], -1)
+        assert np.array_equal(dns._taps.cpu().numpy(), taps_ref)
+
+
+def test_cifar3_train_step_vs_oracle(hip):
+    """BASELINE config 1 (README.md:52 three-layer CNN): unfused BN / A / P / P.A / R path"""
+    B = 8
+    model = zoo.cifar3(B, 10, seed=3)
+    rng = np.random.RandomState(1)
+    x = rng.uniform(0, 1, (B, 3, 32, 32)).astype(np.float32)
+    metas = [{"image_class": int(rng.randint(0, 10)), "bbox": [], "class": []} for _ in range(B)]
+    rconv = model.layers[-2]
+    rconv.omega.set_value(rng.normal(0, 0.05, rconv.omega.value.shape))
+    om = OM.OracleModel(model.export_json(), B)
+    om_free = OM.OracleModel(model.export_json(), B)
+    model.build_train_func("sgd")
+    for it in range(2):
+        cost, costs = model.train_step(x, metas, 0, it, 0.1, [0.9], 1e-4)
+        if it == 0:
+            fcost, _ = om_free.train_step(x, metas, it, 0.1, 0.9, 1e-4, "sgd")
+            assert abs(cost - fcost) <= 1e-3 * abs(fcost), (cost, fcost)
+            for i, a in _product_acts(model).items():
+                rel_close(a, om_free.acts[i], 1e-3, "activation L%d" % i)
+        ocost, _ = _forced_step_check(model, om, x, metas, it, 0.1, 0.9, 1e-4, "sgd", None)
+        assert abs(cost - ocost) <= 1e-4 * abs(ocost), (cost, ocost)
+    # inference: BN test mode (double eps) + softmax probabilities
+    p = model.predict_output_step(x)
+    om.forward(x, None, train=False)
+    logits = om.out.v.reshape(B, 10).astype(np.float64)
+    ref = np.exp(OL.log_softmax(logits, axis=1))
+    rel_close(p, ref, 1e-3, "predict")
+
+
+def test_full_size_properties(hip):
+    """BASELINE config 3 at full size (B=32, 512x512): properties that do not need the slow CPU oracle"""
+    B = 32
+    x, metas = zoo.synthetic_batch(B, 512, seed=1)
+    xd = torch.from_numpy(x).cuda()
+    results = []
+    for run in range(2):
+        model = zoo.denet34(B, "skip", 512, seed=1)
+        _warm_corner_head(model, 7.5, 0.3)
+        model.build_train_func("nesterov")
+        random.seed(1)
+        c0 = model.train_step(xd, metas, 0, 0, 0.1, [0.9], 1e-4)
+        c1 = model.train_step(xd, metas, 0, 1, 0.1, [0.9], 1e-4)
+        results.append((c0, c1, model.P.clone()))
+        assert np.isfinite(c0[0]) and np.isfinite(c1[0])
+    # determinism: no atomics on floating point anywhere in the step
+    assert results[0][0] == results[1][0] and results[0][1] == results[1][1]
+    assert torch.equal(results[0][2], results[1][2])
+    # RoI proposal: sortedness + idempotence at full size, against the oracle on the same map
+    cl, dns = model.layers[30], model.layers[31]
+    pr = cl.corner_pr
+    b1 = ops.build_samples(pr, 0.01, 576, 1024, 0)
+    b2 = ops.build_samples(pr, 0.01, 576, 1024, 0)
+    assert all(torch.equal(a, b) for a, b in zip(b1, b2))
+    cnt = b1[2].cpu().numpy()
+    absd = b1[1].cpu().numpy()
+    assert cnt.sum() > 0
+    for b in range(B):
+        assert np.all(np.diff(absd[b, :cnt[b]]) >= 0)
+    check_samples(pr.cpu().numpy(), 0.01, 24, 1024, 0)
+    # gather checksum: every output row is a copy of fmap rows at the recorded taps
+    fmap, coff, F = cl.sample_map()
+    out = dns.output.data.view(B * 576, -1)
+    taps = dns._taps.long()
+    rows = torch.arange(B * 576, device="cuda") // 576
+    for t in (0, 24, 48):
+        src = fmap.view(B, -1, fmap.shape[-1])[rows, taps[:, t], coff:coff + F]
+        assert torch.equal(out[:, t * F:(t + 1) * F], src)
+    assert float(out[:, 49 * F + 2:].abs().max()) == 0.0
