@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of one DeNet-34 skip training step at 512x512 (BASELINE.json metric) on N MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+         bench.py --gpus N --steps K --warmup W
+
+A "step" = one full training step of the hot path on one synthetic MSCOCO-shaped batch of 32 images per GPU:
+host targets -> forward (conv/BN stack, corner map, GPU RoI proposal, RoI editing, sparse gather, RoI head) ->
+costs -> backward -> (N>1: RCCL gradient all-reduce overlapped with backward) -> fused nesterov update.
+Inputs are resident in HBM before the timed region. Rank 0 prints ONE JSON line.
+
+Extra legs (rank 0, N=1 only; outside the timed region):
+  roofline      the dominant kernel (implicit-GEMM convolution instantiation with the largest total time) is timed
+                live with HIP events on the launch stream over `steps` further instrumented steps;
+                achieved = algorithmic FLOPs per launch / average launch duration; peak = fp32 MFMA 157.3 TFLOP/s.
+  cpu_baseline  the numpy/C++ oracle (oracle/, a CPU restatement of the reference path, kind "port") runs ONE
+                training step of the same model at batch 1 on the host cores.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_IMAGE_STEP = 164.3e9     # 3 x 2 x 27.38 GMAC (conv/GEMM only, no recompute)
+PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BATCH_PER_GPU = 32                # papers/dss/denet34.sh:43 --batch-size 32
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--regime", default="cold", choices=["cold", "warm"],
+                    help="cold = weights as initialised (corner bias +5: no detector RoIs, SURVEY §8d); warm = corner "
+                         "head re-biased so that ~1%% of the cells fire")
+    args = ap.parse_args()
+
+    import numpy
+    import torch
+    from denet_amd import ops
+    from denet_amd.model import zoo
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (one rank per GPU)" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dp = None
+    if world > 1:
+        from denet_amd.multi import DataParallel
+        dp = DataParallel(backend="nccl")
+
+    # identical initial weights on every rank (seed), per-rank data shard (seed + rank)
+    model = zoo.denet34(BATCH_PER_GPU, "skip", 512, class_num=80, seed=1)
+    if args.regime == "warm":
+        rng = numpy.random.RandomState(3)
+        conv = model.layers[30].layers[-1]
+        w = conv.omega.get_value().copy()
+        w[:4] = rng.normal(0, 0.3, w[:4].shape)
+        conv.omega.set_value(w)
+        b = conv.beta.get_value().copy()
+        b[:4] = 7.5
+        conv.beta.set_value(b)
+    model.build_train_func("nesterov")
+    if dp is not None:
+        model.dist = dp
+        dp.broadcast_state(model)
+    x, metas = zoo.synthetic_batch(BATCH_PER_GPU, 512, 80, seed=1 + rank)
+    xd = torch.from_numpy(x).cuda()
+    random.seed(1 + rank)
+    lr, mom, decay = 0.1, [0.9], 1e-4     # papers/dss/denet34.sh:43
+
+    def sync():
+        if dp is not None:
+            dp.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(args.warmup):
+        model.train_step(xd, metas, 0, it, lr, mom, decay)
+        it += 1
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cost, _ = model.train_step(xd, metas, 0, it, lr, mom, decay)
+        it += 1
+    sync()
+    dt = time.perf_counter() - t0
+    if dp is not None:
+        dt = dp.max_over_ranks(dt)
+    if not numpy.isfinite(cost):
+        raise SystemExit("non-finite cost %r" % cost)
+    images = BATCH_PER_GPU * world * args.steps
+    value = images / dt
+
+    out = {
+        "metric": "images/sec train step, DeNet-34 skip 512x512",
+        "value": round(value, 2),
+        "unit": "images/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "DeNet-34 skip full DSS head (corner + sparse RoI + classify) 512x512 synthetic "
+                               "MSCOCO, full train step (targets, fwd, bwd, nesterov), %s corner regime" % args.regime,
+                   "global_batch": BATCH_PER_GPU * world, "batch_per_gpu": BATCH_PER_GPU, "classes": 80,
+                   "rois_per_image": 576, "parallelism": "dp%d" % world, "solver": "nesterov",
+                   "final_cost": round(float(cost), 5)},
+        "step_tflops_algorithmic": round(value * FLOP_PER_IMAGE_STEP / 1e12, 2),
+        "step_frac_of_fp32_mfma_peak": round(value * FLOP_PER_IMAGE_STEP / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
+    }
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        prof = ops.KernelProfile()
+        ops.PROFILE = prof
+        nprof = max(1, min(args.steps, 5))
+        for _ in range(nprof):
+            model.train_step(xd, metas, 0, it, lr, mom, decay)
+            it += 1
+        ops.PROFILE = None
+        agg = prof.summary()
+        name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        avg_ms = a["ms"] / a["launches"]
+        achieved = (a["flops"] / a["launches"]) / (avg_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2),
+                           "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": a["launches"] // nprof, "avg_launch_ms": round(avg_ms, 4),
+                           "flop_per_launch": round(a["flops"] / a["launches"]),
+                           "all_igemm": {k: {"launches_per_step": v["launches"] // nprof,
+                                             "ms_per_step": round(v["ms"] / nprof, 3),
+                                             "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                                         for k, v in sorted(agg.items())}}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import model as OM
+        cores = len(os.sched_getaffinity(0))
+        m1 = zoo.denet34(1, "skip", 512, class_num=80, seed=1)
+        om = OM.OracleModel(m1.export_json(), 1)
+        x1, metas1 = zoo.synthetic_batch(1, 512, 80, seed=1)
+        random.seed(1)
+        t0 = time.perf_counter()
+        om.train_step(x1, metas1, 0, lr, mom[0], decay, "nesterov")
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(1.0 / cdt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+                               "sample": "1 full train step at batch 1 of the same model (numpy im2col+BLAS conv, "
+                                         "C++ RoI proposal), %.1f s" % cdt}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

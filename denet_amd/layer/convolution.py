@@ -138,10 +138,14 @@ class ConvLayer(AbstractLayer):
     def _w(self):
         return self.omega.dev.view(self.omega.dev_shape)
 
+    def _logical(self):
+        return (self.filter_shape[1], self.filter_shape[0])
+
     def forward(self, ctx, add=None):
         x = self.input.data
         self.output.data = ops.conv_fwd(x, self._w(), bias=self.beta.dev if self.use_bias else None, add=add,
-                                        stride=self.stride[0], pad=self.pad, s_real=self.filter_shape[3])
+                                        stride=self.stride[0], pad=self.pad, s_real=self.filter_shape[3],
+                                        logical=self._logical())
 
     def backward(self, ctx):
         dy = self.output.grad
@@ -149,9 +153,9 @@ class ConvLayer(AbstractLayer):
         st, pad, sr = self.stride[0], self.pad, self.filter_shape[3]
         if self.enabled and self.omega.grad is not None:
             ops.conv_wgrad(x, dy, self.omega.dev_shape, stride=st, pad=pad, s_real=sr,
-                           out=self.omega.grad.view(self.omega.dev_shape))
+                           out=self.omega.grad.view(self.omega.dev_shape), logical=self._logical())
             if self.use_bias:
                 ops.colsum(dy.view(-1, self.kp), out=self.beta.grad)
         if getattr(self.input, "requires_grad", True):
             self.input.grad = ops.conv_dgrad(dy, self._w(), tuple(x.shape), add=self.input.grad, stride=st, pad=pad,
-                                             s_real=sr)
+                                             s_real=sr, logical=self._logical())

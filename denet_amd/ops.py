@@ -36,6 +36,52 @@ WS = Workspace()
 WGRAD_WS_BYTES = 512 << 20
 
 
+class KernelProfile:
+    """Live per-kernel timing with HIP events on the stream the kernels are launched on (bench.py's roofline
+    leg). Each convolution launch is bracketed by two events; algorithmic FLOPs = 2 * MACs of the layer."""
+
+    def __init__(self):
+        self.records = []
+
+    def bracket(self, name, flops):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.append((name, flops, s, e))
+        return s, e
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, flops, s, e in self.records:
+            a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            a["launches"] += 1
+            a["ms"] += s.elapsed_time(e)
+            a["flops"] += flops
+        return agg
+
+
+PROFILE = None
+
+
+def _igemm_name(mode, g):
+    """mirrors the tile selection of csrc/igemm.hip (launch_igemm instantiation per geometry)"""
+    N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
+    if mode == "fwd":
+        tile = "128x128" if K >= 128 else "128x64"
+    elif mode == "dgrad":
+        tile = "128x128" if C >= 128 else "128x64"
+    else:
+        tile = "128x128" if K >= 128 else "64x128"
+    return "igemm_kernel<%s,%s>" % (mode, tile)
+
+
+def _conv_flops(g, logical=None):
+    """algorithmic FLOPs = 2 * MACs over the LOGICAL channel counts (padding channels / taps do not count)"""
+    N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
+    if logical is not None:
+        C, K = logical
+    return 2.0 * N * OH * OW * K * R * s_real * C
+
+
 def conv_geom(x_shape, w_shape, stride, pad, s_real=None):
     N, H, W, C = x_shape
     K, R, S, Cw = w_shape
@@ -46,28 +92,43 @@ def conv_geom(x_shape, w_shape, stride, pad, s_real=None):
     return N, H, W, C, K, R, S, s_real, stride, pad, OH, OW
 
 
-def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None):
+def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, logical=None):
     g = conv_geom(x.shape, w.shape, stride, pad, s_real)
     N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
     y = out if out is not None else empty(N, OH, OW, K)
+    if PROFILE is not None:
+        ev = PROFILE.bracket(_igemm_name("fwd", g), _conv_flops(g, logical))
+        ev[0].record()
     check(_L().denet_conv_fwd(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), *g, stream_ptr()), "conv_fwd")
+    if PROFILE is not None:
+        ev[1].record()
     return y
 
 
-def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None):
+def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None, logical=None):
     g = conv_geom(x_shape, w.shape, stride, pad, s_real)
     assert tuple(dy.shape) == (g[0], g[10], g[11], g[4]), (dy.shape, g)
     dx = out if out is not None else empty(*x_shape)
+    if PROFILE is not None:
+        ev = PROFILE.bracket(_igemm_name("dgrad", g), _conv_flops(g, logical))
+        ev[0].record()
     check(_L().denet_conv_dgrad(ptr(dy), ptr(w), ptr(add), ptr(dx), *g, stream_ptr()), "conv_dgrad")
+    if PROFILE is not None:
+        ev[1].record()
     return dx
 
 
-def conv_wgrad(x, dy, w_shape, stride=1, pad=0, s_real=None, out=None):
+def conv_wgrad(x, dy, w_shape, stride=1, pad=0, s_real=None, out=None, logical=None):
     g = conv_geom(x.shape, w_shape, stride, pad, s_real)
     assert tuple(dy.shape) == (g[0], g[10], g[11], g[4]), (dy.shape, g)
     dw = out if out is not None else empty(*w_shape)
     ws = WS.get("wgrad", WGRAD_WS_BYTES)
+    if PROFILE is not None:
+        ev = PROFILE.bracket(_igemm_name("wgrad", g), _conv_flops(g, logical))
+        ev[0].record()
     check(_L().denet_conv_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel(), *g, stream_ptr()), "conv_wgrad")
+    if PROFILE is not None:
+        ev[1].record()
     return dw
 
 
