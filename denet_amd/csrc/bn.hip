@@ -79,7 +79,17 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
     s = 0;
     ss = 0;
     if (c < C) {
-        for (int j = jl; j < gy; j += 8) {
+        int j = jl;
+        // 4 independent row loads in flight per lane: the loop is latency bound, not bandwidth bound
+        for (; j + 24 < gy; j += 32) {
+            const double a0 = partial[(long)j * 2 * C + c], b0 = partial[(long)j * 2 * C + C + c];
+            const double a1 = partial[(long)(j + 8) * 2 * C + c], b1 = partial[(long)(j + 8) * 2 * C + C + c];
+            const double a2 = partial[(long)(j + 16) * 2 * C + c], b2 = partial[(long)(j + 16) * 2 * C + C + c];
+            const double a3 = partial[(long)(j + 24) * 2 * C + c], b3 = partial[(long)(j + 24) * 2 * C + C + c];
+            s += (a0 + a1) + (a2 + a3);
+            ss += (b0 + b1) + (b2 + b3);
+        }
+        for (; j < gy; j += 8) {
             s += partial[(long)j * 2 * C + c];
             ss += partial[(long)j * 2 * C + C + c];
         }

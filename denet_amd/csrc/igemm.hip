@@ -464,8 +464,8 @@ extern "C" int denet_conv_dgrad(const float* dy, const float* w, const float* ad
 }
 
 extern "C" size_t denet_conv_wgrad_workspace_bytes(int N, int C, int K, int R, int S, int OH, int OW) {
-    // upper bound used by the launcher below: at most 64 split slices
-    return (size_t)64 * K * R * S * C * sizeof(float);
+    // upper bound used by the launcher below: at most 512 split slices
+    return (size_t)512 * K * R * S * C * sizeof(float);
 }
 
 extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes,
@@ -486,13 +486,13 @@ extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, floa
     p.tiles_m = ceil_div(K, bm); p.tiles_n = ceil_div(p.NC, 128);
     const long wsize = (long)K * p.NC;
     p.split_stride = wsize;
-    // split the pixel reduction so that the grid fills the chip (>= ~1024 workgroups), keeping
-    // at least 8 chunks per slice; bounded by the caller's workspace
+    // split the pixel reduction so that the grid fills the chip (~2048 workgroups = 4 waves of 2 per CU),
+    // keeping at least 8 chunks per slice; bounded by the caller's workspace
     int tiles = p.tiles_m * p.tiles_n;
-    int splits = ceil_div(1024, tiles);
+    int splits = ceil_div(2048, tiles);
     splits = splits < 1 ? 1 : splits;
     if (splits > p.ksteps / 8) splits = p.ksteps / 8;
-    if (splits > 64) splits = 64;
+    if (splits > 512) splits = 512;
     if (splits < 1) splits = 1;
     size_t max_by_ws = workspace ? workspace_bytes / ((size_t)wsize * sizeof(float)) : 0;
     if ((size_t)splits > max_by_ws) splits = (int)max_by_ws;

@@ -119,17 +119,36 @@ class DeNetSparseLayer(AbstractLayer):
 
     # ---- corner detector -> sample boxes ------------------------------------------------------------------
     def _device_samples(self, store_shared=False):
+        """GPU RoI proposal + ONE device->host copy of its packed result (boxes, |d|, counts)"""
+        import torch
         cl = self.corner_layer
         assert cl.corner_pr is not None, "run the model forward up to the corner layer first"
-        box, absd, count = ops.build_samples(cl.corner_pr, float(self.corner_threshold), self.sample_count,
-                                             self.corner_max, int(self.local_max))
+        B, S = self.batch_size, self.sample_count
+        words = B * S * 5 + B
+        if getattr(self, "_res_dev", None) is None:
+            self._res_dev = torch.empty(words, dtype=torch.int32, device="cuda")
+            self._res_host = torch.empty(words, dtype=torch.int32).pin_memory()
+        r = self._res_dev
+        box = r[:B * S * 4].view(B, S, 4)
+        absd = r[B * S * 4:B * S * 5].view(torch.float32).view(B, S)
+        count = r[B * S * 5:]
+        ops.build_samples(cl.corner_pr, float(self.corner_threshold), S, self.corner_max, int(self.local_max),
+                          out=(box, absd, count))
         if store_shared:
             cl.sample_shared = cl.conv.output.data
-        box, absd, count = box.cpu(), absd.cpu(), count.cpu()     # one small D2H, implicit sync
-        samples = ops.samples_finish_host(box, absd, count, cl.height, cl.width).numpy().astype(numpy.float64)
-        counts = count.tolist()
-        prs = [samples[b, :counts[b], 0] for b in range(self.batch_size)]
-        boxes = [samples[b, :counts[b], 1:5] for b in range(self.batch_size)]
+        self._res_host.copy_(r, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        h = self._res_host
+        hcount = h[B * S * 5:]
+        if int(hcount.sum()) == 0:        # cold detector: nothing proposed
+            empty_pr, empty_bx = numpy.zeros((0,)), numpy.zeros((0, 4))
+            return [empty_pr] * B, [empty_bx] * B
+        hbox = h[:B * S * 4].view(B, S, 4)
+        habsd = h[B * S * 4:B * S * 5].view(torch.float32).view(B, S)
+        samples = ops.samples_finish_host(hbox, habsd, hcount, cl.height, cl.width).numpy().astype(numpy.float64)
+        counts = hcount.tolist()
+        prs = [samples[b, :counts[b], 0] for b in range(B)]
+        boxes = [samples[b, :counts[b], 1:5] for b in range(B)]
         return prs, boxes
 
     def get_samples(self, data_x, train=False, store_shared=False):
@@ -168,10 +187,46 @@ class DeNetSparseLayer(AbstractLayer):
     def edit_samples(self, prs, boxes, metas):
         """training-time RoI list editing (denet_sparse.py:184-201), call for call on the stdlib generator:
         random.sample when the detector produced too many boxes, then 4 uniform draws per random box in the order
-        x0, y0, x1, y1, then ground truth written over the tail of the list."""
+        x0, y0, x1, y1, then ground truth written over the tail of the list. Draws of consecutive images that need
+        no trimming are taken from the generator in one vectorised batch (same stream, same order)."""
         total_cover = total_bbox = 0
-        out_pr, out_boxes = [], []
+        S = self.sample_count
+        n_keep = S - math.floor(self.random_sample * S)
+        B = len(metas)
+        out_pr = [None] * B
+        out_boxes = [None] * B
         mirror = PyRandomMirror()
+
+        def fill(first, last, kept):
+            """random boxes for images first..last-1 (none of them trims): one bulk draw, split in image order"""
+            ks = [S - len(kept[b][1]) for b in range(first, last)]
+            r = mirror.doubles(4 * sum(ks)).reshape(-1, 4)
+            # random.uniform(a, b) = a + (b - a) * random()
+            x0 = 0.0 + (1.0 - 0.0) * r[:, 0]
+            y0 = 0.0 + (1.0 - 0.0) * r[:, 1]
+            x1 = x0 + (1.0 - x0) * r[:, 2]
+            y1 = y0 + (1.0 - y0) * r[:, 3]
+            rnd = numpy.stack([x0, y0, x1, y1], axis=1)
+            off = 0
+            for b, k in zip(range(first, last), ks):
+                pr, bx = kept[b]
+                if k > 0:
+                    bx = numpy.concatenate([bx, rnd[off:off + k]], axis=0) if len(bx) else rnd[off:off + k].copy()
+                    pr = numpy.concatenate([pr, numpy.zeros(k)]) if len(pr) else numpy.zeros(k)
+                    off += k
+                else:
+                    bx, pr = bx.copy(), pr.copy()
+                if self.sample_gt:
+                    gt = metas[b]["bbox"]
+                    n = len(gt)
+                    if n > 0:
+                        # sample_bboxs[b][-(index+1)] = (1.0, bbox): ground truth k lands at position -(k+1)
+                        bx[S - n:] = numpy.asarray(gt, dtype=numpy.float64)[::-1]
+                        pr[S - n:] = 1.0
+                out_pr[b], out_boxes[b] = pr, bx
+
+        kept = {}
+        run_start = 0
         for b, meta in enumerate(metas):
             pr, bx = prs[b], boxes[b]
             if self.log_coverage:
@@ -183,33 +238,16 @@ class DeNetSparseLayer(AbstractLayer):
                             break
                 total_cover += cover
                 total_bbox += len(meta["bbox"])
-
-            n = self.sample_count - math.floor(self.random_sample * self.sample_count)
-            if len(bx) > n:
+            if len(bx) > n_keep:
+                # the trim of image b happens after the random boxes of images < b were drawn
+                fill(run_start, b, kept)
+                run_start = b
                 mirror.push()
-                keep = random.sample(range(len(bx)), n)     # same draws as random.sample(list, n)
+                keep = random.sample(range(len(bx)), n_keep)     # same draws as random.sample(list, n)
                 mirror.pull()
                 pr, bx = pr[keep], bx[keep]
-
-            k = self.sample_count - len(bx)
-            if k > 0:
-                r = mirror.doubles(4 * k).reshape(k, 4)
-                # random.uniform(a, b) = a + (b - a) * random()
-                x0 = 0.0 + (1.0 - 0.0) * r[:, 0]
-                y0 = 0.0 + (1.0 - 0.0) * r[:, 1]
-                x1 = x0 + (1.0 - x0) * r[:, 2]
-                y1 = y0 + (1.0 - y0) * r[:, 3]
-                bx = numpy.concatenate([bx, numpy.stack([x0, y0, x1, y1], axis=1)], axis=0)
-                pr = numpy.concatenate([pr, numpy.zeros(k)])
-            else:
-                bx, pr = bx.copy(), pr.copy()
-
-            if self.sample_gt:
-                for index, bbox in enumerate(meta["bbox"]):
-                    bx[-(index + 1)] = bbox
-                    pr[-(index + 1)] = 1.0
-            out_pr.append(pr)
-            out_boxes.append(bx)
+            kept[b] = (pr, bx)
+        fill(run_start, B, kept)
         mirror.push()
         self.coverage = (total_cover, total_bbox)
         return out_pr, out_boxes

@@ -33,7 +33,7 @@ class Workspace:
 
 
 WS = Workspace()
-WGRAD_WS_BYTES = 512 << 20
+WGRAD_WS_BYTES = 1024 << 20
 
 
 class KernelProfile:
@@ -310,14 +310,17 @@ def detect_loss(logits, det_target, bbox_valid, bbox_target, roi_bbox, dlogits, 
                                  bbox_factor, int(bounded_iou), stream_ptr()), "detect_loss")
 
 
-def build_samples(corner_pr, corner_threshold, sample_count, max_corners=1024, local_max=0):
+def build_samples(corner_pr, corner_threshold, sample_count, max_corners=1024, local_max=0, out=None):
     """Device part of build_samples: returns (box int32 [B,S,4], absd fp32 [B,S], count int32 [B]) on device."""
     B, _, cn, H, W = corner_pr.shape
     nbytes = _L().denet_build_samples_workspace_bytes(B, cn, H, W, max_corners, sample_count)
     ws = WS.get("samples", nbytes)
-    box = torch.empty((B, sample_count, 4), dtype=torch.int32, device="cuda")
-    absd = empty(B, sample_count)
-    count = torch.empty((B,), dtype=torch.int32, device="cuda")
+    if out is not None:
+        box, absd, count = out
+    else:
+        box = torch.empty((B, sample_count, 4), dtype=torch.int32, device="cuda")
+        absd = empty(B, sample_count)
+        count = torch.empty((B,), dtype=torch.int32, device="cuda")
     check(_L().denet_build_samples(ptr(corner_pr), ptr(box), ptr(absd), ptr(count), ptr(ws), ws.numel(), B, cn, H, W,
                                    corner_threshold, sample_count, max_corners, local_max, stream_ptr()),
           "build_samples")
