@@ -17,6 +17,7 @@
 //                 reduction order is a fixed permutation of k (legal: the sum is over the same terms).
 // Launch:         1-D grid over tiles with an XCD-aware remap (8 XCDs, private L2 each).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -46,8 +47,8 @@ struct IgemmParams {
     FastDiv div_row_w;  // fwd/wgrad: OW       dgrad: W
 };
 
-template <int MODE, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+template <int MODE, int BM, int BN, int WM, int WN, int NBUF>
+__global__ __launch_bounds__(256, (NBUF == 1 ? 3 : 2)) void igemm_kernel(const IgemmParams p) {
     constexpr bool A_KIN = (MODE != MODE_WGRAD);
     constexpr bool B_KIN = (MODE == MODE_FWD);
     constexpr int TM = BM / (32 * WM);
@@ -64,8 +65,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     constexpr int LPR_B = BN / 4, RPP_B = 256 / LPR_B;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sA = smem;              // [2][SZA]
-    float* sB = smem + 2 * SZA;    // [2][SZB]
+    float* sA = smem;                 // [NBUF][SZA]
+    float* sB = smem + NBUF * SZA;    // [NBUF][SZB]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -327,9 +328,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
         for (int s = 0; s < nsteps; ++s) {
             const bool more = (s + 1 < nsteps);
             if (more) load_chunk(step_begin + s + 1);
-            compute(s & 1);
-            if (more) store_chunk((s + 1) & 1);
-            __syncthreads();
+            if (NBUF == 2) {
+                compute(s & 1);
+                if (more) store_chunk((s + 1) & 1);
+                __syncthreads();
+            } else {
+                // one LDS buffer: half the LDS -> 3 workgroups per CU cover each other's barrier bubbles
+                compute(0);
+                __syncthreads();
+                if (more) store_chunk(0);
+                __syncthreads();
+            }
         }
     }
 
@@ -369,16 +378,16 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __rest
     }
 }
 
-template <int MODE, int BM, int BN, int WM, int WN>
+template <int MODE, int BM, int BN, int WM, int WN, int NBUF = 2>
 int launch_igemm(const IgemmParams& p, int splits, hipStream_t stream) {
     constexpr bool A_KIN = (MODE != MODE_WGRAD);
     constexpr bool B_KIN = (MODE == MODE_FWD);
     constexpr int SZA = A_KIN ? BM * LDK : BK * BM;
     constexpr int SZB = B_KIN ? BN * LDK : BK * BN;
-    constexpr size_t lds = 2 * (size_t)(SZA + SZB) * sizeof(float);
+    constexpr size_t lds = NBUF * (size_t)(SZA + SZB) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<MODE, BM, BN, WM, WN>,
+        hipError_t e = hipFuncSetAttribute((const void*)igemm_kernel<MODE, BM, BN, WM, WN, NBUF>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             denet_set_error("igemm: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
@@ -387,9 +396,22 @@ int launch_igemm(const IgemmParams& p, int splits, hipStream_t stream) {
         attr_set = true;
     }
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits, 1);
-    hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, NBUF>), grid, dim3(256), lds, stream, p);
     DENET_CHECK_LAUNCH("igemm");
     return DENET_OK;
+}
+
+// LDS buffering per launch: with >= 3 workgroups per CU available, the single-buffer variant (half the LDS, 3
+// resident workgroups cover each other's barrier bubbles) wins; small grids keep the double buffer.
+// DENET_IGEMM_NBUF=1|2 forces one variant (experiments).
+int nbuf_choice(long nblocks) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("DENET_IGEMM_NBUF");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 1 || forced == 2) return forced;
+    return nblocks >= 3 * 256 ? 1 : 2;
 }
 
 int ilog2_exact(int v) {
@@ -435,9 +457,11 @@ extern "C" int denet_conv_fwd(const float* x, const float* w, const float* bias,
     p.div_row_hw.init(OH * OW); p.div_row_w.init(OW);
     if (K >= 128) {
         p.tiles_m = ceil_div(p.M, 128); p.tiles_n = ceil_div(K, 128);
+        if (nbuf_choice((long)p.tiles_m * p.tiles_n) == 1) return launch_igemm<MODE_FWD, 128, 128, 2, 2, 1>(p, 1, stream);
         return launch_igemm<MODE_FWD, 128, 128, 2, 2>(p, 1, stream);
     }
     p.tiles_m = ceil_div(p.M, 128); p.tiles_n = ceil_div(K, 64);
+    if (nbuf_choice((long)p.tiles_m * p.tiles_n) == 1) return launch_igemm<MODE_FWD, 128, 64, 2, 2, 1>(p, 1, stream);
     return launch_igemm<MODE_FWD, 128, 64, 2, 2>(p, 1, stream);
 }
 
@@ -457,9 +481,11 @@ extern "C" int denet_conv_dgrad(const float* dy, const float* w, const float* ad
     p.div_row_hw.init(H * W); p.div_row_w.init(W);
     if (C >= 128) {
         p.tiles_m = ceil_div(p.M, 128); p.tiles_n = ceil_div(C, 128);
+        if (nbuf_choice((long)p.tiles_m * p.tiles_n) == 1) return launch_igemm<MODE_DGRAD, 128, 128, 2, 2, 1>(p, 1, stream);
         return launch_igemm<MODE_DGRAD, 128, 128, 2, 2>(p, 1, stream);
     }
     p.tiles_m = ceil_div(p.M, 128); p.tiles_n = ceil_div(C, 64);
+    if (nbuf_choice((long)p.tiles_m * p.tiles_n) == 1) return launch_igemm<MODE_DGRAD, 128, 64, 2, 2, 1>(p, 1, stream);
     return launch_igemm<MODE_DGRAD, 128, 64, 2, 2>(p, 1, stream);
 }
 
@@ -505,9 +531,11 @@ extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, floa
     p.steps_per_split = ceil_div(p.ksteps, splits);
     splits = ceil_div(p.ksteps, p.steps_per_split);
     if (big_m)
-        rc = launch_igemm<MODE_WGRAD, 128, 128, 2, 2>(p, splits, stream);
+        rc = nbuf_choice((long)tiles * splits) == 1 ? launch_igemm<MODE_WGRAD, 128, 128, 2, 2, 1>(p, splits, stream)
+                                : launch_igemm<MODE_WGRAD, 128, 128, 2, 2>(p, splits, stream);
     else
-        rc = launch_igemm<MODE_WGRAD, 64, 128, 2, 2>(p, splits, stream);
+        rc = nbuf_choice((long)tiles * splits) == 1 ? launch_igemm<MODE_WGRAD, 64, 128, 2, 2, 1>(p, splits, stream)
+                                : launch_igemm<MODE_WGRAD, 64, 128, 2, 2>(p, splits, stream);
     if (rc) return rc;
     if (splits > 1) {
         DENET_CHECK_ARG(wsize % 4 == 0, "conv_wgrad: weight size not a multiple of 4");

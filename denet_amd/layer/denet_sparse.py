@@ -24,25 +24,47 @@ TAP_CUDA = 1     # denet_sparse_op.py:65-71
 class PyRandomMirror:
     """Vectorised draws from the stdlib `random` stream. numpy's RandomState is the same MT19937 with the same
     53-bit double construction as CPython's `random`, so the generator state can be moved across, doubles drawn
-    in bulk, and the advanced state moved back: bit-identical to calling random.random() n times."""
+    in bulk, and the advanced state moved back: bit-identical to calling random.random() n times. sample() runs
+    CPython's random.sample(range(n), k) algorithm on the same state in native host code
+    (denet_host_py_random_sample)."""
+    _rs = None
 
     def __init__(self):
-        self.rs = numpy.random.RandomState()
+        # one generator object for the process: an unseeded RandomState() gathers OS entropy on construction
+        if PyRandomMirror._rs is None:
+            PyRandomMirror._rs = numpy.random.RandomState(0)
+        self.rs = PyRandomMirror._rs
         self.pull()
 
     def pull(self):
         """adopt the current state of the stdlib generator"""
         st = random.getstate()
         self._version, self._gauss = st[0], st[2]
-        self.rs.set_state(("MT19937", numpy.array(st[1][:-1], dtype=numpy.uint32), int(st[1][-1])))
+        self.key = numpy.array(st[1][:-1], dtype=numpy.uint32)
+        self.pos = numpy.array([st[1][-1]], dtype=numpy.int32)
 
     def push(self):
         """hand the advanced state back to the stdlib generator"""
-        ns = self.rs.get_state()
-        random.setstate((self._version, tuple(ns[1].tolist()) + (int(ns[2]),), self._gauss))
+        random.setstate((self._version, tuple(self.key.tolist()) + (int(self.pos[0]),), self._gauss))
 
     def doubles(self, n):
-        return self.rs.random_sample(n) if n > 0 else numpy.zeros((0,), dtype=numpy.float64)
+        if n <= 0:
+            return numpy.zeros((0,), dtype=numpy.float64)
+        self.rs.set_state(("MT19937", self.key, int(self.pos[0])))
+        v = self.rs.random_sample(n)
+        ns = self.rs.get_state()
+        self.key = numpy.ascontiguousarray(ns[1], dtype=numpy.uint32)
+        self.pos[0] = int(ns[2])
+        return v
+
+    def sample(self, n, k):
+        """indices chosen by random.sample(range(n), k) (== the positions random.sample(list, k) picks)"""
+        from .. import lib as _lib
+        out = numpy.empty(k, dtype=numpy.int32)
+        pool = numpy.empty(n, dtype=numpy.int32)
+        _lib.check(_lib.load().denet_host_py_random_sample(self.key.ctypes.data, self.pos.ctypes.data, int(n), int(k),
+                                                           pool.ctypes.data, out.ctypes.data), "py_random_sample")
+        return out
 
 
 def py_random_doubles(n):
@@ -137,7 +159,7 @@ class DeNetSparseLayer(AbstractLayer):
         if store_shared:
             cl.sample_shared = cl.conv.output.data
         self._res_host.copy_(r, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        ops.wait_stream()
         h = self._res_host
         hcount = h[B * S * 5:]
         if int(hcount.sum()) == 0:        # cold detector: nothing proposed
@@ -242,9 +264,7 @@ class DeNetSparseLayer(AbstractLayer):
                 # the trim of image b happens after the random boxes of images < b were drawn
                 fill(run_start, b, kept)
                 run_start = b
-                mirror.push()
-                keep = random.sample(range(len(bx)), n_keep)     # same draws as random.sample(list, n)
-                mirror.pull()
+                keep = mirror.sample(len(bx), n_keep)             # same draws as random.sample(list, n)
                 pr, bx = pr[keep], bx[keep]
             kept[b] = (pr, bx)
         fill(run_start, B, kept)

@@ -198,6 +198,8 @@ class ModelCNN:
         """allocate the flat device buffers (parameters, gradients, momentum, BN statistics) and hand each
         Param its views; layout = [weights (layer order) | biases (layer order) | frozen]"""
         import torch
+        from .. import host_tuning
+        host_tuning()
         weights, biases = [], []
         for layer in self.layers:
             weights += layer.weights()

@@ -62,6 +62,16 @@ class KernelProfile:
 PROFILE = None
 
 
+def wait_stream():
+    """host wait for everything queued on the current stream. Polls an event instead of a blocking
+    hipStreamSynchronize: the interrupt-driven wait was measured to wake up 10-30 ms late now and then on the
+    GPU box, which is a third of a training step; the mid-step RoI hand-off is latency critical."""
+    ev = torch.cuda.Event()
+    ev.record()
+    while not ev.query():
+        pass
+
+
 def _igemm_name(mode, g):
     """mirrors the tile selection of csrc/igemm.hip (launch_igemm instantiation per geometry)"""
     N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g

@@ -38,6 +38,11 @@ const char* denet_last_error(void);
 int denet_abi_version(void);
 int denet_device_info(int device, int* cu_count, int* clock_khz, char* arch, int arch_len);
 
+/* host helper of the RoI list editing (denet/layer/denet_sparse.py:184-187 `random.sample(list, n)`): advances a copy
+ * of CPython's MT19937 state exactly like random.sample(range(n), k) and returns the k chosen indices.
+ * mt_host: 624 state words, pos_host: the position word (random.getstate()[1][624]); all HOST pointers.        */
+int denet_host_py_random_sample(unsigned* mt_host, int* pos_host, int n, int k, int* pool_ws_host, int* out_host);
+
 /* ---- convolution  (denet/layer/convolution.py:80-83 -> cuDNN conv fwd; model_cnn.py:318 tensor.grad ->
  *      cuDNN bwd-data / bwd-filter).  x:[N,H,W,C]  w:[K,R,S,C]  y:[N,OH,OW,K]; `S` may be padded beyond the
  *      real tap count S_real when C < 32 (first layer: C=4, S=8, S_real=7); `add` (optional, shape of the
