@@ -366,16 +366,27 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 3 : 2)) void igemm_kernel(const I
     }
 }
 
-// sums the split-K slices of a weight-gradient workspace
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long n4, int splits,
-                                     long stride4) {
+// sums the split-K slices of a weight-gradient workspace: a workgroup owns 64 float4 columns, its 4 waves take
+// every 4th slice (4 loads in flight each) and combine through LDS in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                            long n4, int splits, long stride4) {
+    __shared__ f32x4 red[4][64];
     const f32x4* w4 = (const f32x4*)ws;
-    f32x4* o4 = (f32x4*)out;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        f32x4 s = w4[i];
-        for (int z = 1; z < splits; ++z) s += w4[i + z * stride4];
-        o4[i] = s;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long col = (long)blockIdx.x * 64 + lane;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (col < n4) {
+        int z = wv;
+        for (; z + 12 < splits; z += 16) {
+            const f32x4 a = w4[col + (long)z * stride4], b = w4[col + (long)(z + 4) * stride4];
+            const f32x4 c = w4[col + (long)(z + 8) * stride4], d = w4[col + (long)(z + 12) * stride4];
+            s += (a + b) + (c + d);
+        }
+        for (; z < splits; z += 4) s += w4[col + (long)z * stride4];
     }
+    red[wv][lane] = s;
+    __syncthreads();
+    if (wv == 0 && col < n4) ((f32x4*)out)[col] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 template <int MODE, int BM, int BN, int WM, int WN, int NBUF = 2>
@@ -540,8 +551,7 @@ extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, floa
     if (splits > 1) {
         DENET_CHECK_ARG(wsize % 4 == 0, "conv_wgrad: weight size not a multiple of 4");
         long n4 = wsize / 4;
-        int blocks = (int)((n4 + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
+        int blocks = (int)((n4 + 63) / 64);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, dw, n4, splits, n4);
         DENET_CHECK_LAUNCH("splitk_reduce");
     }

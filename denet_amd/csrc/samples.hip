@@ -223,17 +223,38 @@ __global__ __launch_bounds__(256) void pair_hist_kernel(PairCtx c, const ImgStat
         if (sh[i]) atomicAdd(&h[i], sh[i]);
 }
 
+// one workgroup per image: parallel scan of the histogram (256 threads x 16 bins)
 template <int LEVEL>
-__global__ void pair_pick_kernel(ImgState* __restrict__ state, unsigned* __restrict__ hist, int sample_count, int B) {
-    // one thread per image: a 4096-bin scan is tiny
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    ImgState st = state[b];
+__global__ __launch_bounds__(256) void pair_pick_kernel(ImgState* __restrict__ state, unsigned* __restrict__ hist,
+                                                        int sample_count, int B) {
+    __shared__ unsigned ssum[256];
+    __shared__ unsigned s_sel, s_cum;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
     unsigned* h = hist + (long)b * 4096;
-    const int nbins = (LEVEL == 2) ? 256 : 4096;
+    constexpr int NB = (LEVEL == 2) ? 256 : 4096;
+    constexpr int PER = NB / 256;
+    unsigned loc[PER];
+    unsigned mine = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        loc[i] = h[tid * PER + i];
+        mine += loc[i];
+        h[tid * PER + i] = 0u;          // ready for the next level
+    }
+    ssum[tid] = mine;
+    if (tid == 0) { s_sel = NB - 1; s_cum = 0xFFFFFFFFu; }
+    __syncthreads();
+    // inclusive scan over the 256 per-thread sums
+    for (int o = 1; o < 256; o <<= 1) {
+        const unsigned v = (tid >= o) ? ssum[tid - o] : 0u;
+        __syncthreads();
+        ssum[tid] += v;
+        __syncthreads();
+    }
+    ImgState st = state[b];
+    const unsigned total = ssum[255];
     if (LEVEL == 0) {
-        unsigned total = 0;
-        for (int i = 0; i < 4096; ++i) total += h[i];
         st.total = total;
         st.need = (unsigned)sample_count;
         st.prefix = 0;
@@ -241,22 +262,32 @@ __global__ void pair_pick_kernel(ImgState* __restrict__ state, unsigned* __restr
         if (st.done) st.prefix = 0xFFFFFFFFu;
     }
     if (!st.done) {
-        unsigned cum = 0;
-        int sel = nbins - 1;
-        for (int i = 0; i < nbins; ++i) {
-            if (cum + h[i] >= st.need) {
-                sel = i;
-                break;
+        // the first bin whose inclusive cumulative count reaches `need`
+        const unsigned before = ssum[tid] - mine;
+        if (before < st.need && ssum[tid] >= st.need) {
+            unsigned cum = before;
+            for (int i = 0; i < PER; ++i) {
+                if (cum + loc[i] >= st.need) {
+                    s_sel = tid * PER + i;
+                    s_cum = cum;
+                    break;
+                }
+                cum += loc[i];
             }
-            cum += h[i];
         }
-        st.need -= cum;
-        if (LEVEL == 0) st.prefix = (unsigned)sel << 20;
-        else if (LEVEL == 1) st.prefix |= (unsigned)sel << 8;
-        else st.prefix |= (unsigned)sel;
     }
-    for (int i = 0; i < nbins; ++i) h[i] = 0u;
-    state[b] = st;
+    __syncthreads();
+    if (tid == 0) {
+        if (!st.done) {
+            const unsigned sel = s_sel;
+            const unsigned cum = (s_cum == 0xFFFFFFFFu) ? 0u : s_cum;   // unreachable: need <= total at every level
+            st.need -= cum;
+            if (LEVEL == 0) st.prefix = sel << 20;
+            else if (LEVEL == 1) st.prefix |= sel << 8;
+            else st.prefix |= sel;
+        }
+        state[b] = st;
+    }
 }
 
 struct Cand {
@@ -407,13 +438,13 @@ extern "C" int denet_build_samples(const float* corner_pr, int* out_box, float* 
     PairCtx c;
     c.pr = corner_pr; c.corners = corners; c.ncorner = ncorner; c.bitmap = bitmap;
     c.Cn = Cn; c.H = H; c.W = W; c.max_corners = max_corners; c.nwords = l.nwords;
-    const dim3 pg(NBLK_PAIR, B), pickg((B + 63) / 64);
+    const dim3 pg(NBLK_PAIR, B), pickg(B);
     hipLaunchKernelGGL(pair_hist_kernel<0>, pg, dim3(256), 0, stream, c, state, hist);
-    hipLaunchKernelGGL(pair_pick_kernel<0>, pickg, dim3(64), 0, stream, state, hist, sample_count, B);
+    hipLaunchKernelGGL(pair_pick_kernel<0>, pickg, dim3(256), 0, stream, state, hist, sample_count, B);
     hipLaunchKernelGGL(pair_hist_kernel<1>, pg, dim3(256), 0, stream, c, state, hist);
-    hipLaunchKernelGGL(pair_pick_kernel<1>, pickg, dim3(64), 0, stream, state, hist, sample_count, B);
+    hipLaunchKernelGGL(pair_pick_kernel<1>, pickg, dim3(256), 0, stream, state, hist, sample_count, B);
     hipLaunchKernelGGL(pair_hist_kernel<2>, pg, dim3(256), 0, stream, c, state, hist);
-    hipLaunchKernelGGL(pair_pick_kernel<2>, pickg, dim3(64), 0, stream, state, hist, sample_count, B);
+    hipLaunchKernelGGL(pair_pick_kernel<2>, pickg, dim3(256), 0, stream, state, hist, sample_count, B);
     hipLaunchKernelGGL(pair_collect_kernel, pg, dim3(256), 0, stream, c, state, cand, sample_count);
     int NP2 = 1;
     while (NP2 < sample_count + TIE_CAP) NP2 <<= 1;
