@@ -43,8 +43,9 @@ struct IgemmParams {
     int tiles_m, tiles_n;
     long split_stride;  // wgrad: elements between split slices of the workspace
     int npix;           // N*OH*OW
-    FastDiv div_row_hw; // fwd/wgrad: OH*OW    dgrad: H*W
-    FastDiv div_row_w;  // fwd/wgrad: OW       dgrad: W
+    FastDiv div_row_hw; // fwd/wgrad: OH*OW    dgrad: Hc*Wc (pixels of one stride-parity class per image)
+    FastDiv div_row_w;  // fwd/wgrad: OW       dgrad: Wc
+    int Hc, Wc;         // dgrad: H/stride, W/stride
 };
 
 template <int MODE, int BM, int BN, int WM, int WN, int NBUF>
@@ -84,6 +85,19 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 3 : 2)) void igemm_kernel(const I
     if (MODE == MODE_WGRAD) {
         step_begin = blockIdx.y * p.steps_per_split;
         step_end = min(p.ksteps, step_begin + p.steps_per_split);
+    }
+    // dgrad with stride > 1: blockIdx.y enumerates the stride^2 parity classes of input pixels. A pixel of class
+    // (py,px) only receives taps r = r0 + stride*r', s = s0 + stride*s' (the others hit "holes" of the strided
+    // output), so each class is a dense problem over its own tap subset: no wasted MFMA work.
+    int dg_py = 0, dg_px = 0, dg_r0 = 0, dg_s0 = 0, dg_rc = p.R, dg_sc = p.S;
+    if (MODE == MODE_DGRAD && p.stride > 1) {
+        dg_py = blockIdx.y >> p.sshift;
+        dg_px = blockIdx.y & (p.stride - 1);
+        dg_r0 = (dg_py + p.pad) & (p.stride - 1);
+        dg_s0 = (dg_px + p.pad) & (p.stride - 1);
+        dg_rc = (p.R > dg_r0) ? ((p.R - dg_r0 + p.stride - 1) >> p.sshift) : 0;
+        dg_sc = (p.S > dg_s0) ? ((p.S - dg_s0 + p.stride - 1) >> p.sshift) : 0;
+        step_end = dg_rc * dg_sc * (p.K / BK);
     }
     const int nsteps = step_end - step_begin;
 
@@ -137,11 +151,11 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 3 : 2)) void igemm_kernel(const I
             const int m = m0 + row8 + 32 * i;
             if (m < p.M) {
                 const uint32_t n = p.div_row_hw.div(m);
-                const uint32_t rem = m - n * (p.H * p.W);
-                const uint32_t iy = p.div_row_w.div(rem);
-                const uint32_t ix = rem - iy * p.W;
-                a_y[i] = (int)iy + p.pad;
-                a_x[i] = (int)ix + p.pad;
+                const uint32_t rem = m - n * (p.Hc * p.Wc);
+                const uint32_t ya = p.div_row_w.div(rem);
+                const uint32_t xa = rem - ya * p.Wc;
+                a_y[i] = (int)ya * p.stride + dg_py + p.pad - dg_r0;
+                a_x[i] = (int)xa * p.stride + dg_px + p.pad - dg_s0;
                 a_off[i] = (int)n * (p.OH * p.OW * p.K) + 4 * q8;
             } else {
                 a_y[i] = -(1 << 24);
@@ -205,18 +219,18 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 3 : 2)) void igemm_kernel(const I
                 }
             }
         } else if (MODE == MODE_DGRAD) {
-            const int smask = p.stride - 1;
 #pragma unroll
             for (int i = 0; i < PA; ++i) {
-                const int ty = a_y[i] - cur_r;
-                const int tx = a_x[i] - cur_s;
+                // (iy + pad - r) is a multiple of the stride by construction of the class
+                const int ty = a_y[i] - (cur_r << p.sshift);
+                const int tx = a_x[i] - (cur_s << p.sshift);
                 const int oy = ty >> p.sshift;
                 const int ox = tx >> p.sshift;
-                const bool ok = (ty >= 0) && (tx >= 0) && (((ty | tx) & smask) == 0) &&
-                                (oy < p.OH) && (ox < p.OW);
+                const bool ok = (ty >= 0) && (tx >= 0) && (oy < p.OH) && (ox < p.OW);
                 ra[i] = ok ? *(const f32x4*)(p.act + (a_off[i] + (oy * p.OW + ox) * p.K + cur_c)) : zero4;
             }
-            const int uoff = cur_c * (p.R * p.S * p.C) + (cur_r * p.S + cur_s) * p.C;
+            const int uoff = cur_c * (p.R * p.S * p.C) +
+                             ((dg_r0 + (cur_r << p.sshift)) * p.S + dg_s0 + (cur_s << p.sshift)) * p.C;
 #pragma unroll
             for (int i = 0; i < PB; ++i)
                 rb[i] = b_ok[i] ? *(const f32x4*)(p.wgt + (b_off[i] + uoff)) : zero4;
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 3 : 2)) void igemm_kernel(const I
             if (cur_c >= p.K) {
                 cur_c = 0;
                 cur_s += 1;
-                if (cur_s >= p.S) {
+                if (cur_s >= dg_sc) {
                     cur_s = 0;
                     cur_r += 1;
                 }
@@ -356,7 +370,14 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 3 : 2)) void igemm_kernel(const I
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m < p.M) {
-                    const long idx = (long)m * p.NC + n;
+                    long idx = (long)m * p.NC + n;
+                    if (MODE == MODE_DGRAD && p.stride > 1) {
+                        const uint32_t ni = p.div_row_hw.div(m);
+                        const uint32_t rem = m - ni * (p.Hc * p.Wc);
+                        const uint32_t ya = p.div_row_w.div(rem);
+                        const uint32_t xa = rem - ya * p.Wc;
+                        idx = (((long)ni * p.H + (ya * p.stride + dg_py)) * p.W + (xa * p.stride + dg_px)) * p.NC + n;
+                    }
                     float v = acc[i][j][r] + bv;
                     if (MODE != MODE_WGRAD && p.add) v += p.add[idx];
                     out[idx] = v;
@@ -406,23 +427,52 @@ int launch_igemm(const IgemmParams& p, int splits, hipStream_t stream) {
         }
         attr_set = true;
     }
-    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits, 1);
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits, 1);   // y: wgrad split slices / dgrad parity classes
     hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, NBUF>), grid, dim3(256), lds, stream, p);
     DENET_CHECK_LAUNCH("igemm");
     return DENET_OK;
 }
 
-// LDS buffering per launch: with >= 3 workgroups per CU available, the single-buffer variant (half the LDS, 3
-// resident workgroups cover each other's barrier bubbles) wins; small grids keep the double buffer.
-// DENET_IGEMM_NBUF=1|2 forces one variant (experiments).
-int nbuf_choice(long nblocks) {
+// Launch-shape selection. The chip runs 256 CUs x `cap` resident workgroups (cap = 2 with the double LDS buffer,
+// 3 with the single buffer); a grid that needs a partial extra round wastes up to a whole round. The launchers
+// price each candidate (tile, buffering) by rounds x tile area / relative tile efficiency and take the cheapest.
+// DENET_IGEMM_NBUF=1|2 forces the buffering (experiments).
+int forced_nbuf() {
     static int forced = -1;
     if (forced < 0) {
         const char* e = getenv("DENET_IGEMM_NBUF");
         forced = e ? atoi(e) : 0;
     }
-    if (forced == 1 || forced == 2) return forced;
-    return nblocks >= 3 * 256 ? 1 : 2;
+    return forced;
+}
+
+struct Choice {
+    double cost;
+    int tile;   // index of the tile candidate
+    int nbuf;
+};
+
+// nblocks[t]: grid size with tile candidate t; area[t]: BM*BN; eff[t]: relative MFMA efficiency of the tile.
+// Measured behaviour behind the rules: with >= 4 rounds of work the single-buffer variant streams ~12 % faster
+// (3 resident workgroups cover each other's barrier bubbles); for small grids what counts is the number of
+// rounds, and a half-size tile pays off only when the full tile cannot fill the chip once.
+Choice choose_launch(const long* nblocks, const double* area, const double* eff, int ntiles) {
+    Choice best = {1e300, 0, 2};
+    for (int t = 0; t < ntiles; ++t) {
+        for (int nbuf = 1; nbuf <= 2; ++nbuf) {
+            if (forced_nbuf() && forced_nbuf() != nbuf) continue;
+            const long cap = (nbuf == 1) ? 3 : 2;
+            const long slots = 256 * cap;
+            const long nb = nblocks[t];
+            double rounds;
+            if (nb >= 4 * slots) rounds = (double)nb / slots;          // streaming regime: no quantisation
+            else rounds = (double)((nb + slots - 1) / slots);
+            const double per_round = area[t] / eff[t] * (nbuf == 1 ? 1.5 / 1.12 : 1.0);
+            const double cost = rounds * per_round;
+            if (cost < best.cost) best = {cost, t, nbuf};
+        }
+    }
+    return best;
 }
 
 int ilog2_exact(int v) {
@@ -466,14 +516,22 @@ extern "C" int denet_conv_fwd(const float* x, const float* w, const float* bias,
     p.M = N * OH * OW; p.NC = K; p.ksteps = R * S * C / BK; p.steps_per_split = p.ksteps;
     p.npix = p.M;
     p.div_row_hw.init(OH * OW); p.div_row_w.init(OW);
-    if (K >= 128) {
-        p.tiles_m = ceil_div(p.M, 128); p.tiles_n = ceil_div(K, 128);
-        if (nbuf_choice((long)p.tiles_m * p.tiles_n) == 1) return launch_igemm<MODE_FWD, 128, 128, 2, 2, 1>(p, 1, stream);
-        return launch_igemm<MODE_FWD, 128, 128, 2, 2>(p, 1, stream);
+    {
+        const long tm = ceil_div(p.M, 128);
+        const long nb[2] = {tm * ceil_div(K, 128), tm * ceil_div(K, 64)};
+        const double area[2] = {128.0 * 128.0, 128.0 * 64.0}, eff[2] = {1.0, 0.85};
+        const Choice c = (K >= 128) ? choose_launch(nb, area, eff, 2) : choose_launch(nb + 1, area + 1, eff + 1, 1);
+        const int tile = (K >= 128) ? c.tile : 1;
+        p.tiles_m = (int)tm;
+        if (tile == 0) {
+            p.tiles_n = ceil_div(K, 128);
+            return c.nbuf == 1 ? launch_igemm<MODE_FWD, 128, 128, 2, 2, 1>(p, 1, stream)
+                               : launch_igemm<MODE_FWD, 128, 128, 2, 2, 2>(p, 1, stream);
+        }
+        p.tiles_n = ceil_div(K, 64);
+        return c.nbuf == 1 ? launch_igemm<MODE_FWD, 128, 64, 2, 2, 1>(p, 1, stream)
+                           : launch_igemm<MODE_FWD, 128, 64, 2, 2, 2>(p, 1, stream);
     }
-    p.tiles_m = ceil_div(p.M, 128); p.tiles_n = ceil_div(K, 64);
-    if (nbuf_choice((long)p.tiles_m * p.tiles_n) == 1) return launch_igemm<MODE_FWD, 128, 64, 2, 2, 1>(p, 1, stream);
-    return launch_igemm<MODE_FWD, 128, 64, 2, 2>(p, 1, stream);
 }
 
 extern "C" int denet_conv_dgrad(const float* dy, const float* w, const float* add, float* dx, int N, int H, int W,
@@ -487,17 +545,28 @@ extern "C" int denet_conv_dgrad(const float* dy, const float* w, const float* ad
     p.act = dy; p.wgt = w; p.out = dx; p.bias = nullptr; p.add = add;
     p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K;
     p.R = R; p.S = S; p.S_real = S_real; p.stride = stride; p.sshift = ilog2_exact(stride); p.pad = pad;
-    p.M = N * H * W; p.NC = C; p.ksteps = R * S * K / BK; p.steps_per_split = p.ksteps;
+    DENET_CHECK_ARG(H % stride == 0 && W % stride == 0, "conv_dgrad: H, W must be multiples of the stride");
+    const int classes = stride * stride;
+    p.Hc = H / stride; p.Wc = W / stride;
+    p.M = N * p.Hc * p.Wc; p.NC = C; p.ksteps = R * S * K / BK; p.steps_per_split = p.ksteps;
     p.npix = N * OH * OW;
-    p.div_row_hw.init(H * W); p.div_row_w.init(W);
-    if (C >= 128) {
-        p.tiles_m = ceil_div(p.M, 128); p.tiles_n = ceil_div(C, 128);
-        if (nbuf_choice((long)p.tiles_m * p.tiles_n) == 1) return launch_igemm<MODE_DGRAD, 128, 128, 2, 2, 1>(p, 1, stream);
-        return launch_igemm<MODE_DGRAD, 128, 128, 2, 2>(p, 1, stream);
+    p.div_row_hw.init(p.Hc * p.Wc); p.div_row_w.init(p.Wc);
+    {
+        const long tm = ceil_div(p.M, 128);
+        const long nb[2] = {tm * ceil_div(C, 128) * classes, tm * ceil_div(C, 64) * classes};
+        const double area[2] = {128.0 * 128.0, 128.0 * 64.0}, eff[2] = {1.0, 0.85};
+        const Choice c = (C >= 128) ? choose_launch(nb, area, eff, 2) : choose_launch(nb + 1, area + 1, eff + 1, 1);
+        const int tile = (C >= 128) ? c.tile : 1;
+        p.tiles_m = (int)tm;
+        if (tile == 0) {
+            p.tiles_n = ceil_div(C, 128);
+            return c.nbuf == 1 ? launch_igemm<MODE_DGRAD, 128, 128, 2, 2, 1>(p, classes, stream)
+                               : launch_igemm<MODE_DGRAD, 128, 128, 2, 2, 2>(p, classes, stream);
+        }
+        p.tiles_n = ceil_div(C, 64);
+        return c.nbuf == 1 ? launch_igemm<MODE_DGRAD, 128, 64, 2, 2, 1>(p, classes, stream)
+                           : launch_igemm<MODE_DGRAD, 128, 64, 2, 2, 2>(p, classes, stream);
     }
-    p.tiles_m = ceil_div(p.M, 128); p.tiles_n = ceil_div(C, 64);
-    if (nbuf_choice((long)p.tiles_m * p.tiles_n) == 1) return launch_igemm<MODE_DGRAD, 128, 64, 2, 2, 1>(p, 1, stream);
-    return launch_igemm<MODE_DGRAD, 128, 64, 2, 2>(p, 1, stream);
 }
 
 extern "C" size_t denet_conv_wgrad_workspace_bytes(int N, int C, int K, int R, int S, int OH, int OW) {
@@ -526,7 +595,12 @@ extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, floa
     // split the pixel reduction so that the grid fills the chip (~2048 workgroups = 4 waves of 2 per CU),
     // keeping at least 8 chunks per slice; bounded by the caller's workspace
     int tiles = p.tiles_m * p.tiles_n;
-    int splits = ceil_div(2048, tiles);
+    static int target_blocks = -1;
+    if (target_blocks < 0) {
+        const char* e = getenv("DENET_WGRAD_BLOCKS");
+        target_blocks = e ? atoi(e) : 2048;
+    }
+    int splits = ceil_div(target_blocks, tiles);
     splits = splits < 1 ? 1 : splits;
     if (splits > p.ksteps / 8) splits = p.ksteps / 8;
     if (splits > 512) splits = 512;
@@ -541,11 +615,14 @@ extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, floa
     }
     p.steps_per_split = ceil_div(p.ksteps, splits);
     splits = ceil_div(p.ksteps, p.steps_per_split);
+    const long wg_nb[1] = {(long)tiles * splits};
+    const double wg_area[1] = {1.0}, wg_eff[1] = {1.0};
+    const int wg_nbuf = choose_launch(wg_nb, wg_area, wg_eff, 1).nbuf;
     if (big_m)
-        rc = nbuf_choice((long)tiles * splits) == 1 ? launch_igemm<MODE_WGRAD, 128, 128, 2, 2, 1>(p, splits, stream)
+        rc = wg_nbuf == 1 ? launch_igemm<MODE_WGRAD, 128, 128, 2, 2, 1>(p, splits, stream)
                                 : launch_igemm<MODE_WGRAD, 128, 128, 2, 2>(p, splits, stream);
     else
-        rc = nbuf_choice((long)tiles * splits) == 1 ? launch_igemm<MODE_WGRAD, 64, 128, 2, 2, 1>(p, splits, stream)
+        rc = wg_nbuf == 1 ? launch_igemm<MODE_WGRAD, 64, 128, 2, 2, 1>(p, splits, stream)
                                 : launch_igemm<MODE_WGRAD, 64, 128, 2, 2>(p, splits, stream);
     if (rc) return rc;
     if (splits > 1) {
