@@ -57,9 +57,10 @@ def main():
             raise SystemExit("--gpus %d needs the torch.distributed.run launcher (one rank per GPU)" % args.gpus)
     torch.cuda.set_device(local_rank)
     dp = None
-    if world > 1:
+    if world > 1 or os.environ.get("DENET_FORCE_DP") == "1":      # DENET_FORCE_DP: exercise the RCCL path on 1 GPU
         from denet_amd.multi import DataParallel
         dp = DataParallel(backend="nccl")
+        dp.force_collectives = os.environ.get("DENET_FORCE_DP") == "1"
 
     # identical initial weights on every rank (seed), per-rank data shard (seed + rank)
     model = zoo.denet34(BATCH_PER_GPU, "skip", 512, class_num=80, seed=1)
@@ -164,6 +165,8 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if dp is not None:
+        dp.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

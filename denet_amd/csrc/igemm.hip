@@ -46,6 +46,7 @@ struct IgemmParams {
     FastDiv div_row_hw; // fwd/wgrad: OH*OW    dgrad: Hc*Wc (pixels of one stride-parity class per image)
     FastDiv div_row_w;  // fwd/wgrad: OW       dgrad: Wc
     int Hc, Wc;         // dgrad: H/stride, W/stride
+    int wg_split_slow;  // wgrad: 1 = split slice is the slow (XCD-local) index of the linear workgroup id
 };
 
 template <int MODE, int BM, int BN, int WM, int WN, int NBUF>
@@ -75,15 +76,32 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 3 : 2)) void igemm_kernel(const I
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
+    // XCD-aware linear workgroup id. fwd/dgrad: consecutive ids walk the N tiles of one M tile, then the next M
+    // tile, so an XCD's L2 holds a contiguous range of pixels. wgrad: the split slice is the SLOW index — all
+    // (K x RSC) tiles of one pixel range run on the same XCD and share its x / dy rows in L2 (with the slice on
+    // grid.y every XCD streamed the whole of x and dy: 8x the HBM traffic).
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = bid % p.tiles_n;
-    const int tile_m = bid / p.tiles_n;
+    const uint32_t ntiles = (uint32_t)(p.tiles_m * p.tiles_n);
+    uint32_t tile_id = bid;
+    int split_id = 0;
+    if (MODE == MODE_WGRAD) {
+        if (p.wg_split_slow) {
+            tile_id = bid % ntiles;
+            split_id = (int)(bid / ntiles);
+        } else {
+            const uint32_t nsplit = gridDim.x / ntiles;
+            split_id = (int)(bid % nsplit);
+            tile_id = bid / nsplit;
+        }
+    }
+    const int tile_n = tile_id % p.tiles_n;
+    const int tile_m = tile_id / p.tiles_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
     int step_begin = 0, step_end = p.ksteps;
     if (MODE == MODE_WGRAD) {
-        step_begin = blockIdx.y * p.steps_per_split;
+        step_begin = split_id * p.steps_per_split;
         step_end = min(p.ksteps, step_begin + p.steps_per_split);
     }
     // dgrad with stride > 1: blockIdx.y enumerates the stride^2 parity classes of input pixels. A pixel of class
@@ -298,39 +316,49 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 3 : 2)) void igemm_kernel(const I
     const int fa = A_KIN ? (wm * TM * 32 + li) * LDK + 4 * lh : (4 * lh) * BM + wm * TM * 32 + li;
     const int fb = B_KIN ? (wn * TN * 32 + li) * LDK + 4 * lh : (4 * lh) * BN + wn * TN * 32 + li;
 
+    // MFMA phase of one K chunk. Operand fragments are double buffered in registers: the LDS reads of 8-wide k
+    // block kb+1 are issued BEFORE the 16 MFMAs of block kb, so the ~100+ cycle LDS latency is always covered by
+    // a full block of matrix work (the compiler otherwise places the reads 1-4 MFMAs ahead of their use).
+    auto load_frags = [&](const float* cA, const float* cB, int kb, float (&av)[TM][4], float (&bv)[TN][4]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (A_KIN) {
+                const f32x4 t = *(const f32x4*)(cA + i * 32 * LDK + kb * 8);
+                av[i][0] = t[0]; av[i][1] = t[1]; av[i][2] = t[2]; av[i][3] = t[3];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) av[i][t] = cA[(kb * 8 + t) * BM + i * 32];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (B_KIN) {
+                const f32x4 t = *(const f32x4*)(cB + j * 32 * LDK + kb * 8);
+                bv[j][0] = t[0]; bv[j][1] = t[1]; bv[j][2] = t[2]; bv[j][3] = t[3];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bv[j][t] = cB[(kb * 8 + t) * BN + j * 32];
+            }
+        }
+    };
+
     auto compute = [&](int buf) {
         const float* cA = sA + buf * SZA + fa;
         const float* cB = sB + buf * SZB + fb;
+        float av[2][TM][4], bv[2][TN][4];
+        load_frags(cA, cB, 0, av[0], bv[0]);
 #pragma unroll
         for (int kb = 0; kb < BK / 8; ++kb) {
-            float av[TM][4], bv[TN][4];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if (A_KIN) {
-                    const f32x4 t = *(const f32x4*)(cA + i * 32 * LDK + kb * 8);
-                    av[i][0] = t[0]; av[i][1] = t[1]; av[i][2] = t[2]; av[i][3] = t[3];
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) av[i][t] = cA[(kb * 8 + t) * BM + i * 32];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if (B_KIN) {
-                    const f32x4 t = *(const f32x4*)(cB + j * 32 * LDK + kb * 8);
-                    bv[j][0] = t[0]; bv[j][1] = t[1]; bv[j][2] = t[2]; bv[j][3] = t[3];
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) bv[j][t] = cB[(kb * 8 + t) * BN + j * 32];
-                }
-            }
+            if (kb + 1 < BK / 8) load_frags(cA, cB, kb + 1, av[(kb + 1) & 1], bv[(kb + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the matrix block
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], bv[j][t], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb & 1][i][t], bv[kb & 1][j][t], acc[i][j],
+                                                                         0, 0, 0);
         }
     };
 
@@ -358,7 +386,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? 3 : 2)) void igemm_kernel(const I
 
     // ---------------- epilogue ----------------
     float* out = p.out;
-    if (MODE == MODE_WGRAD) out += (long)blockIdx.y * p.split_stride;
+    if (MODE == MODE_WGRAD) out += (long)split_id * p.split_stride;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -410,8 +438,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     if (wv == 0 && col < n4) ((f32x4*)out)[col] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
+// the instantiation chosen by the last conv launch of this thread (profiling / roofline bookkeeping)
+thread_local int g_last_cfg[5] = {0, 0, 0, 0, 0};   // mode, BM, BN, NBUF, grid.y
+
 template <int MODE, int BM, int BN, int WM, int WN, int NBUF = 2>
 int launch_igemm(const IgemmParams& p, int splits, hipStream_t stream) {
+    g_last_cfg[0] = MODE; g_last_cfg[1] = BM; g_last_cfg[2] = BN; g_last_cfg[3] = NBUF; g_last_cfg[4] = splits;
     constexpr bool A_KIN = (MODE != MODE_WGRAD);
     constexpr bool B_KIN = (MODE == MODE_FWD);
     constexpr int SZA = A_KIN ? BM * LDK : BK * BM;
@@ -427,7 +459,9 @@ int launch_igemm(const IgemmParams& p, int splits, hipStream_t stream) {
         }
         attr_set = true;
     }
-    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits, 1);   // y: wgrad split slices / dgrad parity classes
+    // wgrad folds the split slices into grid.x (see the id decode in the kernel); dgrad: y = stride parity classes
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n) * (MODE == MODE_WGRAD ? (unsigned)splits : 1u),
+              MODE == MODE_WGRAD ? 1u : (unsigned)splits, 1);
     hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, NBUF>), grid, dim3(256), lds, stream, p);
     DENET_CHECK_LAUNCH("igemm");
     return DENET_OK;
@@ -502,6 +536,15 @@ int check_geom(int N, int H, int W, int C, int K, int R, int S, int S_real, int 
 }
 
 }  // namespace
+
+extern "C" int denet_conv_last_config(int* mode, int* bm, int* bn, int* nbuf, int* grid_y) {
+    if (mode) *mode = g_last_cfg[0];
+    if (bm) *bm = g_last_cfg[1];
+    if (bn) *bn = g_last_cfg[2];
+    if (nbuf) *nbuf = g_last_cfg[3];
+    if (grid_y) *grid_y = g_last_cfg[4];
+    return DENET_OK;
+}
 
 extern "C" int denet_conv_fwd(const float* x, const float* w, const float* bias, const float* add, float* y, int N,
                               int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH,
@@ -585,6 +628,14 @@ extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, floa
     p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K;
     p.R = R; p.S = S; p.S_real = S_real; p.stride = stride; p.sshift = ilog2_exact(stride); p.pad = pad;
     p.M = K; p.NC = R * S * C; p.npix = N * OH * OW;
+    {
+        static int v = -1;
+        if (v < 0) {
+            const char* e = getenv("DENET_WGRAD_SPLIT_SLOW");
+            v = e ? atoi(e) : 1;
+        }
+        p.wg_split_slow = v;
+    }
     p.ksteps = ceil_div(p.npix, BK);
     p.div_row_hw.init(OH * OW); p.div_row_w.init(OW);
     const bool big_m = (K >= 128);
@@ -592,21 +643,44 @@ extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, floa
     p.tiles_m = ceil_div(K, bm); p.tiles_n = ceil_div(p.NC, 128);
     const long wsize = (long)K * p.NC;
     p.split_stride = wsize;
-    // split the pixel reduction so that the grid fills the chip (~2048 workgroups = 4 waves of 2 per CU),
-    // keeping at least 8 chunks per slice; bounded by the caller's workspace
-    int tiles = p.tiles_m * p.tiles_n;
-    static int target_blocks = -1;
-    if (target_blocks < 0) {
+    // Split-K selection. Every candidate (rounds r of a full chip, LDS buffering) fixes the number of slices so
+    // that tiles x slices just fills r rounds; its price is r x (chunks per workgroup + fixed overhead) x chunk
+    // time, plus the second-stage reduction that has to read slices x |dw| bytes. Measured constants: a 128x128
+    // chunk takes ~4.2 us with 2 resident workgroups per CU and ~5.6 us with 3; HBM-side reduce ~3 TB/s.
+    const int tiles = p.tiles_m * p.tiles_n;
+    const size_t max_by_ws = workspace ? workspace_bytes / ((size_t)wsize * sizeof(float)) : 0;
+    static int forced_blocks = -1;
+    if (forced_blocks < 0) {
         const char* e = getenv("DENET_WGRAD_BLOCKS");
-        target_blocks = e ? atoi(e) : 2048;
+        forced_blocks = e ? atoi(e) : 0;
     }
-    int splits = ceil_div(target_blocks, tiles);
-    splits = splits < 1 ? 1 : splits;
-    if (splits > p.ksteps / 8) splits = p.ksteps / 8;
-    if (splits > 512) splits = 512;
-    if (splits < 1) splits = 1;
-    size_t max_by_ws = workspace ? workspace_bytes / ((size_t)wsize * sizeof(float)) : 0;
-    if ((size_t)splits > max_by_ws) splits = (int)max_by_ws;
+    int splits = 1, wg_nbuf = 2;
+    {
+        const double chunk_us2 = (big_m ? 4.2 : 2.4), chunk_us3 = chunk_us2 * 1.5 / 1.12;
+        double best = 1e300;
+        for (int nbuf = 1; nbuf <= 2; ++nbuf) {
+            if (forced_nbuf() && forced_nbuf() != nbuf) continue;
+            const int slots = 256 * (nbuf == 1 ? 3 : 2);
+            for (int r = 1; r <= 6; ++r) {
+                int sp = forced_blocks ? ceil_div(forced_blocks, tiles) : (r * slots) / tiles;
+                if (sp < 1) sp = 1;
+                if (sp > p.ksteps / 4) sp = p.ksteps / 4 > 0 ? p.ksteps / 4 : 1;
+                if (sp > 512) sp = 512;
+                if ((size_t)sp > max_by_ws && sp > 1) sp = max_by_ws > 0 ? (int)max_by_ws : 1;
+                const int per = ceil_div(p.ksteps, sp);
+                sp = ceil_div(p.ksteps, per);
+                const long nb = (long)tiles * sp;
+                const double rounds = (double)((nb + slots - 1) / slots);
+                const double t_main = rounds * (per + 2.0) * (nbuf == 1 ? chunk_us3 : chunk_us2);
+                const double t_red = sp > 1 ? 3.0 + (double)sp * wsize * 4.0 / 3.0e6 : 0.0;
+                if (t_main + t_red < best) {
+                    best = t_main + t_red;
+                    splits = sp;
+                    wg_nbuf = nbuf;
+                }
+            }
+        }
+    }
     if (splits <= 1) {
         splits = 1;
         p.out = dw;
@@ -615,9 +689,6 @@ extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, floa
     }
     p.steps_per_split = ceil_div(p.ksteps, splits);
     splits = ceil_div(p.ksteps, p.steps_per_split);
-    const long wg_nb[1] = {(long)tiles * splits};
-    const double wg_area[1] = {1.0}, wg_eff[1] = {1.0};
-    const int wg_nbuf = choose_launch(wg_nb, wg_area, wg_eff, 1).nbuf;
     if (big_m)
         rc = wg_nbuf == 1 ? launch_igemm<MODE_WGRAD, 128, 128, 2, 2, 1>(p, splits, stream)
                                 : launch_igemm<MODE_WGRAD, 128, 128, 2, 2>(p, splits, stream);

@@ -34,6 +34,7 @@ class DataParallel:
         self.world_size = dist.get_world_size()
         self.rank = dist.get_rank()
         self.scale_fn = scale_fn
+        self.force_collectives = False     # run the collectives even at world_size 1 (single-GPU smoke of the path)
         self._buckets = None
         self._pending = []
 
@@ -77,12 +78,12 @@ class DataParallel:
 
     def layer_done(self, model, layer):
         r = self._trigger.get(id(layer))
-        if r is not None and self.world_size > 1:
+        if r is not None and (self.world_size > 1 or self.force_collectives):
             lo, hi = r
             self._pending.append(self.dist.all_reduce(model.G[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True))
 
     def finish_step(self, model):
-        if self.world_size > 1:
+        if self.world_size > 1 or self.force_collectives:
             d = self.dist
             if model.n_trainable > model.n_weights:
                 self._pending.append(d.all_reduce(model.G[model.n_weights:model.n_trainable], op=d.ReduceOp.SUM,

@@ -45,8 +45,9 @@ class KernelProfile:
 
     def bracket(self, name, flops):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.records.append((name, flops, s, e))
-        return s, e
+        rec = [name, flops, s, e]
+        self.records.append(rec)
+        return s, e, rec
 
     def summary(self):
         torch.cuda.synchronize()
@@ -72,16 +73,14 @@ def wait_stream():
         pass
 
 
-def _igemm_name(mode, g):
-    """mirrors the tile selection of csrc/igemm.hip (launch_igemm instantiation per geometry)"""
-    N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
-    if mode == "fwd":
-        tile = "128x128" if K >= 128 else "128x64"
-    elif mode == "dgrad":
-        tile = "128x128" if C >= 128 else "128x64"
-    else:
-        tile = "128x128" if K >= 128 else "64x128"
-    return "igemm_kernel<%s,%s>" % (mode, tile)
+def _last_igemm_name():
+    """name of the instantiation the C side picked for the launch just issued (matches rocprofv3's kernel names:
+    igemm_kernel<MODE, BM, BN, 2, 2, NBUF>)"""
+    import ctypes
+    v = [ctypes.c_int() for _ in range(5)]
+    _L().denet_conv_last_config(*[ctypes.byref(x) for x in v])
+    mode, bm, bn, nbuf, _ = [x.value for x in v]
+    return "igemm_kernel<%d, %d, %d, 2, 2, %d>" % (mode, bm, bn, nbuf)
 
 
 def _conv_flops(g, logical=None):
@@ -107,11 +106,12 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
     N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
     y = out if out is not None else empty(N, OH, OW, K)
     if PROFILE is not None:
-        ev = PROFILE.bracket(_igemm_name("fwd", g), _conv_flops(g, logical))
+        ev = PROFILE.bracket(None, _conv_flops(g, logical))
         ev[0].record()
     check(_L().denet_conv_fwd(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), *g, stream_ptr()), "conv_fwd")
     if PROFILE is not None:
         ev[1].record()
+        ev[2][0] = _last_igemm_name()
     return y
 
 
@@ -120,11 +120,12 @@ def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None,
     assert tuple(dy.shape) == (g[0], g[10], g[11], g[4]), (dy.shape, g)
     dx = out if out is not None else empty(*x_shape)
     if PROFILE is not None:
-        ev = PROFILE.bracket(_igemm_name("dgrad", g), _conv_flops(g, logical))
+        ev = PROFILE.bracket(None, _conv_flops(g, logical))
         ev[0].record()
     check(_L().denet_conv_dgrad(ptr(dy), ptr(w), ptr(add), ptr(dx), *g, stream_ptr()), "conv_dgrad")
     if PROFILE is not None:
         ev[1].record()
+        ev[2][0] = _last_igemm_name()
     return dx
 
 
@@ -134,11 +135,12 @@ def conv_wgrad(x, dy, w_shape, stride=1, pad=0, s_real=None, out=None, logical=N
     dw = out if out is not None else empty(*w_shape)
     ws = WS.get("wgrad", WGRAD_WS_BYTES)
     if PROFILE is not None:
-        ev = PROFILE.bracket(_igemm_name("wgrad", g), _conv_flops(g, logical))
+        ev = PROFILE.bracket(None, _conv_flops(g, logical))
         ev[0].record()
     check(_L().denet_conv_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel(), *g, stream_ptr()), "conv_wgrad")
     if PROFILE is not None:
         ev[1].record()
+        ev[2][0] = _last_igemm_name()
     return dw
 
 

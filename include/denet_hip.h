@@ -52,6 +52,9 @@ int denet_conv_fwd(const float* x, const float* w, const float* bias, const floa
 int denet_conv_dgrad(const float* dy, const float* w, const float* add, float* dx, int N, int H, int W, int C, int K,
                      int R, int S, int S_real, int stride, int pad, int OH, int OW, hipStream_t stream);
 size_t denet_conv_wgrad_workspace_bytes(int N, int C, int K, int R, int S, int OH, int OW);
+/* kernel instantiation picked by this thread's last conv launch: mode 0 fwd / 1 dgrad / 2 wgrad, tile BMxBN, LDS
+ * buffers, grid.y (wgrad split slices / dgrad stride classes) — profiling bookkeeping only                      */
+int denet_conv_last_config(int* mode, int* bm, int* bn, int* nbuf, int* grid_y);
 int denet_conv_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes, int N,
                      int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH, int OW,
                      hipStream_t stream);
