@@ -159,8 +159,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // partial[gy][2][C] : sum(g), sum(g*xhat)  with g = dy * (relu ? y>0 : 1)
+// relu mask: y > 0 when the forward output is given (residual-fused blocks), else recomputed from x with the
+// forward's own expression fmaf(x, gamma*invstd, beta - mean*gamma*invstd) > 0 (bit-identical, saves a pass)
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                              const float* __restrict__ dy,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, long M, int C, int LC,
                                                              int relu, double* __restrict__ partial) {
@@ -168,11 +172,13 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     const int tid = threadIdx.x;
     const int cl = tid % LC, rsub = tid / LC, RS = 256 / LC;
     const int c = (blockIdx.x * LC + cl) * 4;
-    float mu[4], is[4];
+    float mu[4], is[4], sc[4], sh[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         mu[k] = mean[c + k];
         is[k] = invstd[c + k];
+        sc[k] = gamma[c + k] * is[k];
+        sh[k] = (beta ? beta[c + k] : 0.f) - mu[k] * sc[k];
     }
     double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
     for (long r = (long)blockIdx.y * RS + rsub; r < M; r += (long)gridDim.y * RS) {
@@ -180,9 +186,14 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         const f32x4 xv = *(const f32x4*)(x + o);
         f32x4 g = *(const f32x4*)(dy + o);
         if (relu) {
-            const f32x4 yv = *(const f32x4*)(y + o);
+            if (y) {
+                const f32x4 yv = *(const f32x4*)(y + o);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+                for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = fmaf(xv[k], sc[k], sh[k]) > 0.f ? g[k] : 0.f;
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -241,6 +252,7 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restr
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy,
                                                            const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, float* __restrict__ dx,
@@ -248,12 +260,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const int tid = threadIdx.x;
     const int cl = tid % LC, rsub = tid / LC, RS = 256 / LC;
     const int c = (blockIdx.x * LC + cl) * 4;
-    float mu[4], is[4], sc[4], mg[4], mgx[4];
+    float mu[4], is[4], sc[4], sh[4], mg[4], mgx[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         mu[k] = mean[c + k];
         is[k] = invstd[c + k];
         sc[k] = gamma[c + k] * is[k];
+        sh[k] = (beta ? beta[c + k] : 0.f) - mu[k] * sc[k];
         mg[k] = coef[c + k];
         mgx[k] = coef[C + c + k];
     }
@@ -262,9 +275,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const f32x4 xv = *(const f32x4*)(x + o);
         f32x4 g = *(const f32x4*)(dy + o);
         if (relu) {
-            const f32x4 yv = *(const f32x4*)(y + o);
+            if (y) {
+                const f32x4 yv = *(const f32x4*)(y + o);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+                for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = fmaf(xv[k], sc[k], sh[k]) > 0.f ? g[k] : 0.f;
+            }
         }
         f32x4 d;
 #pragma unroll
@@ -329,21 +347,21 @@ extern "C" int denet_bn_fwd_test(const float* x, const float* res, float* y, con
     return DENET_OK;
 }
 
-extern "C" int denet_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma,
+extern "C" int denet_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                             const float* save_mean, const float* save_invstd, float* dx, float* dres, float* dgamma,
                             float* dbeta, void* workspace, long M, int C, int relu, hipStream_t stream) {
     DENET_CHECK_ARG(x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta && workspace,
                     "bn_bwd: null pointer");
-    DENET_CHECK_ARG(!relu || y, "bn_bwd: relu mask needs the forward output");
+    DENET_CHECK_ARG(!relu || y || beta, "bn_bwd: the relu mask needs the forward output y, or beta to recompute it");
     DENET_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "bn_bwd: bad shape M=%ld C=%d", M, C);
     BnMap m = bn_map(M, C);
     double* partial = (double*)workspace;
     float* coef = (float*)(partial + (size_t)m.gy * 2 * C);
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, save_mean, save_invstd,
-                       M, C, m.LC, relu, partial);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, gamma, beta, save_mean,
+                       save_invstd, M, C, m.LC, relu, partial);
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, partial, m.gy, M, C, dgamma,
                        dbeta, coef);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, gamma, save_mean,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, gamma, beta, save_mean,
                        save_invstd, coef, dx, dres, M, C, m.LC, relu);
     DENET_CHECK_LAUNCH("bn_bwd");
     return DENET_OK;

@@ -88,7 +88,7 @@ class BatchNormLayer(AbstractLayer):
         if get_train():
             y, sm, si = ops.bn_fwd_train(x, self.omega.dev, self.beta.dev, self.mean.dev, self.stdinv.dev,
                                          self.momentum, self.eps, relu=relu, res=res)
-            self._save = (sm, si, relu, out_act)
+            self._save = (sm, si, relu, out_act, res is not None)
         else:
             y = ops.bn_fwd_test(x, self.omega.dev, self.beta.dev, self.mean.dev, self.stdinv.dev, self.eps, relu=relu,
                                 res=res)
@@ -97,9 +97,12 @@ class BatchNormLayer(AbstractLayer):
     def backward(self, ctx, want_dres=False):
         if not self.enabled:
             return None
-        sm, si, relu, out_act = self._save
-        dx, dres, _, _ = ops.bn_bwd(self.input.data, out_act.data, out_act.grad, self.omega.dev, sm, si, relu=relu,
-                                    want_dres=want_dres, dgamma=self.omega.grad, dbeta=self.beta.grad)
+        sm, si, relu, out_act, has_res = self._save
+        # without a residual input the relu mask is recomputed from x in the kernel (no read of y)
+        y = out_act.data if (relu and has_res) else None
+        dx, dres, _, _ = ops.bn_bwd(self.input.data, y, out_act.grad, self.omega.dev, sm, si, relu=relu,
+                                    want_dres=want_dres, dgamma=self.omega.grad, dbeta=self.beta.grad,
+                                    beta=self.beta.dev)
         self.input.add_grad(dx)
         return dres
 

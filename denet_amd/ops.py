@@ -168,14 +168,16 @@ def bn_fwd_test(x, gamma, beta, run_mean, run_stdinv, eps=1e-5, relu=False, res=
     return y
 
 
-def bn_bwd(x, y, dy, gamma, save_mean, save_invstd, relu=False, want_dres=False, dgamma=None, dbeta=None, dx=None):
+def bn_bwd(x, y, dy, gamma, save_mean, save_invstd, relu=False, want_dres=False, dgamma=None, dbeta=None, dx=None,
+           beta=None):
+    """y may be None for a relu layer without residual when beta is given: the mask is recomputed from x"""
     C = x.shape[-1]
     M = x.numel() // C
     dx = dx if dx is not None else torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     dgamma = dgamma if dgamma is not None else empty(C)
     dbeta = dbeta if dbeta is not None else empty(C)
-    check(_L().denet_bn_bwd(ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(save_mean), ptr(save_invstd), ptr(dx), ptr(dres),
+    check(_L().denet_bn_bwd(ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_invstd), ptr(dx), ptr(dres),
                             ptr(dgamma), ptr(dbeta), ptr(_bn_ws(M, C)), M, C, int(relu), stream_ptr()), "bn_bwd")
     return dx, dres, dgamma, dbeta
 

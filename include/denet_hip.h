@@ -70,9 +70,11 @@ int denet_bn_fwd_train(const float* x, const float* res, float* y, const float* 
 int denet_bn_fwd_test(const float* x, const float* res, float* y, const float* gamma, const float* beta,
                       const float* run_mean, const float* run_stdinv, void* workspace, long M, int C, float eps,
                       int relu, hipStream_t stream);
-int denet_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* save_mean,
-                 const float* save_invstd, float* dx, float* dres, float* dgamma, float* dbeta, void* workspace, long M,
-                 int C, int relu, hipStream_t stream);
+/* relu mask of the backward: y > 0 if y is given; if y is NULL it is recomputed from x (needs beta) — the fused
+ * residual blocks pass y, plain BNA layers pass NULL and save one pass over the activation                       */
+int denet_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
+                 const float* save_mean, const float* save_invstd, float* dx, float* dres, float* dgamma, float* dbeta,
+                 void* workspace, long M, int C, int relu, hipStream_t stream);
 
 /* ---- pooling  (denet/layer/pool.py:28-40 dnn_pool max / average_inc_pad;
  *      denet/layer/pool_inv_op.py:38-63 k_pool_inv, :144-169 k_pool_inv_grad)                             */
