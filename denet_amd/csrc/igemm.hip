@@ -50,7 +50,7 @@ struct IgemmParams {
 };
 
 template <int MODE, int BM, int BN, int WM, int WN, int NBUF>
-__global__ __launch_bounds__(256, (NBUF == 1 ? 3 : 2)) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : 2)) void igemm_kernel(const IgemmParams p) {
     constexpr bool A_KIN = (MODE != MODE_WGRAD);
     constexpr bool B_KIN = (MODE == MODE_FWD);
     constexpr int TM = BM / (32 * WM);
@@ -495,13 +495,13 @@ Choice choose_launch(const long* nblocks, const double* area, const double* eff,
     for (int t = 0; t < ntiles; ++t) {
         for (int nbuf = 1; nbuf <= 2; ++nbuf) {
             if (forced_nbuf() && forced_nbuf() != nbuf) continue;
-            const long cap = (nbuf == 1) ? 3 : 2;
+            const long cap = (nbuf == 1) ? (area[t] <= 128.0 * 64.0 ? 4 : 3) : 2;
             const long slots = 256 * cap;
             const long nb = nblocks[t];
             double rounds;
             if (nb >= 4 * slots) rounds = (double)nb / slots;          // streaming regime: no quantisation
             else rounds = (double)((nb + slots - 1) / slots);
-            const double per_round = area[t] / eff[t] * (nbuf == 1 ? 1.5 / 1.12 : 1.0);
+            const double per_round = area[t] / eff[t] * (nbuf == 1 ? (cap / 2.0) / 1.12 : 1.0);
             const double cost = rounds * per_round;
             if (cost < best.cost) best = {cost, t, nbuf};
         }

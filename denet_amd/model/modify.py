@@ -47,17 +47,22 @@ def convert_bn_relu(model):
             dst.append(_bn_to_bnrelu(l))
             i += 2
             continue
-        if l["type"] == "resnet" and "bnrelu" not in l["version"]:
+        if l["type"] == "resnet" and "bnrelu" not in l["version"] and l["activation"] == "relu":
+            # the reference rewrites sub-layers [2],[3] (and [4],[5] with a bottleneck) of `original` blocks
+            # (modify.py:91-106); fusing every [batchnorm, activation] pair of the block is the same edit for
+            # those and also covers pre-activation blocks (which the reference's index arithmetic does not)
             l = copy.copy(l)
-            if "pre-activation" not in l["version"] and "preactivation" not in l["version"]:
-                subs = list(l["layers"])
-                # sub-layer list: [initial, conv, bn, act, conv, (bn, act, conv), bn, (shortcut ...)]
-                subs[2] = _bn_to_bnrelu(subs[2])
-                del subs[3]
-                if l["bottleneck"] > 0:
-                    subs[4] = _bn_to_bnrelu(subs[4])
-                    del subs[5]
-                l["layers"] = subs
+            subs, fused, k = list(l["layers"]), [], 0
+            while k < len(subs):
+                nx = subs[k + 1] if k + 1 < len(subs) else None
+                if subs[k]["type"] == "batchnorm" and nx is not None and nx["type"] == "activation" \
+                        and nx["activation"] == "relu":
+                    fused.append(_bn_to_bnrelu(subs[k]))
+                    k += 2
+                else:
+                    fused.append(subs[k])
+                    k += 1
+            l["layers"] = fused
             l["version"] = l["version"] + ",bnrelu"
         dst.append(l)
         i += 1

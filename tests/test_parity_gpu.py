@@ -135,14 +135,16 @@ def _force_list(model):
         elif t == "resnet":
             main, sc = layer._main(), layer._shortcut()
             for s in main:
-                fused_tail = (s is main[-1]) and ("pre-activation" not in layer.version)
-                if s.type_name == "activation" and s.activation == "none":
+                fused_tail = (s is main[-1])     # original: last BN fused with add+ReLU; pre-activation: the
+                if s.type_name == "activation" and s.activation == "none":   # residual add rides in the last conv
                     continue
-                out.append(None if fused_tail else nchw(s.output))   # the last BN is fused with add+ReLU
+                out.append(None if fused_tail else nchw(s.output))
             for s in sc:
                 out.append(nchw(s.output))
             out.append(nchw(layer.output))
         elif t == "skip":
+            if len(layer.layers) > 1:
+                out.append(None)          # 1x1 projection of the tap: its epilogue already holds the skip add
             out.append(nchw(layer.output))
         elif t in ("denet-corner", "denet-detect"):
             out.append(nchw(layer.conv.output))
@@ -352,3 +354,83 @@ def test_full_size_properties(hip):
         src = fmap.view(B, -1, fmap.shape[-1])[rows, taps[:, t], coff:coff + F]
         assert torch.equal(out[:, t * F:(t + 1) * F], src)
     assert float(out[:, 49 * F + 2:].abs().max()) == 0.0
+
+
+def _generic_step_check(desc, data_shape, B, solver="nesterov", steps=2, convert=False, class_num=10, seed=11):
+    from denet_amd.model import model_cnn, modify
+    np.random.seed(seed)
+    model = model_cnn.ModelCNN()
+    model.batch_size = B
+    model.class_num = class_num
+    model.build(desc, data_shape, "relu", "half", ["he-backward"])
+    if convert:
+        model = modify.convert_bn_relu(model)
+    rng = np.random.RandomState(seed)
+    x = rng.uniform(0, 1, (B,) + tuple(data_shape)).astype(np.float32)
+    metas = [{"image_class": int(rng.randint(0, class_num)), "bbox": [], "class": []} for _ in range(B)]
+    # non-trivial BN parameters and a non-zero classifier so that every gradient path carries signal
+    for l in model.layers[1:]:
+        for p in l.biases():
+            p.set_value(p.value + rng.normal(0, 0.1, p.value.shape).astype(np.float32))
+    rconv = model.layers[-2]
+    rconv.omega.set_value(rng.normal(0, 0.05, rconv.omega.value.shape))
+    om = OM.OracleModel(model.export_json(), B)
+    om_free = OM.OracleModel(model.export_json(), B)
+    model.build_train_func(solver)
+    for it in range(steps):
+        cost, _ = model.train_step(x, metas, 0, it, 0.05, [0.9], 1e-4)
+        if it == 0:
+            fcost, _ = om_free.train_step(x, metas, it, 0.05, 0.9, 1e-4, solver)
+            assert abs(cost - fcost) <= 1e-3 * abs(fcost), (cost, fcost)
+            for i, a in _product_acts(model).items():
+                rel_close(a, om_free.acts[i], 1e-3, "activation L%d %s" % (i, model.layers[i].type_name))
+        ocost, _ = _forced_step_check(model, om, x, metas, it, 0.05, 0.9, 1e-4, solver, None)
+        assert abs(cost - ocost) <= 1e-4 * abs(ocost), (cost, ocost)
+    return model
+
+
+@pytest.mark.parametrize("convert", [False, True])
+def test_resnet_variants_vs_oracle(hip, convert):
+    """pre-activation and original residual blocks, basic and bottleneck bodies, projection shortcuts with and
+    without BN (denet/layer/resnet.py:52-113), unfused BN + A and the --convert-bn-relu fused form"""
+    desc = "C.B[32,3] BN A nRSN[2,64,3,2,32] nRSN.O[2,64,3,1,32] nRSN[1,96,3,2] RSN.O[96,3] P.A[4] R"
+    model = _generic_step_check(desc, (3, 16, 16), 4, convert=convert)
+    versions = [l.version for l in model.layers if l.type_name == "resnet"]
+    assert any("pre-activation" in v for v in versions) and any("original" in v for v in versions)
+    assert all(("bnrelu" in v) == (convert and "original" in v) or "pre-activation" in v for v in versions)
+
+
+def test_skip_projection_vs_oracle(hip):
+    """SKIP with a channel mismatch projects the tap with a 1x1 convolution (denet/layer/skip.py:78-86)"""
+    desc = "C[32,3] BNA SKIPSRC[0] C[64,3,2] BNA PI[2] SKIP[0] BNA P.A[16] R"
+    model = _generic_step_check(desc, (3, 16, 16), 4, solver="sgd")
+    skip = [l for l in model.layers if l.type_name == "skip"][0]
+    assert len(skip.layers) == 2 and skip.layers[1].filter_shape == (64, 32, 1, 1)
+
+
+@pytest.mark.parametrize("head,rule", [("DND.JB[0.5,1,1]", 0), ("DND.B[0.4,2,0.5]", 1), ("DND[0.5,1,1]", 1)])
+def test_denet_head_variants_vs_oracle(hip, head, rule):
+    """joint-fitness classes + bounded-IoU box cost (denet_detect.py:180-183, 266-286) and the CUDA tap rule"""
+    B, IMG = 2, 128
+    model = zoo.denet34(B, "skip", IMG, class_num=80, seed=1, head_desc=zoo.DENET34_SKIP_DESC.replace("DND[0.5,1,1]", head))
+    rng = np.random.RandomState(5)
+    dconv = model.layers[40].layers[0]
+    dconv.omega.set_value(rng.normal(0, 0.05, dconv.omega.value.shape))
+    dconv.beta.set_value(rng.normal(0, 0.05, dconv.beta.value.shape))
+    model.layers[31].tap_rule = rule
+    _warm_corner_head(model, 4.0, 0.3)
+    x, metas = zoo.synthetic_batch(B, IMG, seed=3)
+    om = OM.OracleModel(model.export_json(), B, tap_rule=rule)
+    model.build_train_func("nesterov")
+    random.seed(9)
+    cost, costs = model.train_step(x, metas, 0, 0, 0.05, [0.9], 1e-4)
+    roi_lists = model.layers[31].sample_bbox_list
+    ocost, ocosts = _forced_step_check(model, om, x, metas, 0, 0.05, 0.9, 1e-4, "nesterov", roi_lists)
+    assert abs(cost - ocost) <= 1e-4 * abs(ocost), (cost, ocost)
+    for c, oc in zip(costs, ocosts):
+        assert abs(c - oc) <= 1e-4 * max(abs(oc), 1e-6), (costs, ocosts)
+    ys, xs = om.taps
+    taps_ref = (ys[:, :, None] * (IMG // 8) + xs[:, None, :]).reshape(ys.shape[0], -1)
+    assert np.array_equal(model.layers[31]._taps.cpu().numpy(), taps_ref)
+    if "J" in head:
+        assert model.layers[40].s0 == 401
