@@ -1,0 +1,222 @@
+// Inference tail of the DeNet detector: decoding of the detection head and per-class NMS.
+//   denet_detect_decode      reference denet/layer/denet_detect.py:76-100 (log-softmax over the class logits, box
+//                            decoding from the regressors) and :330-349 (joint-fitness marginalisation)
+//   denet_detect_nms         reference denet/layer/denet_detect.cc:99-173 build_detections_nms with hard NMS
+//                            (:73-97 perform_nms): an instance is dropped iff a strictly better-scored instance of
+//                            the same class overlaps it by more than the threshold
+//   denet_soft_nms_host      reference denet/layer/denet_detect.cc:35-71 perform_soft_nms (Gaussian, log-domain
+//                            scores, sequential by construction) — host code on the candidates kept by the GPU
+// Compiled with -ffp-contract=off: IoU comparisons against a threshold must not depend on FMA contraction.
+#include "common.h"
+#include <math.h>
+#include <vector>
+
+namespace {
+
+// one wave per RoI. logits [M,CP]: s0 class(-fitness) logits then 4 regressors.
+// det_pr [M, class_num+1] log-probabilities, fitness [M, class_num+1], bbox [M,4] decoded boxes (or the RoI itself)
+__global__ __launch_bounds__(256) void detect_decode_kernel(const float* __restrict__ logits,
+                                                            const float* __restrict__ roi, float* __restrict__ det_pr,
+                                                            float* __restrict__ fitness, float* __restrict__ bbox, int M,
+                                                            int CP, int class_num, int fit_num, int jointfit, int nreg,
+                                                            float t0) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int s0 = jointfit ? class_num * fit_num + 1 : class_num + 1;
+    const float* z = logits + (long)m * CP;
+    float mx = -INFINITY;
+    for (int c = lane; c < s0; c += 64) mx = fmaxf(mx, z[c]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float se = 0.f;
+    for (int c = lane; c < s0; c += 64) se += expf(z[c] - mx);
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+    const float lse = logf(se);
+    float* dp = det_pr + (long)m * (class_num + 1);
+    float* fp = fitness + (long)m * (class_num + 1);
+    if (!jointfit) {
+        for (int c = lane; c < s0; c += 64) {
+            const float lp = (z[c] - mx) - lse;
+            dp[c] = lp;
+            fp[c] = lp;      // denet_detect.py:388: fitness = copy(det_pr)
+        }
+    } else {
+        // det_fit (class, f) log-probabilities -> det_pr[c] = logsumexp_f, fitness[c] = log sum_f exp(lp) * val[f],
+        // val[f] = t0 + f*(1-t0)/fit_num (denet_detect.py:333-349)
+        for (int c = lane; c < class_num; c += 64) {
+            float lmax = -INFINITY;
+            for (int f = 0; f < fit_num; ++f) lmax = fmaxf(lmax, (z[c * fit_num + f] - mx) - lse);
+            float s = 0.f, sv = 0.f;
+            for (int f = 0; f < fit_num; ++f) {
+                const float lp = (z[c * fit_num + f] - mx) - lse;
+                s += expf(lp - lmax);
+                sv += expf(lp) * (t0 + (float)f * (1.0f - t0) / (float)fit_num);
+            }
+            dp[c] = lmax + logf(s);
+            fp[c] = logf(sv);
+        }
+        if (lane == 0) {
+            const float lp = (z[s0 - 1] - mx) - lse;
+            dp[class_num] = lp;
+            fp[class_num] = lp;
+        }
+    }
+    if (lane == 0) {
+        const float x0 = roi[m * 4 + 0], y0 = roi[m * 4 + 1], x1 = roi[m * 4 + 2], y1 = roi[m * 4 + 3];
+        float* b = bbox + (long)m * 4;
+        if (nreg == 4) {
+            // denet_detect.py:87-100
+            const float scx = 0.5f * (x0 + x1), scy = 0.5f * (y0 + y1), sw = x1 - x0, sh = y1 - y0;
+            const float* r = z + s0;
+            const float pcx = r[0] * sw + scx, pcy = r[1] * sh + scy;
+            const float pw = expf(r[2]) * sw, ph = expf(r[3]) * sh;
+            b[0] = pcx - pw * 0.5f;
+            b[1] = pcy - ph * 0.5f;
+            b[2] = pcx + pw * 0.5f;
+            b[3] = pcy + ph * 0.5f;
+        } else {
+            b[0] = x0; b[1] = y0; b[2] = x1; b[3] = y1;
+        }
+    }
+}
+
+__device__ __forceinline__ float box_iou(float ax0, float ay0, float ax1, float ay1, float bx0, float by0, float bx1,
+                                         float by1) {
+    // denet_detect.cc:13-31, operation for operation in fp32
+    const float dx = fmaxf(0.0f, fminf(ax1, bx1) - fmaxf(ax0, bx0));
+    const float dy = fmaxf(0.0f, fminf(ay1, by1) - fmaxf(ay0, by0));
+    const float ai = dx * dy;
+    const float aa = (ax1 - ax0) * (ay1 - ay0);
+    const float ab = (bx1 - bx0) * (by1 - by0);
+    const float au = aa + ab - ai;
+    return ai / au;
+}
+
+// one workgroup per (class, image): keep[b, cls, i] = 1 iff RoI i is a surviving detection of class cls
+__global__ __launch_bounds__(256) void detect_nms_kernel(const float* __restrict__ det_pr,
+                                                         const float* __restrict__ fitness,
+                                                         const float* __restrict__ bbox, const int* __restrict__ count,
+                                                         unsigned char* __restrict__ keep, int S, int C1,
+                                                         float log_thr, float nms_thr, int do_nms) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* s_score = sm;              // [S]
+    float* s_box = sm + S;            // [S][4]
+    int* s_idx = (int*)(sm + 5 * S);  // [S]
+    __shared__ int s_w[4];
+    __shared__ int s_n;
+    const int cls = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = min(count[b], S);
+    unsigned char* kp = keep + ((long)b * (C1 - 1) + cls) * S;
+    for (int i = tid; i < S; i += 256) kp[i] = 0;
+    // candidates in RoI order (ballot compaction keeps the reference's j,i scan order)
+    int base = 0;
+    for (int chunk = 0; chunk < nb; chunk += 256) {
+        const int i = chunk + tid;
+        const long m = (long)b * S + i;
+        const bool pred = (i < nb) && (det_pr[m * C1 + cls] >= log_thr);
+        const unsigned long long mask = __ballot(pred);
+        if (lane == 0) s_w[wave] = __popcll(mask);
+        __syncthreads();
+        int wb = 0, tot = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) wb += s_w[w];
+            tot += s_w[w];
+        }
+        if (pred) {
+            const int k = base + wb + __popcll(mask & ((1ull << lane) - 1ull));
+            s_score[k] = fitness[m * C1 + cls];
+            s_idx[k] = i;
+            s_box[k * 4 + 0] = bbox[m * 4 + 0];
+            s_box[k * 4 + 1] = bbox[m * 4 + 1];
+            s_box[k * 4 + 2] = bbox[m * 4 + 2];
+            s_box[k * 4 + 3] = bbox[m * 4 + 3];
+        }
+        base += tot;
+        __syncthreads();
+    }
+    const int n = base;
+    for (int a = tid; a < n; a += 256) {
+        bool unique = true;
+        if (do_nms) {
+            const float sa = s_score[a];
+            const float ax0 = s_box[a * 4], ay0 = s_box[a * 4 + 1], ax1 = s_box[a * 4 + 2], ay1 = s_box[a * 4 + 3];
+            for (int o = 0; o < n; ++o) {
+                if (sa < s_score[o] &&
+                    box_iou(ax0, ay0, ax1, ay1, s_box[o * 4], s_box[o * 4 + 1], s_box[o * 4 + 2], s_box[o * 4 + 3]) > nms_thr) {
+                    unique = false;
+                    break;
+                }
+            }
+        }
+        if (unique) kp[s_idx[a]] = 1;
+    }
+}
+
+}  // namespace
+
+extern "C" int denet_detect_decode(const float* logits, const float* roi_bbox, float* det_pr, float* fitness,
+                                   float* bbox, int M, int CP, int class_num, int jointfit, int nreg,
+                                   float overlap_threshold, hipStream_t stream) {
+    DENET_CHECK_ARG(logits && roi_bbox && det_pr && fitness && bbox, "detect_decode: null pointer");
+    DENET_CHECK_ARG(nreg == 0 || nreg == 4, "detect_decode: nreg must be 0 or 4");
+    const int fit_num = 5;
+    const int s0 = jointfit ? class_num * fit_num + 1 : class_num + 1;
+    DENET_CHECK_ARG(s0 + nreg <= CP, "detect_decode: CP too small");
+    hipLaunchKernelGGL(detect_decode_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, logits, roi_bbox, det_pr, fitness,
+                       bbox, M, CP, class_num, fit_num, jointfit, nreg, overlap_threshold);
+    DENET_CHECK_LAUNCH("detect_decode");
+    return DENET_OK;
+}
+
+extern "C" int denet_detect_nms(const float* det_pr, const float* fitness, const float* bbox, const int* count,
+                                unsigned char* keep, int B, int S, int class_num, float pr_threshold,
+                                float nms_threshold, hipStream_t stream) {
+    DENET_CHECK_ARG(det_pr && fitness && bbox && count && keep, "detect_nms: null pointer");
+    DENET_CHECK_ARG(S > 0 && S <= 4096 && class_num > 0, "detect_nms: bad sizes");
+    const int do_nms = (nms_threshold > 0.0f && nms_threshold < 1.0f) ? 1 : 0;   // denet_detect.cc:76
+    const size_t lds = (size_t)S * 6 * sizeof(float);
+    hipLaunchKernelGGL(detect_nms_kernel, dim3(class_num, B), dim3(256), lds, stream, det_pr, fitness, bbox, count, keep,
+                       S, class_num + 1, logf(pr_threshold), nms_threshold, do_nms);
+    DENET_CHECK_LAUNCH("detect_nms");
+    return DENET_OK;
+}
+
+// Gaussian soft-NMS of ONE class on the host (denet_detect.cc:35-71): scores are log-probabilities, every selected
+// instance lowers the others by iou^2/threshold, instances below -6.9 are discarded; output in selection order.
+// score/box: n candidates in RoI order; out_order[k] = index into the candidate list, out_score[k] its final score.
+extern "C" int denet_soft_nms_host(const float* score, const float* box, int n, float nms_threshold,
+                                   int* out_order, float* out_score, int* out_n) {
+    DENET_CHECK_ARG((n == 0) || (score && box), "soft_nms_host: null pointer");
+    DENET_CHECK_ARG(out_order && out_score && out_n, "soft_nms_host: null output");
+    std::vector<float> s(score, score + n);
+    std::vector<int> alive(n);
+    for (int i = 0; i < n; ++i) alive[i] = i;
+    const float discard = -6.9f;
+    int k = 0;
+    while (!alive.empty()) {
+        size_t mi = 0;
+        for (size_t j = 0; j < alive.size(); ++j)
+            if (s[alive[j]] > s[alive[mi]]) mi = j;
+        const int M = alive[mi];
+        out_order[k] = M;
+        out_score[k] = s[M];
+        ++k;
+        alive.erase(alive.begin() + mi);
+        const float* bm = box + (size_t)M * 4;
+        std::vector<int> next;
+        for (int j : alive) {
+            const float* bj = box + (size_t)j * 4;
+            const float dx = fmaxf(0.0f, fminf(bm[2], bj[2]) - fmaxf(bm[0], bj[0]));
+            const float dy = fmaxf(0.0f, fminf(bm[3], bj[3]) - fmaxf(bm[1], bj[1]));
+            const float ai = dx * dy;
+            const float au = (bm[2] - bm[0]) * (bm[3] - bm[1]) + (bj[2] - bj[0]) * (bj[3] - bj[1]) - ai;
+            const float iou = ai / au;
+            s[j] -= iou * iou / nms_threshold;
+            if (!(s[j] < discard)) next.push_back(j);
+        }
+        alive.swap(next);
+    }
+    *out_n = k;
+    return DENET_OK;
+}

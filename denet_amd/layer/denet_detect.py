@@ -221,3 +221,59 @@ class DeNetDetectLayer(AbstractLayer):
     def backward(self, ctx):
         if self.conv.output.grad is not None:
             self.conv.backward(ctx)
+
+    # ---- inference ------------------------------------------------------------------------------
+    def get_detections(self, model, data_x, data_m, params):
+        """list of {"detections": [(pr, cls, (x0, y0, x1, y1)), ...], "meta": meta} per image — the return value of
+        the reference's get_detections (denet_detect.py:316-424): corner detector -> RoIs -> head in test mode ->
+        per-class threshold + NMS (build_detections_nms, denet_detect.cc:99-173)"""
+        import torch
+        pr_threshold = params.get("prThreshold", 0.01)
+        nms_threshold = params.get("nmsThreshold", 0.5)
+        sp = self.sparse_layer
+        saved = (sp.corner_threshold, sp.corner_max)
+        sp.corner_threshold = params.get("cornerThreshold", sp.corner_threshold)
+        sp.corner_max = params.get("cornerMax", 1024)
+        use_soft_nms = params.get("useSoftNMS", 0) == 1
+        timer = common.Timer()
+        try:
+            model.forward(data_x, None, train=False)
+        finally:
+            sp.corner_threshold, sp.corner_max = saved
+        B, S = self.batch_size, self.sample_num * self.sample_num
+        logits = self.conv.output.data.view(B * S, self.conv.kp)
+        t0, _ = self._thresholds()
+        det_pr, fitness, bbox = ops.detect_decode(logits, sp.sample_bbox, self.class_num, self.use_jointfit, self.s1, t0)
+        counts = numpy.array([len(bx) for bx in sp.sample_boxes], dtype=numpy.int32)
+        self.last_outputs = (det_pr, fitness, bbox, counts)
+        results = []
+        fit_h = fitness.cpu().numpy()
+        box_h = bbox.cpu().numpy()
+        if not use_soft_nms:
+            keep = ops.detect_nms(det_pr, fitness, bbox, torch.from_numpy(counts).cuda(), B, S, self.class_num,
+                                  pr_threshold, nms_threshold).cpu().numpy()
+            for b in range(B):
+                cls_idx, roi_idx = numpy.nonzero(keep[b])          # class-major, RoI order inside a class
+                rows = b * S + roi_idx
+                prs = numpy.exp(fit_h[rows, cls_idx])
+                dets = [(float(p), int(c), tuple(float(v) for v in box_h[r])) for p, c, r in zip(prs, cls_idx, rows)]
+                results.append({"detections": dets, "meta": data_m[b] if data_m is not None else None})
+        else:
+            det_h = det_pr.cpu().numpy()
+            log_thr = numpy.log(numpy.float32(pr_threshold))
+            for b in range(B):
+                dets = []
+                rows = numpy.arange(b * S, b * S + counts[b])
+                for cls in range(self.class_num):
+                    cand = rows[det_h[rows, cls] >= log_thr]
+                    if len(cand) == 0:
+                        continue
+                    if 0.0 < nms_threshold < 1.0:
+                        order, score = ops.soft_nms_host(fit_h[cand, cls], box_h[cand], nms_threshold)
+                    else:
+                        order, score = numpy.arange(len(cand)), fit_h[cand, cls]
+                    for k, sc in zip(order, numpy.exp(score.astype(numpy.float32))):
+                        dets.append((float(sc), cls, tuple(float(v) for v in box_h[cand[k]])))
+                results.append({"detections": dets, "meta": data_m[b] if data_m is not None else None})
+        self.detect_ms = timer.current_ms()
+        return results

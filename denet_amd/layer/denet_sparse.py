@@ -288,6 +288,10 @@ class DeNetSparseLayer(AbstractLayer):
     # ---- execution ----------------------------------------------------------------------------------------
     def forward(self, ctx):
         cl = self.corner_layer
+        if not get_train():
+            # inference (denet_detect.py:369-375): RoIs straight from the corner detector, no editing
+            self.sample_pr, self.sample_boxes = self._device_samples(store_shared=True)
+            self._upload_boxes()
         if get_train() or cl.sample_shared is None:
             fmap, coff, F = cl.sample_map()
         else:

@@ -51,6 +51,9 @@ SIGNATURES = {
     "denet_sparse_fwd": (I, [P, P, P, P] + [I] * 10 + [P]),
     "denet_sparse_bwd": (I, [P, P, P, P] + [I] * 10 + [P]),
     "denet_detect_loss": (I, [P] * 8 + [I] * 5 + [F, F, I, P]),
+    "denet_detect_decode": (I, [P] * 5 + [I] * 5 + [F, P]),
+    "denet_detect_nms": (I, [P] * 5 + [I, I, I, F, F, P]),
+    "denet_soft_nms_host": (I, [P, P, I, F, P, P, P]),
     "denet_build_samples_workspace_bytes": (Z, [I] * 6),
     "denet_build_samples": (I, [P, P, P, P, P, Z] + [I] * 4 + [F, I, I, I, P]),
     "denet_samples_finish_host": (I, [P, P, P, I, I, I, I, P]),

@@ -1,0 +1,123 @@
+"""model-train — single-GPU training driver with the CLI flag surface of the reference's denet/model/train.py
+(:46-156): --model / --model-desc, --solver, --learn-rate, --learn-momentum, --learn-decay, --learn-anneal,
+--learn-anneal-epochs, --batch-size, --seed, --border-mode, --activation, --weight-init, --cost-factors, --epochs,
+--output-prefix. The reference's dataset loaders are outside the hot path; `--train synthetic[,k=v]`
+feeds MSCOCO-shaped synthetic batches with the same meta-dict contract (image_loader.py:134-136), and any object
+with `export(batch_size) -> (x, metas, n)` (dataset/__init__.py:349-366) can be passed to train() directly."""
+import argparse
+import math
+import random
+import sys
+
+import numpy
+
+from . import model_cnn
+from . import zoo
+
+
+class SyntheticDataset:
+    """`samples` synthetic images with boxes/classes; export() follows DatasetAbstract.export"""
+
+    def __init__(self, samples=64, image=512, class_num=80, channels=3, seed=1):
+        self.samples, self.image, self.class_num, self.channels, self.seed = samples, image, class_num, channels, seed
+        self.class_labels = {"class%i" % i: i for i in range(class_num)}
+        self.subset_num = 1
+        self._x, self._m = zoo.synthetic_batch(samples, image, class_num, seed)
+
+    def __len__(self):
+        return self.samples
+
+    def get_data_shape(self):
+        return (self.channels, self.image, self.image)
+
+    def get_class_num(self):
+        return self.class_num
+
+    def shuffle(self):
+        order = list(range(self.samples))
+        random.shuffle(order)
+        self._x = self._x[order]
+        self._m = [self._m[i] for i in order]
+
+    def load_from_subset(self, subset):
+        pass
+
+    def export(self, batch_size):
+        n = int(math.ceil(self.samples / batch_size)) * batch_size
+        x, m = self._x, list(self._m)
+        if n > self.samples:   # pad with copies like the reference pads the last batch
+            reps = n - self.samples
+            x = numpy.concatenate([x, x[:reps]], axis=0)
+            m = m + m[:reps]
+        return x, m, self.samples
+
+
+def load_dataset(spec, seed):
+    parts = spec.split(",")
+    if parts[0] != "synthetic":
+        raise NotImplementedError("only `synthetic[,samples=N,image=S,classes=C]` data is provided: the reference's "
+                                  "dataset loaders are outside the hot path")
+    kw = {}
+    for p in parts[1:]:
+        k, v = p.split("=")
+        kw[{"samples": "samples", "image": "image", "classes": "class_num"}[k]] = int(v)
+    return SyntheticDataset(seed=seed, **kw)
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description="Train a convolutional network (MI355X hot path of lachlants/denet)")
+    parser.add_argument("--model", required=False, default=None, help="Model (.mdl.gz) to continue training.")
+    parser.add_argument("--cost-factors", default=[], nargs="+", help="Multiplicative factors for model costs")
+    parser.add_argument("--train", default="synthetic", help="training data: synthetic[,samples=N,image=S,classes=C]")
+    parser.add_argument("--border-mode", default="valid")
+    parser.add_argument("--output-prefix", default="./model")
+    parser.add_argument("--activation", default="relu")
+    parser.add_argument("--solver", type=str, default="nesterov")
+    parser.add_argument("--weight-init", nargs="+", default=["he-backward"])
+    parser.add_argument("--learn-rate", type=float, default=0.1)
+    parser.add_argument("--learn-momentum", type=float, default=[0.0, 0.0], nargs="+")
+    parser.add_argument("--learn-anneal", type=float, default=1)
+    parser.add_argument("--learn-anneal-epochs", nargs="+", type=int, default=[])
+    parser.add_argument("--learn-decay", type=float, default=0.0)
+    parser.add_argument("--epochs", type=int, default=30)
+    parser.add_argument("--batch-size", type=int, default=32)
+    parser.add_argument("--seed", type=int, default=23455)
+    parser.add_argument("--disable-intermediate", default=False, action="store_true")
+    parser.add_argument("--skip-layer-updates", type=int, nargs="+", default=[])
+    parser.add_argument("--model-desc", default=["C[100,7]", "P[2]", "C[150,4]", "P[2]", "C[250,4]", "P[2]", "C[300,1]", "R"],
+                        nargs="+", type=str)
+    return parser
+
+
+def train(args, train_data, log=print):
+    """the epoch loop of train.py:117-151 (shuffle, train_epoch, learning-rate annealing, checkpoint per epoch)"""
+    model = model_cnn.initialize(args, train_data.get_data_shape(), train_data.class_labels, train_data.get_class_num())
+    model.build_train_func(args.solver, args.cost_factors)
+    learn_rate = args.learn_rate
+    costs = []
+    for epoch in range(args.epochs):
+        train_data.shuffle()
+        for subset in range(train_data.subset_num):
+            train_data.load_from_subset(subset)
+            cost = model.train_epoch(train_data, epoch, learn_rate, args.learn_momentum, args.learn_decay)
+            costs.append(cost)
+            log("epoch %i subset %i - cost: %.4f (lr %g)" % (epoch, subset, cost, learn_rate))
+        if len(args.learn_anneal_epochs) == 0 or (epoch + 1) in args.learn_anneal_epochs:
+            learn_rate *= args.learn_anneal
+        if not args.disable_intermediate:
+            model_cnn.save_to_file(model, args.output_prefix + "_epoch%03i.mdl.gz" % epoch)
+    model_cnn.save_to_file(model, args.output_prefix + "_epoch%03i_final.mdl.gz" % (args.epochs - 1))
+    return model, costs
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    random.seed(args.seed)
+    numpy.random.seed(args.seed)
+    train_data = load_dataset(args.train, args.seed)
+    train(args, train_data)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -348,3 +348,33 @@ def samples_finish_host(box, absd, count, H, W):
     check(_L().denet_samples_finish_host(box.data_ptr(), absd.data_ptr(), count.data_ptr(), B, S, H, W,
                                          out.data_ptr()), "samples_finish_host")
     return out
+
+
+def detect_decode(logits, roi_bbox, class_num, jointfit, nreg, overlap_threshold):
+    M, CP = logits.shape
+    det_pr, fitness, bbox = empty(M, class_num + 1), empty(M, class_num + 1), empty(M, 4)
+    check(_L().denet_detect_decode(ptr(logits), ptr(roi_bbox), ptr(det_pr), ptr(fitness), ptr(bbox), M, CP, class_num,
+                                   int(jointfit), nreg, float(overlap_threshold), stream_ptr()), "detect_decode")
+    return det_pr, fitness, bbox
+
+
+def detect_nms(det_pr, fitness, bbox, count, B, S, class_num, pr_threshold, nms_threshold):
+    keep = torch.empty((B, class_num, S), dtype=torch.uint8, device="cuda")
+    check(_L().denet_detect_nms(ptr(det_pr), ptr(fitness), ptr(bbox), ptr(count), ptr(keep), B, S, class_num,
+                                float(pr_threshold), float(nms_threshold), stream_ptr()), "detect_nms")
+    return keep
+
+
+def soft_nms_host(score, box, nms_threshold):
+    """numpy in / numpy out: (order, final scores) of one class' candidates (Gaussian soft-NMS)"""
+    import ctypes
+    import numpy
+    n = int(score.shape[0])
+    score = numpy.ascontiguousarray(score, dtype=numpy.float32)
+    box = numpy.ascontiguousarray(box, dtype=numpy.float32)
+    order = numpy.empty(max(n, 1), dtype=numpy.int32)
+    out = numpy.empty(max(n, 1), dtype=numpy.float32)
+    k = ctypes.c_int(0)
+    check(_L().denet_soft_nms_host(score.ctypes.data, box.ctypes.data, n, float(nms_threshold), order.ctypes.data,
+                                   out.ctypes.data, ctypes.addressof(k)), "soft_nms_host")
+    return order[:k.value], out[:k.value]

@@ -130,6 +130,19 @@ int denet_detect_loss(const float* logits, const float* det_target, const float*
                       const float* roi_bbox, float* dlogits, float* costs, void* workspace, int M, int batch, int CP,
                       int ncls, int nreg, float cost_factor, float bbox_factor, int bounded_iou, hipStream_t stream);
 
+/* ---- inference tail  (denet/layer/denet_detect.py:76-100 class log-softmax + box decoding, :330-349
+ *      joint-fitness marginalisation; denet/layer/denet_detect.cc:99-173 build_detections_nms, :73-97 hard NMS,
+ *      :35-71 Gaussian soft-NMS).  logits:[M,CP]; det_pr/fitness:[M,class_num+1] log domain; bbox:[M,4];
+ *      count:[B] valid RoIs per image; keep:[B,class_num,S] bytes (1 = surviving detection). The soft-NMS variant is
+ *      sequential by construction and runs on the host over one class' candidates.                           */
+int denet_detect_decode(const float* logits, const float* roi_bbox, float* det_pr, float* fitness, float* bbox, int M,
+                        int CP, int class_num, int jointfit, int nreg, float overlap_threshold, hipStream_t stream);
+int denet_detect_nms(const float* det_pr, const float* fitness, const float* bbox, const int* count,
+                     unsigned char* keep, int B, int S, int class_num, float pr_threshold, float nms_threshold,
+                     hipStream_t stream);
+int denet_soft_nms_host(const float* score_host, const float* box_host, int n, float nms_threshold,
+                        int* out_order_host, float* out_score_host, int* out_n_host);
+
 /* ---- corner selection + RoI proposal  (denet/layer/denet_sparse.cc:489-557 run_build_samples, :321-471
  *      search_corners, :271-308 get_sample; Python-facing wrapper build_samples :559-668, which the reference
  *      calls on the HOST with a D2H copy of the corner map, denet/layer/denet_sparse.py:129-139).

@@ -495,3 +495,38 @@ def solver_update(p, m, g, lr, momentum, iteration, decay, is_weight, mode="nest
         m2 = rho * m + (F32(1.0) - rho) * g
         p2 = p - F32(lr) * m2
     return p2.astype(F32), m2.astype(F32)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# inference decode: denet/layer/denet_detect.py:76-100 (det_pr, bbox_predict), :330-349 (joint fitness)
+# ---------------------------------------------------------------------------------------------------------
+def detect_outputs(out, sample_bbox, class_num, jointfit, t0, use_bbox_reg=True):
+    """out (B, s0[+4], sn, sn) -> det_pr (B,C+1,sn,sn), fitness (B,C+1,sn,sn), bbox (B,sn,sn,4)"""
+    B, _, sn, _ = out.shape
+    fit = 5
+    s0 = class_num * fit + 1 if jointfit else class_num + 1
+    o = out.astype(F32)
+    lp = log_softmax(o[:, :s0], axis=1).astype(F32)
+    if jointfit:
+        det_fit = lp[:, :class_num * fit].reshape(B, class_num, fit, sn, sn)
+        null = lp[:, class_num * fit]
+        m = det_fit.max(axis=2)
+        det_pr = m + np.log(np.sum(np.exp(det_fit - m[:, :, None]), axis=2))
+        det_pr = np.concatenate([det_pr, null[:, None]], axis=1).astype(F32)
+        val = np.array([t0 + i * (1.0 - t0) / fit for i in range(fit)], dtype=F32)
+        fitness = np.log(np.sum(np.exp(det_fit) * val[None, None, :, None, None], axis=2))
+        fitness = np.concatenate([fitness, null[:, None]], axis=1).astype(F32)
+    else:
+        det_pr = lp
+        fitness = lp.copy()
+    if use_bbox_reg:
+        reg = o[:, s0:s0 + 4]
+        sb = sample_bbox.astype(F32)
+        scx, scy = F32(0.5) * (sb[..., 0] + sb[..., 2]), F32(0.5) * (sb[..., 1] + sb[..., 3])
+        sw, sh = sb[..., 2] - sb[..., 0], sb[..., 3] - sb[..., 1]
+        pcx, pcy = reg[:, 0] * sw + scx, reg[:, 1] * sh + scy
+        pw, ph = np.exp(reg[:, 2]) * sw, np.exp(reg[:, 3]) * sh
+        bbox = np.stack([pcx - pw * F32(0.5), pcy - ph * F32(0.5), pcx + pw * F32(0.5), pcy + ph * F32(0.5)], axis=-1)
+    else:
+        bbox = sample_bbox
+    return det_pr, fitness, bbox.astype(F32)

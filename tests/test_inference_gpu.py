@@ -1,0 +1,171 @@
+"""Inference tail: class/fitness/box decode + per-class NMS of the detection head against the oracle
+(oracle/layers.py:detect_outputs restates denet_detect.py:76-100,330-349; oracle/build_samples.cc restates
+build_detections_nms of denet_detect.cc:99-173). Membership, class, order and boxes are exact on the same decoded
+arrays; the decode itself (exp/log) is floating point: 1e-5 relative."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from denet_amd import ops
+from denet_amd.model import zoo
+from oracle import layers as OL
+from oracle import model as OM
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_nms(det_pr, fitness, bbox, counts, B, sn, C1, pr_thr, nms_thr, soft):
+    """arrays in the product's [B*S, C1] / [B*S, 4] layout -> list[B] of (pr, cls, box) rows from the oracle"""
+    S = sn * sn
+    det = np.ascontiguousarray(det_pr.reshape(B, sn, sn, C1).transpose(0, 3, 1, 2), dtype=np.float32)
+    fit = np.ascontiguousarray(fitness.reshape(B, sn, sn, C1).transpose(0, 3, 1, 2), dtype=np.float32)
+    bx = np.ascontiguousarray(bbox.reshape(B, sn, sn, 4), dtype=np.float32)
+    num = np.ascontiguousarray(counts, dtype=np.int32)
+    max_out = S * (C1 - 1)
+    out = np.zeros((B, max_out, 6), np.float32)
+    cnt = np.zeros(B, np.int32)
+    f = OM.oracle_lib().oracle_build_detections_nms
+    f.argtypes = [ctypes.c_float, ctypes.c_float, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 2
+    f(pr_thr, nms_thr, int(soft), det.ctypes.data, fit.ctypes.data, bx.ctypes.data, num.ctypes.data, B, C1, sn, max_out,
+      out.ctypes.data, cnt.ctypes.data)
+    return [out[b, :cnt[b]] for b in range(B)]
+
+
+def _clustered_boxes(rng, B, S):
+    centres = rng.rand(B, 6, 2)
+    pick = rng.randint(0, 6, (B, S))
+    c = np.take_along_axis(centres, pick[..., None].repeat(2, -1), 1) + rng.normal(0, 0.02, (B, S, 2))
+    wh = 0.2 + 0.05 * rng.rand(B, S, 2)
+    return np.concatenate([c - wh / 2, c + wh / 2], -1).astype(np.float32)
+
+
+def _product_lists(keep, fit_h, box_h, B, S):
+    res = []
+    for b in range(B):
+        cls_idx, roi_idx = np.nonzero(keep[b])
+        rows = b * S + roi_idx
+        res.append(np.concatenate([np.exp(fit_h[rows, cls_idx])[:, None], cls_idx[:, None].astype(np.float32),
+                                   box_h[rows]], 1).astype(np.float32).reshape(-1, 6))
+    return res
+
+
+@pytest.mark.parametrize("jointfit", [0, 1])
+@pytest.mark.parametrize("sn", [4, 24])
+def test_detect_decode_and_nms_vs_oracle(hip, jointfit, sn):
+    rng = np.random.RandomState(10 + sn + jointfit)
+    B, C, S = 3, 7, sn * sn
+    s0 = C * 5 + 1 if jointfit else C + 1
+    CP = (s0 + 4 + 31) // 32 * 32
+    t0 = 0.5
+    logits = np.zeros((B * S, CP), np.float32)
+    logits[:, :s0] = rng.normal(0, 2.5, (B * S, s0))
+    logits[:, s0:s0 + 4] = rng.normal(0, 0.2, (B * S, 4))
+    roi = _clustered_boxes(rng, B, S).reshape(B * S, 4)
+    counts = np.array([S, S // 3, 0], np.int32)
+    det_pr, fitness, bbox = ops.detect_decode(torch.from_numpy(logits).cuda(), torch.from_numpy(roi).cuda(), C, jointfit, 4, t0)
+    det_h, fit_h, box_h = det_pr.cpu().numpy(), fitness.cpu().numpy(), bbox.cpu().numpy()
+    # decode against the numpy restatement (NCHW like the reference)
+    out_nchw = logits[:, :s0 + 4].reshape(B, sn, sn, s0 + 4).transpose(0, 3, 1, 2)
+    o_det, o_fit, o_box = OL.detect_outputs(out_nchw, roi.reshape(B, sn, sn, 4), C, bool(jointfit), t0)
+    np.testing.assert_allclose(det_h.reshape(B, sn, sn, C + 1).transpose(0, 3, 1, 2), o_det, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(fit_h.reshape(B, sn, sn, C + 1).transpose(0, 3, 1, 2), o_fit, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(box_h.reshape(B, sn, sn, 4), o_box, rtol=1e-5, atol=1e-6)
+    # NMS: exact against the oracle on the SAME decoded arrays
+    for pr_thr, nms_thr in ((0.1, 0.5), (0.3, 0.3), (0.1, 1.0), (0.2, 0.0)):
+        keep = ops.detect_nms(det_pr, fitness, bbox, torch.from_numpy(counts).cuda(), B, S, C, pr_thr, nms_thr).cpu().numpy()
+        got = _product_lists(keep, fit_h, box_h, B, S)
+        ref = _oracle_nms(det_h, fit_h, box_h, counts, B, sn, C + 1, pr_thr, nms_thr, False)
+        for b in range(B):
+            assert got[b].shape == ref[b].shape, (b, pr_thr, nms_thr, got[b].shape, ref[b].shape)
+            assert np.array_equal(got[b][:, 1:], ref[b][:, 1:])
+            np.testing.assert_allclose(got[b][:, 0], ref[b][:, 0], rtol=2e-6)
+        if 0 < nms_thr < 1:
+            assert 0 < sum(len(g) for g in got) < int((det_h[:, :C] >= np.log(np.float32(pr_thr))).sum()), "NMS did nothing"
+    assert len(got[2]) == 0
+
+
+def test_soft_nms_host_vs_oracle(hip):
+    rng = np.random.RandomState(3)
+    B, sn, C = 1, 12, 1
+    S = sn * sn
+    box = _clustered_boxes(rng, B, S).reshape(S, 4)
+    fit = np.log(rng.uniform(0.02, 1.0, (S, 2))).astype(np.float32)
+    counts = np.array([S - 5], np.int32)
+    for nms_thr in (0.3, 0.6):
+        ref = _oracle_nms(fit, fit, box, counts, B, sn, C + 1, 0.05, nms_thr, True)[0]
+        cand = np.arange(counts[0])[fit[:counts[0], 0] >= np.log(np.float32(0.05))]
+        order, score = ops.soft_nms_host(fit[cand, 0], box[cand], nms_thr)
+        assert len(order) == len(ref) and 0 < len(ref) < len(cand)
+        assert np.array_equal(box[cand[order]], ref[:, 2:])
+        np.testing.assert_allclose(np.exp(score), ref[:, 0], rtol=2e-6)
+
+
+@pytest.mark.parametrize("soft", [0, 1])
+def test_denet34_get_detections_vs_oracle(hip, soft):
+    """whole inference path on DeNet-34 skip (128x128): test-mode forward -> corner detector RoIs -> head -> NMS"""
+    from tests.test_parity_gpu import _warm_corner_head, rel_close
+    B, IMG = 2, 128
+    model = zoo.denet34(B, "skip", IMG, class_num=20, seed=1)
+    rng = np.random.RandomState(5)
+    dnd = model.layers[40]
+    dconv = dnd.layers[0]
+    dconv.omega.set_value(rng.normal(0, 0.3, dconv.omega.value.shape))
+    _warm_corner_head(model, 4.0, 0.3)
+    x, metas = zoo.synthetic_batch(B, IMG, seed=2)
+    params = {"prThreshold": 0.08, "nmsThreshold": 0.5, "cornerThreshold": 0.02, "useSoftNMS": soft}
+    # test-mode BN on untrained running statistics blows the activations up: rescale the head filters so that the
+    # class logits are O(1) and the box regression outputs O(0.1), like a trained head
+    dnd.get_detections(model, x, metas, params)
+    raw = dnd.conv.output.data.float().cpu().numpy().reshape(-1, dnd.conv.kp)
+    s0 = dnd.s0
+    w = dconv.omega.get_value().copy()
+    w[:s0] *= 2.0 / raw[:, :s0].std()
+    w[s0:s0 + 4] *= 0.2 / raw[:, s0:s0 + 4].std()
+    dconv.omega.set_value(w)
+    results = dnd.get_detections(model, x, metas, params)
+    dns, cl = model.layers[31], model.layers[30]
+    # RoI proposal: exact on the product's corner map
+    lists = OM.oracle_build_samples(cl.corner_pr.cpu().numpy(), 0.02, dns.sample_num, 1024, 0)
+    assert sum(len(l) for l in lists) > 0
+    got_lists = dns.sample_bbox_list
+    for g, r in zip(got_lists, lists):        # order inside a group of exactly equal scores is unspecified (std::partial_sort)
+        assert [p for p, _ in g] == [p for p, _ in r]
+        i = 0
+        while i < len(r):
+            j = i
+            while j + 1 < len(r) and r[j + 1][0] == r[i][0]:
+                j += 1
+            if not (j + 1 == len(r) and len(r) == dns.sample_count):   # a tie group cut by the top-K boundary
+                assert sorted(bx for _, bx in g[i:j + 1]) == sorted(bx for _, bx in r[i:j + 1])
+            i = j + 1
+    lists = got_lists
+    # head: oracle forward in test mode on the same RoIs
+    om = OM.OracleModel(model.export_json(), B)
+    om.forward(x, None, train=False, sample_override=lists)
+    rel_close(cl.corner_pr.cpu().numpy(), om.corner_pr, 1e-3, "corner_pr (test mode)")
+    det_pr, fitness, bbox, counts = dnd.last_outputs
+    assert counts.tolist() == [len(l) for l in lists]
+    sn = dns.sample_num
+    t0 = dnd._thresholds()[0]
+    o_det, o_fit, o_box = OL.detect_outputs(om.detect_out.v, om.sample_bbox, 20, bool(dnd.use_jointfit), t0)
+    C1 = 21
+    valid = (np.arange(sn * sn)[None] < counts[:, None]).reshape(B, 1, sn, sn)
+    d = det_pr.cpu().numpy().reshape(B, sn, sn, C1).transpose(0, 3, 1, 2)
+    np.testing.assert_allclose(np.where(valid, d, 0), np.where(valid, o_det, 0), rtol=1e-3, atol=1e-3)
+    bx = bbox.cpu().numpy().reshape(B, sn, sn, 4)
+    v4 = valid.reshape(B, sn, sn, 1)
+    np.testing.assert_allclose(np.where(v4, bx, 0), np.where(v4, o_box, 0), rtol=1e-3, atol=1e-4)
+    # threshold + NMS: exact on the product's decoded arrays
+    ref = _oracle_nms(det_pr.cpu().numpy(), fitness.cpu().numpy(), bbox.cpu().numpy(), counts, B, sn, C1, 0.08, 0.5, soft)
+    total = 0
+    for b in range(B):
+        dets = results[b]["detections"]
+        assert results[b]["meta"] is metas[b]
+        assert len(dets) == len(ref[b])
+        total += len(dets)
+        for (pr, cls, box), r in zip(dets, ref[b]):
+            assert cls == int(r[1]) and np.array_equal(np.array(box, np.float32), r[2:])
+            assert abs(pr - r[0]) <= 2e-6 * r[0]
+    assert total > 0, "no detections: the test exercises nothing"

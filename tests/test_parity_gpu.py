@@ -434,3 +434,24 @@ def test_denet_head_variants_vs_oracle(hip, head, rule):
     assert np.array_equal(model.layers[31]._taps.cpu().numpy(), taps_ref)
     if "J" in head:
         assert model.layers[40].s0 == 401
+
+
+def test_model_train_cli_trains_and_checkpoints(hip, tmp_path):
+    """the model-train flag surface: a few epochs on synthetic data reduce the cost; the .mdl.gz reloads"""
+    from denet_amd.model import train as train_mod, model_cnn
+    prefix = str(tmp_path / "m")
+    args = train_mod.build_parser().parse_args(
+        ["--train", "synthetic,samples=32,image=32,classes=10", "--batch-size", "16", "--epochs", "6", "--seed", "3",
+         "--solver", "nesterov", "--learn-rate", "0.05", "--learn-momentum", "0.9", "--learn-decay", "1e-4",
+         "--learn-anneal", "0.5", "--learn-anneal-epochs", "4", "--border-mode", "half", "--output-prefix", prefix,
+         "--model-desc"] + zoo.CIFAR3_DESC.split())
+    random.seed(args.seed)
+    np.random.seed(args.seed)
+    data = train_mod.load_dataset(args.train, args.seed)
+    model, costs = train_mod.train(args, data, log=lambda *a: None)
+    assert np.isfinite(costs).all() and costs[-1] < 0.7 * costs[0], costs
+    m2 = model_cnn.load_from_file(prefix + "_epoch005_final.mdl.gz", 16)
+    x, metas, _ = data.export(16)
+    p1 = model.predict_output_step(x[:16])
+    p2 = m2.predict_output_step(x[:16])
+    np.testing.assert_allclose(p1, p2, rtol=1e-5, atol=1e-6)
