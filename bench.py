@@ -32,6 +32,34 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mf
 BATCH_PER_GPU = 32                # papers/dss/denet34.sh:43 --batch-size 32
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE need
+    separate passes, so they cannot be collected inside this run): profiles/rNN_*_pmc_traffic.json, written by
+    tools/pmc_traffic.py from the same bench command. None if no such summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        k = json.load(f)["kernels"].get(kernel)
+    if not k or k.get("write_bytes_per_launch") is None:
+        return None
+    return round(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"])
+
+
+def host_cores():
+    """cores the CPU baseline can really use: the affinity mask clipped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,7 +169,7 @@ def main():
         achieved = (a["flops"] / a["launches"]) / (avg_ms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2),
                            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                           "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(name),
                            "launches_per_step": a["launches"] // nprof, "avg_launch_ms": round(avg_ms, 4),
                            "flop_per_launch": round(a["flops"] / a["launches"]),
                            "all_igemm": {k: {"launches_per_step": v["launches"] // nprof,
@@ -151,17 +179,22 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import model as OM
-        cores = len(os.sched_getaffinity(0))
+        cores = host_cores()
         m1 = zoo.denet34(1, "skip", 512, class_num=80, seed=1)
         om = OM.OracleModel(m1.export_json(), 1)
         x1, metas1 = zoo.synthetic_batch(1, 512, 80, seed=1)
         random.seed(1)
-        t0 = time.perf_counter()
-        om.train_step(x1, metas1, 0, lr, mom[0], decay, "nesterov")
-        cdt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": round(1.0 / cdt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-                               "sample": "1 full train step at batch 1 of the same model (numpy im2col+BLAS conv, "
-                                         "C++ RoI proposal), %.1f s" % cdt}
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=cores):      # BLAS threads = the cores this process may really use
+            t0 = time.perf_counter()
+            nsteps = 0
+            while nsteps < 8 and (nsteps == 0 or time.perf_counter() - t0 < 12.0):
+                om.train_step(x1, metas1, nsteps, lr, mom[0], decay, "nesterov")
+                nsteps += 1
+            cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(nsteps / cdt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+                               "sample": "%d full train steps at batch 1 of the same model (numpy im2col+BLAS conv, "
+                                         "C++ RoI proposal), %.1f s" % (nsteps, cdt)}
 
     if rank == 0:
         print(json.dumps(out), flush=True)

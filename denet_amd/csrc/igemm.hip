@@ -17,6 +17,7 @@
 //                 reduction order is a fixed permutation of k (legal: the sum is over the same terms).
 // Launch:         1-D grid over tiles with an XCD-aware remap (8 XCDs, private L2 each).
 #include "common.h"
+#include <vector>
 #include <stdlib.h>
 
 namespace {
@@ -441,6 +442,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // the instantiation chosen by the last conv launch of this thread (profiling / roofline bookkeeping)
 thread_local int g_last_cfg[5] = {0, 0, 0, 0, 0};   // mode, BM, BN, NBUF, grid.y
 
+// optional live timing of the igemm kernel ALONE (bench.py's roofline leg): one event pair per launch, recorded on
+// the stream the kernel runs on, so that the average agrees with rocprofv3's per-kernel duration
+struct ProfRec {
+    hipEvent_t a, b;
+    int cfg[4];
+};
+std::vector<ProfRec> g_prof;
+bool g_prof_on = false;
+
 template <int MODE, int BM, int BN, int WM, int WN, int NBUF = 2>
 int launch_igemm(const IgemmParams& p, int splits, hipStream_t stream) {
     g_last_cfg[0] = MODE; g_last_cfg[1] = BM; g_last_cfg[2] = BN; g_last_cfg[3] = NBUF; g_last_cfg[4] = splits;
@@ -462,7 +472,20 @@ int launch_igemm(const IgemmParams& p, int splits, hipStream_t stream) {
     // wgrad folds the split slices into grid.x (see the id decode in the kernel); dgrad: y = stride parity classes
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n) * (MODE == MODE_WGRAD ? (unsigned)splits : 1u),
               MODE == MODE_WGRAD ? 1u : (unsigned)splits, 1);
+    ProfRec rec;
+    if (g_prof_on) {
+        rec.cfg[0] = MODE; rec.cfg[1] = BM; rec.cfg[2] = BN; rec.cfg[3] = NBUF;
+        if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) {
+            denet_set_error("igemm: hipEventCreate failed");
+            return DENET_ERR_ARG;
+        }
+        hipEventRecord(rec.a, stream);
+    }
     hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, NBUF>), grid, dim3(256), lds, stream, p);
+    if (g_prof_on) {
+        hipEventRecord(rec.b, stream);
+        g_prof.push_back(rec);
+    }
     DENET_CHECK_LAUNCH("igemm");
     return DENET_OK;
 }
@@ -536,6 +559,33 @@ int check_geom(int N, int H, int W, int C, int K, int R, int S, int S_real, int 
 }
 
 }  // namespace
+
+extern "C" int denet_conv_profile(int enable) {
+    for (auto& r : g_prof) {
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    g_prof_on = enable != 0;
+    return DENET_OK;
+}
+
+extern "C" int denet_conv_profile_count(void) { return (int)g_prof.size(); }
+
+extern "C" int denet_conv_profile_read(int i, float* ms, int* mode, int* bm, int* bn, int* nbuf) {
+    DENET_CHECK_ARG(i >= 0 && i < (int)g_prof.size() && ms, "conv_profile_read: index %d out of range", i);
+    hipError_t e = hipEventSynchronize(g_prof[i].b);
+    if (e == hipSuccess) e = hipEventElapsedTime(ms, g_prof[i].a, g_prof[i].b);
+    if (e != hipSuccess) {
+        denet_set_error("conv_profile_read: %s", hipGetErrorString(e));
+        return -(int)e;
+    }
+    if (mode) *mode = g_prof[i].cfg[0];
+    if (bm) *bm = g_prof[i].cfg[1];
+    if (bn) *bn = g_prof[i].cfg[2];
+    if (nbuf) *nbuf = g_prof[i].cfg[3];
+    return DENET_OK;
+}
 
 extern "C" int denet_conv_last_config(int* mode, int* bm, int* bn, int* nbuf, int* grid_y) {
     if (mode) *mode = g_last_cfg[0];

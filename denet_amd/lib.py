@@ -25,6 +25,9 @@ SIGNATURES = {
     "denet_conv_dgrad": (I, [P, P, P, P] + [I] * 12 + [P]),
     "denet_conv_wgrad_workspace_bytes": (Z, [I] * 7),
     "denet_conv_last_config": (I, [P] * 5),
+    "denet_conv_profile": (I, [I]),
+    "denet_conv_profile_count": (I, []),
+    "denet_conv_profile_read": (I, [I] + [P] * 5),
     "denet_conv_wgrad": (I, [P, P, P, P, Z] + [I] * 12 + [P]),
     "denet_bn_workspace_bytes": (Z, [L, I]),
     "denet_bn_fwd_train": (I, [P] * 10 + [L, I, F, F, I, P]),

@@ -37,26 +37,33 @@ WGRAD_WS_BYTES = 1024 << 20
 
 
 class KernelProfile:
-    """Live per-kernel timing with HIP events on the stream the kernels are launched on (bench.py's roofline
-    leg). Each convolution launch is bracketed by two events; algorithmic FLOPs = 2 * MACs of the layer."""
+    """Live per-kernel timing (bench.py's roofline leg). The C side records one HIP event pair around every igemm
+    kernel launch, on the stream it is launched on (denet_conv_profile, include/denet_hip.h); this side keeps the
+    algorithmic FLOPs (2 * MACs of the layer) of the same launches, in the same order."""
 
     def __init__(self):
-        self.records = []
+        self.flops = []
+        check(_L().denet_conv_profile(1), "conv_profile")
 
-    def bracket(self, name, flops):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        rec = [name, flops, s, e]
-        self.records.append(rec)
-        return s, e, rec
+    def add(self, flops):
+        self.flops.append(flops)
 
     def summary(self):
+        import ctypes
         torch.cuda.synchronize()
+        L = _L()
+        n = L.denet_conv_profile_count()
+        assert n == len(self.flops), "igemm launches (%d) != convolution calls (%d)" % (n, len(self.flops))
         agg = {}
-        for name, flops, s, e in self.records:
+        ms, v = ctypes.c_float(), [ctypes.c_int() for _ in range(4)]
+        for i, flops in enumerate(self.flops):
+            check(L.denet_conv_profile_read(i, ctypes.byref(ms), *[ctypes.byref(x) for x in v]), "conv_profile_read")
+            name = "igemm_kernel<%d, %d, %d, 2, 2, %d>" % tuple(x.value for x in v)
             a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
             a["launches"] += 1
-            a["ms"] += s.elapsed_time(e)
+            a["ms"] += ms.value
             a["flops"] += flops
+        check(L.denet_conv_profile(0), "conv_profile")
         return agg
 
 
@@ -106,12 +113,8 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
     N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
     y = out if out is not None else empty(N, OH, OW, K)
     if PROFILE is not None:
-        ev = PROFILE.bracket(None, _conv_flops(g, logical))
-        ev[0].record()
+        PROFILE.add(_conv_flops(g, logical))
     check(_L().denet_conv_fwd(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), *g, stream_ptr()), "conv_fwd")
-    if PROFILE is not None:
-        ev[1].record()
-        ev[2][0] = _last_igemm_name()
     return y
 
 
@@ -120,12 +123,8 @@ def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None,
     assert tuple(dy.shape) == (g[0], g[10], g[11], g[4]), (dy.shape, g)
     dx = out if out is not None else empty(*x_shape)
     if PROFILE is not None:
-        ev = PROFILE.bracket(None, _conv_flops(g, logical))
-        ev[0].record()
+        PROFILE.add(_conv_flops(g, logical))
     check(_L().denet_conv_dgrad(ptr(dy), ptr(w), ptr(add), ptr(dx), *g, stream_ptr()), "conv_dgrad")
-    if PROFILE is not None:
-        ev[1].record()
-        ev[2][0] = _last_igemm_name()
     return dx
 
 
@@ -135,12 +134,8 @@ def conv_wgrad(x, dy, w_shape, stride=1, pad=0, s_real=None, out=None, logical=N
     dw = out if out is not None else empty(*w_shape)
     ws = WS.get("wgrad", WGRAD_WS_BYTES)
     if PROFILE is not None:
-        ev = PROFILE.bracket(None, _conv_flops(g, logical))
-        ev[0].record()
+        PROFILE.add(_conv_flops(g, logical))
     check(_L().denet_conv_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel(), *g, stream_ptr()), "conv_wgrad")
-    if PROFILE is not None:
-        ev[1].record()
-        ev[2][0] = _last_igemm_name()
     return dw
 
 

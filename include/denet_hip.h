@@ -55,6 +55,12 @@ size_t denet_conv_wgrad_workspace_bytes(int N, int C, int K, int R, int S, int O
 /* kernel instantiation picked by this thread's last conv launch: mode 0 fwd / 1 dgrad / 2 wgrad, tile BMxBN, LDS
  * buffers, grid.y (wgrad split slices / dgrad stride classes) — profiling bookkeeping only                      */
 int denet_conv_last_config(int* mode, int* bm, int* bn, int* nbuf, int* grid_y);
+/* live timing of the igemm kernel alone (bench.py roofline leg): denet_conv_profile(1) starts recording one HIP event
+ * pair per convolution launch on the launch stream, (0) stops and frees; _read returns the duration of launch i and the
+ * instantiation <mode,BM,BN,2,2,NBUF> it used (the name rocprofv3 --kernel-trace shows).                       */
+int denet_conv_profile(int enable);
+int denet_conv_profile_count(void);
+int denet_conv_profile_read(int i, float* ms, int* mode, int* bm, int* bn, int* nbuf);
 int denet_conv_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes, int N,
                      int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH, int OW,
                      hipStream_t stream);
