@@ -90,3 +90,72 @@ extern "C" int denet_host_py_random_sample(uint32_t* mt, int* pos, int n, int k,
     }
     return DENET_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Training-time RoI list editing of a whole batch (denet/layer/denet_sparse.py:184-201), call for call on a copy
+// of the stdlib generator's MT19937 state. Per image, in order:
+//   n_det > n_keep : keep the entries random.sample(list, n_keep) picks (pool branch, see above)
+//   while len < S  : append (0.0, (x0, y0, x1, y1)), x0 = uniform(0,1), y0 = uniform(0,1), x1 = uniform(x0,1),
+//                    y1 = uniform(y0,1); uniform(a,b) = a + (b-a)*random(); random() = genrand_res53
+//   sample_gt      : list[-(k+1)] = (1.0, gt_k)
+// det: [B,S,5] float (pr,x0,y0,x1,y1) rows of denet_samples_finish_host; gt: concatenated [n,4] doubles with
+// gt_off[B+1]. Outputs: out_pr [B,S] and out_box [B,S,4] doubles (the values the reference's Python list would
+// hold) and out_box_f32 [B,S,4] (what build_bbox_array would upload). Pure host code.
+// ---------------------------------------------------------------------------------------------------------
+static inline double mt_random(uint32_t* mt, int* pos) {
+    const uint32_t a = mt_next(mt, pos) >> 5, b = mt_next(mt, pos) >> 6;
+    return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);
+}
+
+extern "C" int denet_host_edit_samples(uint32_t* mt, int* pos, const float* det, const int* count, int B, int S,
+                                       int n_keep, const double* gt, const int* gt_off, int sample_gt, int* ws,
+                                       double* out_pr, double* out_box, float* out_box_f32) {
+#pragma clang fp contract(off)
+    DENET_CHECK_ARG(mt && pos && det && count && ws && out_pr && out_box && out_box_f32, "edit_samples: null pointer");
+    DENET_CHECK_ARG(B > 0 && S > 0 && n_keep >= 0 && n_keep <= S, "edit_samples: bad sizes");
+    DENET_CHECK_ARG(!sample_gt || (gt_off && (gt || gt_off[B] == 0)), "edit_samples: ground truth missing");
+    int* pool = ws;          // [S]
+    int* pick = ws + S;      // [S]
+    for (int b = 0; b < B; ++b) {
+        const float* d = det + (size_t)b * S * 5;
+        double* pr = out_pr + (size_t)b * S;
+        double* bx = out_box + (size_t)b * S * 4;
+        int n = count[b];
+        DENET_CHECK_ARG(n >= 0 && n <= S, "edit_samples: count[%d] = %d out of range", b, n);
+        if (n > n_keep) {
+            int rc = denet_host_py_random_sample(mt, pos, n, n_keep, pool, pick);
+            if (rc != DENET_OK) return rc;
+            n = n_keep;
+            for (int i = 0; i < n; ++i) {
+                const float* r = d + (size_t)pick[i] * 5;
+                pr[i] = r[0];
+                for (int c = 0; c < 4; ++c) bx[i * 4 + c] = r[1 + c];
+            }
+        } else {
+            for (int i = 0; i < n; ++i) {
+                pr[i] = d[i * 5];
+                for (int c = 0; c < 4; ++c) bx[i * 4 + c] = d[i * 5 + 1 + c];
+            }
+        }
+        for (int i = n; i < S; ++i) {
+            const double x0 = 0.0 + (1.0 - 0.0) * mt_random(mt, pos);
+            const double y0 = 0.0 + (1.0 - 0.0) * mt_random(mt, pos);
+            const double x1 = x0 + (1.0 - x0) * mt_random(mt, pos);
+            const double y1 = y0 + (1.0 - y0) * mt_random(mt, pos);
+            pr[i] = 0.0;
+            bx[i * 4 + 0] = x0; bx[i * 4 + 1] = y0; bx[i * 4 + 2] = x1; bx[i * 4 + 3] = y1;
+        }
+        if (sample_gt) {
+            const int g0 = gt_off[b], ng = gt_off[b + 1] - g0;
+            DENET_CHECK_ARG(ng >= 0 && ng <= S, "edit_samples: image %d has %d ground-truth boxes (> %d RoIs)", b, ng, S);
+            for (int k = 0; k < ng; ++k) {
+                const int i = S - 1 - k;
+                pr[i] = 1.0;
+                for (int c = 0; c < 4; ++c) bx[i * 4 + c] = gt[(size_t)(g0 + k) * 4 + c];
+            }
+        }
+        float* f = out_box_f32 + (size_t)b * S * 4;
+        for (int i = 0; i < S * 4; ++i) f[i] = (float)bx[i];
+    }
+    return DENET_OK;
+}

@@ -140,7 +140,7 @@ class DeNetSparseLayer(AbstractLayer):
         return prs, boxes
 
     # ---- corner detector -> sample boxes ------------------------------------------------------------------
-    def _device_samples(self, store_shared=False):
+    def _device_samples(self, store_shared=False, raw_only=False):
         """GPU RoI proposal + ONE device->host copy of its packed result (boxes, |d|, counts)"""
         import torch
         cl = self.corner_layer
@@ -162,12 +162,17 @@ class DeNetSparseLayer(AbstractLayer):
         ops.wait_stream()
         h = self._res_host
         hcount = h[B * S * 5:]
+        self._raw_samples = None
         if int(hcount.sum()) == 0:        # cold detector: nothing proposed
             empty_pr, empty_bx = numpy.zeros((0,)), numpy.zeros((0, 4))
             return [empty_pr] * B, [empty_bx] * B
         hbox = h[:B * S * 4].view(B, S, 4)
         habsd = h[B * S * 4:B * S * 5].view(torch.float32).view(B, S)
-        samples = ops.samples_finish_host(hbox, habsd, hcount, cl.height, cl.width).numpy().astype(numpy.float64)
+        raw = ops.samples_finish_host(hbox, habsd, hcount, cl.height, cl.width).numpy()
+        self._raw_samples = (raw, hcount.numpy())
+        if raw_only:
+            return None, None
+        samples = raw.astype(numpy.float64)
         counts = hcount.tolist()
         prs = [samples[b, :counts[b], 0] for b in range(B)]
         boxes = [samples[b, :counts[b], 1:5] for b in range(B)]
@@ -272,10 +277,62 @@ class DeNetSparseLayer(AbstractLayer):
         self.coverage = (total_cover, total_bbox)
         return out_pr, out_boxes
 
+    def edit_samples_native(self, det, cnt, metas, out_f32):
+        """edit_samples for the whole batch in one native host call (denet_host_edit_samples): same generator
+        stream, same values. det [B,S,5] float32 rows (pr, box) of the detector, cnt [B]; out_f32 [B*S,4] float32
+        receives the array build_bbox_array would produce. Returns (pr [B,S], boxes [B,S,4]) as float64."""
+        from .. import lib as _lib
+        B, S = self.batch_size, self.sample_count
+        n_keep = S - math.floor(self.random_sample * S)
+        ws = numpy.empty(2 * S, dtype=numpy.int32)
+        det = numpy.ascontiguousarray(det, dtype=numpy.float32)
+        cnt = numpy.ascontiguousarray(cnt, dtype=numpy.int32)
+        gts = [numpy.asarray(m["bbox"], dtype=numpy.float64).reshape(-1, 4) for m in metas] if self.sample_gt else []
+        off = numpy.zeros(B + 1, dtype=numpy.int32)
+        if self.sample_gt:
+            numpy.cumsum([len(g) for g in gts], out=off[1:])
+        gt = numpy.ascontiguousarray(numpy.concatenate(gts, axis=0)) if off[-1] > 0 else numpy.zeros((1, 4))
+        out_pr = numpy.empty((B, S), dtype=numpy.float64)
+        out_box = numpy.empty((B, S, 4), dtype=numpy.float64)
+        assert out_f32.dtype == numpy.float32 and out_f32.size == B * S * 4 and out_f32.flags.c_contiguous
+        mirror = PyRandomMirror()
+        _lib.check(_lib.load().denet_host_edit_samples(
+            mirror.key.ctypes.data, mirror.pos.ctypes.data, det.ctypes.data, cnt.ctypes.data, B, S, n_keep,
+            gt.ctypes.data, off.ctypes.data, int(bool(self.sample_gt)), ws.ctypes.data, out_pr.ctypes.data,
+            out_box.ctypes.data, out_f32.ctypes.data), "edit_samples")
+        mirror.push()
+        return out_pr, out_box
+
+    def _edit_and_upload_native(self, metas):
+        import torch
+        B, S = self.batch_size, self.sample_count
+        if self._pinned is None:
+            self._pinned = torch.empty((B * S, 4), dtype=torch.float32).pin_memory()
+        if self._raw_samples is not None:
+            det, cnt = self._raw_samples
+        else:
+            det, cnt = numpy.zeros((B, S, 5), dtype=numpy.float32), numpy.zeros(B, dtype=numpy.int32)
+        f32 = self._pinned.numpy()
+        out_pr, out_box = self.edit_samples_native(det, cnt, metas, f32)
+        self.sample_pr, self.sample_boxes = list(out_pr), list(out_box)
+        self.sample_bbox = self._pinned.cuda(non_blocking=True)
+        self.sample_bbox_f32 = f32.reshape(B, S, 4)
+
+    def _native_edit_ok(self, metas):
+        """random.sample's pool branch (n <= setsize) covers every possible trim, and no coverage logging"""
+        S = self.sample_count
+        k = S - math.floor(self.random_sample * S)
+        setsize = 21 + (4 ** math.ceil(math.log(k * 3, 4)) if k > 5 else 0)
+        return S <= setsize and not self.log_coverage and len(metas) == self.batch_size
+
     def get_target(self, model, data_x, metas):
-        prs, boxes = self._device_samples()
-        self.sample_pr, self.sample_boxes = self.edit_samples(prs, boxes, metas)
-        self._upload_boxes()
+        native = self._native_edit_ok(metas)
+        prs, boxes = self._device_samples(raw_only=native)
+        if native:
+            self._edit_and_upload_native(metas)
+        else:
+            self.sample_pr, self.sample_boxes = self.edit_samples(prs, boxes, metas)
+            self._upload_boxes()
         return None
 
     def export_json(self):

@@ -42,6 +42,13 @@ int denet_device_info(int device, int* cu_count, int* clock_khz, char* arch, int
  * of CPython's MT19937 state exactly like random.sample(range(n), k) and returns the k chosen indices.
  * mt_host: 624 state words, pos_host: the position word (random.getstate()[1][624]); all HOST pointers.        */
 int denet_host_py_random_sample(unsigned* mt_host, int* pos_host, int n, int k, int* pool_ws_host, int* out_host);
+/* the whole training-time RoI list editing of a batch (denet/layer/denet_sparse.py:184-201: random.sample trim,
+ * 4 random.uniform draws per random box, ground truth over the tail), call for call on the same generator state.
+ * det:[B,S,5] rows of denet_samples_finish_host; gt: concatenated [n,4] doubles, gt_off:[B+1]; ws: 2*S ints.
+ * out_pr:[B,S], out_box:[B,S,4] doubles (the reference's Python list values), out_box_f32: the uploaded array. */
+int denet_host_edit_samples(unsigned* mt_host, int* pos_host, const float* det_host, const int* count_host, int B, int S,
+                            int n_keep, const double* gt_host, const int* gt_off_host, int sample_gt, int* ws_host,
+                            double* out_pr_host, double* out_box_host, float* out_box_f32_host);
 
 /* ---- convolution  (denet/layer/convolution.py:80-83 -> cuDNN conv fwd; model_cnn.py:318 tensor.grad ->
  *      cuDNN bwd-data / bwd-filter).  x:[N,H,W,C]  w:[K,R,S,C]  y:[N,OH,OW,K]; `S` may be padded beyond the

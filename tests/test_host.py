@@ -140,6 +140,40 @@ def test_roi_editing_matches_reference_loop(denet_small):
     np.testing.assert_array_equal(dns._bbox_array(b2), OL.bbox_array(ref, 2, 24))
 
 
+@pytest.mark.parametrize("random_sample", [0.1, 0.0, 0.5])
+def test_native_roi_editing_matches_reference_loop(denet_small, random_sample):
+    """denet_host_edit_samples (one native call per batch) == the reference's Python loop on stdlib random"""
+    dns = denet_small.layers[31]
+    old = dns.random_sample
+    dns.random_sample = random_sample
+    try:
+        _, metas = zoo.synthetic_batch(2, 128, seed=4)
+        rng = np.random.RandomState(5)
+        S = 576
+        det = np.zeros((2, S, 5), np.float32)
+        cnt = np.array([S, 31], np.int32)
+        lists = []
+        for b in range(2):
+            k = cnt[b]
+            det[b, :k, 1:] = np.sort(rng.uniform(0, 1, (k, 4)), axis=1)
+            det[b, :k, 0] = rng.uniform(0, 0.5, k)
+            lists.append([(float(r[0]), tuple(float(v) for v in r[1:])) for r in det[b, :k]])
+        assert dns._native_edit_ok(metas)
+        f32 = np.empty((2 * S, 4), np.float32)
+        random.seed(9)
+        pr, bx = dns.edit_samples_native(det, cnt, metas, f32)
+        after = random.random()
+        random.seed(9)
+        ref = OL.edit_samples(lists, metas, S, random_sample, True)
+        assert random.random() == after, "generator stream diverged"
+        for b in range(2):
+            assert np.array_equal(np.array([s[1] for s in ref[b]]), bx[b])
+            assert np.array_equal(np.array([s[0] for s in ref[b]]), pr[b])
+        np.testing.assert_array_equal(f32.reshape(2, 24, 24, 4), OL.bbox_array(ref, 2, 24))
+    finally:
+        dns.random_sample = old
+
+
 @pytest.mark.parametrize("jointfit", [False, True])
 def test_detect_and_corner_targets_match_reference_loops(jointfit):
     head = zoo.DENET34_SKIP_DESC.replace("DND[0.5,1,1]", "DND.J[0.5,1,1]") if jointfit else None
