@@ -18,6 +18,7 @@
 // Launch:         1-D grid over tiles with an XCD-aware remap (8 XCDs, private L2 each).
 #include "common.h"
 #include <vector>
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -48,10 +49,22 @@ struct IgemmParams {
     FastDiv div_row_w;  // fwd/wgrad: OW       dgrad: Wc
     int Hc, Wc;         // dgrad: H/stride, W/stride
     int wg_split_slow;  // wgrad: 1 = split slice is the slow (XCD-local) index of the linear workgroup id
+    unsigned act_bytes, wgt_bytes;  // extents of `act` / `wgt` (buffer descriptors: out-of-range lanes read 0)
 };
 
+// Guarded operand loads are BRANCH-FREE: a lane whose tap falls into the zero padding (or beyond the tensor) gets
+// an offset past the descriptor's extent and the buffer unit returns 0. (`ok ? *ptr : 0` compiles to an exec-mask
+// branch per load: every branch ends the scheduling region, so nothing can be interleaved with the MFMAs, and the
+// waitcnt pass falls back to vmcnt(0) behind it.)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int OOB_OFFSET = (int)0xF0000000u;   // >= any extent check_geom admits; cannot wrap when 15 is added
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int elem_off, bool ok) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, ok ? elem_off * 4 : OOB_OFFSET, 0, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+
 template <int MODE, int BM, int BN, int WM, int WN, int NBUF>
-__global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : 2)) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (NBUF == 2 ? 2 : 1))) void igemm_kernel(const IgemmParams p) {
     constexpr bool A_KIN = (MODE != MODE_WGRAD);
     constexpr bool B_KIN = (MODE == MODE_FWD);
     constexpr int TM = BM / (32 * WM);
@@ -212,22 +225,61 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : 2
     const bool wg_rowok = (MODE == MODE_WGRAD) ? (m0 + 4 * qa < p.K) : true;
 
     f32x4 ra[PA], rb[PB];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc((void*)p.act, 0, p.act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, p.wgt_bytes, 0x00020000);
 
-    // loads the reduction chunk `kc` (absolute chunk index) into ra/rb
-    auto load_chunk = [&](int kc) {
+    // ---- chunk loader, split so that the pipelined main loop can slot single passes behind MFMAs ----------
+    // prep(kc): wave-uniform offsets of reduction chunk `kc` (fwd/dgrad walk the cursor, wgrad is absolute);
+    // load_a(i) / load_b(i): pass i (one float4 per thread) into ra[i] / rb[i]; advance(): cursor to the next chunk
+    int u_off = 0, u_offb = 0, u_ty = 0, u_tx = 0, u_pix0 = 0;
+    auto prep = [&](int kc) {
         if (MODE == MODE_FWD) {
-            const int uoff = (cur_r * p.W + cur_s) * p.C + cur_c;
-#pragma unroll
-            for (int i = 0; i < PA; ++i) {
-                const bool ok = ((unsigned)(a_y[i] + cur_r) < (unsigned)p.H) &&
-                                ((unsigned)(a_x[i] + cur_s) < (unsigned)p.W);
-                ra[i] = ok ? *(const f32x4*)(p.act + (a_off[i] + uoff)) : zero4;
-            }
-#pragma unroll
-            for (int i = 0; i < PB; ++i)
-                rb[i] = b_ok[i] ? *(const f32x4*)(p.wgt + (b_off[i] + kc * BK)) : zero4;
-            // advance cursor
+            u_off = (cur_r * p.W + cur_s) * p.C + cur_c;
+            u_offb = kc * BK;
+        } else if (MODE == MODE_DGRAD) {
+            u_ty = cur_r << p.sshift;
+            u_tx = cur_s << p.sshift;
+            u_off = cur_c;
+            u_offb = cur_c * (p.R * p.S * p.C) + ((dg_r0 + u_ty) * p.S + dg_s0 + u_tx) * p.C;
+        } else {
+            u_pix0 = kc * BK;
+        }
+    };
+    auto load_a = [&](int i) {
+        if (MODE == MODE_FWD) {
+            const bool ok = ((unsigned)(a_y[i] + cur_r) < (unsigned)p.H) && ((unsigned)(a_x[i] + cur_s) < (unsigned)p.W);
+            ra[i] = buf_load4(r_act, a_off[i] + u_off, ok);
+        } else if (MODE == MODE_DGRAD) {
+            // (iy + pad - r) is a multiple of the stride by construction of the class
+            const int ty = a_y[i] - u_ty;
+            const int tx = a_x[i] - u_tx;
+            const int oy = ty >> p.sshift;
+            const int ox = tx >> p.sshift;
+            const bool ok = (ty >= 0) && (tx >= 0) && (oy < p.OH) && (ox < p.OW);
+            ra[i] = buf_load4(r_act, a_off[i] + (oy * p.OW + ox) * p.K + u_off, ok);
+        } else {
+            const int pix = u_pix0 + kra + RPP_A * i;
+            const bool ok = wg_rowok && (pix < p.npix);
+            ra[i] = buf_load4(r_wgt, u_pix0 * p.K + a_off[i], ok);
+        }
+    };
+    auto load_b = [&](int i) {
+        if (MODE == MODE_FWD || MODE == MODE_DGRAD) {
+            rb[i] = buf_load4(r_wgt, b_off[i] + u_offb, b_ok[i]);
+        } else {
+            const int pix = u_pix0 + krb + RPP_B * i;
+            const uint32_t n = p.div_row_hw.div(pix);
+            const uint32_t rem = pix - n * (p.OH * p.OW);
+            const uint32_t oy = p.div_row_w.div(rem);
+            const uint32_t ox = rem - oy * p.OW;
+            const int iy = (int)oy * p.stride - p.pad + wg_r;
+            const int ix = (int)ox * p.stride - p.pad + wg_s;
+            const bool ok = wg_colok && (pix < p.npix) && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
+            rb[i] = buf_load4(r_act, (((int)n * p.H + iy) * p.W + ix) * p.C + wg_c, ok);
+        }
+    };
+    auto advance = [&]() {
+        if (MODE == MODE_FWD) {
             cur_c += BK;
             if (cur_c >= p.C) {
                 cur_c = 0;
@@ -238,21 +290,6 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : 2
                 }
             }
         } else if (MODE == MODE_DGRAD) {
-#pragma unroll
-            for (int i = 0; i < PA; ++i) {
-                // (iy + pad - r) is a multiple of the stride by construction of the class
-                const int ty = a_y[i] - (cur_r << p.sshift);
-                const int tx = a_x[i] - (cur_s << p.sshift);
-                const int oy = ty >> p.sshift;
-                const int ox = tx >> p.sshift;
-                const bool ok = (ty >= 0) && (tx >= 0) && (oy < p.OH) && (ox < p.OW);
-                ra[i] = ok ? *(const f32x4*)(p.act + (a_off[i] + (oy * p.OW + ox) * p.K + cur_c)) : zero4;
-            }
-            const int uoff = cur_c * (p.R * p.S * p.C) +
-                             ((dg_r0 + (cur_r << p.sshift)) * p.S + dg_s0 + (cur_s << p.sshift)) * p.C;
-#pragma unroll
-            for (int i = 0; i < PB; ++i)
-                rb[i] = b_ok[i] ? *(const f32x4*)(p.wgt + (b_off[i] + uoff)) : zero4;
             cur_c += BK;
             if (cur_c >= p.K) {
                 cur_c = 0;
@@ -262,28 +299,29 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : 2
                     cur_r += 1;
                 }
             }
-        } else {
-            const int pix0 = kc * BK;
-#pragma unroll
-            for (int i = 0; i < PA; ++i) {
-                const int pix = pix0 + kra + RPP_A * i;
-                const bool ok = wg_rowok && (pix < p.npix);
-                ra[i] = ok ? *(const f32x4*)(p.wgt + ((long)pix0 * p.K + a_off[i])) : zero4;
-            }
-#pragma unroll
-            for (int i = 0; i < PB; ++i) {
-                const int pix = pix0 + krb + RPP_B * i;
-                const uint32_t n = p.div_row_hw.div(pix);
-                const uint32_t rem = pix - n * (p.OH * p.OW);
-                const uint32_t oy = p.div_row_w.div(rem);
-                const uint32_t ox = rem - oy * p.OW;
-                const int iy = (int)oy * p.stride - p.pad + wg_r;
-                const int ix = (int)ox * p.stride - p.pad + wg_s;
-                const bool ok = wg_colok && (pix < p.npix) && ((unsigned)iy < (unsigned)p.H) &&
-                                ((unsigned)ix < (unsigned)p.W);
-                rb[i] = ok ? *(const f32x4*)(p.act + ((((int)n * p.H + iy) * p.W + ix) * p.C + wg_c)) : zero4;
-            }
         }
+    };
+    // loads the reduction chunk `kc` (absolute chunk index) into ra/rb
+    auto load_chunk = [&](int kc) {
+        prep(kc);
+#pragma unroll
+        for (int i = 0; i < PA; ++i) load_a(i);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) load_b(i);
+        advance();
+    };
+
+    auto write_a = [&](float* dA, int i) {
+        if (A_KIN)
+            *(f32x4*)(dA + (row8 + 32 * i) * LDK + 4 * q8) = ra[i];
+        else
+            *(f32x4*)(dA + (kra + RPP_A * i) * BM + 4 * qa) = ra[i];
+    };
+    auto write_b = [&](float* dB, int i) {
+        if (B_KIN)
+            *(f32x4*)(dB + (row8 + 32 * i) * LDK + 4 * q8) = rb[i];
+        else
+            *(f32x4*)(dB + (krb + RPP_B * i) * BN + 4 * qb) = rb[i];
     };
 
     auto store_chunk = [&](int buf) {
@@ -363,25 +401,120 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : 2
         }
     };
 
-    if (nsteps > 0) {
-        // position the uniform cursor at step_begin (only wgrad splits; it has no cursor)
-        load_chunk(step_begin);
-        store_chunk(0);
-        __syncthreads();
-        for (int s = 0; s < nsteps; ++s) {
-            const bool more = (s + 1 < nsteps);
-            if (more) load_chunk(step_begin + s + 1);
-            if (NBUF == 2) {
-                compute(s & 1);
-                if (more) store_chunk((s + 1) & 1);
-                __syncthreads();
-            } else {
-                // one LDS buffer: half the LDS -> 3 workgroups per CU cover each other's barrier bubbles
+    if (NBUF == 1) {
+        if (nsteps > 0) {
+            // one LDS buffer: a third of the LDS -> 3-4 workgroups per CU cover each other's barrier bubbles
+            load_chunk(step_begin);
+            store_chunk(0);
+            __syncthreads();
+            for (int s = 0; s < nsteps; ++s) {
+                const bool more = (s + 1 < nsteps);
+                if (more) load_chunk(step_begin + s + 1);
                 compute(0);
                 __syncthreads();
                 if (more) store_chunk(0);
                 __syncthreads();
             }
+        }
+    } else if (nsteps > 0) {
+        // ---- pipelined main loop (NBUF = 2 or 3 LDS buffers, ONE register staging set) --------------------
+        // Iteration s multiplies chunk s out of LDS buffer s % NBUF. Its MFMAs come in BK/8 blocks; behind the
+        // first MFMAs of every block the scheduler is told (sched_group_barrier) to slot, one per MFMA:
+        //   - the fragment reads of the NEXT block (register double buffer),
+        //   - pass `kb` of the staging: ds_write of chunk s+AH (its loads were issued one iteration ago), then
+        //     the global loads of chunk s+AH+1 into the SAME registers (write-then-reload, AH = NBUF-1).
+        // A v_mfma_f32_32x32x2 occupies the matrix pipe for 64 cycles; one LDS / VMEM / few VALU instructions
+        // issue in its shadow for free, whereas the same instructions in a burst between MFMA blocks drain the
+        // pipe (measured: 75 % -> 90 % MFMA utilisation on GEMM-shaped layers). With 3 buffers the first
+        // fragments of chunk s+1 are read before the barrier as well (nothing is exposed after it); with 2
+        // buffers they are read right after the barrier and two workgroups per CU cover that bubble.
+        constexpr int AH = NBUF - 1;
+        constexpr int KB = BK / 8;
+        static_assert(PA <= KB && PB <= KB, "one staging pass per MFMA block");
+        float av[2][TM][4], bv[2][TN][4];
+        // prologue: chunks 0..AH-1 -> LDS, chunk AH -> registers
+        load_chunk(step_begin);
+        store_chunk(0);
+        if (NBUF == 3 && nsteps > 1) {
+            load_chunk(step_begin + 1);
+            store_chunk(1);
+        }
+        if (nsteps > AH) load_chunk(step_begin + AH);
+        __syncthreads();
+        load_frags(sA + fa, sB + fb, 0, av[0], bv[0]);
+        int cur = 0;
+        auto body = [&](int s, auto WF, auto LF, auto NF) {
+            constexpr bool do_w = decltype(WF)::value, do_l = decltype(LF)::value, has_next = decltype(NF)::value;
+            const int nxt = (cur == NBUF - 1) ? 0 : cur + 1;                                // buffer of chunk s+1
+            const int wbuf = (NBUF == 2) ? nxt : ((nxt == NBUF - 1) ? 0 : nxt + 1);         // buffer of chunk s+AH
+            const float* cA = sA + cur * SZA + fa;
+            const float* cB = sB + cur * SZB + fb;
+            float* wA = sA + wbuf * SZA;
+            float* wB = sB + wbuf * SZB;
+            if (do_l) prep(step_begin + s + AH + 1);
+            auto step = [&](auto KBI) {
+                constexpr int kb = decltype(KBI)::value;
+                constexpr bool rd = (kb + 1 < KB) || (NBUF == 3 && has_next);
+                if (kb + 1 < KB) load_frags(cA, cB, kb + 1, av[(kb + 1) & 1], bv[(kb + 1) & 1]);
+                else if (NBUF == 3 && has_next) load_frags(sA + nxt * SZA + fa, sB + nxt * SZB + fb, 0, av[0], bv[0]);
+                if constexpr (kb < PA) {
+                    if (do_w) write_a(wA, kb);
+                    if (do_l) load_a(kb);
+                }
+                if constexpr (kb < PB) {
+                    if (do_w) write_b(wB, kb);
+                    if (do_l) load_b(kb);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb & 1][i][t], bv[kb & 1][j][t], acc[i][j],
+                                                                             0, 0, 0);
+                // issue order of this block
+                constexpr int NM = 4 * TM * TN;
+                constexpr int NR = rd ? (A_KIN ? TM : 4 * TM) + (B_KIN ? TN : 4 * TN) : 0;
+                constexpr int NW = do_w ? ((kb < PA) ? 1 : 0) + ((kb < PB) ? 1 : 0) : 0;
+                constexpr int HALF = (NM / 2 > 0) ? NM / 2 : 1;
+                constexpr int RP = NR ? (NR + HALF - 1) / HALF : 1;
+                constexpr int RS = NR ? (NR + RP - 1) / RP : 0;
+                constexpr int WS = (NW < NM - RS) ? NW : ((NM - RS > 0) ? NM - RS : 0);
+#pragma unroll
+                for (int g = 0; g < RS; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, RP, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < WS; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    if (do_l) {
+                        __builtin_amdgcn_sched_group_barrier(0x002, MODE == MODE_WGRAD ? 12 : 6, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
+                if constexpr (NM - RS - WS > 0) __builtin_amdgcn_sched_group_barrier(0x008, NM - RS - WS, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            step(std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{});
+            if (do_l) advance();
+            __syncthreads();
+            if (NBUF == 2 && has_next) load_frags(sA + nxt * SZA + fa, sB + nxt * SZB + fb, 0, av[0], bv[0]);
+            cur = nxt;
+        };
+        {
+            using T = std::true_type;
+            using F = std::false_type;
+            int s = 0;
+            for (; s + AH + 1 < nsteps; ++s) body(s, T{}, T{}, T{});
+            for (; s + AH < nsteps; ++s) body(s, T{}, F{}, T{});
+            for (; s + 1 < nsteps; ++s) body(s, F{}, F{}, T{});
+            for (; s < nsteps; ++s) body(s, F{}, F{}, F{});
         }
     }
 
@@ -479,16 +612,21 @@ int launch_igemm(const IgemmParams& p, int splits, hipStream_t stream) {
             denet_set_error("igemm: hipEventCreate failed");
             return DENET_ERR_ARG;
         }
-        hipEventRecord(rec.a, stream);
+        (void)hipEventRecord(rec.a, stream);
     }
     hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, NBUF>), grid, dim3(256), lds, stream, p);
     if (g_prof_on) {
-        hipEventRecord(rec.b, stream);
+        (void)hipEventRecord(rec.b, stream);
         g_prof.push_back(rec);
     }
     DENET_CHECK_LAUNCH("igemm");
     return DENET_OK;
 }
+
+#define LAUNCH_NBUF(MODE_, BM_, BN_, nbuf_, p_, splits_, stream_)                                        \
+    ((nbuf_) == 1   ? launch_igemm<MODE_, BM_, BN_, 2, 2, 1>(p_, splits_, stream_)                       \
+     : (nbuf_) == 2 ? launch_igemm<MODE_, BM_, BN_, 2, 2, 2>(p_, splits_, stream_)                       \
+                    : launch_igemm<MODE_, BM_, BN_, 2, 2, 3>(p_, splits_, stream_))
 
 // Launch-shape selection. The chip runs 256 CUs x `cap` resident workgroups (cap = 2 with the double LDS buffer,
 // 3 with the single buffer); a grid that needs a partial extra round wastes up to a whole round. The launchers
@@ -513,12 +651,14 @@ struct Choice {
 // Measured behaviour behind the rules: with >= 4 rounds of work the single-buffer variant streams ~12 % faster
 // (3 resident workgroups cover each other's barrier bubbles); for small grids what counts is the number of
 // rounds, and a half-size tile pays off only when the full tile cannot fill the chip once.
-Choice choose_launch(const long* nblocks, const double* area, const double* eff, int ntiles) {
+// `want_nbuf`: the loop structure measured fastest for the mode / reduction length (see the callers); the tile shape
+// is then chosen for that structure's occupancy.
+Choice choose_launch(const long* nblocks, const double* area, const double* eff, int ntiles, int want_nbuf) {
     Choice best = {1e300, 0, 2};
     for (int t = 0; t < ntiles; ++t) {
-        for (int nbuf = 1; nbuf <= 2; ++nbuf) {
-            if (forced_nbuf() && forced_nbuf() != nbuf) continue;
-            const long cap = (nbuf == 1) ? (area[t] <= 128.0 * 64.0 ? 4 : 3) : 2;
+        for (int nbuf = 1; nbuf <= 3; ++nbuf) {
+            if ((forced_nbuf() ? forced_nbuf() : want_nbuf) != nbuf) continue;
+            const long cap = (nbuf == 1) ? (area[t] <= 128.0 * 64.0 ? 4 : 3) : (nbuf == 2 ? 2 : 1);
             const long slots = 256 * cap;
             const long nb = nblocks[t];
             double rounds;
@@ -552,9 +692,10 @@ int check_geom(int N, int H, int W, int C, int K, int R, int S, int S_real, int 
     }
     DENET_CHECK_ARG((H + 2 * pad - R) / stride + 1 >= OH && OH > 0, "conv: OH=%d inconsistent", OH);
     DENET_CHECK_ARG((W + 2 * pad - S_real) / stride + 1 >= OW && OW > 0, "conv: OW=%d inconsistent", OW);
-    DENET_CHECK_ARG((long)N * H * W * C < (1L << 31) && (long)N * OH * OW * K < (1L << 31) &&
-                        (long)K * R * S * C < (1L << 31),
-                    "conv: tensor exceeds 2^31 elements");
+    // operands are addressed through 32-bit buffer descriptors (byte offsets); 0xF0000000 is the out-of-range marker
+    DENET_CHECK_ARG((long)N * H * W * C * 4 < 0xF0000000L && (long)N * OH * OW * K * 4 < 0xF0000000L &&
+                        (long)K * R * S * C * 4 < 0xF0000000L,
+                    "conv: tensor exceeds the 32-bit buffer extent (3.75 GiB)");
     return DENET_OK;
 }
 
@@ -562,8 +703,8 @@ int check_geom(int N, int H, int W, int C, int K, int R, int S, int S_real, int 
 
 extern "C" int denet_conv_profile(int enable) {
     for (auto& r : g_prof) {
-        hipEventDestroy(r.a);
-        hipEventDestroy(r.b);
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
     }
     g_prof.clear();
     g_prof_on = enable != 0;
@@ -606,6 +747,7 @@ extern "C" int denet_conv_fwd(const float* x, const float* w, const float* bias,
     p.act = x; p.wgt = w; p.out = y; p.bias = bias; p.add = add;
     p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K;
     p.R = R; p.S = S; p.S_real = S_real; p.stride = stride; p.sshift = ilog2_exact(stride); p.pad = pad;
+    p.act_bytes = (unsigned)((size_t)N * H * W * C * 4); p.wgt_bytes = (unsigned)((size_t)K * R * S * C * 4);
     p.M = N * OH * OW; p.NC = K; p.ksteps = R * S * C / BK; p.steps_per_split = p.ksteps;
     p.npix = p.M;
     p.div_row_hw.init(OH * OW); p.div_row_w.init(OW);
@@ -613,17 +755,19 @@ extern "C" int denet_conv_fwd(const float* x, const float* w, const float* bias,
         const long tm = ceil_div(p.M, 128);
         const long nb[2] = {tm * ceil_div(K, 128), tm * ceil_div(K, 64)};
         const double area[2] = {128.0 * 128.0, 128.0 * 64.0}, eff[2] = {1.0, 0.85};
-        const Choice c = (K >= 128) ? choose_launch(nb, area, eff, 2) : choose_launch(nb + 1, area + 1, eff + 1, 1);
+        // measured (tools/bench_conv.py): the pipelined 2-buffer loop wins on forward once the reduction has >= 24
+        // chunks (+4...14 %); shorter reductions (stem, 64-channel 3x3, 1x1 on 128 channels) amortise its longer
+        // prologue badly and run faster on the single-buffer loop at 3-4 workgroups per CU
+        const int want = (p.ksteps >= 24) ? 2 : 1;
+        const Choice c = (K >= 128) ? choose_launch(nb, area, eff, 2, want) : choose_launch(nb + 1, area + 1, eff + 1, 1, want);
         const int tile = (K >= 128) ? c.tile : 1;
         p.tiles_m = (int)tm;
         if (tile == 0) {
             p.tiles_n = ceil_div(K, 128);
-            return c.nbuf == 1 ? launch_igemm<MODE_FWD, 128, 128, 2, 2, 1>(p, 1, stream)
-                               : launch_igemm<MODE_FWD, 128, 128, 2, 2, 2>(p, 1, stream);
+            return LAUNCH_NBUF(MODE_FWD, 128, 128, c.nbuf, p, 1, stream);
         }
         p.tiles_n = ceil_div(K, 64);
-        return c.nbuf == 1 ? launch_igemm<MODE_FWD, 128, 64, 2, 2, 1>(p, 1, stream)
-                           : launch_igemm<MODE_FWD, 128, 64, 2, 2, 2>(p, 1, stream);
+        return LAUNCH_NBUF(MODE_FWD, 128, 64, c.nbuf, p, 1, stream);
     }
 }
 
@@ -639,6 +783,7 @@ extern "C" int denet_conv_dgrad(const float* dy, const float* w, const float* ad
     p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K;
     p.R = R; p.S = S; p.S_real = S_real; p.stride = stride; p.sshift = ilog2_exact(stride); p.pad = pad;
     DENET_CHECK_ARG(H % stride == 0 && W % stride == 0, "conv_dgrad: H, W must be multiples of the stride");
+    p.act_bytes = (unsigned)((size_t)N * OH * OW * K * 4); p.wgt_bytes = (unsigned)((size_t)K * R * S * C * 4);
     const int classes = stride * stride;
     p.Hc = H / stride; p.Wc = W / stride;
     p.M = N * p.Hc * p.Wc; p.NC = C; p.ksteps = R * S * K / BK; p.steps_per_split = p.ksteps;
@@ -648,17 +793,17 @@ extern "C" int denet_conv_dgrad(const float* dy, const float* w, const float* ad
         const long tm = ceil_div(p.M, 128);
         const long nb[2] = {tm * ceil_div(C, 128) * classes, tm * ceil_div(C, 64) * classes};
         const double area[2] = {128.0 * 128.0, 128.0 * 64.0}, eff[2] = {1.0, 0.85};
-        const Choice c = (C >= 128) ? choose_launch(nb, area, eff, 2) : choose_launch(nb + 1, area + 1, eff + 1, 1);
+        // dgrad / wgrad read K-outer LDS tiles (4x the fragment-read instructions): the single-buffer loop at 3-4
+        // workgroups per CU measured faster than the pipelined one on every DeNet-34 layer but two (within 3 %)
+        const Choice c = (C >= 128) ? choose_launch(nb, area, eff, 2, 1) : choose_launch(nb + 1, area + 1, eff + 1, 1, 1);
         const int tile = (C >= 128) ? c.tile : 1;
         p.tiles_m = (int)tm;
         if (tile == 0) {
             p.tiles_n = ceil_div(C, 128);
-            return c.nbuf == 1 ? launch_igemm<MODE_DGRAD, 128, 128, 2, 2, 1>(p, classes, stream)
-                               : launch_igemm<MODE_DGRAD, 128, 128, 2, 2, 2>(p, classes, stream);
+            return LAUNCH_NBUF(MODE_DGRAD, 128, 128, c.nbuf, p, classes, stream);
         }
         p.tiles_n = ceil_div(C, 64);
-        return c.nbuf == 1 ? launch_igemm<MODE_DGRAD, 128, 64, 2, 2, 1>(p, classes, stream)
-                           : launch_igemm<MODE_DGRAD, 128, 64, 2, 2, 2>(p, classes, stream);
+        return LAUNCH_NBUF(MODE_DGRAD, 128, 64, c.nbuf, p, classes, stream);
     }
 }
 
@@ -677,6 +822,7 @@ extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, floa
     p.act = x; p.wgt = dy; p.bias = nullptr; p.add = nullptr;
     p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K;
     p.R = R; p.S = S; p.S_real = S_real; p.stride = stride; p.sshift = ilog2_exact(stride); p.pad = pad;
+    p.act_bytes = (unsigned)((size_t)N * H * W * C * 4); p.wgt_bytes = (unsigned)((size_t)N * OH * OW * K * 4);
     p.M = K; p.NC = R * S * C; p.npix = N * OH * OW;
     {
         static int v = -1;
@@ -708,9 +854,9 @@ extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, floa
     {
         const double chunk_us2 = (big_m ? 4.2 : 2.4), chunk_us3 = chunk_us2 * 1.5 / 1.12;
         double best = 1e300;
-        for (int nbuf = 1; nbuf <= 2; ++nbuf) {
-            if (forced_nbuf() && forced_nbuf() != nbuf) continue;
-            const int slots = 256 * (nbuf == 1 ? 3 : 2);
+        for (int nbuf = 1; nbuf <= 3; ++nbuf) {
+            if ((forced_nbuf() ? forced_nbuf() : 1) != nbuf) continue;
+            const int slots = 256 * (nbuf == 1 ? 3 : (nbuf == 2 ? 2 : 1));
             for (int r = 1; r <= 6; ++r) {
                 int sp = forced_blocks ? ceil_div(forced_blocks, tiles) : (r * slots) / tiles;
                 if (sp < 1) sp = 1;
@@ -740,11 +886,9 @@ extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, floa
     p.steps_per_split = ceil_div(p.ksteps, splits);
     splits = ceil_div(p.ksteps, p.steps_per_split);
     if (big_m)
-        rc = wg_nbuf == 1 ? launch_igemm<MODE_WGRAD, 128, 128, 2, 2, 1>(p, splits, stream)
-                                : launch_igemm<MODE_WGRAD, 128, 128, 2, 2>(p, splits, stream);
+        rc = LAUNCH_NBUF(MODE_WGRAD, 128, 128, wg_nbuf, p, splits, stream);
     else
-        rc = wg_nbuf == 1 ? launch_igemm<MODE_WGRAD, 64, 128, 2, 2, 1>(p, splits, stream)
-                                : launch_igemm<MODE_WGRAD, 64, 128, 2, 2>(p, splits, stream);
+        rc = LAUNCH_NBUF(MODE_WGRAD, 64, 128, wg_nbuf, p, splits, stream);
     if (rc) return rc;
     if (splits > 1) {
         DENET_CHECK_ARG(wsize % 4 == 0, "conv_wgrad: weight size not a multiple of 4");
