@@ -73,23 +73,26 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     }
 }
 
-// second stage: a workgroup reduces 32 channels, 8 lanes stride over the partial rows
+// second stage: a workgroup reduces FC channels, FJ = 256/FC lanes stride over the partial rows. The stage is
+// latency bound (a few hundred KB, a chain of dependent row loads per lane): 8 channels x 32 row lanes keeps the
+// chain at gy/128 rounds of 4 loads in flight and spreads the work over C/8 workgroups.
+constexpr int FC = 8, FJ = 256 / FC;
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partial, int gy, int C, int c, int jl,
                                                 double& s, double& ss) {
     s = 0;
     ss = 0;
     if (c < C) {
         int j = jl;
-        // 4 independent row loads in flight per lane: the loop is latency bound, not bandwidth bound
-        for (; j + 24 < gy; j += 32) {
+        // 4 independent row loads in flight per lane
+        for (; j + 3 * FJ < gy; j += 4 * FJ) {
             const double a0 = partial[(long)j * 2 * C + c], b0 = partial[(long)j * 2 * C + C + c];
-            const double a1 = partial[(long)(j + 8) * 2 * C + c], b1 = partial[(long)(j + 8) * 2 * C + C + c];
-            const double a2 = partial[(long)(j + 16) * 2 * C + c], b2 = partial[(long)(j + 16) * 2 * C + C + c];
-            const double a3 = partial[(long)(j + 24) * 2 * C + c], b3 = partial[(long)(j + 24) * 2 * C + C + c];
+            const double a1 = partial[(long)(j + FJ) * 2 * C + c], b1 = partial[(long)(j + FJ) * 2 * C + C + c];
+            const double a2 = partial[(long)(j + 2 * FJ) * 2 * C + c], b2 = partial[(long)(j + 2 * FJ) * 2 * C + C + c];
+            const double a3 = partial[(long)(j + 3 * FJ) * 2 * C + c], b3 = partial[(long)(j + 3 * FJ) * 2 * C + C + c];
             s += (a0 + a1) + (a2 + a3);
             ss += (b0 + b1) + (b2 + b3);
         }
-        for (; j < gy; j += 8) {
+        for (; j < gy; j += FJ) {
             s += partial[(long)j * 2 * C + c];
             ss += partial[(long)j * 2 * C + C + c];
         }
@@ -101,16 +104,16 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __res
                                                              float* __restrict__ save_invstd,
                                                              float* __restrict__ run_mean,
                                                              float* __restrict__ run_stdinv) {
-    __shared__ double red[2][8][32];
-    const int cl = threadIdx.x & 31, jl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double red[2][FJ][FC];
+    const int cl = threadIdx.x % FC, jl = threadIdx.x / FC;
+    const int c = blockIdx.x * FC + cl;
     double s, ss;
     reduce_partials(partial, gy, C, c, jl, s, ss);
     red[0][jl][cl] = s;
     red[1][jl][cl] = ss;
     __syncthreads();
     if (jl != 0 || c >= C) return;
-    for (int j = 1; j < 8; ++j) {
+    for (int j = 1; j < FJ; ++j) {
         s += red[0][j][cl];
         ss += red[1][j][cl];
     }
@@ -229,16 +232,16 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restrict__ partial, int gy, long M, int C,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            float* __restrict__ coef) {
-    __shared__ double red[2][8][32];
-    const int cl = threadIdx.x & 31, jl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double red[2][FJ][FC];
+    const int cl = threadIdx.x % FC, jl = threadIdx.x / FC;
+    const int c = blockIdx.x * FC + cl;
     double s, ss;
     reduce_partials(partial, gy, C, c, jl, s, ss);
     red[0][jl][cl] = s;
     red[1][jl][cl] = ss;
     __syncthreads();
     if (jl != 0 || c >= C) return;
-    for (int j = 1; j < 8; ++j) {
+    for (int j = 1; j < FJ; ++j) {
         s += red[0][j][cl];
         ss += red[1][j][cl];
     }
@@ -324,7 +327,7 @@ extern "C" int denet_bn_fwd_train(const float* x, const float* res, float* y, co
     BnMap m = bn_map(M, C);
     double* partial = (double*)workspace;
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, M, C, m.LC, partial);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, partial, m.gy, M, C, eps,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, m.gy, M, C, eps,
                        momentum, save_mean, save_invstd, run_mean, run_stdinv);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, res, y, gamma, beta, save_mean,
                        save_invstd, M, C, m.LC, relu);
@@ -359,7 +362,7 @@ extern "C" int denet_bn_bwd(const float* x, const float* y, const float* dy, con
     float* coef = (float*)(partial + (size_t)m.gy * 2 * C);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, gamma, beta, save_mean,
                        save_invstd, M, C, m.LC, relu, partial);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, partial, m.gy, M, C, dgamma,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, m.gy, M, C, dgamma,
                        dbeta, coef);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, gamma, beta, save_mean,
                        save_invstd, coef, dx, dres, M, C, m.LC, relu);

@@ -381,7 +381,11 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
         }
     };
 
+    // a wave whose 32*TN columns lie entirely in the padding of the last N tile (e.g. wgrad of a 64-channel 3x3:
+    // 576 = 4.5 x 128 columns) skips its matrix work; it still helps staging and keeps the barriers
+    const bool wave_active = (n0 + wn * TN * 32 < p.NC) && (m0 + wm * TM * 32 < p.M);
     auto compute = [&](int buf) {
+        if (!wave_active) return;
         const float* cA = sA + buf * SZA + fa;
         const float* cB = sB + buf * SZB + fb;
         float av[2][TM][4], bv[2][TN][4];
@@ -401,9 +405,11 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
         }
     };
 
-    if (NBUF == 1) {
+    // single-buffer loop flavour: the interleaved form pays on the narrow tiles (8 MFMAs per block: +4...8 %), costs
+    // 2-4 % on 128x128 dgrad and spills on wgrad (its loader state is large) - measured with tools/bench_conv.py
+    constexpr bool IL1 = (MODE != MODE_WGRAD) && (BN == 64);
+    if (NBUF == 1 && !IL1) {
         if (nsteps > 0) {
-            // one LDS buffer: a third of the LDS -> 3-4 workgroups per CU cover each other's barrier bubbles
             load_chunk(step_begin);
             store_chunk(0);
             __syncthreads();
@@ -415,6 +421,76 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
                 if (more) store_chunk(0);
                 __syncthreads();
             }
+        }
+    } else if (NBUF == 1) {
+        if (nsteps > 0) {
+            // one LDS buffer: a third of the LDS -> 3-4 workgroups per CU cover each other's barrier bubbles. The
+            // global loads of chunk s+1 are slotted pass by pass behind the MFMAs of chunk s (no burst in front of
+            // the matrix block); the LDS writes have to wait for the barrier that ends the reads of chunk s.
+            constexpr int KB = BK / 8;
+            static_assert(PA <= KB && PB <= KB, "one staging pass per MFMA block");
+            float av[2][TM][4], bv[2][TN][4];
+            load_chunk(step_begin);
+            store_chunk(0);
+            __syncthreads();
+            load_frags(sA + fa, sB + fb, 0, av[0], bv[0]);
+            auto body1 = [&](int s, auto LF) {
+                constexpr bool do_l = decltype(LF)::value;
+                if (do_l) prep(step_begin + s + 1);
+                auto step = [&](auto KBI) {
+                    constexpr int kb = decltype(KBI)::value;
+                    constexpr bool rd = (kb + 1 < KB);
+                    if (rd) load_frags(sA + fa, sB + fb, kb + 1, av[(kb + 1) & 1], bv[(kb + 1) & 1]);
+                    if constexpr (kb < PA) {
+                        if (do_l) load_a(kb);
+                    }
+                    if constexpr (kb < PB) {
+                        if (do_l) load_b(kb);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb & 1][i][t], bv[kb & 1][j][t],
+                                                                                 acc[i][j], 0, 0, 0);
+                    constexpr int NM = 4 * TM * TN;
+                    constexpr int NR = rd ? (A_KIN ? TM : 4 * TM) + (B_KIN ? TN : 4 * TN) : 0;
+                    constexpr int NL = do_l ? ((kb < PA) ? 1 : 0) + ((kb < PB) ? 1 : 0) : 0;
+                    constexpr int HALF = (NM / 2 > 0) ? NM / 2 : 1;
+                    constexpr int RP = NR ? (NR + HALF - 1) / HALF : 1;
+                    constexpr int RS = NR ? (NR + RP - 1) / RP : 0;
+                    constexpr int LS = (NL < NM - RS) ? NL : ((NM - RS > 0) ? NM - RS : 0);
+#pragma unroll
+                    for (int g = 0; g < RS; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, RP, 0);
+                    }
+#pragma unroll
+                    for (int g = 0; g < LS; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, MODE == MODE_WGRAD ? 12 : 6, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                    if constexpr (NM - RS - LS > 0) __builtin_amdgcn_sched_group_barrier(0x008, NM - RS - LS, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                step(std::integral_constant<int, 0>{});
+                step(std::integral_constant<int, 1>{});
+                step(std::integral_constant<int, 2>{});
+                step(std::integral_constant<int, 3>{});
+                if (do_l) {
+                    advance();
+                    __syncthreads();
+                    store_chunk(0);
+                    __syncthreads();
+                    load_frags(sA + fa, sB + fb, 0, av[0], bv[0]);
+                }
+            };
+            int s = 0;
+            for (; s + 1 < nsteps; ++s) body1(s, std::true_type{});
+            body1(s, std::false_type{});
         }
     } else if (nsteps > 0) {
         // ---- pipelined main loop (NBUF = 2 or 3 LDS buffers, ONE register staging set) --------------------
