@@ -58,6 +58,12 @@ def overlap(bbox0, bbox1=(0, 0, 1, 1)):
     return dx * dy
 
 
+def overlap_rel(bbox0, bbox1=(0, 0, 1, 1)):
+    """share of bbox0 that lies inside bbox1 (denet/common/__init__.py:97-102)"""
+    a = (bbox0[2] - bbox0[0]) * (bbox0[3] - bbox0[1])
+    return overlap(bbox0, bbox1) / a if a > 0 else 0.0
+
+
 def overlap_iou(bbox0, bbox1=(0, 0, 1, 1)):
     a0 = (bbox0[2] - bbox0[0]) * (bbox0[3] - bbox0[1])
     a1 = (bbox1[2] - bbox1[0]) * (bbox1[3] - bbox1[1])
@@ -84,6 +90,15 @@ def convert_num(s):
             return float(s)
         except ValueError:
             return s
+
+
+def get_params_dict(params):
+    """"a=1,b=0.5,flag" -> {"a": 1, "b": 0.5, "flag": True} (denet/common/__init__.py:200-208; predict.py:168)"""
+    out = {}
+    for item in params.split(","):
+        name, _, value = item.partition("=")
+        out[name] = convert_num(value) if "=" in item else True
+    return out
 
 
 def get_overlap_iou(obj_bboxs, sample_bboxs):

@@ -15,41 +15,57 @@ from . import model_cnn
 from . import zoo
 
 
-class SyntheticDataset:
-    """`samples` synthetic images with boxes/classes; export() follows DatasetAbstract.export"""
+class ArrayDataset:
+    """In-memory dataset of (C,H,W) float arrays + meta dictionaries with the surface ModelCNN.train_epoch and the
+    training driver use from the reference's DatasetAbstract (denet/dataset/__init__.py:43-366): len, get_data_shape,
+    get_class_num, shuffle, load_from_subset, export. export() pads the last batch with samples drawn by
+    random.randint like the reference (:349-366) - the draws are part of the stdlib stream the RoI editing shares."""
 
-    def __init__(self, samples=64, image=512, class_num=80, channels=3, seed=1):
-        self.samples, self.image, self.class_num, self.channels, self.seed = samples, image, class_num, channels, seed
+    def __init__(self, data_x, metas, class_num):
+        self._x = numpy.ascontiguousarray(data_x, dtype=numpy.float32)
+        self._m = list(metas)
+        self.class_num = class_num
         self.class_labels = {"class%i" % i: i for i in range(class_num)}
         self.subset_num = 1
-        self._x, self._m = zoo.synthetic_batch(samples, image, class_num, seed)
 
     def __len__(self):
-        return self.samples
+        return len(self._m)
 
     def get_data_shape(self):
-        return (self.channels, self.image, self.image)
+        return tuple(self._x.shape[1:])
 
     def get_class_num(self):
         return self.class_num
 
-    def shuffle(self):
-        order = list(range(self.samples))
-        random.shuffle(order)
+    def get_metas(self):
+        return list(self._m)
+
+    def shuffle(self, mode="random"):
+        if mode != "random":
+            raise Exception("Unknown shuffle mode:", mode)
+        order = list(range(len(self)))
+        random.shuffle(order)       # same draws and same permutation as random.shuffle(self.data)
         self._x = self._x[order]
         self._m = [self._m[i] for i in order]
 
     def load_from_subset(self, subset):
         pass
 
-    def export(self, batch_size):
-        n = int(math.ceil(self.samples / batch_size)) * batch_size
-        x, m = self._x, list(self._m)
-        if n > self.samples:   # pad with copies like the reference pads the last batch
-            reps = n - self.samples
-            x = numpy.concatenate([x, x[:reps]], axis=0)
-            m = m + m[:reps]
-        return x, m, self.samples
+    def export(self, batch_size=1, dtype=numpy.float32):
+        n = len(self)
+        size = batch_size * int(math.ceil(n / batch_size))
+        index = list(range(n)) + [random.randint(0, n - 1) for _ in range(size - n)]
+        x = self._x if size == n else self._x[index]
+        return x.astype(dtype, copy=False), [self._m[i] for i in index], n
+
+
+class SyntheticDataset(ArrayDataset):
+    """`samples` synthetic images with boxes/classes (there is no network for the real datasets)"""
+
+    def __init__(self, samples=64, image=512, class_num=80, channels=3, seed=1):
+        self.samples, self.image, self.channels, self.seed = samples, image, channels, seed
+        x, m = zoo.synthetic_batch(samples, image, class_num, seed)
+        super().__init__(x, m, class_num)
 
 
 def load_dataset(spec, seed):

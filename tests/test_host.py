@@ -194,6 +194,62 @@ def test_detect_and_corner_targets_match_reference_loops(jointfit):
     np.testing.assert_array_equal(cval.reshape(dnc.corner_shape), OL.corner_target(metas, dnc.corner_shape))
 
 
+def test_host_helpers_match_imported_reference():
+    """fixtures written by tests/golden/make_common_fixtures.py, which IMPORTS the reference's denet.common in the
+    build container (the one reference package that loads without Theano)"""
+    import json
+    from denet_amd import common as C
+    from denet_amd.common import json_util as J
+    fix = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "common_fixtures.json")))
+    for e in fix["convert_num"]:
+        got = C.convert_num(e["in"])
+        assert type(got).__name__ == e["type"], e
+        assert (repr(got) == e["out"]) if isinstance(e["out"], str) and e["type"] == "float" else (got == e["out"]), e
+    for e in fix["get_params_dict"]:
+        assert C.get_params_dict(e["in"]) == e["out"], e
+    u = fix["ndarray_unpack"]
+    got = C.ndarray_unpack(np.array(u["v"], np.float32), [tuple(s) for s in u["shapes"]])
+    for g, r in zip(got, u["out"]):
+        assert np.array_equal(g, np.array(r, np.float32))
+    for e in fix["overlap"]:
+        a, b = tuple(e["a"]), tuple(e["b"])
+        assert C.overlap(a, b) == e["overlap"] and C.overlap_iou(a, b) == e["iou"] and C.overlap_rel(a, b) == e["rel"]
+        assert C.overlap_iou(a) == e["iou_unit"] and C.overlap_rel(a) == e["rel_unit"]
+    for name, e in fix["codec"].items():
+        arr = J.numpy_from_json(e["encoded"])
+        assert str(arr.dtype) == e["dtype"] and list(arr.shape) == e["shape"], name
+        assert np.array_equal(arr.astype(np.float64).reshape(-1), np.array(e["values"])), name
+        back = J.numpy_from_json(json.loads(json.dumps(J.numpy_to_json(arr))))
+        assert back.dtype == arr.dtype and np.array_equal(back, arr), name
+    mdl = J.json_from_gz(os.path.join(os.path.dirname(__file__), "golden", "ref_codec.mdl.gz"))
+    conv, bn = mdl["layers"]
+    assert conv["weight"].dtype == np.float32 and conv["weight"].shape == (32, 3, 3, 3)
+    assert np.array_equal(conv["weight"].reshape(-1), np.array(fix["mdl"]["weight"], np.float32))
+    assert np.array_equal(conv["bias"], np.array(fix["mdl"]["bias"], np.float32))
+    assert np.array_equal(bn["std"], np.array(fix["mdl"]["std"], np.float32))
+    # dataset surface of train_epoch: same shuffle permutation, same padding draws, same generator state afterwards
+    from denet_amd.model.train import ArrayDataset
+    d = fix["dataset"]
+    arrs = np.array(d["samples"], np.float32).reshape(-1, 3, 4, 4)
+    ds = ArrayDataset(arrs, [{"id": i, "image_class": i % 3} for i in range(len(arrs))], 3)
+    random.seed(d["seed"])
+    ds.shuffle()
+    x, metas, n = ds.export(d["batch"])
+    assert n == d["size"] and list(x.shape) == d["x_shape"] and [m["id"] for m in metas] == d["ids"]
+    assert abs(float(x.astype(np.float64).sum()) - d["x_sum"]) < 1e-9 and random.random() == d["next_random"]
+    for k, m in enumerate(metas):
+        assert np.array_equal(x[k], arrs[m["id"]])
+    # the reference's layer dictionaries load into the product's layers (same JSON keys)
+    from denet_amd.model.model_cnn import ModelCNN
+    m = ModelCNN()
+    m.batch_size, m.class_num = 1, 2
+    m.build("C.B[32,3] BN", (3, 8, 8), "relu", "half", ["he-backward"])
+    m.layers[1].import_json(conv)
+    m.layers[2].import_json(bn)
+    assert np.array_equal(m.layers[1].omega.get_value(), conv["weight"])
+    assert np.array_equal(m.layers[2].stdinv.get_value(), bn["std"])      # "std" holds the running INVERSE std
+
+
 def test_cabi_exports_every_declared_symbol():
     """the shared library loads and exports exactly what include/denet_hip.h declares (no compute calls)"""
     hdr = open(os.path.join(ROOT, "include", "denet_hip.h")).read()
