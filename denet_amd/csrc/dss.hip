@@ -143,14 +143,20 @@ __global__ __launch_bounds__(256) void sparse_fwd_kernel(const float* __restrict
         o[k] = (k == ntap * F) ? bh : (k == ntap * F + 1) ? bw : 0.f;
 }
 
-// per image: sort (cell << 15 | tap_slot) ascending in LDS (bitonic, 32768 slots = 128 KiB)
+// per (image, run): the tap slots [run*32768, (run+1)*32768) of the image are sorted by (cell << 15 | slot - base)
+// ascending in LDS (bitonic, 32768 slots = 128 KiB). Runs partition the slots by range, so walking run 0, run 1, ...
+// visits the entries of a cell in ascending slot order - the same order one full sort would give.
 __global__ __launch_bounds__(1024) void sparse_sort_kernel(const int* __restrict__ taps, unsigned* __restrict__ sorted,
-                                                           int n) {
+                                                           int n_total) {
     extern __shared__ __attribute__((aligned(16))) unsigned skey[];
     constexpr int NS = 32768;
     const int b = blockIdx.x;
+    const int base = blockIdx.y * NS;
+    const int n = min(NS, n_total - base);
+    taps += (long)b * n_total + base;
+    sorted += (long)b * n_total + base;
     for (int i = threadIdx.x; i < NS; i += 1024)
-        skey[i] = (i < n) ? (((unsigned)taps[(long)b * n + i] << 15) | (unsigned)i) : 0xFFFFFFFFu;
+        skey[i] = (i < n) ? (((unsigned)taps[i] << 15) | (unsigned)i) : 0xFFFFFFFFu;
     __syncthreads();
     for (int k = 2; k <= NS; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(1024) void sparse_sort_kernel(const int* __restrict
             __syncthreads();
         }
     }
-    for (int i = threadIdx.x; i < n; i += 1024) sorted[(long)b * n + i] = skey[i];
+    for (int i = threadIdx.x; i < n; i += 1024) sorted[i] = skey[i];
 }
 
 __device__ __forceinline__ int lower_bound_u32(const unsigned* a, int n, unsigned v) {
@@ -192,19 +198,25 @@ __global__ __launch_bounds__(256) void sparse_bwd_kernel(const float* __restrict
     const int b = (int)(cellg / HW);
     const int cell = (int)(cellg - (long)b * HW);
     const int n = rois_per_image * ntap;
-    const unsigned* sl = sorted + (long)b * n;
-    const int start = lower_bound_u32(sl, n, (unsigned)cell << 15);
-    const int end = lower_bound_u32(sl, n, (unsigned)(cell + 1) << 15);
     const int F4 = F / 4;
     const int epi = 64 / F4;  // entries per iteration
     const int e = lane / F4, f4 = lane - e * F4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (e < epi) {
-        for (int i = start + e; i < end; i += epi) {
-            const unsigned slot = sl[i] & 0x7FFFu;
-            const int roi = slot / ntap, tap = slot - roi * ntap;
-            acc += *(const f32x4*)(dy + ((long)b * rois_per_image + roi) * KP + (long)tap * F + f4 * 4);
+    // a lane keeps ONE accumulator over all runs: the sum of a cell is the same left-to-right chain as for one run
+    for (int base = 0, k = 0; base < n; base += 32768) {
+        const unsigned* sl = sorted + (long)b * n + base;
+        const int nr = min(32768, n - base);
+        const int start = lower_bound_u32(sl, nr, (unsigned)cell << 15);
+        const int end = lower_bound_u32(sl, nr, (unsigned)(cell + 1) << 15);
+        if (e < epi) {
+            // entry j of the cell (counted over all runs) belongs to lane group j % epi
+            for (int i = start + ((e - k % epi + epi) % epi); i < end; i += epi) {
+                const unsigned slot = (sl[i] & 0x7FFFu) + (unsigned)base;
+                const int roi = slot / ntap, tap = slot - roi * ntap;
+                acc += *(const f32x4*)(dy + ((long)b * rois_per_image + roi) * KP + (long)tap * F + f4 * 4);
+            }
         }
+        k += end - start;
     }
     f32x4 tot = acc;
     for (int k = 1; k < epi; ++k) {
@@ -345,7 +357,7 @@ extern "C" int denet_corner_fwd(const float* conv, float* corner_pr, int B, int 
     return DENET_OK;
 }
 
-extern "C" size_t denet_loss_workspace_bytes(void) { return (size_t)2 * 8192 * sizeof(double); }
+extern "C" size_t denet_loss_workspace_bytes(void) { return (size_t)2 * 65536 * sizeof(double); }
 
 extern "C" int denet_corner_loss(const float* corner_pr, const float* target, float* dconv, float* cost,
                                  void* workspace, int B, int H, int W, int CP, int Cn, float cost_factor,
@@ -387,8 +399,7 @@ extern "C" int denet_sparse_bwd(const float* dy, const int* taps, unsigned* sort
     DENET_CHECK_ARG(dy && taps && sorted_ws && dfmap, "sparse_bwd: null pointer");
     const int ntap = gs * gs;
     const int n = rois_per_image * ntap;
-    DENET_CHECK_ARG(n <= 32768, "sparse_bwd: %d taps per image exceed the 32768-slot LDS sort", n);
-    DENET_CHECK_ARG(H * W <= (1 << 16), "sparse_bwd: feature map too large for 16-bit cell keys");
+    DENET_CHECK_ARG(H * W <= (1 << 17) - 1, "sparse_bwd: feature map too large for 17-bit cell keys");
     DENET_CHECK_ARG(F % 4 == 0 && F / 4 <= 64 && coff % 4 == 0 && CP % 4 == 0 && KP % 4 == 0,
                     "sparse_bwd: F/coff/CP/KP must be multiples of 4 and F <= 256");
     DENET_CHECK_ARG(zero_from >= coff + F && zero_from <= CP, "sparse_bwd: zero_from out of range");
@@ -402,7 +413,7 @@ extern "C" int denet_sparse_bwd(const float* dy, const int* taps, unsigned* sort
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(sparse_sort_kernel, dim3(B), dim3(1024), 32768 * 4, stream, taps, sorted_ws, n);
+    hipLaunchKernelGGL(sparse_sort_kernel, dim3(B, (n + 32767) / 32768), dim3(1024), 32768 * 4, stream, taps, sorted_ws, n);
     const long ncell = (long)B * H * W;
     hipLaunchKernelGGL(sparse_bwd_kernel, dim3((unsigned)((ncell + 3) / 4)), dim3(256), 0, stream, dy, sorted_ws, dfmap,
                        H * W, CP, coff, F, rois_per_image, ntap, KP, zero_from, ncell);
@@ -420,7 +431,7 @@ extern "C" int denet_detect_loss(const float* logits, const float* det_target, c
     DENET_CHECK_ARG(!bounded_iou || roi_bbox, "detect_loss: bounded IoU needs the RoI boxes");
     DENET_CHECK_ARG(ncls + nreg <= CP, "detect_loss: CP too small");
     const int g = (M + 3) / 4;
-    DENET_CHECK_ARG(g <= 8192, "detect_loss: too many RoIs (%d)", M);
+    DENET_CHECK_ARG(g <= 65536, "detect_loss: too many RoIs (%d)", M);
     const float det_scale = cost_factor / (float)batch;
     // bbox_factor is applied twice in the reference: get_errors :295 and cost :310
     const float bbox_scale = bbox_factor * bbox_factor / (float)batch;

@@ -16,6 +16,15 @@ DENET34_SKIP_DESC = ("PI[2] C[256,3] SKIP[1] BNA PI[2] C[128,3] SKIP[0] BNA DNC[
                      "C[1536,1] BNA C.B[1024,1] BNA C.B[768,1] BNA C.B[512,1] BNA DND[0.5,1,1]")
 DENET34_STD_DESC = ("PI[2] C.B[256,3] BNA PI[2] C.B[128,3] BNA DNC[96,100] DNS[7,24,0.01,0.1] C.B[1536,1] BNA "
                     "C.B[1024,1] BNA C.B[768,1] BNA C.B[512,1] BNA DND[0.5,1,1]")
+# ResNet-101 (bottleneck blocks 3/4/23/3): the desc string is not in the reference tree (the recipe downloads
+# models/imagenet/resnet101.mdl.gz); it follows from the nRSN grammar (resnet.py:124-131: num, filters, size, stride,
+# bottleneck) and is consistent with the layer indices denet101.sh:84-90 inserts at (7, 12, 24, 37 after --layer-remove 3)
+RESNET101_DESC = ("C.B[64,7,2] BN A P[3,2,1] nRSN.O[3,256,3,1,64] nRSN.O[4,512,3,2,128] nRSN.O[23,1024,3,2,256] "
+                  "nRSN.O[3,2048,3,2,512] P.A[7] R.TB")
+DENET101_WIDE_DESC = ("PI[2] C[1024,3] SKIP[2] BNA PI[2] C[512,3] SKIP[1] BNA PI[2] C[256,3] SKIP[0] BNA SPLIT DNC[128,200] "
+                      "DNS[7,48,0.01,0.1] C.B[2048,1] BNA C.B[1536,1] BNA C.B[1024,1] BNA C.B[768,1] BNA DND[0.5,1,1]")
+DENET101_SKIP_DESC = ("PI[2] C.B[384,3] SKIP[1] BNA PI[2] C.B[192,3] SKIP[0] BNA DNC[128,50] DNS[7,24,0.01,0.1] C.B[2048,1] BNA "
+                      "C.B[1536,1] BNA C.B[1024,1] BNA C.B[768,1] BNA DND[0.5,1,1]")
 CIFAR3_DESC = "C[128,3] BN A P[2] C[256,3] BN A P[2] C[512,3] BN A P.A[8] R"
 
 
@@ -47,6 +56,32 @@ def denet34(batch_size, variant="skip", image=512, class_num=80, seed=1, head_de
         desc = DENET34_STD_DESC
     else:
         raise Exception("unknown DeNet-34 variant " + variant)
+    m = modify.layer_append(m, head_desc or desc)
+    return m
+
+
+def denet101(batch_size, variant="wide", image=512, class_num=80, seed=1, head_desc=None):
+    """DeNet-101 <variant> (BASELINE config 5 is `wide`, B=16): the surgery of papers/dss/denet101.sh:82-90,
+    head descs :11-21. `wide` taps three scales (256@128^2 via a plain SKIPSRC, 512@64^2, 1024@32^2) and proposes
+    48x48 = 2304 RoIs per image."""
+    numpy.random.seed(seed)
+    m = model_cnn.ModelCNN()
+    m.batch_size = batch_size
+    m.class_num = 1000
+    m.build(RESNET101_DESC, (3, 224, 224), "relu", "half", ["he-backward"])
+    m = modify.modify_bn(m, 1, 0.9, 1e-5)
+    m = modify.convert_bn_relu(m)
+    m = modify.layer_remove(m, 3)
+    m = modify.set_class_num(m, class_num)
+    m = modify.set_image_size(m, image, image)
+    if variant == "wide":
+        m = modify.layer_insert(m, ["7:SKIPSRC[0]", "12:SKIPSRC.X[1]", "24:SPLIT", "37:SKIPSRC.X[2]"])
+        desc = DENET101_WIDE_DESC
+    elif variant == "skip":
+        m = modify.layer_insert(m, ["11:SKIPSRC.X[0]", "18:SKIPSRC.X[1]"])
+        desc = DENET101_SKIP_DESC
+    else:
+        raise Exception("unknown DeNet-101 variant " + variant)
     m = modify.layer_append(m, head_desc or desc)
     return m
 

@@ -223,7 +223,7 @@ def _forced_step_check(model, om, x, metas, it, lr, mu, decay, solver, roi_lists
 def _warm_corner_head(model, bias, std, seed=3):
     """makes the corner detector fire: random corner filters + a lower bias (SURVEY §8d 'warm' regime)"""
     rng = np.random.RandomState(seed)
-    conv = model.layers[30].layers[-1]
+    conv = [l for l in model.layers if l.type_name == "denet-corner"][0].layers[-1]
     w = conv.omega.get_value().copy()
     w[:4] = rng.normal(0, std, w[:4].shape)
     conv.omega.set_value(w)
@@ -434,6 +434,33 @@ def test_denet_head_variants_vs_oracle(hip, head, rule):
     assert np.array_equal(model.layers[31]._taps.cpu().numpy(), taps_ref)
     if "J" in head:
         assert model.layers[40].s0 == 401
+
+
+def test_denet101_wide_train_step_vs_oracle(hip):
+    """BASELINE config 5 at reduced size: ResNet-101 bottleneck backbone, three skip scales (one through a plain
+    SKIPSRC), SPLIT points, 48x48 = 2304 RoIs per image, joint-fitness + bounded-IoU head (papers/dss/denet101.sh)"""
+    B, IMG = 1, 128
+    model = zoo.denet101(B, "wide", IMG, class_num=80, seed=1,
+                         head_desc=zoo.DENET101_WIDE_DESC.replace("DND[0.5,1,1]", "DND.JB[0.5,1,1]"))
+    by_type = lambda t: [l for l in model.layers if l.type_name == t][0]
+    dnd, dns = by_type("denet-detect"), by_type("denet-sparse")
+    assert dns.sample_count == 2304 and dns.output_shape[1] == 7 * 7 * 128 + 2
+    rng = np.random.RandomState(5)
+    dconv = dnd.layers[0]
+    dconv.omega.set_value(rng.normal(0, 0.05, dconv.omega.value.shape))
+    _warm_corner_head(model, 4.0, 0.3)
+    x, metas = zoo.synthetic_batch(B, IMG, seed=3)
+    om = OM.OracleModel(model.export_json(), B)
+    model.build_train_func("nesterov")
+    random.seed(9)
+    cost, costs = model.train_step(x, metas, 0, 0, 0.05, [0.9], 1e-4)
+    roi_lists = dns.sample_bbox_list
+    assert len(roi_lists[0]) == 2304
+    ocost, ocosts = _forced_step_check(model, om, x, metas, 0, 0.05, 0.9, 1e-4, "nesterov", roi_lists)
+    assert abs(cost - ocost) <= 1e-4 * abs(ocost), (cost, ocost)
+    ys, xs = om.taps
+    taps_ref = (ys[:, :, None] * (IMG // 4) + xs[:, None, :]).reshape(ys.shape[0], -1)
+    assert np.array_equal(dns._taps.cpu().numpy(), taps_ref)
 
 
 def test_model_train_cli_trains_and_checkpoints(hip, tmp_path):
