@@ -103,7 +103,6 @@ __global__ __launch_bounds__(256) void detect_nms_kernel(const float* __restrict
     float* s_box = sm + S;            // [S][4]
     int* s_idx = (int*)(sm + 5 * S);  // [S]
     __shared__ int s_w[4];
-    __shared__ int s_n;
     const int cls = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = min(count[b], S);
