@@ -3,6 +3,8 @@
 // leaves a thread-local message behind.
 #include "common.h"
 #include <stdarg.h>
+#include <math.h>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -156,6 +158,102 @@ extern "C" int denet_host_edit_samples(uint32_t* mt, int* pos, const float* det,
         }
         float* f = out_box_f32 + (size_t)b * S * 4;
         for (int i = 0; i < S * 4; ++i) f[i] = (float)bx[i];
+    }
+    return DENET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Detection targets of a batch (denet/layer/denet_detect.py:147-235), RoI-major: row m = b*S + index.
+// IoU matrix in float32 with the operation order of the compiled Theano function (common/theano_util.py:38-59);
+// every GT/RoI pair with IoU > t0 sets its class (or class x fitness-bin, :180-183, double arithmetic on the
+// float32 IoU) and clears the null class; per RoI the arg-max GT gives the box-regression target if IoU > t1
+// (:194-213, double arithmetic, stored as float32); rows are normalised to sum 1 and divided by S (:216-226).
+// gt: concatenated [n,4] doubles, gt_off [B+1], gt_class [n]; roi [B,S,4] doubles (the edited RoI list).
+// det [B*S,s0], valid [B*S] (or null), reg [B*S,8] (or null). Pure host code.
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int denet_host_detect_targets(const double* gt, const int* gt_off, const int* gt_class, const double* roi,
+                                         int B, int S, int s0, int null_class, int fitness_num, int jointfit,
+                                         double t0, double t1, float* det, float* valid, float* reg) {
+#pragma clang fp contract(off)
+    DENET_CHECK_ARG(gt_off && roi && det && B > 0 && S > 0 && s0 > 0, "detect_targets: bad arguments");
+    DENET_CHECK_ARG(null_class >= 0 && null_class < s0, "detect_targets: null class out of range");
+    DENET_CHECK_ARG((valid == nullptr) == (reg == nullptr), "detect_targets: valid and reg go together");
+    const float t0f = (float)t0, t1f = (float)t1, Sf = (float)S;
+    const float inv_s = 1.0f / Sf;
+    std::vector<float> gx, garea, ov;
+    for (int b = 0; b < B; ++b) {
+        const int g0 = gt_off[b], ng = gt_off[b + 1] - g0;
+        DENET_CHECK_ARG(ng >= 0 && (ng == 0 || (gt && gt_class)), "detect_targets: ground truth of image %d missing", b);
+        gx.resize((size_t)ng * 4);
+        garea.resize(ng);
+        ov.resize(ng);
+        for (int k = 0; k < ng; ++k) {
+            for (int c = 0; c < 4; ++c) gx[k * 4 + c] = (float)gt[(size_t)(g0 + k) * 4 + c];
+            garea[k] = (gx[k * 4 + 2] - gx[k * 4 + 0]) * (gx[k * 4 + 3] - gx[k * 4 + 1]);
+        }
+        for (int i = 0; i < S; ++i) {
+            const size_t row = (size_t)b * S + i;
+            float* d = det + row * s0;
+            for (int c = 0; c < s0; ++c) d[c] = 0.f;
+            d[null_class] = 1.f;
+            float* r = reg ? reg + row * 8 : nullptr;
+            if (r) {
+                r[0] = r[1] = r[4] = r[5] = 0.f;
+                r[2] = r[3] = r[6] = r[7] = 1.f;
+                valid[row] = 0.f;
+            }
+            if (ng == 0) {
+                d[null_class] = inv_s;      // (1 / 1) / S
+                continue;
+            }
+            const double* yd = roi + row * 4;
+            const float y0 = (float)yd[0], y1 = (float)yd[1], y2 = (float)yd[2], y3 = (float)yd[3];
+            const float yarea = (y2 - y0) * (y3 - y1);
+            int best = 0;
+            bool best_nan = false;
+            for (int k = 0; k < ng; ++k) {
+                const float* x = &gx[k * 4];
+                const float dx = fmaxf(fminf(x[2], y2) - fmaxf(x[0], y0), 0.f);
+                const float dy = fmaxf(fminf(x[3], y3) - fmaxf(x[1], y1), 0.f);
+                const float inter = dx * dy;
+                const float uni = (garea[k] + yarea) - inter;
+                const float v = inter / uni;
+                ov[k] = v;
+                // numpy.argmax: the first maximum, a NaN counts as the maximum
+                if (!best_nan) {
+                    if (v != v) { best = k; best_nan = true; }
+                    else if (k > 0 && v > ov[best]) best = k;
+                }
+                if (v > t0f) {
+                    int col = gt_class[g0 + k];
+                    if (jointfit) {
+                        const double sf = ((double)v - t0) / (1.0 - t0);
+                        long f = (long)((double)fitness_num * sf);
+                        f = f < 0 ? 0 : (f > fitness_num - 1 ? fitness_num - 1 : f);
+                        col = col * fitness_num + (int)f;
+                    }
+                    DENET_CHECK_ARG(col >= 0 && col < s0, "detect_targets: class column %d out of range", col);
+                    d[col] = 1.f;
+                    d[null_class] = 0.f;
+                }
+            }
+            float sum = 0.f;
+            for (int c = 0; c < s0; ++c) sum += d[c];
+            for (int c = 0; c < s0; ++c)
+                if (d[c] != 0.f) d[c] = (d[c] / sum) / Sf;
+            if (r && ov[best] > t1f) {
+                const double* t = gt + (size_t)(g0 + best) * 4;
+                valid[row] = inv_s;
+                r[0] = (float)(0.5 * (t[0] + t[2]));
+                r[1] = (float)(0.5 * (t[1] + t[3]));
+                r[2] = (float)(t[2] - t[0]);
+                r[3] = (float)(t[3] - t[1]);
+                r[4] = (float)(0.5 * (yd[0] + yd[2]));
+                r[5] = (float)(0.5 * (yd[1] + yd[3]));
+                r[6] = (float)(yd[2] - yd[0]);
+                r[7] = (float)(yd[3] - yd[1]);
+            }
+        }
     }
     return DENET_OK;
 }

@@ -108,7 +108,7 @@ class DeNetCornerLayer(AbstractLayer):
         if getattr(self, "_pinned", None) is None or self._pinned.numel() != v.size:
             self._pinned = torch.empty(v.size, dtype=torch.float32).pin_memory()
         self._pinned.copy_(torch.from_numpy(v))
-        self._target = self._pinned.cuda(non_blocking=True)
+        self._target, self._target_ev = ops.upload_async(self._pinned)
 
     def forward(self, ctx):
         self.conv.forward(ctx)
@@ -131,6 +131,7 @@ class DeNetCornerLayer(AbstractLayer):
         if want_grad:
             # if no RoI gather follows, the sampling / padding channels carry no gradient: start from zeros
             dconv = self.alloc_dconv(zero=not ctx.has_sparse)
+        ops.wait_upload(getattr(self, "_target_ev", None))
         ops.corner_loss(self.corner_pr, self._target, dconv, cost_out, float(self.cost_factor))
 
     def backward(self, ctx):

@@ -99,7 +99,39 @@ class DeNetDetectLayer(AbstractLayer):
         return t.numpy()
 
     def build_targets(self, metas):
-        """IoU based target assignment of denet_detect.py:147-235 in RoI-major layout: row m = b*sn*sn + index,
+        """IoU based target assignment of denet_detect.py:147-235 in RoI-major layout (row m = b*sn*sn + index,
+        index = j*sn + i, :174-175), one native host call for the batch (denet_host_detect_targets) writing the
+        pinned staging buffers. returns det [M,s0], bbox_valid [M] or None, bbox_reg [M,8] or None (float32)"""
+        from .. import lib as _lib
+        t0, t1 = self._thresholds()
+        sn, B = self.sample_num, self.batch_size
+        S = sn * sn
+        sp = self.sparse_layer
+        boxes = sp.sample_boxes
+        if any(len(bx) != S for bx in boxes):
+            return self.build_targets_numpy(metas)        # short RoI lists (inference-style calls): general path
+        roi = numpy.ascontiguousarray(numpy.stack(boxes, axis=0), dtype=numpy.float64)
+        gts = [numpy.asarray(m["bbox"], dtype=numpy.float64).reshape(-1, 4) for m in metas]
+        off = numpy.zeros(B + 1, dtype=numpy.int32)
+        numpy.cumsum([len(g) for g in gts], out=off[1:])
+        gt = numpy.ascontiguousarray(numpy.concatenate(gts, axis=0)) if off[-1] > 0 else numpy.zeros((1, 4))
+        cls = numpy.ascontiguousarray(numpy.concatenate([numpy.asarray(m["class"], dtype=numpy.int32).reshape(-1)
+                                                         for m in metas]) if off[-1] > 0 else numpy.zeros(1), dtype=numpy.int32)
+        det = self._buf("det", (B * S, self.s0))
+        valid = reg = None
+        if self.use_bbox_reg:
+            valid = self._buf("valid", (B * S,))
+            reg = self._buf("reg", (B * S, 8))
+        _lib.check(_lib.load().denet_host_detect_targets(
+            gt.ctypes.data, off.ctypes.data, cls.ctypes.data, roi.ctypes.data, B, S, self.s0, self.null_class,
+            self.fitness_num, int(bool(self.use_jointfit)), float(t0), float(t1), det.ctypes.data,
+            valid.ctypes.data if valid is not None else None, reg.ctypes.data if reg is not None else None),
+            "detect_targets")
+        return det, valid, reg
+
+    def build_targets_numpy(self, metas):
+        """the same assignment with numpy (general RoI counts; the checker of the native path in tests/test_host.py):
+        IoU based target assignment of denet_detect.py:147-235 in RoI-major layout: row m = b*sn*sn + index,
         index = j*sn + i (:174-175). The per-match Python loops of the reference become fancy indexing — every
         assignment writes the constants 1.0 / 0.0, so the order of the matches is immaterial.
         returns det [M,s0], bbox_valid [M] or None, bbox_reg [M,8] or None (float32)"""
@@ -181,10 +213,12 @@ class DeNetDetectLayer(AbstractLayer):
         import torch
         det, valid, reg = self.build_targets(metas)
         b = self._bufs
-        t = {"det": b["det"].cuda(non_blocking=True), "valid": None, "reg": None}
+        t = {"valid": None, "reg": None}
+        t["det"], ev = ops.upload_async(b["det"])
         if self.use_bbox_reg:
-            t["valid"] = b["valid"].cuda(non_blocking=True)
-            t["reg"] = b["reg"].cuda(non_blocking=True)
+            t["valid"], _ = ops.upload_async(b["valid"])
+            t["reg"], ev = ops.upload_async(b["reg"])
+        t["event"] = ev           # the copies are ordered on the copy stream: the last event covers all three
         self._targets = t
 
     def set_target(self, ctx, yt_index, yt_value):
@@ -212,6 +246,7 @@ class DeNetDetectLayer(AbstractLayer):
         lg = logits.view(M, self.conv.kp)
         dl = ops.empty(M, self.conv.kp) if want_grad else None
         t = self._targets
+        ops.wait_upload(t.get("event"))
         ops.detect_loss(lg, t["det"], t["valid"], t["reg"], self.sparse_layer.sample_bbox, dl, cost_out,
                         self.batch_size, self.s0, self.s1, float(self.cost_factor), float(self.bbox_factor),
                         bool(self.use_bounded_iou))

@@ -22,6 +22,7 @@ SIGNATURES = {
     "denet_device_info": (I, [I, P, P, P, I]),
     "denet_host_py_random_sample": (I, [P, P, I, I, P, P]),
     "denet_host_edit_samples": (I, [P, P, P, P, I, I, I, P, P, I, P, P, P, P]),
+    "denet_host_detect_targets": (I, [P, P, P, P, I, I, I, I, I, I, ctypes.c_double, ctypes.c_double, P, P, P]),
     "denet_conv_fwd": (I, [P, P, P, P, P] + [I] * 12 + [P]),
     "denet_conv_dgrad": (I, [P, P, P, P] + [I] * 12 + [P]),
     "denet_conv_wgrad_workspace_bytes": (Z, [I] * 7),

@@ -69,6 +69,28 @@ class KernelProfile:
 
 PROFILE = None
 
+_COPY_STREAM = None
+
+
+def upload_async(pinned):
+    """H2D copy of a pinned host tensor on a dedicated copy stream: a target array issued on the compute stream
+    would sit between two kernels and stall them for the PCIe time (4-8 MB = 0.1-0.3 ms per step). Returns
+    (device tensor, event); the consumer calls wait_upload(event) right before the first kernel that reads it."""
+    global _COPY_STREAM
+    if _COPY_STREAM is None:
+        _COPY_STREAM = torch.cuda.Stream()
+    with torch.cuda.stream(_COPY_STREAM):
+        dev = pinned.cuda(non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(_COPY_STREAM)
+    dev.record_stream(torch.cuda.current_stream())
+    return dev, ev
+
+
+def wait_upload(ev):
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+
 
 def wait_stream():
     """host wait for everything queued on the current stream. Polls an event instead of a blocking

@@ -49,6 +49,13 @@ int denet_host_py_random_sample(unsigned* mt_host, int* pos_host, int n, int k, 
 int denet_host_edit_samples(unsigned* mt_host, int* pos_host, const float* det_host, const int* count_host, int B, int S,
                             int n_keep, const double* gt_host, const int* gt_off_host, int sample_gt, int* ws_host,
                             double* out_pr_host, double* out_box_host, float* out_box_f32_host);
+/* detection targets of a batch (denet/layer/denet_detect.py:147-235) in RoI-major layout: fp32 IoU matrix in the
+ * operation order of common/theano_util.py:38-59, class / class x fitness-bin targets for IoU > t0, box-regression
+ * target of the arg-max ground truth for IoU > t1, rows normalised and divided by S. gt: concatenated [n,4] doubles,
+ * gt_off:[B+1], gt_class:[n]; roi:[B,S,4] doubles; det:[B*S,s0]; valid:[B*S] and reg:[B*S,8] or both NULL.      */
+int denet_host_detect_targets(const double* gt_host, const int* gt_off_host, const int* gt_class_host,
+                              const double* roi_host, int B, int S, int s0, int null_class, int fitness_num,
+                              int jointfit, double t0, double t1, float* det_host, float* valid_host, float* reg_host);
 
 /* ---- convolution  (denet/layer/convolution.py:80-83 -> cuDNN conv fwd; model_cnn.py:318 tensor.grad ->
  *      cuDNN bwd-data / bwd-filter).  x:[N,H,W,C]  w:[K,R,S,C]  y:[N,OH,OW,K]; `S` may be padded beyond the

@@ -184,6 +184,18 @@ def test_detect_and_corner_targets_match_reference_loops(jointfit):
     prs = [np.zeros(0), np.zeros(0)]
     boxes = [np.zeros((0, 4)), np.zeros((0, 4))]
     dns.sample_pr, dns.sample_boxes = dns.edit_samples(prs, boxes, metas)
+    # jittered copies of the ground truth: many IoU > t0 matches, multi-label cells, all fitness bins
+    rng = np.random.RandomState(8)
+    for b in range(2):
+        gt = np.asarray(metas[b]["bbox"], dtype=np.float64)
+        for k in range(200):
+            g = gt[k % len(gt)]
+            dns.sample_boxes[b][k] = np.clip(g + rng.normal(0, 0.04 * (1 + k % 5), 4), 0, 1)
+    n_det, n_valid, n_reg = dnd.build_targets_numpy(metas)
+    n_det, n_valid, n_reg = n_det.copy(), n_valid.copy(), n_reg.copy()
+    d_det, d_valid, d_reg = dnd.build_targets(metas)                       # native host path
+    assert np.array_equal(n_det, d_det) and np.array_equal(n_valid, d_valid) and np.array_equal(n_reg, d_reg)
+    assert (d_det[:, :-1] > 0).sum() > 100
     idx, val = dnd.get_target(m, None, metas)
     det_t, valid, reg_t = OL.detect_target(metas, dns.sample_bbox_list, 2, 24, 80, (0.5, 0.5), True, jointfit)
     ref = np.concatenate([det_t.flatten(), valid.flatten(), reg_t.flatten()])
