@@ -215,6 +215,10 @@ class AbstractLayer(object):
                 self.layers[i].import_json(json_layer)
 
     # ---- executor protocol (this build) ----
+    def begin_step(self, metas):
+        """called for every layer at the start of a training forward pass, before any kernel is queued: host work
+        on the metas that needs no device result (default: nothing)"""
+
     def prepare_target(self, ctx, model, data_x, metas):
         """host-side target construction right before this layer's forward; layers with a faster internal
         representation override this, the default goes through the reference-format get_target()"""

@@ -42,6 +42,13 @@ class PyRandomMirror:
         self._version, self._gauss = st[0], st[2]
         self.key = numpy.array(st[1][:-1], dtype=numpy.uint32)
         self.pos = numpy.array([st[1][-1]], dtype=numpy.int32)
+        self._finger = (st[1][-1], st[1][:4])
+
+    def fresh(self):
+        """True if the stdlib generator has not moved since pull() (any draw advances the position word or, on a
+        refill, rewrites the first state words)"""
+        st = random.getstate()[1]
+        return self._finger == (st[-1], st[:4])
 
     def push(self):
         """hand the advanced state back to the stdlib generator"""
@@ -277,7 +284,23 @@ class DeNetSparseLayer(AbstractLayer):
         self.coverage = (total_cover, total_bbox)
         return out_pr, out_boxes
 
-    def edit_samples_native(self, det, cnt, metas, out_f32):
+    def begin_step(self, metas):
+        """host work of the RoI editing that does not depend on the detector, done at the start of the forward pass
+        while the GPU is busy with the backbone instead of inside the GPU-idle hand-off: ground-truth arrays and the
+        snapshot of the stdlib generator (re-validated with PyRandomMirror.fresh() before use)"""
+        B = self.batch_size
+        prep = {"metas": metas, "mirror": PyRandomMirror()}
+        if self.sample_gt:
+            gts = [numpy.asarray(m["bbox"], dtype=numpy.float64).reshape(-1, 4) for m in metas]
+            off = numpy.zeros(len(metas) + 1, dtype=numpy.int32)
+            numpy.cumsum([len(g) for g in gts], out=off[1:])
+            prep["off"] = off
+            prep["gt"] = numpy.ascontiguousarray(numpy.concatenate(gts, axis=0)) if off[-1] > 0 else numpy.zeros((1, 4))
+        else:
+            prep["off"], prep["gt"] = numpy.zeros(len(metas) + 1, dtype=numpy.int32), numpy.zeros((1, 4))
+        self._prep = prep
+
+    def edit_samples_native(self, det, cnt, metas, out_f32, defer_push=False):
         """edit_samples for the whole batch in one native host call (denet_host_edit_samples): same generator
         stream, same values. det [B,S,5] float32 rows (pr, box) of the detector, cnt [B]; out_f32 [B*S,4] float32
         receives the array build_bbox_array would produce. Returns (pr [B,S], boxes [B,S,4]) as float64."""
@@ -287,20 +310,24 @@ class DeNetSparseLayer(AbstractLayer):
         ws = numpy.empty(2 * S, dtype=numpy.int32)
         det = numpy.ascontiguousarray(det, dtype=numpy.float32)
         cnt = numpy.ascontiguousarray(cnt, dtype=numpy.int32)
-        gts = [numpy.asarray(m["bbox"], dtype=numpy.float64).reshape(-1, 4) for m in metas] if self.sample_gt else []
-        off = numpy.zeros(B + 1, dtype=numpy.int32)
-        if self.sample_gt:
-            numpy.cumsum([len(g) for g in gts], out=off[1:])
-        gt = numpy.ascontiguousarray(numpy.concatenate(gts, axis=0)) if off[-1] > 0 else numpy.zeros((1, 4))
+        prep = getattr(self, "_prep", None)
+        if prep is None or prep["metas"] is not metas:
+            self.begin_step(metas)
+            prep = self._prep
+        self._prep = None
+        off, gt = prep["off"], prep["gt"]
         out_pr = numpy.empty((B, S), dtype=numpy.float64)
         out_box = numpy.empty((B, S, 4), dtype=numpy.float64)
         assert out_f32.dtype == numpy.float32 and out_f32.size == B * S * 4 and out_f32.flags.c_contiguous
-        mirror = PyRandomMirror()
+        mirror = prep["mirror"] if prep["mirror"].fresh() else PyRandomMirror()
         _lib.check(_lib.load().denet_host_edit_samples(
             mirror.key.ctypes.data, mirror.pos.ctypes.data, det.ctypes.data, cnt.ctypes.data, B, S, n_keep,
             gt.ctypes.data, off.ctypes.data, int(bool(self.sample_gt)), ws.ctypes.data, out_pr.ctypes.data,
             out_box.ctypes.data, out_f32.ctypes.data), "edit_samples")
-        mirror.push()
+        if defer_push:
+            self._pending_push = mirror      # handed back to the stdlib generator once the gather is queued
+        else:
+            mirror.push()
         return out_pr, out_box
 
     def _edit_and_upload_native(self, metas):
@@ -313,7 +340,7 @@ class DeNetSparseLayer(AbstractLayer):
         else:
             det, cnt = numpy.zeros((B, S, 5), dtype=numpy.float32), numpy.zeros(B, dtype=numpy.int32)
         f32 = self._pinned.numpy()
-        out_pr, out_box = self.edit_samples_native(det, cnt, metas, f32)
+        out_pr, out_box = self.edit_samples_native(det, cnt, metas, f32, defer_push=True)
         self.sample_pr, self.sample_boxes = list(out_pr), list(out_box)
         self.sample_bbox = self._pinned.cuda(non_blocking=True)
         self.sample_bbox_f32 = f32.reshape(B, S, 4)
@@ -357,6 +384,9 @@ class DeNetSparseLayer(AbstractLayer):
         out, self._taps = ops.sparse_fwd(fmap, self.sample_bbox, coff, F, self.sample_count, self.grid_size,
                                          self.output.cp, self.tap_rule)
         self.output.data = out.view(self.batch_size, self.sample_num, self.sample_num, self.output.cp)
+        mirror = self.__dict__.pop("_pending_push", None)
+        if mirror is not None:
+            mirror.push()
 
     def backward(self, ctx):
         cl = self.corner_layer

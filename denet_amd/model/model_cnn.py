@@ -307,6 +307,9 @@ class ModelCNN:
             a.grad = None
         self._upload_input(data_x)
         ctx = StepContext(self)
+        if train and data_m is not None:
+            for layer in self.layers[1:]:
+                layer.begin_step(data_m)
         for layer in self.layers[1:]:
             if train and data_m is not None:
                 layer.prepare_target(ctx, self, data_x, data_m)
