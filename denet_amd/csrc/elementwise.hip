@@ -4,6 +4,7 @@
 //   the plain `A` relu layer (denet/layer/activation.py:31-34), conv-bias gradient (column sums),
 //   and the fused solver update (denet/model/model_cnn.py:282-294, 321-331).
 #include "common.h"
+#include <math.h>
 
 namespace {
 
@@ -143,6 +144,23 @@ __global__ __launch_bounds__(256) void solver_kernel(float* __restrict__ p, floa
     }
 }
 
+// adam (model_cnn.py:296-305): m' = b1*m + (1-b1)*g ; v' = b2*v + (1-b2)*g*g ; p' = p - lr*(m'*c1)/(sqrt(v'*c2) + 1e-8)
+// with c1 = 1/(1-b1^(it+1)), c2 = 1/(1-b2^(it+1)) evaluated on the host in double
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ g, long n, long n_decay, float lr, float b1,
+                                                   float b2, float c1, float c2, float decay, float gscale) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float pv = p[i];
+        float gv = g[i] * gscale;
+        if (i < n_decay) gv += decay * pv;
+        const float mv = b1 * m[i] + (1.0f - b1) * gv;
+        const float vv = b2 * v[i] + (1.0f - b2) * (gv * gv);
+        p[i] = pv - lr * (mv * c1) / (sqrtf(vv * c2) + 1e-8f);
+        m[i] = mv;
+        v[i] = vv;
+    }
+}
+
 __global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long n, float s) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= s;
 }
@@ -213,6 +231,19 @@ extern "C" int denet_solver_step(float* params, float* moments, const float* gra
     hipLaunchKernelGGL(solver_kernel, dim3(grid_for(n)), dim3(256), 0, stream, params, moments, grads, n, n_decay, lr,
                        momentum, rho, decay, grad_scale, mode);
     DENET_CHECK_LAUNCH("solver_step");
+    return DENET_OK;
+}
+
+extern "C" int denet_solver_adam(float* params, float* m, float* v, const float* grads, long n, long n_decay, float lr,
+                                 float beta1, float beta2, int iteration, float decay, float grad_scale,
+                                 hipStream_t stream) {
+    DENET_CHECK_ARG(params && m && v && grads && n > 0 && n_decay >= 0 && n_decay <= n, "solver_adam: bad args");
+    DENET_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && iteration >= 0, "solver_adam: bad betas");
+    const float c1 = (float)(1.0 / (1.0 - pow((double)beta1, (double)iteration + 1.0)));
+    const float c2 = (float)(1.0 / (1.0 - pow((double)beta2, (double)iteration + 1.0)));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, stream, params, m, v, grads, n, n_decay, lr, beta1,
+                       beta2, c1, c2, decay, grad_scale);
+    DENET_CHECK_LAUNCH("solver_adam");
     return DENET_OK;
 }
 

@@ -49,6 +49,7 @@ SIGNATURES = {
     "denet_colsum_workspace_bytes": (Z, [L, I]),
     "denet_colsum": (I, [P, P, P, L, I, P]),
     "denet_solver_step": (I, [P, P, P, L, L, F, F, I, F, F, I, P]),
+    "denet_solver_adam": (I, [P, P, P, P, L, L, F, F, F, I, F, F, P]),
     "denet_scale": (I, [P, L, F, P]),
     "denet_corner_fwd": (I, [P, P] + [I] * 5 + [P]),
     "denet_loss_workspace_bytes": (Z, []),

@@ -23,7 +23,7 @@ from ..common import json_util
 from ..layer import Act, InitialLayer, round_up
 from ..layer.layer_types import layer_types
 
-SOLVER_MODES = {"sgd": 0, "torch": 1, "nesterov": 1}
+SOLVER_MODES = {"sgd": 0, "torch": 1, "nesterov": 1, "adam": 2}
 
 
 def load_from_json(json_obj, batch_size=32, layer_range=None):
@@ -265,7 +265,7 @@ class ModelCNN:
 
     def build_train_func(self, solver_mode="sgd", cost_factors=[], use_acc_mode=False, skip_build=False):
         if solver_mode not in SOLVER_MODES:
-            raise NotImplementedError("solver '%s' is outside the hot path (sgd, torch, nesterov are provided)" % solver_mode)
+            raise NotImplementedError("unknown solver '%s' (sgd, torch, nesterov, adam)" % solver_mode)
         if use_acc_mode:
             raise NotImplementedError("--use-acc-mode is outside the hot path")
         self.solver_mode = solver_mode
@@ -343,8 +343,18 @@ class ModelCNN:
         self.backward(ctx)
         scale = 1.0 / self.dist.world_size if self.dist is not None else 1.0
         n_decay = self.n_trainable if self.bias_decay else self.n_weights
-        ops.solver_step(self.P[:self.n_trainable], self.M[:self.n_trainable], self.G[:self.n_trainable], n_decay,
-                        float(learn_rate), float(momentum[0]), it, float(decay), SOLVER_MODES[self.solver_mode], scale)
+        if self.solver_mode == "adam":
+            import torch
+            assert len(momentum) >= 2, "adam takes momentum = (beta1, beta2)"
+            if getattr(self, "V", None) is None:
+                self.V = torch.zeros_like(self.M)       # second-moment accumulators (model_cnn.py:299)
+            ops.solver_adam(self.P[:self.n_trainable], self.M[:self.n_trainable], self.V[:self.n_trainable],
+                            self.G[:self.n_trainable], n_decay, float(learn_rate), float(momentum[0]),
+                            float(momentum[1]), it, float(decay), scale)
+        else:
+            ops.solver_step(self.P[:self.n_trainable], self.M[:self.n_trainable], self.G[:self.n_trainable], n_decay,
+                            float(learn_rate), float(momentum[0]), it, float(decay), SOLVER_MODES[self.solver_mode],
+                            scale)
         if not fetch_cost:
             return None
         costs = self.cost_buf[:2 * len(self.cost_layers)].cpu().numpy().reshape(-1, 2)

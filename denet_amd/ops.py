@@ -296,6 +296,11 @@ def solver_step(params, moments, grads, n_decay, lr, momentum, iteration, decay,
                                  int(iteration), decay, grad_scale, int(mode), stream_ptr()), "solver_step")
 
 
+def solver_adam(params, m, v, grads, n_decay, lr, beta1, beta2, iteration, decay, grad_scale=1.0):
+    check(_L().denet_solver_adam(ptr(params), ptr(m), ptr(v), ptr(grads), params.numel(), int(n_decay), lr, beta1, beta2,
+                                 int(iteration), decay, grad_scale, stream_ptr()), "solver_adam")
+
+
 def corner_fwd(conv, cn):
     B, H, W, CP = conv.shape
     pr = empty(B, 2, cn, H, W)

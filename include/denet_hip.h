@@ -122,6 +122,10 @@ size_t denet_colsum_workspace_bytes(long M, int C);
 int denet_colsum(const float* x, float* out, void* workspace, long M, int C, hipStream_t stream);
 int denet_solver_step(float* params, float* moments, const float* grads, long n, long n_decay, float lr,
                       float momentum, int iteration, float decay, float grad_scale, int mode, hipStream_t stream);
+/* adam (denet/model/model_cnn.py:296-305): first / second moment buffers m, v; momentum = (beta1, beta2); the bias
+ * corrections 1/(1-beta^(iteration+1)) are evaluated on the host in double; eps = 1e-8                         */
+int denet_solver_adam(float* params, float* m, float* v, const float* grads, long n, long n_decay, float lr,
+                      float beta1, float beta2, int iteration, float decay, float grad_scale, hipStream_t stream);
 int denet_scale(float* x, long n, float s, hipStream_t stream);
 
 /* ---- DeNet corner map  (denet/layer/denet_corner.py:50-53 log_softmax([x,-x]); :126-134 cost)

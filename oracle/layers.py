@@ -483,6 +483,20 @@ def regression_cost(logits, classes, want_grad=True):
 # ---------------------------------------------------------------------------------------------------------
 # solver: denet/model/model_cnn.py:282-294, 321-331
 # ---------------------------------------------------------------------------------------------------------
+def adam_update(p, m, v, g, lr, betas, iteration, decay, is_weight):
+    """model_cnn.py:296-305 (+ L2 :323-324); bias corrections in double, the state in float32"""
+    p, m, v, g = p.astype(F32), m.astype(F32), v.astype(F32), g.astype(F32)
+    if is_weight:
+        g = g + F32(decay) * p
+    b1, b2 = F32(betas[0]), F32(betas[1])
+    m2 = b1 * m + (F32(1.0) - b1) * g
+    v2 = b2 * v + (F32(1.0) - b2) * (g * g)
+    c1 = F32(1.0 / (1.0 - float(b1) ** (iteration + 1)))
+    c2 = F32(1.0 / (1.0 - float(b2) ** (iteration + 1)))
+    p2 = p - F32(lr) * (m2 * c1) / (np.sqrt(v2 * c2) + F32(1e-8))
+    return p2.astype(F32), m2.astype(F32), v2.astype(F32)
+
+
 def solver_update(p, m, g, lr, momentum, iteration, decay, is_weight, mode="nesterov"):
     p, m, g = p.astype(F32), m.astype(F32), g.astype(F32)
     if is_weight:

@@ -403,7 +403,12 @@ class OracleModel:
         backprop(self.cost_roots)
         for p in self.params():
             g = p.g if p.g is not None else np.zeros_like(p.v)
-            p.v, p.m = L.solver_update(p.v, p.m, g.astype(F32), lr, momentum, iteration, decay, p.is_weight, solver)
+            if solver == "adam":
+                if getattr(p, "v2", None) is None:
+                    p.v2 = np.zeros_like(p.v)
+                p.v, p.m, p.v2 = L.adam_update(p.v, p.m, p.v2, g.astype(F32), lr, momentum, iteration, decay, p.is_weight)
+            else:
+                p.v, p.m = L.solver_update(p.v, p.m, g.astype(F32), lr, momentum, iteration, decay, p.is_weight, solver)
         for n in self.bn_nodes():
             if "new_stats" in n:
                 n["mean"], n["stdinv"] = n.pop("new_stats")
