@@ -393,27 +393,42 @@ extern "C" int denet_sparse_fwd(const float* fmap, const float* bbox, float* out
     return DENET_OK;
 }
 
-extern "C" int denet_sparse_bwd(const float* dy, const int* taps, unsigned* sorted_ws, float* dfmap, int B, int H,
-                                int W, int CP, int coff, int F, int rois_per_image, int gs, int KP, int zero_from,
-                                hipStream_t stream) {
-    DENET_CHECK_ARG(dy && taps && sorted_ws && dfmap, "sparse_bwd: null pointer");
-    const int ntap = gs * gs;
-    const int n = rois_per_image * ntap;
-    DENET_CHECK_ARG(H * W <= (1 << 17) - 1, "sparse_bwd: feature map too large for 17-bit cell keys");
-    DENET_CHECK_ARG(F % 4 == 0 && F / 4 <= 64 && coff % 4 == 0 && CP % 4 == 0 && KP % 4 == 0,
-                    "sparse_bwd: F/coff/CP/KP must be multiples of 4 and F <= 256");
-    DENET_CHECK_ARG(zero_from >= coff + F && zero_from <= CP, "sparse_bwd: zero_from out of range");
+// sorts the tap list of every image into runs (see sparse_sort_kernel); depends only on `taps`, so the host may queue
+// it on a side stream right after the forward gather, off the critical path of the backward sweep
+extern "C" int denet_sparse_sort(const int* taps, unsigned* sorted_ws, int B, int H, int W, int rois_per_image, int gs,
+                                 hipStream_t stream) {
+    DENET_CHECK_ARG(taps && sorted_ws && B > 0 && rois_per_image > 0 && gs > 0, "sparse_sort: bad arguments");
+    DENET_CHECK_ARG(H * W <= (1 << 17) - 1, "sparse_sort: feature map too large for 17-bit cell keys");
+    const int n = rois_per_image * gs * gs;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)sparse_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            32768 * 4);
         if (e != hipSuccess) {
-            denet_set_error("sparse_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            denet_set_error("sparse_sort: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return -(int)e;
         }
         attr_set = true;
     }
     hipLaunchKernelGGL(sparse_sort_kernel, dim3(B, (n + 32767) / 32768), dim3(1024), 32768 * 4, stream, taps, sorted_ws, n);
+    DENET_CHECK_LAUNCH("sparse_sort");
+    return DENET_OK;
+}
+
+// taps == NULL: `sorted_ws` already holds the runs written by denet_sparse_sort for the same tap list
+extern "C" int denet_sparse_bwd(const float* dy, const int* taps, unsigned* sorted_ws, float* dfmap, int B, int H,
+                                int W, int CP, int coff, int F, int rois_per_image, int gs, int KP, int zero_from,
+                                hipStream_t stream) {
+    DENET_CHECK_ARG(dy && sorted_ws && dfmap, "sparse_bwd: null pointer");
+    const int ntap = gs * gs;
+    DENET_CHECK_ARG(H * W <= (1 << 17) - 1, "sparse_bwd: feature map too large for 17-bit cell keys");
+    DENET_CHECK_ARG(F % 4 == 0 && F / 4 <= 64 && coff % 4 == 0 && CP % 4 == 0 && KP % 4 == 0,
+                    "sparse_bwd: F/coff/CP/KP must be multiples of 4 and F <= 256");
+    DENET_CHECK_ARG(zero_from >= coff + F && zero_from <= CP, "sparse_bwd: zero_from out of range");
+    if (taps) {
+        int rc = denet_sparse_sort(taps, sorted_ws, B, H, W, rois_per_image, gs, stream);
+        if (rc) return rc;
+    }
     const long ncell = (long)B * H * W;
     hipLaunchKernelGGL(sparse_bwd_kernel, dim3((unsigned)((ncell + 3) / 4)), dim3(256), 0, stream, dy, sorted_ws, dfmap,
                        H * W, CP, coff, F, rois_per_image, ntap, KP, zero_from, ncell);

@@ -384,6 +384,10 @@ class DeNetSparseLayer(AbstractLayer):
         out, self._taps = ops.sparse_fwd(fmap, self.sample_bbox, coff, F, self.sample_count, self.grid_size,
                                          self.output.cp, self.tap_rule)
         self.output.data = out.view(self.batch_size, self.sample_num, self.sample_num, self.output.cp)
+        self._sorted_ev = None
+        if get_train():
+            fm = fmap.shape
+            self._sorted_ev = ops.sparse_sort_async(self._taps, fm[0], fm[1], fm[2], self.sample_count, self.grid_size)
         mirror = self.__dict__.pop("_pending_push", None)
         if mirror is not None:
             mirror.push()
@@ -393,4 +397,4 @@ class DeNetSparseLayer(AbstractLayer):
         dconv = cl.alloc_dconv(zero=False)
         dy = self.output.grad.view(-1, self.output.cp)
         ops.sparse_bwd(dy, self._taps, dconv, cl.corner_num, cl.sample_feat, self.sample_count, self.grid_size,
-                       cl.corner_num + cl.sample_feat)
+                       cl.corner_num + cl.sample_feat, presorted=getattr(self, "_sorted_ev", None))

@@ -55,6 +55,7 @@ SIGNATURES = {
     "denet_loss_workspace_bytes": (Z, []),
     "denet_corner_loss": (I, [P] * 5 + [I] * 5 + [F, P]),
     "denet_sparse_fwd": (I, [P, P, P, P] + [I] * 10 + [P]),
+    "denet_sparse_sort": (I, [P, P] + [I] * 5 + [P]),
     "denet_sparse_bwd": (I, [P, P, P, P] + [I] * 10 + [P]),
     "denet_detect_loss": (I, [P] * 8 + [I] * 5 + [F, F, I, P]),
     "denet_detect_decode": (I, [P] * 5 + [I] * 5 + [F, P]),

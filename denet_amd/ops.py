@@ -329,12 +329,32 @@ def sparse_fwd(fmap, bbox, coff, F, rois_per_image, gs, kp, tap_rule=0):
     return out, taps
 
 
-def sparse_bwd(dy, taps, dfmap, coff, F, rois_per_image, gs, zero_from):
+_SORT_STREAM = None
+
+
+def sparse_sort_async(taps, B, H, W, rois_per_image, gs):
+    """queues the tap sort of the gather gradient on a side stream right after the forward gather (it needs only the
+    taps); returns the event sparse_bwd(presorted=...) waits for"""
+    global _SORT_STREAM
+    if _SORT_STREAM is None:
+        _SORT_STREAM = torch.cuda.Stream()
+    ws = WS.get("sparse_sort", B * rois_per_image * gs * gs * 4)
+    _SORT_STREAM.wait_stream(torch.cuda.current_stream())          # taps are written by sparse_fwd on this stream
+    with torch.cuda.stream(_SORT_STREAM):
+        check(_L().denet_sparse_sort(ptr(taps), ptr(ws), B, H, W, rois_per_image, gs, stream_ptr()), "sparse_sort")
+        ev = torch.cuda.Event()
+        ev.record(_SORT_STREAM)
+    return ev
+
+
+def sparse_bwd(dy, taps, dfmap, coff, F, rois_per_image, gs, zero_from, presorted=None):
     B, H, W, CP = dfmap.shape
     kp = dy.shape[-1]
     ws = WS.get("sparse_sort", B * rois_per_image * gs * gs * 4)
-    check(_L().denet_sparse_bwd(ptr(dy), ptr(taps), ptr(ws), ptr(dfmap), B, H, W, CP, coff, F, rois_per_image, gs, kp,
-                                zero_from, stream_ptr()), "sparse_bwd")
+    if presorted is not None:
+        torch.cuda.current_stream().wait_event(presorted)
+    check(_L().denet_sparse_bwd(ptr(dy), None if presorted is not None else ptr(taps), ptr(ws), ptr(dfmap), B, H, W, CP,
+                                coff, F, rois_per_image, gs, kp, zero_from, stream_ptr()), "sparse_bwd")
     return dfmap
 
 

@@ -144,6 +144,10 @@ int denet_corner_loss(const float* corner_pr, const float* target, float* dconv,
  *      sum (LDS bitonic sort of the taps per image) instead of the reference's atomicAdd scatter.         */
 int denet_sparse_fwd(const float* fmap, const float* bbox, float* out, int* taps, int B, int H, int W, int CP,
                      int coff, int F, int rois_per_image, int gs, int KP, int tap_rule, hipStream_t stream);
+/* denet_sparse_sort: the per-image sort of the tap list alone (it depends only on `taps`; a caller may queue it on a
+ * side stream during the forward pass); denet_sparse_bwd with taps == NULL then consumes the sorted runs.         */
+int denet_sparse_sort(const int* taps, unsigned* sorted_ws, int B, int H, int W, int rois_per_image, int gs,
+                      hipStream_t stream);
 int denet_sparse_bwd(const float* dy, const int* taps, unsigned* sorted_ws, float* dfmap, int B, int H, int W, int CP,
                      int coff, int F, int rois_per_image, int gs, int KP, int zero_from, hipStream_t stream);
 
