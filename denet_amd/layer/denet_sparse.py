@@ -9,6 +9,7 @@ backbone is not run a second time (the reference compiles a separate `corner_fun
 float64 arrays (the values of the reference's Python floats); `sample_bbox_list` materialises the reference's
 list-of-tuples view on demand."""
 import math
+import os
 import random
 
 import numpy
@@ -385,7 +386,7 @@ class DeNetSparseLayer(AbstractLayer):
                                          self.output.cp, self.tap_rule)
         self.output.data = out.view(self.batch_size, self.sample_num, self.sample_num, self.output.cp)
         self._sorted_ev = None
-        if get_train():
+        if get_train() and os.environ.get("DENET_SIDE_SORT", "1") == "1":
             fm = fmap.shape
             self._sorted_ev = ops.sparse_sort_async(self._taps, fm[0], fm[1], fm[2], self.sample_count, self.grid_size)
         mirror = self.__dict__.pop("_pending_push", None)
