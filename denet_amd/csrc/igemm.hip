@@ -17,6 +17,7 @@
 //                 reduction order is a fixed permutation of k (legal: the sum is over the same terms).
 // Launch:         1-D grid over tiles with an XCD-aware remap (8 XCDs, private L2 each).
 #include "common.h"
+#include <map>
 #include <vector>
 #include <type_traits>
 #include <stdlib.h>
@@ -729,9 +730,51 @@ struct Choice {
 // rounds, and a half-size tile pays off only when the full tile cannot fill the chip once.
 // `want_nbuf`: the loop structure measured fastest for the mode / reduction length (see the callers); the tile shape
 // is then chosen for that structure's occupancy.
+// ---- measured launch configurations (denet_conv_tune) ---------------------------------------------------
+// key: mode + geometry; value: tile index, loop structure (NBUF) and, for wgrad, the round count that fixes the split
+struct TuneKey {
+    int v[11];
+    bool operator<(const TuneKey& o) const {
+        for (int i = 0; i < 11; ++i)
+            if (v[i] != o.v[i]) return v[i] < o.v[i];
+        return false;
+    }
+};
+struct TuneVal {
+    int tile, nbuf, rounds;
+};
+std::map<TuneKey, TuneVal> g_tuned;
+thread_local TuneVal t_try = {-1, 0, 0};     // candidate being timed by denet_conv_tune (tile < 0: none)
+
+TuneKey tune_key(int mode, int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad) {
+    return TuneKey{{mode, N, H, W, C, K, R, S, S_real, stride, pad}};
+}
+
+// the configuration to use: the candidate under test, else a measured entry, else nothing (heuristics apply)
+bool tuned_choice(const TuneKey& k, TuneVal* out) {
+    if (t_try.tile >= 0) {
+        *out = t_try;
+        return true;
+    }
+    auto it = g_tuned.find(k);
+    if (it == g_tuned.end()) return false;
+    *out = it->second;
+    return true;
+}
+
+int forced_tile() {      // DENET_IGEMM_TILE: 1 = first candidate (128x128), 2 = second (128x64); tuning aid
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("DENET_IGEMM_TILE");
+        forced = e ? atoi(e) : 0;
+    }
+    return forced;
+}
+
 Choice choose_launch(const long* nblocks, const double* area, const double* eff, int ntiles, int want_nbuf) {
     Choice best = {1e300, 0, 2};
     for (int t = 0; t < ntiles; ++t) {
+        if (forced_tile() && ntiles > 1 && forced_tile() - 1 != t) continue;
         for (int nbuf = 1; nbuf <= 3; ++nbuf) {
             if ((forced_nbuf() ? forced_nbuf() : want_nbuf) != nbuf) continue;
             const long cap = (nbuf == 1) ? (area[t] <= 128.0 * 64.0 ? 4 : 3) : (nbuf == 2 ? 2 : 1);
@@ -804,6 +847,89 @@ extern "C" int denet_conv_profile_read(int i, float* ms, int* mode, int* bm, int
     return DENET_OK;
 }
 
+extern "C" int denet_conv_fwd(const float* x, const float* w, const float* bias, const float* add, float* y, int N,
+                              int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH,
+                              int OW, hipStream_t stream);
+extern "C" int denet_conv_dgrad(const float* dy, const float* w, const float* add, float* dx, int N, int H, int W,
+                                int C, int K, int R, int S, int S_real, int stride, int pad, int OH, int OW,
+                                hipStream_t stream);
+extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes,
+                                int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad,
+                                int OH, int OW, hipStream_t stream);
+
+// Times the candidate launch configurations of one convolution pass on the caller's own buffers and remembers the
+// fastest for this geometry (every candidate computes the same result, so `out` is valid afterwards). mode 0 = fwd
+// (a = x, b = w, bias/add as in denet_conv_fwd), 1 = dgrad (a = dy, b = w, add), 2 = wgrad (a = x, b = dy, out = dw,
+// workspace). The ONLY entry point that synchronises the stream. fwd/dgrad candidates accumulate in the same order
+// (bit-identical results); wgrad candidates differ in the split-K grouping, the choice is fixed for the process.
+extern "C" int denet_conv_tune(int mode, const float* a, const float* b, const float* bias, const float* add, float* out,
+                               float* workspace, size_t workspace_bytes, int N, int H, int W, int C, int K, int R, int S,
+                               int S_real, int stride, int pad, int OH, int OW, hipStream_t stream) {
+    DENET_CHECK_ARG(mode >= 0 && mode <= 2, "conv_tune: mode must be 0, 1 or 2");
+    const TuneKey key = tune_key(mode, N, H, W, C, K, R, S, S_real, stride, pad);
+    auto run = [&]() -> int {
+        if (mode == MODE_FWD) return denet_conv_fwd(a, b, bias, add, out, N, H, W, C, K, R, S, S_real, stride, pad, OH, OW, stream);
+        if (mode == MODE_DGRAD) return denet_conv_dgrad(a, b, add, out, N, H, W, C, K, R, S, S_real, stride, pad, OH, OW, stream);
+        return denet_conv_wgrad(a, b, out, workspace, workspace_bytes, N, H, W, C, K, R, S, S_real, stride, pad, OH, OW, stream);
+    };
+    std::vector<TuneVal> cand;
+    if (mode == MODE_WGRAD) {
+        for (int r = 1; r <= 6; ++r) cand.push_back(TuneVal{0, 1, r});
+        for (int r = 1; r <= 3; ++r) cand.push_back(TuneVal{0, 2, r});
+    } else {
+        const int ndim = (mode == MODE_FWD) ? K : C;
+        for (int t = (ndim >= 128 ? 0 : 1); t < 2; ++t)
+            for (int nbuf = 1; nbuf <= 2; ++nbuf) cand.push_back(TuneVal{t, nbuf, 0});
+    }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        denet_set_error("conv_tune: hipEventCreate failed");
+        return DENET_ERR_ARG;
+    }
+    const bool prof_was_on = g_prof_on;
+    g_prof_on = false;
+    float best_ms = 1e30f;
+    TuneVal best = cand[0];
+    int rc = DENET_OK;
+    for (const TuneVal& c : cand) {
+        t_try = c;
+        rc = run();                                  // warm-up (also sets the LDS attribute of the instantiation)
+        if (rc) break;
+        float ms_min = 1e30f;
+        for (int rep = 0; rep < 3 && !rc; ++rep) {
+            (void)hipEventRecord(e0, stream);
+            rc = run();
+            (void)hipEventRecord(e1, stream);
+            if (hipEventSynchronize(e1) != hipSuccess) rc = DENET_ERR_ARG;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (ms < ms_min) ms_min = ms;
+        }
+        if (rc) break;
+        if (ms_min < best_ms) {
+            best_ms = ms_min;
+            best = c;
+        }
+    }
+    t_try = TuneVal{-1, 0, 0};
+    g_prof_on = prof_was_on;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    g_tuned[key] = best;
+    return run();                                    // leave the result of the chosen configuration in `out`
+}
+
+extern "C" int denet_conv_tuned(int mode, int N, int H, int W, int C, int K, int R, int S, int S_real, int stride,
+                                int pad, int* tile, int* nbuf, int* rounds) {
+    auto it = g_tuned.find(tune_key(mode, N, H, W, C, K, R, S, S_real, stride, pad));
+    if (it == g_tuned.end()) return 1;
+    if (tile) *tile = it->second.tile;
+    if (nbuf) *nbuf = it->second.nbuf;
+    if (rounds) *rounds = it->second.rounds;
+    return DENET_OK;
+}
+
 extern "C" int denet_conv_last_config(int* mode, int* bm, int* bn, int* nbuf, int* grid_y) {
     if (mode) *mode = g_last_cfg[0];
     if (bm) *bm = g_last_cfg[1];
@@ -835,8 +961,13 @@ extern "C" int denet_conv_fwd(const float* x, const float* w, const float* bias,
         // chunks (+4...14 %); shorter reductions (stem, 64-channel 3x3, 1x1 on 128 channels) amortise its longer
         // prologue badly and run faster on the single-buffer loop at 3-4 workgroups per CU
         const int want = (p.ksteps >= 24) ? 2 : 1;
-        const Choice c = (K >= 128) ? choose_launch(nb, area, eff, 2, want) : choose_launch(nb + 1, area + 1, eff + 1, 1, want);
-        const int tile = (K >= 128) ? c.tile : 1;
+        Choice c = (K >= 128) ? choose_launch(nb, area, eff, 2, want) : choose_launch(nb + 1, area + 1, eff + 1, 1, want);
+        int tile = (K >= 128) ? c.tile : 1;
+        TuneVal tv;
+        if (tuned_choice(tune_key(MODE_FWD, N, H, W, C, K, R, S, S_real, stride, pad), &tv)) {
+            tile = (K >= 128) ? tv.tile : 1;
+            c.nbuf = tv.nbuf;
+        }
         p.tiles_m = (int)tm;
         if (tile == 0) {
             p.tiles_n = ceil_div(K, 128);
@@ -871,8 +1002,13 @@ extern "C" int denet_conv_dgrad(const float* dy, const float* w, const float* ad
         const double area[2] = {128.0 * 128.0, 128.0 * 64.0}, eff[2] = {1.0, 0.85};
         // dgrad / wgrad read K-outer LDS tiles (4x the fragment-read instructions): the single-buffer loop at 3-4
         // workgroups per CU measured faster than the pipelined one on every DeNet-34 layer but two (within 3 %)
-        const Choice c = (C >= 128) ? choose_launch(nb, area, eff, 2, 1) : choose_launch(nb + 1, area + 1, eff + 1, 1, 1);
-        const int tile = (C >= 128) ? c.tile : 1;
+        Choice c = (C >= 128) ? choose_launch(nb, area, eff, 2, 1) : choose_launch(nb + 1, area + 1, eff + 1, 1, 1);
+        int tile = (C >= 128) ? c.tile : 1;
+        TuneVal tv;
+        if (tuned_choice(tune_key(MODE_DGRAD, N, H, W, C, K, R, S, S_real, stride, pad), &tv)) {
+            tile = (C >= 128) ? tv.tile : 1;
+            c.nbuf = tv.nbuf;
+        }
         p.tiles_m = (int)tm;
         if (tile == 0) {
             p.tiles_n = ceil_div(C, 128);
@@ -930,10 +1066,13 @@ extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, floa
     {
         const double chunk_us2 = (big_m ? 4.2 : 2.4), chunk_us3 = chunk_us2 * 1.5 / 1.12;
         double best = 1e300;
+        TuneVal tv = {0, 0, 0};
+        const bool have_tv = tuned_choice(tune_key(MODE_WGRAD, N, H, W, C, K, R, S, S_real, stride, pad), &tv);
         for (int nbuf = 1; nbuf <= 3; ++nbuf) {
-            if ((forced_nbuf() ? forced_nbuf() : 1) != nbuf) continue;
+            if ((have_tv ? tv.nbuf : (forced_nbuf() ? forced_nbuf() : 1)) != nbuf) continue;
             const int slots = 256 * (nbuf == 1 ? 3 : (nbuf == 2 ? 2 : 1));
             for (int r = 1; r <= 6; ++r) {
+                if (have_tv && tv.rounds != r) continue;
                 int sp = forced_blocks ? ceil_div(forced_blocks, tiles) : (r * slots) / tiles;
                 if (sp < 1) sp = 1;
                 if (sp > p.ksteps / 4) sp = p.ksteps / 4 > 0 ? p.ksteps / 4 : 1;

@@ -3,6 +3,8 @@
 Tensors are NHWC fp32, contiguous, on the current HIP device. No torch arithmetic happens here; every
 function enqueues hand-written HIP kernels on the current torch stream and returns.
 """
+import os
+
 import torch
 
 from . import lib as _lib
@@ -130,10 +132,28 @@ def conv_geom(x_shape, w_shape, stride, pad, s_real=None):
     return N, H, W, C, K, R, S, s_real, stride, pad, OH, OW
 
 
+# launch configurations are measured once per (pass, geometry) on the first call (denet_conv_tune); DENET_AUTOTUNE=0
+# keeps the built-in heuristics
+AUTOTUNE = os.environ.get("DENET_AUTOTUNE", "1") != "0"
+_TUNED = set()
+
+
+def _tune_first(mode, g, a, b, bias, add, out, ws):
+    """True if this call was served by the tuner (which leaves the pass's result in `out`)"""
+    if not AUTOTUNE or PROFILE is not None or (mode, g) in _TUNED:
+        return False
+    _TUNED.add((mode, g))
+    check(_L().denet_conv_tune(mode, ptr(a), ptr(b), ptr(bias), ptr(add), ptr(out), ptr(ws), ws.numel() if ws is not None
+                               else 0, *g, stream_ptr()), "conv_tune")
+    return True
+
+
 def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, logical=None):
     g = conv_geom(x.shape, w.shape, stride, pad, s_real)
     N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
     y = out if out is not None else empty(N, OH, OW, K)
+    if _tune_first(0, g, x, w, bias, add, y, None):
+        return y
     if PROFILE is not None:
         PROFILE.add(_conv_flops(g, logical))
     check(_L().denet_conv_fwd(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), *g, stream_ptr()), "conv_fwd")
@@ -144,6 +164,8 @@ def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None,
     g = conv_geom(x_shape, w.shape, stride, pad, s_real)
     assert tuple(dy.shape) == (g[0], g[10], g[11], g[4]), (dy.shape, g)
     dx = out if out is not None else empty(*x_shape)
+    if _tune_first(1, g, dy, w, None, add, dx, None):
+        return dx
     if PROFILE is not None:
         PROFILE.add(_conv_flops(g, logical))
     check(_L().denet_conv_dgrad(ptr(dy), ptr(w), ptr(add), ptr(dx), *g, stream_ptr()), "conv_dgrad")
@@ -155,6 +177,8 @@ def conv_wgrad(x, dy, w_shape, stride=1, pad=0, s_real=None, out=None, logical=N
     assert tuple(dy.shape) == (g[0], g[10], g[11], g[4]), (dy.shape, g)
     dw = out if out is not None else empty(*w_shape)
     ws = WS.get("wgrad", WGRAD_WS_BYTES)
+    if _tune_first(2, g, x, dy, None, None, dw, ws):
+        return dw
     if PROFILE is not None:
         PROFILE.add(_conv_flops(g, logical))
     check(_L().denet_conv_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel(), *g, stream_ptr()), "conv_wgrad")

@@ -68,6 +68,15 @@ int denet_conv_dgrad(const float* dy, const float* w, const float* add, float* d
 size_t denet_conv_wgrad_workspace_bytes(int N, int C, int K, int R, int S, int OH, int OW);
 /* kernel instantiation picked by this thread's last conv launch: mode 0 fwd / 1 dgrad / 2 wgrad, tile BMxBN, LDS
  * buffers, grid.y (wgrad split slices / dgrad stride classes) — profiling bookkeeping only                      */
+/* measured launch configuration: times the candidate tile shapes / loop structures (wgrad: split-K round counts) of one
+ * convolution pass on the caller's own buffers, remembers the fastest for this geometry and leaves the pass's result in
+ * `out`. mode 0 = fwd (a = x, b = w), 1 = dgrad (a = dy, b = w), 2 = wgrad (a = x, b = dy, out = dw). This is the ONE
+ * entry point that synchronises `stream`. denet_conv_tuned reports the remembered choice (returns 1 if none).    */
+int denet_conv_tune(int mode, const float* a, const float* b, const float* bias, const float* add, float* out,
+                    float* workspace, size_t workspace_bytes, int N, int H, int W, int C, int K, int R, int S, int S_real,
+                    int stride, int pad, int OH, int OW, hipStream_t stream);
+int denet_conv_tuned(int mode, int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad,
+                     int* tile, int* nbuf, int* rounds);
 int denet_conv_last_config(int* mode, int* bm, int* bn, int* nbuf, int* grid_y);
 /* live timing of the igemm kernel alone (bench.py roofline leg): denet_conv_profile(1) starts recording one HIP event
  * pair per convolution launch on the launch stream, (0) stops and frees; _read returns the duration of launch i and the

@@ -49,6 +49,14 @@ for name, H, W, C, K, R, st, pad, cnt in SHAPES:
         t_d = 0.0
     print("%-10s fwd %7.3f ms %6.1f TF | dgrad %7.3f ms %6.1f TF | wgrad %7.3f ms %6.1f TF  (x%d)" % (
         name, t_f, flop / t_f / 1e9, t_d, (flop / t_d / 1e9 if t_d else 0), t_w, flop / t_w / 1e9, cnt), flush=True)
+    if ops.AUTOTUNE:
+        import ctypes
+        cfg = []
+        for mode in (0, 1, 2):
+            v = [ctypes.c_int(-1) for _ in range(3)]
+            ops._L().denet_conv_tuned(mode, B, H, W, C, K, R, S, R, st, pad, *[ctypes.byref(a) for a in v])
+            cfg.append("%s/n%d/r%d" % ({0: "128x128", 1: "128x64", -1: "-"}[v[0].value], v[1].value, v[2].value))
+        print("           tuned: fwd %s | dgrad %s | wgrad %s" % tuple(cfg), flush=True)
     tot["fwd"] += t_f * cnt; tot["dgrad"] += t_d * cnt; tot["wgrad"] += t_w * cnt
     totflop += flop * cnt
 print("total ms:", tot, "sum %.1f ms" % sum(tot.values()), " fwd GFLOP %.1f" % (totflop / 1e9))
