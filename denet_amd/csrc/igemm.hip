@@ -50,6 +50,7 @@ struct IgemmParams {
     FastDiv div_row_w;  // fwd/wgrad: OW       dgrad: Wc
     int Hc, Wc;         // dgrad: H/stride, W/stride
     int wg_split_slow;  // wgrad: 1 = split slice is the slow (XCD-local) index of the linear workgroup id
+    long batch_act, batch_wgt, batch_out;  // fwd: element strides of blockIdx.y (batched GEMM of the Winograd path), else 0
     unsigned act_bytes, wgt_bytes;  // extents of `act` / `wgt` (buffer descriptors: out-of-range lanes read 0)
 };
 
@@ -226,8 +227,12 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
     const bool wg_rowok = (MODE == MODE_WGRAD) ? (m0 + 4 * qa < p.K) : true;
 
     f32x4 ra[PA], rb[PB];
-    const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc((void*)p.act, 0, p.act_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, p.wgt_bytes, 0x00020000);
+    // fwd: blockIdx.y selects one GEMM of a batch (same shapes, strided operands); the descriptors cover one member
+    const long by = (MODE == MODE_FWD) ? (long)blockIdx.y : 0;
+    const __amdgpu_buffer_rsrc_t r_act =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.act + by * p.batch_act), 0, p.act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_wgt =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.wgt + by * p.batch_wgt), 0, p.wgt_bytes, 0x00020000);
 
     // ---- chunk loader, split so that the pipelined main loop can slot single passes behind MFMAs ----------
     // prep(kc): wave-uniform offsets of reduction chunk `kc` (fwd/dgrad walk the cursor, wgrad is absolute);
@@ -598,6 +603,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
     // ---------------- epilogue ----------------
     float* out = p.out;
     if (MODE == MODE_WGRAD) out += (long)split_id * p.split_stride;
+    if (MODE == MODE_FWD) out += by * p.batch_out;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -856,6 +862,32 @@ extern "C" int denet_conv_dgrad(const float* dy, const float* w, const float* ad
 extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes,
                                 int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad,
                                 int OH, int OW, hipStream_t stream);
+
+// Batch of `batch` independent GEMMs out_b[M,Nc] = a_b[M,Kc] * w_b[Nc,Kc]^T (all row-major, K contiguous) through the
+// forward kernel: the component products of the Winograd path (winograd.hip). Strides in elements.
+int denet_gemm_batched_nt(const float* a, const float* w, float* out, int batch, int M, int Nc, int Kc, long stride_a,
+                          long stride_w, long stride_out, hipStream_t stream) {
+    DENET_CHECK_ARG(a && w && out && batch > 0 && batch <= 65535 && M > 0, "gemm_batched: bad arguments");
+    DENET_CHECK_ARG(Nc % 32 == 0 && Kc % 32 == 0, "gemm_batched: Nc, Kc must be multiples of 32");
+    DENET_CHECK_ARG((long)M * Kc * 4 < 0xF0000000L && (long)Nc * Kc * 4 < 0xF0000000L, "gemm_batched: operand too large");
+    IgemmParams p = {};
+    p.act = a; p.wgt = w; p.out = out;
+    p.N = 1; p.H = 1; p.W = M; p.C = Kc; p.OH = 1; p.OW = M; p.K = Nc;
+    p.R = 1; p.S = 1; p.S_real = 1; p.stride = 1; p.sshift = 0; p.pad = 0;
+    p.act_bytes = (unsigned)((size_t)M * Kc * 4); p.wgt_bytes = (unsigned)((size_t)Nc * Kc * 4);
+    p.batch_act = stride_a; p.batch_wgt = stride_w; p.batch_out = stride_out;
+    p.M = M; p.NC = Nc; p.ksteps = Kc / BK; p.steps_per_split = p.ksteps; p.npix = M;
+    p.div_row_hw.init(M); p.div_row_w.init(M);
+    p.tiles_m = ceil_div(M, 128);
+    // short reductions (<= 16 chunks): the single-buffer loop at 3-4 workgroups per CU; 128x64 when N is small
+    const int nbuf = (p.ksteps >= 24) ? 2 : 1;
+    if (Nc >= 128 && (long)p.tiles_m * ceil_div(Nc, 128) * batch >= 1024) {
+        p.tiles_n = ceil_div(Nc, 128);
+        return LAUNCH_NBUF(MODE_FWD, 128, 128, nbuf, p, batch, stream);
+    }
+    p.tiles_n = ceil_div(Nc, 64);
+    return LAUNCH_NBUF(MODE_FWD, 128, 64, nbuf, p, batch, stream);
+}
 
 // Times the candidate launch configurations of one convolution pass on the caller's own buffers and remembers the
 // fastest for this geometry (every candidate computes the same result, so `out` is valid afterwards). mode 0 = fwd

@@ -152,23 +152,103 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
     g = conv_geom(x.shape, w.shape, stride, pad, s_real)
     N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
     y = out if out is not None else empty(N, OH, OW, K)
-    if _tune_first(0, g, x, w, bias, add, y, None):
+    tuned_now = _tune_first(0, g, x, w, bias, add, y, None)     # leaves the direct kernel's result in y
+
+    def direct():
+        check(_L().denet_conv_fwd(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), *g, stream_ptr()), "conv_fwd")
+
+    # the implementation is fixed on the first call and that call already returns ITS result (run-to-run determinism)
+    if _use_wino(0, g, direct, lambda: conv_wino_fwd(x, w, bias, add, out=y)):
+        if PROFILE is not None:
+            PROFILE.add(_conv_flops(g, logical) / 2.25)     # the FLOPs its batched GEMM really executes
+        return conv_wino_fwd(x, w, bias, add, out=y)
+    if tuned_now:
         return y
     if PROFILE is not None:
         PROFILE.add(_conv_flops(g, logical))
-    check(_L().denet_conv_fwd(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), *g, stream_ptr()), "conv_fwd")
+    direct()
     return y
+
+
+# Winograd F(2x2,3x3) is an alternative implementation of the eligible 3x3 layers; which one runs is measured once per
+# (pass, geometry) right after the direct kernel has been tuned. DENET_WINOGRAD=0 disables the path.
+WINOGRAD = os.environ.get("DENET_WINOGRAD", "1") != "0"
+_WINO = {}
+
+
+def _time_ms(fn, reps=3):
+    fn()
+    best = 1e30
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        e.synchronize()
+        best = min(best, s.elapsed_time(e))
+    return best
+
+
+def _use_wino(mode, g, direct, wino):
+    """decides (once) between the direct and the Winograd implementation of this pass by timing both"""
+    key = (mode, g)
+    use = _WINO.get(key)
+    if use is None:
+        if not (WINOGRAD and AUTOTUNE and conv_wino_ok(g)):
+            use = False
+        elif PROFILE is not None:
+            return False                 # undecided while a profile is being recorded: direct kernel, decide later
+        else:
+            use = _time_ms(wino) < 0.97 * _time_ms(direct)
+        _WINO[key] = use
+    return use
+
+
+def conv_wino_ok(g):
+    """geometry the Winograd F(2x2,3x3) path covers: 3x3, stride 1, pad 1, even H/W, channels multiple of 32"""
+    N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
+    return R == 3 and S == 3 and s_real == 3 and stride == 1 and pad == 1 and H % 2 == 0 and W % 2 == 0 \
+        and C % 32 == 0 and K % 32 == 0
+
+
+def conv_wino_fwd(x, w, bias=None, add=None, out=None):
+    N, H, W, C = x.shape
+    K = w.shape[0]
+    y = out if out is not None else empty(N, H, W, K)
+    ws = WS.get("wino", _L().denet_conv_wino_workspace_bytes(N, H, W, C, K))
+    check(_L().denet_conv_wino_fwd(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), ptr(ws), ws.numel(), N, H, W, C, K,
+                                   stream_ptr()), "conv_wino_fwd")
+    return y
+
+
+def conv_wino_dgrad(dy, w, add=None, out=None):
+    N, H, W, K = dy.shape
+    C = w.shape[3]
+    dx = out if out is not None else empty(N, H, W, C)
+    ws = WS.get("wino", _L().denet_conv_wino_workspace_bytes(N, H, W, C, K))
+    check(_L().denet_conv_wino_dgrad(ptr(dy), ptr(w), ptr(add), ptr(dx), ptr(ws), ws.numel(), N, H, W, C, K,
+                                     stream_ptr()), "conv_wino_dgrad")
+    return dx
 
 
 def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None, logical=None):
     g = conv_geom(x_shape, w.shape, stride, pad, s_real)
     assert tuple(dy.shape) == (g[0], g[10], g[11], g[4]), (dy.shape, g)
     dx = out if out is not None else empty(*x_shape)
-    if _tune_first(1, g, dy, w, None, add, dx, None):
+    tuned_now = _tune_first(1, g, dy, w, None, add, dx, None)
+
+    def direct():
+        check(_L().denet_conv_dgrad(ptr(dy), ptr(w), ptr(add), ptr(dx), *g, stream_ptr()), "conv_dgrad")
+
+    if _use_wino(1, g, direct, lambda: conv_wino_dgrad(dy, w, add, out=dx)):
+        if PROFILE is not None:
+            PROFILE.add(_conv_flops(g, logical) / 2.25)
+        return conv_wino_dgrad(dy, w, add, out=dx)
+    if tuned_now:
         return dx
     if PROFILE is not None:
         PROFILE.add(_conv_flops(g, logical))
-    check(_L().denet_conv_dgrad(ptr(dy), ptr(w), ptr(add), ptr(dx), *g, stream_ptr()), "conv_dgrad")
+    direct()
     return dx
 
 

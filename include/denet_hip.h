@@ -68,6 +68,14 @@ int denet_conv_dgrad(const float* dy, const float* w, const float* add, float* d
 size_t denet_conv_wgrad_workspace_bytes(int N, int C, int K, int R, int S, int OH, int OW);
 /* kernel instantiation picked by this thread's last conv launch: mode 0 fwd / 1 dgrad / 2 wgrad, tile BMxBN, LDS
  * buffers, grid.y (wgrad split slices / dgrad stride classes) — profiling bookkeeping only                      */
+/* Winograd F(2x2,3x3) path of the same stride-1 pad-1 3x3 convolution (forward / data gradient): 2.25x fewer
+ * multiplications, three extra HBM-bound transforms; pays for many channels. H, W even; C, K multiples of 32.
+ * workspace: denet_conv_wino_workspace_bytes (transformed filters, input tiles and products).                  */
+size_t denet_conv_wino_workspace_bytes(int N, int H, int W, int C, int K);
+int denet_conv_wino_fwd(const float* x, const float* w, const float* bias, const float* add, float* y, float* workspace,
+                        size_t workspace_bytes, int N, int H, int W, int C, int K, hipStream_t stream);
+int denet_conv_wino_dgrad(const float* dy, const float* w, const float* add, float* dx, float* workspace,
+                          size_t workspace_bytes, int N, int H, int W, int C, int K, hipStream_t stream);
 /* measured launch configuration: times the candidate tile shapes / loop structures (wgrad: split-K round counts) of one
  * convolution pass on the caller's own buffers, remembers the fastest for this geometry and leaves the pass's result in
  * `out`. mode 0 = fwd (a = x, b = w), 1 = dgrad (a = dy, b = w), 2 = wgrad (a = x, b = dy, out = dw). This is the ONE

@@ -401,3 +401,33 @@ def test_detect_loss(hip, bounded):
     ops.detect_loss(logits.detach(), t, valid, bt, roi, dl, costs, B, ncls, 4, cost_factor, bbox_factor, bounded)
     _close(costs, torch.stack([c_det, c_bbox]).detach(), rtol=1e-4)
     _close(dl, logits.grad, rtol=2e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 32, 64), (3, 16, 12, 64, 32), (2, 32, 32, 256, 128)])
+def test_conv_winograd_vs_direct(hip, shape):
+    """Winograd F(2x2,3x3) forward / data gradient of the 3x3 stride-1 pad-1 convolution against the direct
+    implicit-GEMM kernels (same sums, different rounding: 1e-5 relative) incl. bias and residual add epilogues"""
+    from denet_amd import ops
+    N, H, W, C, K = shape
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(N, H, W, C, device="cuda", generator=g)
+    w = torch.randn(K, 3, 3, C, device="cuda", generator=g) * 0.1
+    bias = torch.randn(K, device="cuda", generator=g)
+    add = torch.randn(N, H, W, K, device="cuda", generator=g)
+    dy = torch.randn(N, H, W, K, device="cuda", generator=g)
+    addx = torch.randn(N, H, W, C, device="cuda", generator=g)
+    old = ops.AUTOTUNE
+    ops.AUTOTUNE = False
+    try:
+        ref = ops.conv_fwd(x, w, bias=bias, add=add, stride=1, pad=1)
+        got = ops.conv_wino_fwd(x, w, bias=bias, add=add)
+        scale = float(ref.abs().max())
+        assert float((ref - got).abs().max()) <= 2e-5 * scale
+        ref2 = ops.conv_fwd(x, w, stride=1, pad=1)
+        got2 = ops.conv_wino_fwd(x, w)
+        assert float((ref2 - got2).abs().max()) <= 2e-5 * float(ref2.abs().max())
+        rd = ops.conv_dgrad(dy, w, tuple(x.shape), add=addx, stride=1, pad=1)
+        gd = ops.conv_wino_dgrad(dy, w, add=addx)
+        assert float((rd - gd).abs().max()) <= 2e-5 * float(rd.abs().max())
+    finally:
+        ops.AUTOTUNE = old
