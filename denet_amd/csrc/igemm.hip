@@ -879,14 +879,63 @@ int denet_gemm_batched_nt(const float* a, const float* w, float* out, int batch,
     p.M = M; p.NC = Nc; p.ksteps = Kc / BK; p.steps_per_split = p.ksteps; p.npix = M;
     p.div_row_hw.init(M); p.div_row_w.init(M);
     p.tiles_m = ceil_div(M, 128);
-    // short reductions (<= 16 chunks): the single-buffer loop at 3-4 workgroups per CU; 128x64 when N is small
-    const int nbuf = (p.ksteps >= 24) ? 2 : 1;
-    if (Nc >= 128 && (long)p.tiles_m * ceil_div(Nc, 128) * batch >= 1024) {
+    // measured choice (denet_gemm_batched_tune) or: single-buffer loop for short reductions, 128x64 when N is small
+    int nbuf = (p.ksteps >= 24) ? 2 : 1;
+    bool big = Nc >= 128 && (long)p.tiles_m * ceil_div(Nc, 128) * batch >= 1024;
+    TuneVal tv;
+    if (tuned_choice(tune_key(3, batch, 1, M, Kc, Nc, 1, 1, 1, 1, 0), &tv)) {
+        nbuf = tv.nbuf;
+        big = (tv.tile == 0) && Nc >= 128;
+    }
+    if (big) {
         p.tiles_n = ceil_div(Nc, 128);
         return LAUNCH_NBUF(MODE_FWD, 128, 128, nbuf, p, batch, stream);
     }
     p.tiles_n = ceil_div(Nc, 64);
     return LAUNCH_NBUF(MODE_FWD, 128, 64, nbuf, p, batch, stream);
+}
+
+// measures the launch configuration of the batched GEMM for these sizes (synchronises the stream)
+int denet_gemm_batched_tune(const float* a, const float* w, float* out, int batch, int M, int Nc, int Kc, long stride_a,
+                            long stride_w, long stride_out, hipStream_t stream) {
+    const TuneKey key = tune_key(3, batch, 1, M, Kc, Nc, 1, 1, 1, 1, 0);
+    if (g_tuned.count(key)) return DENET_OK;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        denet_set_error("gemm_batched_tune: hipEventCreate failed");
+        return DENET_ERR_ARG;
+    }
+    const bool prof_was_on = g_prof_on;
+    g_prof_on = false;
+    float best_ms = 1e30f;
+    TuneVal best = {1, 1, 0};
+    int rc = DENET_OK;
+    for (int t = (Nc >= 128 ? 0 : 1); t < 2 && !rc; ++t)
+        for (int nbuf = 1; nbuf <= 2 && !rc; ++nbuf) {
+            t_try = TuneVal{t, nbuf, 0};
+            rc = denet_gemm_batched_nt(a, w, out, batch, M, Nc, Kc, stride_a, stride_w, stride_out, stream);
+            float ms_min = 1e30f;
+            for (int rep = 0; rep < 3 && !rc; ++rep) {
+                (void)hipEventRecord(e0, stream);
+                rc = denet_gemm_batched_nt(a, w, out, batch, M, Nc, Kc, stride_a, stride_w, stride_out, stream);
+                (void)hipEventRecord(e1, stream);
+                if (hipEventSynchronize(e1) != hipSuccess) rc = DENET_ERR_ARG;
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                if (ms < ms_min) ms_min = ms;
+            }
+            if (!rc && ms_min < best_ms) {
+                best_ms = ms_min;
+                best = t_try;
+            }
+        }
+    t_try = TuneVal{-1, 0, 0};
+    g_prof_on = prof_was_on;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    g_tuned[key] = best;
+    return DENET_OK;
 }
 
 // Times the candidate launch configurations of one convolution pass on the caller's own buffers and remembers the

@@ -13,6 +13,8 @@
 
 int denet_gemm_batched_nt(const float* a, const float* w, float* out, int batch, int M, int Nc, int Kc, long stride_a,
                           long stride_w, long stride_out, hipStream_t stream);
+int denet_gemm_batched_tune(const float* a, const float* w, float* out, int batch, int M, int Nc, int Kc, long stride_a,
+                            long stride_w, long stride_out, hipStream_t stream);
 
 namespace {
 
@@ -167,6 +169,21 @@ int wino_run(bool dgrad, const float* in, const float* w, const float* bias, con
 }
 
 }  // namespace
+
+// measures the launch configuration of the component GEMMs of this geometry (both directions); synchronises
+extern "C" int denet_conv_wino_tune(float* workspace, size_t workspace_bytes, int N, int H, int W, int C, int K,
+                                    hipStream_t stream) {
+    DENET_CHECK_ARG(workspace && H % 2 == 0 && W % 2 == 0 && C % 32 == 0 && K % 32 == 0, "conv_wino_tune: bad arguments");
+    const long T = (long)N * (H / 2) * (W / 2);
+    const size_t nU = (size_t)16 * C * K, nV = (size_t)16 * T * C, nM = (size_t)16 * T * K;
+    DENET_CHECK_ARG(workspace_bytes >= (nU + nV + nM) * sizeof(float), "conv_wino_tune: workspace too small");
+    (void)hipMemsetAsync(workspace, 0, (nU + nV + nM) * sizeof(float), stream);
+    float* U = workspace;
+    // forward: V [T x C] -> M [T x K];  data gradient: V [T x K] -> M [T x C]  (the larger of V / M regions is reused)
+    int rc = denet_gemm_batched_tune(U + nU, U, U + nU + nV, 16, (int)T, K, C, T * C, (long)C * K, T * K, stream);
+    if (rc) return rc;
+    return denet_gemm_batched_tune(U + nU + nV, U, U + nU, 16, (int)T, C, K, T * K, (long)C * K, T * C, stream);
+}
 
 extern "C" size_t denet_conv_wino_workspace_bytes(int N, int H, int W, int C, int K) {
     const size_t T = (size_t)N * (H / 2) * (W / 2);

@@ -199,6 +199,9 @@ def _use_wino(mode, g, direct, wino):
         elif PROFILE is not None:
             return False                 # undecided while a profile is being recorded: direct kernel, decide later
         else:
+            N, H, W, C, K = g[0], g[1], g[2], g[3], g[4]
+            ws = WS.get("wino", _L().denet_conv_wino_workspace_bytes(N, H, W, C, K))
+            check(_L().denet_conv_wino_tune(ptr(ws), ws.numel(), N, H, W, C, K, stream_ptr()), "conv_wino_tune")
             use = _time_ms(wino) < 0.97 * _time_ms(direct)
         _WINO[key] = use
     return use

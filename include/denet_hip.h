@@ -70,8 +70,10 @@ size_t denet_conv_wgrad_workspace_bytes(int N, int C, int K, int R, int S, int O
  * buffers, grid.y (wgrad split slices / dgrad stride classes) — profiling bookkeeping only                      */
 /* Winograd F(2x2,3x3) path of the same stride-1 pad-1 3x3 convolution (forward / data gradient): 2.25x fewer
  * multiplications, three extra HBM-bound transforms; pays for many channels. H, W even; C, K multiples of 32.
- * workspace: denet_conv_wino_workspace_bytes (transformed filters, input tiles and products).                  */
+ * workspace: denet_conv_wino_workspace_bytes (transformed filters, input tiles and products). denet_conv_wino_tune
+ * measures the launch configuration of the component GEMMs once per geometry (it synchronises the stream).     */
 size_t denet_conv_wino_workspace_bytes(int N, int H, int W, int C, int K);
+int denet_conv_wino_tune(float* workspace, size_t workspace_bytes, int N, int H, int W, int C, int K, hipStream_t stream);
 int denet_conv_wino_fwd(const float* x, const float* w, const float* bias, const float* add, float* y, float* workspace,
                         size_t workspace_bytes, int N, int H, int W, int C, int K, hipStream_t stream);
 int denet_conv_wino_dgrad(const float* dy, const float* w, const float* add, float* dx, float* workspace,
