@@ -50,7 +50,8 @@ struct IgemmParams {
     FastDiv div_row_w;  // fwd/wgrad: OW       dgrad: Wc
     int Hc, Wc;         // dgrad: H/stride, W/stride
     int wg_split_slow;  // wgrad: 1 = split slice is the slow (XCD-local) index of the linear workgroup id
-    long batch_act, batch_wgt, batch_out;  // fwd: element strides of blockIdx.y (batched GEMM of the Winograd path), else 0
+    long batch_act, batch_wgt, batch_out;  // fwd / wgrad: element strides of blockIdx.y (batched GEMMs of the Winograd path)
+    int batch;          // wgrad: number of batch members (grid.y), 0 = 1
     unsigned act_bytes, wgt_bytes;  // extents of `act` / `wgt` (buffer descriptors: out-of-range lanes read 0)
 };
 
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
 
     f32x4 ra[PA], rb[PB];
     // fwd: blockIdx.y selects one GEMM of a batch (same shapes, strided operands); the descriptors cover one member
-    const long by = (MODE == MODE_FWD) ? (long)blockIdx.y : 0;
+    const long by = (MODE == MODE_FWD || MODE == MODE_WGRAD) ? (long)blockIdx.y : 0;
     const __amdgpu_buffer_rsrc_t r_act =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.act + by * p.batch_act), 0, p.act_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_wgt =
@@ -603,7 +604,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
     // ---------------- epilogue ----------------
     float* out = p.out;
     if (MODE == MODE_WGRAD) out += (long)split_id * p.split_stride;
-    if (MODE == MODE_FWD) out += by * p.batch_out;
+    if (MODE == MODE_FWD || MODE == MODE_WGRAD) out += by * p.batch_out;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -687,7 +688,7 @@ int launch_igemm(const IgemmParams& p, int splits, hipStream_t stream) {
     }
     // wgrad folds the split slices into grid.x (see the id decode in the kernel); dgrad: y = stride parity classes
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n) * (MODE == MODE_WGRAD ? (unsigned)splits : 1u),
-              MODE == MODE_WGRAD ? 1u : (unsigned)splits, 1);
+              MODE == MODE_WGRAD ? (unsigned)(p.batch > 1 ? p.batch : 1) : (unsigned)splits, 1);
     ProfRec rec;
     if (g_prof_on) {
         rec.cfg[0] = MODE; rec.cfg[1] = BM; rec.cfg[2] = BN; rec.cfg[3] = NBUF;
@@ -824,6 +825,82 @@ int check_geom(int N, int H, int W, int C, int K, int R, int S, int S_real, int 
     return DENET_OK;
 }
 
+// split-K selection, launch and second-stage reduction of a weight-gradient problem described by `p` (p.M = K rows,
+// p.NC columns, p.npix reduction length, p.batch members sharing one launch)
+int wgrad_dispatch(IgemmParams& p, int K, float* dw, float* workspace, size_t workspace_bytes, const TuneKey& key,
+                   hipStream_t stream) {
+    p.ksteps = ceil_div(p.npix, BK);
+    const int batch = p.batch > 1 ? p.batch : 1;
+    int rc = DENET_OK;
+    const bool big_m = (K >= 128);
+    const int bm = big_m ? 128 : 64;
+    p.tiles_m = ceil_div(K, bm); p.tiles_n = ceil_div(p.NC, 128);
+    const long wsize = (long)K * p.NC * batch;     // all batch members of one split slice
+    p.split_stride = wsize;
+    // Split-K selection. Every candidate (rounds r of a full chip, LDS buffering) fixes the number of slices so
+    // that tiles x slices just fills r rounds; its price is r x (chunks per workgroup + fixed overhead) x chunk
+    // time, plus the second-stage reduction that has to read slices x |dw| bytes. Measured constants: a 128x128
+    // chunk takes ~4.2 us with 2 resident workgroups per CU and ~5.6 us with 3; HBM-side reduce ~3 TB/s.
+    const int tiles = p.tiles_m * p.tiles_n * batch;
+    const size_t max_by_ws = workspace ? workspace_bytes / ((size_t)wsize * sizeof(float)) : 0;
+    static int forced_blocks = -1;
+    if (forced_blocks < 0) {
+        const char* e = getenv("DENET_WGRAD_BLOCKS");
+        forced_blocks = e ? atoi(e) : 0;
+    }
+    int splits = 1, wg_nbuf = 2;
+    {
+        const double chunk_us2 = (big_m ? 4.2 : 2.4), chunk_us3 = chunk_us2 * 1.5 / 1.12;
+        double best = 1e300;
+        TuneVal tv = {0, 0, 0};
+        const bool have_tv = tuned_choice(key, &tv);
+        for (int nbuf = 1; nbuf <= 3; ++nbuf) {
+            if ((have_tv ? tv.nbuf : (forced_nbuf() ? forced_nbuf() : 1)) != nbuf) continue;
+            const int slots = 256 * (nbuf == 1 ? 3 : (nbuf == 2 ? 2 : 1));
+            for (int r = 1; r <= 6; ++r) {
+                if (have_tv && tv.rounds != r) continue;
+                int sp = forced_blocks ? ceil_div(forced_blocks, tiles) : (r * slots) / tiles;
+                if (sp < 1) sp = 1;
+                if (sp > p.ksteps / 4) sp = p.ksteps / 4 > 0 ? p.ksteps / 4 : 1;
+                if (sp > 512) sp = 512;
+                if ((size_t)sp > max_by_ws && sp > 1) sp = max_by_ws > 0 ? (int)max_by_ws : 1;
+                const int per = ceil_div(p.ksteps, sp);
+                sp = ceil_div(p.ksteps, per);
+                const long nb = (long)tiles * sp;
+                const double rounds = (double)((nb + slots - 1) / slots);
+                const double t_main = rounds * (per + 2.0) * (nbuf == 1 ? chunk_us3 : chunk_us2);
+                const double t_red = sp > 1 ? 3.0 + (double)sp * wsize * 4.0 / 3.0e6 : 0.0;
+                if (t_main + t_red < best) {
+                    best = t_main + t_red;
+                    splits = sp;
+                    wg_nbuf = nbuf;
+                }
+            }
+        }
+    }
+    if (splits <= 1) {
+        splits = 1;
+        p.out = dw;
+    } else {
+        p.out = workspace;
+    }
+    p.steps_per_split = ceil_div(p.ksteps, splits);
+    splits = ceil_div(p.ksteps, p.steps_per_split);
+    if (big_m)
+        rc = LAUNCH_NBUF(MODE_WGRAD, 128, 128, wg_nbuf, p, splits, stream);
+    else
+        rc = LAUNCH_NBUF(MODE_WGRAD, 64, 128, wg_nbuf, p, splits, stream);
+    if (rc) return rc;
+    if (splits > 1) {
+        DENET_CHECK_ARG(wsize % 4 == 0, "conv_wgrad: weight size not a multiple of 4");
+        long n4 = wsize / 4;
+        int blocks = (int)((n4 + 63) / 64);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, dw, n4, splits, n4);
+        DENET_CHECK_LAUNCH("splitk_reduce");
+    }
+    return DENET_OK;
+}
+
 }  // namespace
 
 extern "C" int denet_conv_profile(int enable) {
@@ -893,6 +970,68 @@ int denet_gemm_batched_nt(const float* a, const float* w, float* out, int batch,
     }
     p.tiles_n = ceil_div(Nc, 64);
     return LAUNCH_NBUF(MODE_FWD, 128, 64, nbuf, p, batch, stream);
+}
+
+// Batch of `batch` independent products dw_b[Kr,Cc] = sum_t dy_b[t,Kr] * x_b[t,Cc] (row-major, t = reduction) through
+// the weight-gradient kernel (1x1 geometry, split-K over t): the filter-gradient products of the Winograd path.
+int denet_wgrad_batched(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes, int batch,
+                        int T, int Cc, int Kr, hipStream_t stream) {
+    DENET_CHECK_ARG(x && dy && dw && batch > 0 && batch <= 65535 && T > 0, "wgrad_batched: bad arguments");
+    DENET_CHECK_ARG(Cc % 32 == 0 && Kr % 32 == 0, "wgrad_batched: channel counts must be multiples of 32");
+    DENET_CHECK_ARG((long)T * Cc * 4 < 0xF0000000L && (long)T * Kr * 4 < 0xF0000000L, "wgrad_batched: operand too large");
+    IgemmParams p = {};
+    p.act = x; p.wgt = dy;
+    p.N = 1; p.H = 1; p.W = T; p.C = Cc; p.OH = 1; p.OW = T; p.K = Kr;
+    p.R = 1; p.S = 1; p.S_real = 1; p.stride = 1; p.sshift = 0; p.pad = 0;
+    p.act_bytes = (unsigned)((size_t)T * Cc * 4); p.wgt_bytes = (unsigned)((size_t)T * Kr * 4);
+    p.batch = batch; p.batch_act = (long)T * Cc; p.batch_wgt = (long)T * Kr; p.batch_out = (long)Kr * Cc;
+    p.M = Kr; p.NC = Cc; p.npix = T;
+    p.wg_split_slow = 1;
+    p.div_row_hw.init(T); p.div_row_w.init(T);
+    return wgrad_dispatch(p, Kr, dw, workspace, workspace_bytes, tune_key(4, batch, 1, T, Cc, Kr, 1, 1, 1, 1, 0), stream);
+}
+
+// measures the split / loop structure of the batched weight-gradient product (synchronises the stream)
+int denet_wgrad_batched_tune(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes, int batch,
+                             int T, int Cc, int Kr, hipStream_t stream) {
+    const TuneKey key = tune_key(4, batch, 1, T, Cc, Kr, 1, 1, 1, 1, 0);
+    if (g_tuned.count(key)) return DENET_OK;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        denet_set_error("wgrad_batched_tune: hipEventCreate failed");
+        return DENET_ERR_ARG;
+    }
+    const bool prof_was_on = g_prof_on;
+    g_prof_on = false;
+    float best_ms = 1e30f;
+    TuneVal best = {0, 1, 1};
+    int rc = DENET_OK;
+    for (int nbuf = 1; nbuf <= 2 && !rc; ++nbuf)
+        for (int r = 1; r <= (nbuf == 1 ? 6 : 3) && !rc; ++r) {
+            t_try = TuneVal{0, nbuf, r};
+            rc = denet_wgrad_batched(x, dy, dw, workspace, workspace_bytes, batch, T, Cc, Kr, stream);
+            float ms_min = 1e30f;
+            for (int rep = 0; rep < 3 && !rc; ++rep) {
+                (void)hipEventRecord(e0, stream);
+                rc = denet_wgrad_batched(x, dy, dw, workspace, workspace_bytes, batch, T, Cc, Kr, stream);
+                (void)hipEventRecord(e1, stream);
+                if (hipEventSynchronize(e1) != hipSuccess) rc = DENET_ERR_ARG;
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                if (ms < ms_min) ms_min = ms;
+            }
+            if (!rc && ms_min < best_ms) {
+                best_ms = ms_min;
+                best = t_try;
+            }
+        }
+    t_try = TuneVal{-1, 0, 0};
+    g_prof_on = prof_was_on;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    g_tuned[key] = best;
+    return DENET_OK;
 }
 
 // measures the launch configuration of the batched GEMM for these sizes (synchronises the stream)
@@ -1125,73 +1264,7 @@ extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, floa
         }
         p.wg_split_slow = v;
     }
-    p.ksteps = ceil_div(p.npix, BK);
     p.div_row_hw.init(OH * OW); p.div_row_w.init(OW);
-    const bool big_m = (K >= 128);
-    const int bm = big_m ? 128 : 64;
-    p.tiles_m = ceil_div(K, bm); p.tiles_n = ceil_div(p.NC, 128);
-    const long wsize = (long)K * p.NC;
-    p.split_stride = wsize;
-    // Split-K selection. Every candidate (rounds r of a full chip, LDS buffering) fixes the number of slices so
-    // that tiles x slices just fills r rounds; its price is r x (chunks per workgroup + fixed overhead) x chunk
-    // time, plus the second-stage reduction that has to read slices x |dw| bytes. Measured constants: a 128x128
-    // chunk takes ~4.2 us with 2 resident workgroups per CU and ~5.6 us with 3; HBM-side reduce ~3 TB/s.
-    const int tiles = p.tiles_m * p.tiles_n;
-    const size_t max_by_ws = workspace ? workspace_bytes / ((size_t)wsize * sizeof(float)) : 0;
-    static int forced_blocks = -1;
-    if (forced_blocks < 0) {
-        const char* e = getenv("DENET_WGRAD_BLOCKS");
-        forced_blocks = e ? atoi(e) : 0;
-    }
-    int splits = 1, wg_nbuf = 2;
-    {
-        const double chunk_us2 = (big_m ? 4.2 : 2.4), chunk_us3 = chunk_us2 * 1.5 / 1.12;
-        double best = 1e300;
-        TuneVal tv = {0, 0, 0};
-        const bool have_tv = tuned_choice(tune_key(MODE_WGRAD, N, H, W, C, K, R, S, S_real, stride, pad), &tv);
-        for (int nbuf = 1; nbuf <= 3; ++nbuf) {
-            if ((have_tv ? tv.nbuf : (forced_nbuf() ? forced_nbuf() : 1)) != nbuf) continue;
-            const int slots = 256 * (nbuf == 1 ? 3 : (nbuf == 2 ? 2 : 1));
-            for (int r = 1; r <= 6; ++r) {
-                if (have_tv && tv.rounds != r) continue;
-                int sp = forced_blocks ? ceil_div(forced_blocks, tiles) : (r * slots) / tiles;
-                if (sp < 1) sp = 1;
-                if (sp > p.ksteps / 4) sp = p.ksteps / 4 > 0 ? p.ksteps / 4 : 1;
-                if (sp > 512) sp = 512;
-                if ((size_t)sp > max_by_ws && sp > 1) sp = max_by_ws > 0 ? (int)max_by_ws : 1;
-                const int per = ceil_div(p.ksteps, sp);
-                sp = ceil_div(p.ksteps, per);
-                const long nb = (long)tiles * sp;
-                const double rounds = (double)((nb + slots - 1) / slots);
-                const double t_main = rounds * (per + 2.0) * (nbuf == 1 ? chunk_us3 : chunk_us2);
-                const double t_red = sp > 1 ? 3.0 + (double)sp * wsize * 4.0 / 3.0e6 : 0.0;
-                if (t_main + t_red < best) {
-                    best = t_main + t_red;
-                    splits = sp;
-                    wg_nbuf = nbuf;
-                }
-            }
-        }
-    }
-    if (splits <= 1) {
-        splits = 1;
-        p.out = dw;
-    } else {
-        p.out = workspace;
-    }
-    p.steps_per_split = ceil_div(p.ksteps, splits);
-    splits = ceil_div(p.ksteps, p.steps_per_split);
-    if (big_m)
-        rc = LAUNCH_NBUF(MODE_WGRAD, 128, 128, wg_nbuf, p, splits, stream);
-    else
-        rc = LAUNCH_NBUF(MODE_WGRAD, 64, 128, wg_nbuf, p, splits, stream);
-    if (rc) return rc;
-    if (splits > 1) {
-        DENET_CHECK_ARG(wsize % 4 == 0, "conv_wgrad: weight size not a multiple of 4");
-        long n4 = wsize / 4;
-        int blocks = (int)((n4 + 63) / 64);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, dw, n4, splits, n4);
-        DENET_CHECK_LAUNCH("splitk_reduce");
-    }
-    return DENET_OK;
+    return wgrad_dispatch(p, K, dw, workspace, workspace_bytes, tune_key(MODE_WGRAD, N, H, W, C, K, R, S, S_real, stride, pad),
+                          stream);
 }

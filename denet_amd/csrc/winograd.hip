@@ -16,6 +16,11 @@ int denet_gemm_batched_nt(const float* a, const float* w, float* out, int batch,
 int denet_gemm_batched_tune(const float* a, const float* w, float* out, int batch, int M, int Nc, int Kc, long stride_a,
                             long stride_w, long stride_out, hipStream_t stream);
 
+int denet_wgrad_batched(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes, int batch,
+                        int T, int Cc, int Kr, hipStream_t stream);
+int denet_wgrad_batched_tune(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes, int batch,
+                             int T, int Cc, int Kr, hipStream_t stream);
+
 namespace {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
@@ -136,6 +141,60 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     }
 }
 
+// filter gradient, step 1: dM[xi][t][k] = (A dy_tile A^T)[xi], the adjoint of the output transform
+__global__ __launch_bounds__(256) void wino_dout_kernel(const float* __restrict__ dy, float* __restrict__ dM, int N, int H,
+                                                        int W, int K, int TH, int TW, long T) {
+    const int k4n = K / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * k4n) return;
+    const int k4 = (int)(idx % k4n);
+    const long t = idx / k4n;
+    const int tx = (int)(t % TW);
+    const int ty = (int)((t / TW) % TH);
+    const int n = (int)(t / ((long)TW * TH));
+    const long o = (((long)n * H + 2 * ty) * W + 2 * tx) * K + k4 * 4;
+    const f32x4 y00 = ld4(dy + o), y01 = ld4(dy + o + K);
+    const f32x4 y10 = ld4(dy + o + (long)W * K), y11 = ld4(dy + o + (long)W * K + K);
+    // A = [[1,0],[1,1],[1,-1],[0,-1]]:  rows of A dy
+    const f32x4 a[4][2] = {{y00, y01}, {y00 + y10, y01 + y11}, {y00 - y10, y01 - y11}, {-y10, -y11}};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float* d = dM + ((long)(4 * i) * T + t) * K + k4 * 4;
+        *(f32x4*)(d) = a[i][0];
+        *(f32x4*)(d + T * K) = a[i][0] + a[i][1];
+        *(f32x4*)(d + 2 * T * K) = a[i][0] - a[i][1];
+        *(f32x4*)(d + 3 * T * K) = -a[i][1];
+    }
+}
+
+// filter gradient, step 3: dw[k][r][s][c] = (G^T dU G)[r][s], the adjoint of the filter transform
+__global__ __launch_bounds__(256) void wino_dfilter_kernel(const float* __restrict__ dU, float* __restrict__ dw, int K, int C) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)K * C) return;
+    const int c = (int)(idx % C);
+    const int k = (int)(idx / C);
+    const long KC = (long)K * C;
+    float u[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[i][j] = dU[(4 * i + j) * KC + (long)k * C + c];
+    float r[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {       // G^T u
+        r[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
+        r[1][j] = 0.5f * (u[1][j] - u[2][j]);
+        r[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {       // (G^T u) G
+        float* o = dw + (((long)k * 3 + i) * 3) * C + c;
+        o[0] = r[i][0] + 0.5f * (r[i][1] + r[i][2]);
+        o[C] = 0.5f * (r[i][1] - r[i][2]);
+        o[2 * C] = 0.5f * (r[i][1] + r[i][2]) + r[i][3];
+    }
+}
+
 int wino_run(bool dgrad, const float* in, const float* w, const float* bias, const float* add, float* out, float* ws,
              size_t ws_bytes, int N, int H, int W, int Cin, int Cout, hipStream_t stream) {
     // in: [N,H,W,Cin]   out: [N,H,W,Cout]   w: KRSC with (K,C) = dgrad ? (Cin,Cout) : (Cout,Cin)
@@ -170,9 +229,36 @@ int wino_run(bool dgrad, const float* in, const float* w, const float* bias, con
 
 }  // namespace
 
+// dw = filter gradient of the 3x3 stride-1 pad-1 convolution; x:[N,H,W,C] dy:[N,H,W,K] dw:[K,3,3,C].
+// workspace (denet_conv_wino_workspace_bytes): dU | V | dM; split_ws: the split-K slices of the batched product.
+extern "C" int denet_conv_wino_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes,
+                                     float* split_ws, size_t split_ws_bytes, int N, int H, int W, int C, int K,
+                                     hipStream_t stream) {
+    DENET_CHECK_ARG(x && dy && dw && workspace, "conv_wino_wgrad: null pointer");
+    DENET_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 32 == 0 && K % 32 == 0, "conv_wino_wgrad: H, W must be even and the channel counts multiples of 32");
+    const int TH = H / 2, TW = W / 2;
+    const long T = (long)N * TH * TW;
+    const size_t nU = (size_t)16 * C * K, nV = (size_t)16 * T * C, nM = (size_t)16 * T * K;
+    DENET_CHECK_ARG(workspace_bytes >= (nU + nV + nM) * sizeof(float), "conv_wino_wgrad: workspace too small");
+    DENET_CHECK_ARG(T < (1L << 31) / 16, "conv_wino_wgrad: too many tiles");
+    float* dU = workspace;
+    float* V = dU + nU;
+    float* dM = V + nV;
+    const long ni = T * (C / 4), no = T * (K / 4);
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, stream, x, V, N, H, W, C, TH, TW, T);
+    hipLaunchKernelGGL(wino_dout_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, stream, dy, dM, N, H, W, K, TH, TW, T);
+    DENET_CHECK_LAUNCH("conv_wino_wgrad transforms");
+    int rc = denet_wgrad_batched(V, dM, dU, split_ws, split_ws_bytes, 16, (int)T, C, K, stream);
+    if (rc) return rc;
+    const long kc = (long)K * C;
+    hipLaunchKernelGGL(wino_dfilter_kernel, dim3((unsigned)((kc + 255) / 256)), dim3(256), 0, stream, dU, dw, K, C);
+    DENET_CHECK_LAUNCH("conv_wino_wgrad filter");
+    return DENET_OK;
+}
+
 // measures the launch configuration of the component GEMMs of this geometry (both directions); synchronises
-extern "C" int denet_conv_wino_tune(float* workspace, size_t workspace_bytes, int N, int H, int W, int C, int K,
-                                    hipStream_t stream) {
+extern "C" int denet_conv_wino_tune(float* workspace, size_t workspace_bytes, float* split_ws, size_t split_ws_bytes, int N,
+                                    int H, int W, int C, int K, hipStream_t stream) {
     DENET_CHECK_ARG(workspace && H % 2 == 0 && W % 2 == 0 && C % 32 == 0 && K % 32 == 0, "conv_wino_tune: bad arguments");
     const long T = (long)N * (H / 2) * (W / 2);
     const size_t nU = (size_t)16 * C * K, nV = (size_t)16 * T * C, nM = (size_t)16 * T * K;
@@ -182,7 +268,9 @@ extern "C" int denet_conv_wino_tune(float* workspace, size_t workspace_bytes, in
     // forward: V [T x C] -> M [T x K];  data gradient: V [T x K] -> M [T x C]  (the larger of V / M regions is reused)
     int rc = denet_gemm_batched_tune(U + nU, U, U + nU + nV, 16, (int)T, K, C, T * C, (long)C * K, T * K, stream);
     if (rc) return rc;
-    return denet_gemm_batched_tune(U + nU + nV, U, U + nU, 16, (int)T, C, K, T * K, (long)C * K, T * C, stream);
+    rc = denet_gemm_batched_tune(U + nU + nV, U, U + nU, 16, (int)T, C, K, T * K, (long)C * K, T * C, stream);
+    if (rc || !split_ws) return rc;
+    return denet_wgrad_batched_tune(U + nU, U + nU + nV, U, split_ws, split_ws_bytes, 16, (int)T, C, K, stream);
 }
 
 extern "C" size_t denet_conv_wino_workspace_bytes(int N, int H, int W, int C, int K) {

@@ -201,7 +201,9 @@ def _use_wino(mode, g, direct, wino):
         else:
             N, H, W, C, K = g[0], g[1], g[2], g[3], g[4]
             ws = WS.get("wino", _L().denet_conv_wino_workspace_bytes(N, H, W, C, K))
-            check(_L().denet_conv_wino_tune(ptr(ws), ws.numel(), N, H, W, C, K, stream_ptr()), "conv_wino_tune")
+            sws = WS.get("wgrad", WGRAD_WS_BYTES)
+            check(_L().denet_conv_wino_tune(ptr(ws), ws.numel(), ptr(sws), sws.numel(), N, H, W, C, K, stream_ptr()),
+                  "conv_wino_tune")
             use = _time_ms(wino) < 0.97 * _time_ms(direct)
         _WINO[key] = use
     return use
@@ -234,6 +236,17 @@ def conv_wino_dgrad(dy, w, add=None, out=None):
     return dx
 
 
+def conv_wino_wgrad(x, dy, out=None):
+    N, H, W, C = x.shape
+    K = dy.shape[3]
+    dw = out if out is not None else empty(K, 3, 3, C)
+    ws = WS.get("wino", _L().denet_conv_wino_workspace_bytes(N, H, W, C, K))
+    sws = WS.get("wgrad", WGRAD_WS_BYTES)
+    check(_L().denet_conv_wino_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel(), ptr(sws), sws.numel(), N, H, W, C, K,
+                                     stream_ptr()), "conv_wino_wgrad")
+    return dw
+
+
 def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None, logical=None):
     g = conv_geom(x_shape, w.shape, stride, pad, s_real)
     assert tuple(dy.shape) == (g[0], g[10], g[11], g[4]), (dy.shape, g)
@@ -260,11 +273,20 @@ def conv_wgrad(x, dy, w_shape, stride=1, pad=0, s_real=None, out=None, logical=N
     assert tuple(dy.shape) == (g[0], g[10], g[11], g[4]), (dy.shape, g)
     dw = out if out is not None else empty(*w_shape)
     ws = WS.get("wgrad", WGRAD_WS_BYTES)
-    if _tune_first(2, g, x, dy, None, None, dw, ws):
+    tuned_now = _tune_first(2, g, x, dy, None, None, dw, ws)
+
+    def direct():
+        check(_L().denet_conv_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel(), *g, stream_ptr()), "conv_wgrad")
+
+    if _use_wino(2, g, direct, lambda: conv_wino_wgrad(x, dy, out=dw)):
+        if PROFILE is not None:
+            PROFILE.add(_conv_flops(g, logical) / 2.25)
+        return conv_wino_wgrad(x, dy, out=dw)
+    if tuned_now:
         return dw
     if PROFILE is not None:
         PROFILE.add(_conv_flops(g, logical))
-    check(_L().denet_conv_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel(), *g, stream_ptr()), "conv_wgrad")
+    direct()
     return dw
 
 

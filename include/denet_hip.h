@@ -73,7 +73,10 @@ size_t denet_conv_wgrad_workspace_bytes(int N, int C, int K, int R, int S, int O
  * workspace: denet_conv_wino_workspace_bytes (transformed filters, input tiles and products). denet_conv_wino_tune
  * measures the launch configuration of the component GEMMs once per geometry (it synchronises the stream).     */
 size_t denet_conv_wino_workspace_bytes(int N, int H, int W, int C, int K);
-int denet_conv_wino_tune(float* workspace, size_t workspace_bytes, int N, int H, int W, int C, int K, hipStream_t stream);
+int denet_conv_wino_tune(float* workspace, size_t workspace_bytes, float* split_ws, size_t split_ws_bytes, int N, int H,
+                         int W, int C, int K, hipStream_t stream);
+int denet_conv_wino_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes,
+                          float* split_ws, size_t split_ws_bytes, int N, int H, int W, int C, int K, hipStream_t stream);
 int denet_conv_wino_fwd(const float* x, const float* w, const float* bias, const float* add, float* y, float* workspace,
                         size_t workspace_bytes, int N, int H, int W, int C, int K, hipStream_t stream);
 int denet_conv_wino_dgrad(const float* dy, const float* w, const float* add, float* dx, float* workspace,

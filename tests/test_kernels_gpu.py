@@ -429,5 +429,8 @@ def test_conv_winograd_vs_direct(hip, shape):
         rd = ops.conv_dgrad(dy, w, tuple(x.shape), add=addx, stride=1, pad=1)
         gd = ops.conv_wino_dgrad(dy, w, add=addx)
         assert float((rd - gd).abs().max()) <= 2e-5 * float(rd.abs().max())
+        rw = ops.conv_wgrad(x, dy, tuple(w.shape), stride=1, pad=1)
+        gw = ops.conv_wino_wgrad(x, dy)
+        assert float((rw - gw).abs().max()) <= 5e-5 * float(rw.abs().max())
     finally:
         ops.AUTOTUNE = old

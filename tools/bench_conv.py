@@ -53,7 +53,8 @@ for name, H, W, C, K, R, st, pad, cnt in SHAPES:
     if ops.conv_wino_ok(g):
         tw_f = timeit(lambda: ops.conv_wino_fwd(x, w))
         tw_d = timeit(lambda: ops.conv_wino_dgrad(dy, w))
-        print("           winograd: fwd %7.3f ms (x%.2f) | dgrad %7.3f ms (x%.2f)" % (tw_f, t_f / tw_f, tw_d, t_d / tw_d), flush=True)
+        tw_w = timeit(lambda: ops.conv_wino_wgrad(x, dy))
+        print("           winograd: fwd %7.3f ms (x%.2f) | dgrad %7.3f ms (x%.2f) | wgrad %7.3f ms (x%.2f)" % (tw_f, t_f / tw_f, tw_d, t_d / tw_d, tw_w, t_w / tw_w), flush=True)
     if ops.AUTOTUNE:
         import ctypes
         cfg = []
