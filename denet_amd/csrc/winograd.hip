@@ -1,12 +1,15 @@
-// Winograd F(2x2,3x3) path for the stride-1 3x3 convolutions with many channels (forward and data gradient).
+// Winograd F(m x m, 3x3) paths (m = 2 or 4) for the stride-1 3x3 convolutions with many channels: forward, data
+// gradient and filter gradient.
 // Reference op: the same `C[k,3]` layer (denet/layer/convolution.py:80-83; its gradient model_cnn.py:318); the
-// minimal-filtering algorithm computes the identical sums with 16 multiplications per 2x2 output tile and channel
-// pair instead of 36 (2.25x fewer MFMA FLOPs), at the price of three HBM-bound transforms:
+// minimal-filtering algorithm computes the identical sums with (m+2)^2 multiplications per m x m output tile and
+// channel pair instead of 9 m^2 (2.25x fewer MFMA FLOPs for m = 2, 4x for m = 4), at the price of HBM-bound transforms:
 //     V[xi][t][c] = (B^T d B)[xi]      d: 4x4 input patch of tile t (xi = 4*i+j)          wino_input_kernel
 //     U[xi][k][c] = (G g G^T)[xi]      g: 3x3 filter (already the correlation taps)        wino_filter_kernel
 //     M[xi][t][k] = sum_c V[xi][t][c] * U[xi][k][c]      16 GEMMs, batched                 igemm forward kernel
 //     y tile      = A^T M A (+ bias, + add)                                                wino_output_kernel
-// fp32 throughout; the result differs from the direct kernel by rounding only (~1e-6 relative).
+// fp32 throughout; the result differs from the direct kernel by rounding only (m = 2: ~1e-6, m = 4: ~1e-5 relative).
+// Filter gradient: dM = A dy A^T (wino_dout_kernel), dU[xi] = dM[xi]^T V[xi] (batched split-K product through the wgrad
+// kernel), dw = G^T dU G (wino_dfilter_kernel).
 // The data gradient of a stride-1 pad-1 3x3 convolution is the same convolution of dy with the taps rotated by 180
 // degrees and the channel roles swapped: wino_filter_kernel<true> writes U'[xi][c][k] from w[k][2-r][2-s][c].
 #include "common.h"
@@ -25,9 +28,51 @@ namespace {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
 
-// one thread per (tile, 4 channels)
+// ---- transform matrices (Lavin & Gray, "Fast algorithms for convolutional neural networks") -----------------
+// F(m x m, 3x3): TS = m + 2 points. Y = A^T [ (G g G^T) .* (B^T d B) ] A for the CORRELATION taps g.
+template <int MO>
+struct Wino;
+template <>
+struct Wino<2> {
+    static constexpr int TS = 4;
+    static constexpr float BT[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
+    static constexpr float G[4][3] = {{1, 0, 0}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0, 0, 1}};
+    static constexpr float AT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+};
+template <>
+struct Wino<4> {
+    static constexpr int TS = 6;
+    static constexpr float BT[6][6] = {{4, 0, -5, 0, 1, 0},  {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                                       {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+    static constexpr float G[6][3] = {{0.25f, 0, 0},
+                                      {-1.f / 6, -1.f / 6, -1.f / 6},
+                                      {-1.f / 6, 1.f / 6, -1.f / 6},
+                                      {1.f / 24, 1.f / 12, 1.f / 6},
+                                      {1.f / 24, -1.f / 12, 1.f / 6},
+                                      {0, 0, 1}};
+    static constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+};
+
+// acc = sum_l coef[l] * v[l] with the compile-time coefficients folded (0 dropped, +-1 without a multiply)
+#define WINO_DOT(acc, NL, COEF, VAL)                       \
+    {                                                      \
+        bool first_ = true;                                \
+        _Pragma("unroll") for (int l_ = 0; l_ < (NL); ++l_) { \
+            const float c_ = (COEF);                       \
+            if (c_ != 0.f) {                               \
+                if (first_) acc = c_ * (VAL);              \
+                else acc += c_ * (VAL);                    \
+                first_ = false;                            \
+            }                                              \
+        }                                                  \
+    }
+
+// V[xi][t][c] = (B^T d B)[xi]: one thread per (tile, 4 channels); d = TS x TS input patch at (MO*ty-1, MO*tx-1)
+template <int MO>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H,
                                                          int W, int C, int TH, int TW, long T) {
+    using WT = Wino<MO>;
+    constexpr int TS = WT::TS;
     const int c4n = C / 4;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= T * c4n) return;
@@ -37,42 +82,39 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     const int ty = (int)((t / TW) % TH);
     const int n = (int)(t / ((long)TW * TH));
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f32x4 d[4][4];
+    f32x4 tt[TS][TS];       // B^T d, built column by column
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int iy = 2 * ty - 1 + i;
+    for (int j = 0; j < TS; ++j) {
+        const int ix = MO * tx - 1 + j;
+        f32x4 d[TS];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ix = 2 * tx - 1 + j;
+        for (int i = 0; i < TS; ++i) {
+            const int iy = MO * ty - 1 + i;
             const bool ok = ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
-            d[i][j] = ok ? ld4(x + (((long)n * H + iy) * W + ix) * C + c4 * 4) : z;
+            d[i] = ok ? ld4(x + (((long)n * H + iy) * W + ix) * C + c4 * 4) : z;
+        }
+#pragma unroll
+        for (int i = 0; i < TS; ++i) {
+            f32x4 acc = z;
+            WINO_DOT(acc, TS, WT::BT[i][l_], d[l_]);
+            tt[i][j] = acc;
         }
     }
-    f32x4 tt[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {       // B^T d
-        tt[0][j] = d[0][j] - d[2][j];
-        tt[1][j] = d[1][j] + d[2][j];
-        tt[2][j] = d[2][j] - d[1][j];
-        tt[3][j] = d[1][j] - d[3][j];
-    }
+    for (int i = 0; i < TS; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {       // (B^T d) B
-        const f32x4 v0 = tt[i][0] - tt[i][2];
-        const f32x4 v1 = tt[i][1] + tt[i][2];
-        const f32x4 v2 = tt[i][2] - tt[i][1];
-        const f32x4 v3 = tt[i][1] - tt[i][3];
-        float* o = V + ((long)(4 * i) * T + t) * C + c4 * 4;
-        *(f32x4*)(o) = v0;
-        *(f32x4*)(o + T * C) = v1;
-        *(f32x4*)(o + 2 * T * C) = v2;
-        *(f32x4*)(o + 3 * T * C) = v3;
-    }
+        for (int j = 0; j < TS; ++j) {
+            f32x4 acc = z;
+            WINO_DOT(acc, TS, WT::BT[j][l_], tt[i][l_]);
+            *(f32x4*)(V + ((long)(TS * i + j) * T + t) * C + c4 * 4) = acc;
+        }
 }
 
-// one thread per (k, c): U[xi][k][c] (DGRAD = false) or U'[xi][c][k] from the rotated taps (DGRAD = true)
-template <bool DGRAD>
+// U[xi][k][c] = (G g G^T)[xi] (DGRAD = false) or U'[xi][c][k] from the rotated taps (DGRAD = true); thread per (k, c)
+template <int MO, bool DGRAD>
 __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int K, int C) {
+    using WT = Wino<MO>;
+    constexpr int TS = WT::TS;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)K * C) return;
     const int c = (int)(idx % C);
@@ -82,29 +124,34 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int s = 0; s < 3; ++s) g[r][s] = w[(((long)k * 3 + (DGRAD ? 2 - r : r)) * 3 + (DGRAD ? 2 - s : s)) * C + c];
-    float a[4][3];
+    float a[TS][3];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {       // G g
-        a[0][s] = g[0][s];
-        a[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
-        a[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
-        a[3][s] = g[2][s];
-    }
+    for (int i = 0; i < TS; ++i)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            float acc = 0.f;
+            WINO_DOT(acc, 3, WT::G[i][l_], g[l_][s]);
+            a[i][s] = acc;
+        }
     const long KC = (long)K * C;
     const long o = DGRAD ? ((long)c * K + k) : ((long)k * C + c);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {       // (G g) G^T
-        U[(4 * i + 0) * KC + o] = a[i][0];
-        U[(4 * i + 1) * KC + o] = 0.5f * (a[i][0] + a[i][1] + a[i][2]);
-        U[(4 * i + 2) * KC + o] = 0.5f * (a[i][0] - a[i][1] + a[i][2]);
-        U[(4 * i + 3) * KC + o] = a[i][2];
-    }
+    for (int i = 0; i < TS; ++i)
+#pragma unroll
+        for (int j = 0; j < TS; ++j) {
+            float acc = 0.f;
+            WINO_DOT(acc, 3, WT::G[j][l_], a[i][l_]);
+            U[(long)(TS * i + j) * KC + o] = acc;
+        }
 }
 
-// one thread per (tile, 4 output channels): y tile = A^T M A (+ bias) (+ add)
+// y tile = A^T M A (+ bias) (+ add): one thread per (tile, 4 output channels)
+template <int MO>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias,
                                                           const float* __restrict__ add, float* __restrict__ y, int N,
                                                           int H, int W, int K, int TH, int TW, long T) {
+    using WT = Wino<MO>;
+    constexpr int TS = WT::TS;
     const int k4n = K / 4;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= T * k4n) return;
@@ -113,37 +160,41 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     const int tx = (int)(t % TW);
     const int ty = (int)((t / TW) % TH);
     const int n = (int)(t / ((long)TW * TH));
-    f32x4 m[4][4];
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s[MO][TS];        // A^T m, column by column
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < TS; ++j) {
+        f32x4 m[TS];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m[i][j] = ld4(Mx + ((long)(4 * i + j) * T + t) * K + k4 * 4);
-    f32x4 s[2][4];
+        for (int i = 0; i < TS; ++i) m[i] = ld4(Mx + ((long)(TS * i + j) * T + t) * K + k4 * 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {       // A^T m
-        s[0][j] = m[0][j] + m[1][j] + m[2][j];
-        s[1][j] = m[1][j] - m[2][j] - m[3][j];
-    }
-    f32x4 b = {0.f, 0.f, 0.f, 0.f};
-    if (bias) b = ld4(bias + k4 * 4);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const f32x4 y0 = s[i][0] + s[i][1] + s[i][2] + b;
-        const f32x4 y1 = s[i][1] - s[i][2] - s[i][3] + b;
-        const long o = (((long)n * H + 2 * ty + i) * W + 2 * tx) * K + k4 * 4;
-        if (add) {
-            *(f32x4*)(y + o) = y0 + ld4(add + o);
-            *(f32x4*)(y + o + K) = y1 + ld4(add + o + K);
-        } else {
-            *(f32x4*)(y + o) = y0;
-            *(f32x4*)(y + o + K) = y1;
+        for (int i = 0; i < MO; ++i) {
+            f32x4 acc = z;
+            WINO_DOT(acc, TS, WT::AT[i][l_], m[l_]);
+            s[i][j] = acc;
         }
     }
+    f32x4 b = z;
+    if (bias) b = ld4(bias + k4 * 4);
+#pragma unroll
+    for (int i = 0; i < MO; ++i)
+#pragma unroll
+        for (int j = 0; j < MO; ++j) {
+            f32x4 acc = z;
+            WINO_DOT(acc, TS, WT::AT[j][l_], s[i][l_]);
+            const long o = (((long)n * H + MO * ty + i) * W + MO * tx + j) * K + k4 * 4;
+            acc += b;
+            if (add) acc += ld4(add + o);
+            *(f32x4*)(y + o) = acc;
+        }
 }
 
 // filter gradient, step 1: dM[xi][t][k] = (A dy_tile A^T)[xi], the adjoint of the output transform
+template <int MO>
 __global__ __launch_bounds__(256) void wino_dout_kernel(const float* __restrict__ dy, float* __restrict__ dM, int N, int H,
                                                         int W, int K, int TH, int TW, long T) {
+    using WT = Wino<MO>;
+    constexpr int TS = WT::TS;
     const int k4n = K / 4;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= T * k4n) return;
@@ -152,77 +203,118 @@ __global__ __launch_bounds__(256) void wino_dout_kernel(const float* __restrict_
     const int tx = (int)(t % TW);
     const int ty = (int)((t / TW) % TH);
     const int n = (int)(t / ((long)TW * TH));
-    const long o = (((long)n * H + 2 * ty) * W + 2 * tx) * K + k4 * 4;
-    const f32x4 y00 = ld4(dy + o), y01 = ld4(dy + o + K);
-    const f32x4 y10 = ld4(dy + o + (long)W * K), y11 = ld4(dy + o + (long)W * K + K);
-    // A = [[1,0],[1,1],[1,-1],[0,-1]]:  rows of A dy
-    const f32x4 a[4][2] = {{y00, y01}, {y00 + y10, y01 + y11}, {y00 - y10, y01 - y11}, {-y10, -y11}};
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a[TS][MO];        // A dy: a[i][j] = sum_l AT[l][i] dy[l][j]
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float* d = dM + ((long)(4 * i) * T + t) * K + k4 * 4;
-        *(f32x4*)(d) = a[i][0];
-        *(f32x4*)(d + T * K) = a[i][0] + a[i][1];
-        *(f32x4*)(d + 2 * T * K) = a[i][0] - a[i][1];
-        *(f32x4*)(d + 3 * T * K) = -a[i][1];
+    for (int j = 0; j < MO; ++j) {
+        f32x4 d[MO];
+#pragma unroll
+        for (int i = 0; i < MO; ++i) d[i] = ld4(dy + (((long)n * H + MO * ty + i) * W + MO * tx + j) * K + k4 * 4);
+#pragma unroll
+        for (int i = 0; i < TS; ++i) {
+            f32x4 acc = z;
+            WINO_DOT(acc, MO, WT::AT[l_][i], d[l_]);
+            a[i][j] = acc;
+        }
     }
+#pragma unroll
+    for (int i = 0; i < TS; ++i)
+#pragma unroll
+        for (int j = 0; j < TS; ++j) {
+            f32x4 acc = z;
+            WINO_DOT(acc, MO, WT::AT[l_][j], a[i][l_]);
+            *(f32x4*)(dM + ((long)(TS * i + j) * T + t) * K + k4 * 4) = acc;
+        }
 }
 
 // filter gradient, step 3: dw[k][r][s][c] = (G^T dU G)[r][s], the adjoint of the filter transform
+template <int MO>
 __global__ __launch_bounds__(256) void wino_dfilter_kernel(const float* __restrict__ dU, float* __restrict__ dw, int K, int C) {
+    using WT = Wino<MO>;
+    constexpr int TS = WT::TS;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)K * C) return;
     const int c = (int)(idx % C);
     const int k = (int)(idx / C);
     const long KC = (long)K * C;
-    float u[4][4];
+    float r[3][TS];         // G^T u, column by column
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < TS; ++j) {
+        float u[TS];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) u[i][j] = dU[(4 * i + j) * KC + (long)k * C + c];
-    float r[3][4];
+        for (int i = 0; i < TS; ++i) u[i] = dU[(long)(TS * i + j) * KC + (long)k * C + c];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {       // G^T u
-        r[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
-        r[1][j] = 0.5f * (u[1][j] - u[2][j]);
-        r[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
+        for (int i = 0; i < 3; ++i) {
+            float acc = 0.f;
+            WINO_DOT(acc, TS, WT::G[l_][i], u[l_]);
+            r[i][j] = acc;
+        }
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {       // (G^T u) G
-        float* o = dw + (((long)k * 3 + i) * 3) * C + c;
-        o[0] = r[i][0] + 0.5f * (r[i][1] + r[i][2]);
-        o[C] = 0.5f * (r[i][1] - r[i][2]);
-        o[2 * C] = 0.5f * (r[i][1] + r[i][2]) + r[i][3];
-    }
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float acc = 0.f;
+            WINO_DOT(acc, TS, WT::G[l_][j], r[i][l_]);
+            dw[(((long)k * 3 + i) * 3 + j) * C + c] = acc;
+        }
 }
 
-int wino_run(bool dgrad, const float* in, const float* w, const float* bias, const float* add, float* out, float* ws,
-             size_t ws_bytes, int N, int H, int W, int Cin, int Cout, hipStream_t stream) {
+struct WinoDims {
+    int TS, NX, TH, TW;
+    long T;
+    size_t nU, nV, nM;
+};
+
+int wino_dims(int mo, int N, int H, int W, int C, int K, WinoDims* d) {
+    DENET_CHECK_ARG(mo == 2 || mo == 4, "conv_wino: output tile must be 2 or 4 (got %d)", mo);
+    DENET_CHECK_ARG(H % mo == 0 && W % mo == 0 && C % 32 == 0 && K % 32 == 0,
+                    "conv_wino: H, W must be multiples of the tile (%d) and the channel counts multiples of 32", mo);
+    d->TS = mo + 2;
+    d->NX = d->TS * d->TS;
+    d->TH = H / mo;
+    d->TW = W / mo;
+    d->T = (long)N * d->TH * d->TW;
+    d->nU = (size_t)d->NX * C * K;
+    d->nV = (size_t)d->NX * d->T * C;
+    d->nM = (size_t)d->NX * d->T * K;
+    DENET_CHECK_ARG(d->T < (1L << 31) / d->NX, "conv_wino: too many tiles");
+    return DENET_OK;
+}
+
+#define WINO_LAUNCH(MO_, KERNEL, NTHREADS, ...)                                                                       \
+    {                                                                                                               \
+        const unsigned blocks_ = (unsigned)(((NTHREADS) + 255) / 256);                                              \
+        if ((MO_) == 2) hipLaunchKernelGGL(KERNEL<2>, dim3(blocks_), dim3(256), 0, stream, __VA_ARGS__);             \
+        else hipLaunchKernelGGL(KERNEL<4>, dim3(blocks_), dim3(256), 0, stream, __VA_ARGS__);                        \
+    }
+
+int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* bias, const float* add, float* out,
+             float* ws, size_t ws_bytes, int N, int H, int W, int Cin, int Cout, hipStream_t stream) {
     // in: [N,H,W,Cin]   out: [N,H,W,Cout]   w: KRSC with (K,C) = dgrad ? (Cin,Cout) : (Cout,Cin)
     DENET_CHECK_ARG(in && w && out && ws, "conv_wino: null pointer");
-    DENET_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && Cin % 32 == 0 && Cout % 32 == 0, "conv_wino: H, W must be even and the channel counts multiples of 32");
-    const int TH = H / 2, TW = W / 2;
-    const long T = (long)N * TH * TW;
-    const size_t nU = (size_t)16 * Cin * Cout, nV = (size_t)16 * T * Cin, nM = (size_t)16 * T * Cout;
-    DENET_CHECK_ARG(ws_bytes >= (nU + nV + nM) * sizeof(float), "conv_wino: workspace too small (%zu < %zu)", ws_bytes,
-                    (nU + nV + nM) * sizeof(float));
-    DENET_CHECK_ARG(T < (1L << 31) / 16, "conv_wino: too many tiles");
-    float* U = ws;
-    float* V = U + nU;
-    float* Mx = V + nV;
-    const long kc = (long)Cin * Cout;
-    if (dgrad)
-        hipLaunchKernelGGL(wino_filter_kernel<true>, dim3((unsigned)((kc + 255) / 256)), dim3(256), 0, stream, w, U, Cin, Cout);
-    else
-        hipLaunchKernelGGL(wino_filter_kernel<false>, dim3((unsigned)((kc + 255) / 256)), dim3(256), 0, stream, w, U, Cout, Cin);
-    const long ni = T * (Cin / 4);
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, stream, in, V, N, H, W, Cin, TH,
-                       TW, T);
-    DENET_CHECK_LAUNCH("conv_wino transforms");
-    int rc = denet_gemm_batched_nt(V, U, Mx, 16, (int)T, Cout, Cin, T * Cin, kc, T * Cout, stream);
+    WinoDims d;
+    int rc = wino_dims(mo, N, H, W, Cin, Cout, &d);
     if (rc) return rc;
-    const long no = T * (Cout / 4);
-    hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, stream, Mx, bias, add, out, N, H,
-                       W, Cout, TH, TW, T);
+    DENET_CHECK_ARG(ws_bytes >= (d.nU + d.nV + d.nM) * sizeof(float), "conv_wino: workspace too small (%zu < %zu)", ws_bytes,
+                    (d.nU + d.nV + d.nM) * sizeof(float));
+    float* U = ws;
+    float* V = U + d.nU;
+    float* Mx = V + d.nV;
+    const long kc = (long)Cin * Cout;
+    const unsigned fb = (unsigned)((kc + 255) / 256);
+    if (dgrad) {
+        if (mo == 2) hipLaunchKernelGGL((wino_filter_kernel<2, true>), dim3(fb), dim3(256), 0, stream, w, U, Cin, Cout);
+        else hipLaunchKernelGGL((wino_filter_kernel<4, true>), dim3(fb), dim3(256), 0, stream, w, U, Cin, Cout);
+    } else {
+        if (mo == 2) hipLaunchKernelGGL((wino_filter_kernel<2, false>), dim3(fb), dim3(256), 0, stream, w, U, Cout, Cin);
+        else hipLaunchKernelGGL((wino_filter_kernel<4, false>), dim3(fb), dim3(256), 0, stream, w, U, Cout, Cin);
+    }
+    WINO_LAUNCH(mo, wino_input_kernel, d.T * (Cin / 4), in, V, N, H, W, Cin, d.TH, d.TW, d.T);
+    DENET_CHECK_LAUNCH("conv_wino transforms");
+    rc = denet_gemm_batched_nt(V, U, Mx, d.NX, (int)d.T, Cout, Cin, d.T * Cin, kc, d.T * Cout, stream);
+    if (rc) return rc;
+    WINO_LAUNCH(mo, wino_output_kernel, d.T * (Cout / 4), Mx, bias, add, out, N, H, W, Cout, d.TH, d.TW, d.T);
     DENET_CHECK_LAUNCH("conv_wino output");
     return DENET_OK;
 }
@@ -232,61 +324,61 @@ int wino_run(bool dgrad, const float* in, const float* w, const float* bias, con
 // dw = filter gradient of the 3x3 stride-1 pad-1 convolution; x:[N,H,W,C] dy:[N,H,W,K] dw:[K,3,3,C].
 // workspace (denet_conv_wino_workspace_bytes): dU | V | dM; split_ws: the split-K slices of the batched product.
 extern "C" int denet_conv_wino_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes,
-                                     float* split_ws, size_t split_ws_bytes, int N, int H, int W, int C, int K,
+                                     float* split_ws, size_t split_ws_bytes, int tile, int N, int H, int W, int C, int K,
                                      hipStream_t stream) {
     DENET_CHECK_ARG(x && dy && dw && workspace, "conv_wino_wgrad: null pointer");
-    DENET_CHECK_ARG(H % 2 == 0 && W % 2 == 0 && C % 32 == 0 && K % 32 == 0, "conv_wino_wgrad: H, W must be even and the channel counts multiples of 32");
-    const int TH = H / 2, TW = W / 2;
-    const long T = (long)N * TH * TW;
-    const size_t nU = (size_t)16 * C * K, nV = (size_t)16 * T * C, nM = (size_t)16 * T * K;
-    DENET_CHECK_ARG(workspace_bytes >= (nU + nV + nM) * sizeof(float), "conv_wino_wgrad: workspace too small");
-    DENET_CHECK_ARG(T < (1L << 31) / 16, "conv_wino_wgrad: too many tiles");
-    float* dU = workspace;
-    float* V = dU + nU;
-    float* dM = V + nV;
-    const long ni = T * (C / 4), no = T * (K / 4);
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, stream, x, V, N, H, W, C, TH, TW, T);
-    hipLaunchKernelGGL(wino_dout_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, stream, dy, dM, N, H, W, K, TH, TW, T);
-    DENET_CHECK_LAUNCH("conv_wino_wgrad transforms");
-    int rc = denet_wgrad_batched(V, dM, dU, split_ws, split_ws_bytes, 16, (int)T, C, K, stream);
+    WinoDims d;
+    int rc = wino_dims(tile, N, H, W, C, K, &d);
     if (rc) return rc;
-    const long kc = (long)K * C;
-    hipLaunchKernelGGL(wino_dfilter_kernel, dim3((unsigned)((kc + 255) / 256)), dim3(256), 0, stream, dU, dw, K, C);
+    DENET_CHECK_ARG(workspace_bytes >= (d.nU + d.nV + d.nM) * sizeof(float), "conv_wino_wgrad: workspace too small");
+    float* dU = workspace;
+    float* V = dU + d.nU;
+    float* dM = V + d.nV;
+    WINO_LAUNCH(tile, wino_input_kernel, d.T * (C / 4), x, V, N, H, W, C, d.TH, d.TW, d.T);
+    WINO_LAUNCH(tile, wino_dout_kernel, d.T * (K / 4), dy, dM, N, H, W, K, d.TH, d.TW, d.T);
+    DENET_CHECK_LAUNCH("conv_wino_wgrad transforms");
+    rc = denet_wgrad_batched(V, dM, dU, split_ws, split_ws_bytes, d.NX, (int)d.T, C, K, stream);
+    if (rc) return rc;
+    WINO_LAUNCH(tile, wino_dfilter_kernel, (long)K * C, dU, dw, K, C);
     DENET_CHECK_LAUNCH("conv_wino_wgrad filter");
     return DENET_OK;
 }
 
-// measures the launch configuration of the component GEMMs of this geometry (both directions); synchronises
-extern "C" int denet_conv_wino_tune(float* workspace, size_t workspace_bytes, float* split_ws, size_t split_ws_bytes, int N,
-                                    int H, int W, int C, int K, hipStream_t stream) {
-    DENET_CHECK_ARG(workspace && H % 2 == 0 && W % 2 == 0 && C % 32 == 0 && K % 32 == 0, "conv_wino_tune: bad arguments");
-    const long T = (long)N * (H / 2) * (W / 2);
-    const size_t nU = (size_t)16 * C * K, nV = (size_t)16 * T * C, nM = (size_t)16 * T * K;
-    DENET_CHECK_ARG(workspace_bytes >= (nU + nV + nM) * sizeof(float), "conv_wino_tune: workspace too small");
-    (void)hipMemsetAsync(workspace, 0, (nU + nV + nM) * sizeof(float), stream);
-    float* U = workspace;
-    // forward: V [T x C] -> M [T x K];  data gradient: V [T x K] -> M [T x C]  (the larger of V / M regions is reused)
-    int rc = denet_gemm_batched_tune(U + nU, U, U + nU + nV, 16, (int)T, K, C, T * C, (long)C * K, T * K, stream);
+// measures the launch configuration of the component GEMMs of this geometry (all three passes); synchronises
+extern "C" int denet_conv_wino_tune(float* workspace, size_t workspace_bytes, float* split_ws, size_t split_ws_bytes,
+                                    int tile, int N, int H, int W, int C, int K, hipStream_t stream) {
+    DENET_CHECK_ARG(workspace, "conv_wino_tune: null workspace");
+    WinoDims d;
+    int rc = wino_dims(tile, N, H, W, C, K, &d);
     if (rc) return rc;
-    rc = denet_gemm_batched_tune(U + nU + nV, U, U + nU, 16, (int)T, C, K, T * K, (long)C * K, T * C, stream);
+    DENET_CHECK_ARG(workspace_bytes >= (d.nU + d.nV + d.nM) * sizeof(float), "conv_wino_tune: workspace too small");
+    (void)hipMemsetAsync(workspace, 0, (d.nU + d.nV + d.nM) * sizeof(float), stream);
+    float* U = workspace;
+    const long T = d.T;
+    // forward: V [T x C] -> M [T x K];  data gradient: V [T x K] -> M [T x C]
+    rc = denet_gemm_batched_tune(U + d.nU, U, U + d.nU + d.nV, d.NX, (int)T, K, C, T * C, (long)C * K, T * K, stream);
+    if (rc) return rc;
+    rc = denet_gemm_batched_tune(U + d.nU + d.nV, U, U + d.nU, d.NX, (int)T, C, K, T * K, (long)C * K, T * C, stream);
     if (rc || !split_ws) return rc;
-    return denet_wgrad_batched_tune(U + nU, U + nU + nV, U, split_ws, split_ws_bytes, 16, (int)T, C, K, stream);
+    return denet_wgrad_batched_tune(U + d.nU, U + d.nU + d.nV, U, split_ws, split_ws_bytes, d.NX, (int)T, C, K, stream);
 }
 
-extern "C" size_t denet_conv_wino_workspace_bytes(int N, int H, int W, int C, int K) {
-    const size_t T = (size_t)N * (H / 2) * (W / 2);
-    return ((size_t)16 * C * K + (size_t)16 * T * C + (size_t)16 * T * K) * sizeof(float);
+extern "C" size_t denet_conv_wino_workspace_bytes(int tile, int N, int H, int W, int C, int K) {
+    const size_t nx = (size_t)(tile + 2) * (tile + 2);
+    const size_t T = (size_t)N * (H / tile) * (W / tile);
+    return (nx * C * K + nx * T * C + nx * T * K) * sizeof(float);
 }
 
-// y = conv3x3(x, w) stride 1 pad 1 (+ bias) (+ add); x:[N,H,W,C] w:[K,3,3,C] y:[N,H,W,K]
+// y = conv3x3(x, w) stride 1 pad 1 (+ bias) (+ add); x:[N,H,W,C] w:[K,3,3,C] y:[N,H,W,K]; tile = 2: F(2x2,3x3), 4: F(4x4,3x3)
 extern "C" int denet_conv_wino_fwd(const float* x, const float* w, const float* bias, const float* add, float* y,
-                                   float* workspace, size_t workspace_bytes, int N, int H, int W, int C, int K,
+                                   float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
                                    hipStream_t stream) {
-    return wino_run(false, x, w, bias, add, y, workspace, workspace_bytes, N, H, W, C, K, stream);
+    return wino_run(tile, false, x, w, bias, add, y, workspace, workspace_bytes, N, H, W, C, K, stream);
 }
 
 // dx = conv3x3_transposed(dy, w) (+ add); dy:[N,H,W,K] w:[K,3,3,C] dx:[N,H,W,C]
 extern "C" int denet_conv_wino_dgrad(const float* dy, const float* w, const float* add, float* dx, float* workspace,
-                                     size_t workspace_bytes, int N, int H, int W, int C, int K, hipStream_t stream) {
-    return wino_run(true, dy, w, nullptr, add, dx, workspace, workspace_bytes, N, H, W, K, C, stream);
+                                     size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
+                                     hipStream_t stream) {
+    return wino_run(tile, true, dy, w, nullptr, add, dx, workspace, workspace_bytes, N, H, W, K, C, stream);
 }

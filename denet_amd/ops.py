@@ -152,28 +152,30 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
     g = conv_geom(x.shape, w.shape, stride, pad, s_real)
     N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
     y = out if out is not None else empty(N, OH, OW, K)
-    tuned_now = _tune_first(0, g, x, w, bias, add, y, None)     # leaves the direct kernel's result in y
+    _tune_first(0, g, x, w, bias, add, y, None)
 
     def direct():
         check(_L().denet_conv_fwd(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), *g, stream_ptr()), "conv_fwd")
 
-    # the implementation is fixed on the first call and that call already returns ITS result (run-to-run determinism)
-    if _use_wino(0, g, direct, lambda: conv_wino_fwd(x, w, bias, add, out=y)):
+    # the implementation is fixed on the first call; the timed candidates scribble over `y`, so the call always ends
+    # with a launch of the chosen one (run-to-run determinism)
+    tile = _wino_tile(0, g, direct, lambda t: conv_wino_fwd(x, w, bias, add, out=y, tile=t))
+    if tile:
         if PROFILE is not None:
-            PROFILE.add(_conv_flops(g, logical) / 2.25)     # the FLOPs its batched GEMM really executes
-        return conv_wino_fwd(x, w, bias, add, out=y)
-    if tuned_now:
-        return y
+            PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])     # the FLOPs its batched GEMM really executes
+        return conv_wino_fwd(x, w, bias, add, out=y, tile=tile)
     if PROFILE is not None:
         PROFILE.add(_conv_flops(g, logical))
     direct()
     return y
 
 
-# Winograd F(2x2,3x3) is an alternative implementation of the eligible 3x3 layers; which one runs is measured once per
-# (pass, geometry) right after the direct kernel has been tuned. DENET_WINOGRAD=0 disables the path.
-WINOGRAD = os.environ.get("DENET_WINOGRAD", "1") != "0"
+# Winograd F(2x2,3x3) / F(4x4,3x3) are alternative implementations of the eligible 3x3 layers; which one runs is measured
+# once per (pass, geometry) right after the direct kernel has been tuned. DENET_WINOGRAD=0 disables the paths,
+# DENET_WINOGRAD=2 allows only F(2x2,3x3).
+WINOGRAD = int(os.environ.get("DENET_WINOGRAD", "4"))
 _WINO = {}
+_WINO_GAIN = {2: 2.25, 4: 4.0}      # direct multiplications / Winograd multiplications
 
 
 def _time_ms(fn, reps=3):
@@ -189,61 +191,72 @@ def _time_ms(fn, reps=3):
     return best
 
 
-def _use_wino(mode, g, direct, wino):
-    """decides (once) between the direct and the Winograd implementation of this pass by timing both"""
+def conv_wino_ok(g, tile=2):
+    """geometry the Winograd F(tile x tile, 3x3) path covers: 3x3, stride 1, pad 1, H/W multiples of the tile,
+    channels multiples of 32"""
+    N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
+    return R == 3 and S == 3 and s_real == 3 and stride == 1 and pad == 1 and H % tile == 0 and W % tile == 0 \
+        and C % 32 == 0 and K % 32 == 0
+
+
+def _wino_tile(mode, g, direct, wino):
+    """decides (once) between the direct kernel (0) and the Winograd tiles (2, 4) for this pass by timing them;
+    wino(tile) runs the pass with the given tile"""
     key = (mode, g)
     use = _WINO.get(key)
     if use is None:
-        if not (WINOGRAD and AUTOTUNE and conv_wino_ok(g)):
-            use = False
+        tiles = [t for t in (2, 4) if t <= WINOGRAD and conv_wino_ok(g, t)] if AUTOTUNE else []
+        if not tiles:
+            use = 0
         elif PROFILE is not None:
-            return False                 # undecided while a profile is being recorded: direct kernel, decide later
+            return 0                     # undecided while a profile is being recorded: direct kernel, decide later
         else:
             N, H, W, C, K = g[0], g[1], g[2], g[3], g[4]
-            ws = WS.get("wino", _L().denet_conv_wino_workspace_bytes(N, H, W, C, K))
             sws = WS.get("wgrad", WGRAD_WS_BYTES)
-            check(_L().denet_conv_wino_tune(ptr(ws), ws.numel(), ptr(sws), sws.numel(), N, H, W, C, K, stream_ptr()),
-                  "conv_wino_tune")
-            use = _time_ms(wino) < 0.97 * _time_ms(direct)
+            best, use = 0.97 * _time_ms(direct), 0
+            for t in tiles:
+                ws = WS.get("wino", _L().denet_conv_wino_workspace_bytes(t, N, H, W, C, K))
+                check(_L().denet_conv_wino_tune(ptr(ws), ws.numel(), ptr(sws), sws.numel(), t, N, H, W, C, K, stream_ptr()),
+                      "conv_wino_tune")
+                ms = _time_ms(lambda: wino(t))
+                if ms < best:
+                    best, use = ms, t
         _WINO[key] = use
     return use
 
 
-def conv_wino_ok(g):
-    """geometry the Winograd F(2x2,3x3) path covers: 3x3, stride 1, pad 1, even H/W, channels multiple of 32"""
-    N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
-    return R == 3 and S == 3 and s_real == 3 and stride == 1 and pad == 1 and H % 2 == 0 and W % 2 == 0 \
-        and C % 32 == 0 and K % 32 == 0
+def _wino_ws(tile, N, H, W, C, K):
+    return WS.get("wino", _L().denet_conv_wino_workspace_bytes(tile, N, H, W, C, K))
 
 
-def conv_wino_fwd(x, w, bias=None, add=None, out=None):
+def conv_wino_fwd(x, w, bias=None, add=None, out=None, tile=2):
     N, H, W, C = x.shape
     K = w.shape[0]
     y = out if out is not None else empty(N, H, W, K)
-    ws = WS.get("wino", _L().denet_conv_wino_workspace_bytes(N, H, W, C, K))
-    check(_L().denet_conv_wino_fwd(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), ptr(ws), ws.numel(), N, H, W, C, K,
+    ws = _wino_ws(tile, N, H, W, C, K)
+    check(_L().denet_conv_wino_fwd(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), ptr(ws), ws.numel(), tile, N, H, W, C, K,
                                    stream_ptr()), "conv_wino_fwd")
     return y
 
 
-def conv_wino_dgrad(dy, w, add=None, out=None):
+def conv_wino_dgrad(dy, w, add=None, out=None, tile=2):
     N, H, W, K = dy.shape
     C = w.shape[3]
     dx = out if out is not None else empty(N, H, W, C)
-    ws = WS.get("wino", _L().denet_conv_wino_workspace_bytes(N, H, W, C, K))
-    check(_L().denet_conv_wino_dgrad(ptr(dy), ptr(w), ptr(add), ptr(dx), ptr(ws), ws.numel(), N, H, W, C, K,
+    ws = _wino_ws(tile, N, H, W, C, K)
+    check(_L().denet_conv_wino_dgrad(ptr(dy), ptr(w), ptr(add), ptr(dx), ptr(ws), ws.numel(), tile, N, H, W, C, K,
                                      stream_ptr()), "conv_wino_dgrad")
     return dx
 
 
-def conv_wino_wgrad(x, dy, out=None):
+def conv_wino_wgrad(x, dy, out=None, tile=2):
     N, H, W, C = x.shape
     K = dy.shape[3]
     dw = out if out is not None else empty(K, 3, 3, C)
-    ws = WS.get("wino", _L().denet_conv_wino_workspace_bytes(N, H, W, C, K))
+    ws = _wino_ws(tile, N, H, W, C, K)
     sws = WS.get("wgrad", WGRAD_WS_BYTES)
-    check(_L().denet_conv_wino_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel(), ptr(sws), sws.numel(), N, H, W, C, K,
-                                     stream_ptr()), "conv_wino_wgrad")
+    check(_L().denet_conv_wino_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel(), ptr(sws), sws.numel(), tile, N, H, W,
+                                     C, K, stream_ptr()), "conv_wino_wgrad")
     return dw
 
 
@@ -251,17 +264,16 @@ def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None,
     g = conv_geom(x_shape, w.shape, stride, pad, s_real)
     assert tuple(dy.shape) == (g[0], g[10], g[11], g[4]), (dy.shape, g)
     dx = out if out is not None else empty(*x_shape)
-    tuned_now = _tune_first(1, g, dy, w, None, add, dx, None)
+    _tune_first(1, g, dy, w, None, add, dx, None)
 
     def direct():
         check(_L().denet_conv_dgrad(ptr(dy), ptr(w), ptr(add), ptr(dx), *g, stream_ptr()), "conv_dgrad")
 
-    if _use_wino(1, g, direct, lambda: conv_wino_dgrad(dy, w, add, out=dx)):
+    tile = _wino_tile(1, g, direct, lambda t: conv_wino_dgrad(dy, w, add, out=dx, tile=t))
+    if tile:
         if PROFILE is not None:
-            PROFILE.add(_conv_flops(g, logical) / 2.25)
-        return conv_wino_dgrad(dy, w, add, out=dx)
-    if tuned_now:
-        return dx
+            PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])
+        return conv_wino_dgrad(dy, w, add, out=dx, tile=tile)
     if PROFILE is not None:
         PROFILE.add(_conv_flops(g, logical))
     direct()
@@ -273,17 +285,16 @@ def conv_wgrad(x, dy, w_shape, stride=1, pad=0, s_real=None, out=None, logical=N
     assert tuple(dy.shape) == (g[0], g[10], g[11], g[4]), (dy.shape, g)
     dw = out if out is not None else empty(*w_shape)
     ws = WS.get("wgrad", WGRAD_WS_BYTES)
-    tuned_now = _tune_first(2, g, x, dy, None, None, dw, ws)
+    _tune_first(2, g, x, dy, None, None, dw, ws)
 
     def direct():
         check(_L().denet_conv_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel(), *g, stream_ptr()), "conv_wgrad")
 
-    if _use_wino(2, g, direct, lambda: conv_wino_wgrad(x, dy, out=dw)):
+    tile = _wino_tile(2, g, direct, lambda t: conv_wino_wgrad(x, dy, out=dw, tile=t))
+    if tile:
         if PROFILE is not None:
-            PROFILE.add(_conv_flops(g, logical) / 2.25)
-        return conv_wino_wgrad(x, dy, out=dw)
-    if tuned_now:
-        return dw
+            PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])
+        return conv_wino_wgrad(x, dy, out=dw, tile=tile)
     if PROFILE is not None:
         PROFILE.add(_conv_flops(g, logical))
     direct()

@@ -68,19 +68,21 @@ int denet_conv_dgrad(const float* dy, const float* w, const float* add, float* d
 size_t denet_conv_wgrad_workspace_bytes(int N, int C, int K, int R, int S, int OH, int OW);
 /* kernel instantiation picked by this thread's last conv launch: mode 0 fwd / 1 dgrad / 2 wgrad, tile BMxBN, LDS
  * buffers, grid.y (wgrad split slices / dgrad stride classes) — profiling bookkeeping only                      */
-/* Winograd F(2x2,3x3) path of the same stride-1 pad-1 3x3 convolution (forward / data gradient): 2.25x fewer
- * multiplications, three extra HBM-bound transforms; pays for many channels. H, W even; C, K multiples of 32.
- * workspace: denet_conv_wino_workspace_bytes (transformed filters, input tiles and products). denet_conv_wino_tune
- * measures the launch configuration of the component GEMMs once per geometry (it synchronises the stream).     */
-size_t denet_conv_wino_workspace_bytes(int N, int H, int W, int C, int K);
-int denet_conv_wino_tune(float* workspace, size_t workspace_bytes, float* split_ws, size_t split_ws_bytes, int N, int H,
-                         int W, int C, int K, hipStream_t stream);
-int denet_conv_wino_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes,
-                          float* split_ws, size_t split_ws_bytes, int N, int H, int W, int C, int K, hipStream_t stream);
+/* Winograd F(m x m, 3x3) paths of the same stride-1 pad-1 3x3 convolution, tile = m in {2, 4}: forward, data gradient and
+ * filter gradient with 2.25x (m = 2) / 4x (m = 4) fewer multiplications and extra HBM-bound transforms; they pay for
+ * many channels. H, W multiples of m; C, K multiples of 32. workspace: denet_conv_wino_workspace_bytes (transformed
+ * filters, input tiles and products); split_ws: split-K slices of the filter-gradient product (as denet_conv_wgrad).
+ * denet_conv_wino_tune measures the launch configuration of the component GEMMs once per geometry (it synchronises). */
+size_t denet_conv_wino_workspace_bytes(int tile, int N, int H, int W, int C, int K);
+int denet_conv_wino_tune(float* workspace, size_t workspace_bytes, float* split_ws, size_t split_ws_bytes, int tile, int N,
+                         int H, int W, int C, int K, hipStream_t stream);
 int denet_conv_wino_fwd(const float* x, const float* w, const float* bias, const float* add, float* y, float* workspace,
-                        size_t workspace_bytes, int N, int H, int W, int C, int K, hipStream_t stream);
+                        size_t workspace_bytes, int tile, int N, int H, int W, int C, int K, hipStream_t stream);
 int denet_conv_wino_dgrad(const float* dy, const float* w, const float* add, float* dx, float* workspace,
-                          size_t workspace_bytes, int N, int H, int W, int C, int K, hipStream_t stream);
+                          size_t workspace_bytes, int tile, int N, int H, int W, int C, int K, hipStream_t stream);
+int denet_conv_wino_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes,
+                          float* split_ws, size_t split_ws_bytes, int tile, int N, int H, int W, int C, int K,
+                          hipStream_t stream);
 /* measured launch configuration: times the candidate tile shapes / loop structures (wgrad: split-K round counts) of one
  * convolution pass on the caller's own buffers, remembers the fastest for this geometry and leaves the pass's result in
  * `out`. mode 0 = fwd (a = x, b = w), 1 = dgrad (a = dy, b = w), 2 = wgrad (a = x, b = dy, out = dw). This is the ONE

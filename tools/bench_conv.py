@@ -50,11 +50,12 @@ for name, H, W, C, K, R, st, pad, cnt in SHAPES:
     print("%-10s fwd %7.3f ms %6.1f TF | dgrad %7.3f ms %6.1f TF | wgrad %7.3f ms %6.1f TF  (x%d)" % (
         name, t_f, flop / t_f / 1e9, t_d, (flop / t_d / 1e9 if t_d else 0), t_w, flop / t_w / 1e9, cnt), flush=True)
     g = ops.conv_geom(x.shape, w.shape, st, pad, R)
-    if ops.conv_wino_ok(g):
-        tw_f = timeit(lambda: ops.conv_wino_fwd(x, w))
-        tw_d = timeit(lambda: ops.conv_wino_dgrad(dy, w))
-        tw_w = timeit(lambda: ops.conv_wino_wgrad(x, dy))
-        print("           winograd: fwd %7.3f ms (x%.2f) | dgrad %7.3f ms (x%.2f) | wgrad %7.3f ms (x%.2f)" % (tw_f, t_f / tw_f, tw_d, t_d / tw_d, tw_w, t_w / tw_w), flush=True)
+    for tile in (2, 4):
+        if ops.conv_wino_ok(g, tile):
+            tw_f = timeit(lambda: ops.conv_wino_fwd(x, w, tile=tile))
+            tw_d = timeit(lambda: ops.conv_wino_dgrad(dy, w, tile=tile))
+            tw_w = timeit(lambda: ops.conv_wino_wgrad(x, dy, tile=tile))
+            print("           winograd F%d: fwd %7.3f ms (x%.2f) | dgrad %7.3f ms (x%.2f) | wgrad %7.3f ms (x%.2f)" % (tile, tw_f, t_f / tw_f, tw_d, t_d / tw_d, tw_w, t_w / tw_w), flush=True)
     if ops.AUTOTUNE:
         import ctypes
         cfg = []
