@@ -289,8 +289,25 @@ int wino_dims(int mo, int N, int H, int W, int C, int K, WinoDims* d) {
         else hipLaunchKernelGGL(KERNEL<4>, dim3(blocks_), dim3(256), 0, stream, __VA_ARGS__);                        \
     }
 
-int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* bias, const float* add, float* out,
-             float* ws, size_t ws_bytes, int N, int H, int W, int Cin, int Cout, hipStream_t stream) {
+int wino_filter(int mo, bool dgrad, const float* w, float* U, int K, int C, hipStream_t stream) {
+    // w: [K,3,3,C]; forward: U[xi][K][C]; data gradient: U'[xi][C][K]
+    const unsigned fb = (unsigned)(((long)K * C + 255) / 256);
+    if (dgrad) {
+        if (mo == 2) hipLaunchKernelGGL((wino_filter_kernel<2, true>), dim3(fb), dim3(256), 0, stream, w, U, K, C);
+        else hipLaunchKernelGGL((wino_filter_kernel<4, true>), dim3(fb), dim3(256), 0, stream, w, U, K, C);
+    } else {
+        if (mo == 2) hipLaunchKernelGGL((wino_filter_kernel<2, false>), dim3(fb), dim3(256), 0, stream, w, U, K, C);
+        else hipLaunchKernelGGL((wino_filter_kernel<4, false>), dim3(fb), dim3(256), 0, stream, w, U, K, C);
+    }
+    DENET_CHECK_LAUNCH("conv_wino filter transform");
+    return DENET_OK;
+}
+
+// u_cached: transformed filters prepared by denet_conv_wino_filter (NULL: transform here); v_keep: where the transformed
+// input is written (NULL: inside the workspace) - the filter gradient of the same layer can reuse it
+int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u_cached, float* v_keep, const float* bias,
+             const float* add, float* out, float* ws, size_t ws_bytes, int N, int H, int W, int Cin, int Cout,
+             hipStream_t stream) {
     // in: [N,H,W,Cin]   out: [N,H,W,Cout]   w: KRSC with (K,C) = dgrad ? (Cin,Cout) : (Cout,Cin)
     DENET_CHECK_ARG(in && w && out && ws, "conv_wino: null pointer");
     WinoDims d;
@@ -298,17 +315,15 @@ int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* b
     if (rc) return rc;
     DENET_CHECK_ARG(ws_bytes >= (d.nU + d.nV + d.nM) * sizeof(float), "conv_wino: workspace too small (%zu < %zu)", ws_bytes,
                     (d.nU + d.nV + d.nM) * sizeof(float));
-    float* U = ws;
-    float* V = U + d.nU;
-    float* Mx = V + d.nV;
+    float* Uw = ws;
+    float* V = v_keep ? v_keep : Uw + d.nU;
+    float* Mx = Uw + d.nU + d.nV;
     const long kc = (long)Cin * Cout;
-    const unsigned fb = (unsigned)((kc + 255) / 256);
-    if (dgrad) {
-        if (mo == 2) hipLaunchKernelGGL((wino_filter_kernel<2, true>), dim3(fb), dim3(256), 0, stream, w, U, Cin, Cout);
-        else hipLaunchKernelGGL((wino_filter_kernel<4, true>), dim3(fb), dim3(256), 0, stream, w, U, Cin, Cout);
-    } else {
-        if (mo == 2) hipLaunchKernelGGL((wino_filter_kernel<2, false>), dim3(fb), dim3(256), 0, stream, w, U, Cout, Cin);
-        else hipLaunchKernelGGL((wino_filter_kernel<4, false>), dim3(fb), dim3(256), 0, stream, w, U, Cout, Cin);
+    const float* U = u_cached;
+    if (!U) {
+        rc = dgrad ? wino_filter(mo, true, w, Uw, Cin, Cout, stream) : wino_filter(mo, false, w, Uw, Cout, Cin, stream);
+        if (rc) return rc;
+        U = Uw;
     }
     WINO_LAUNCH(mo, wino_input_kernel, d.T * (Cin / 4), in, V, N, H, W, Cin, d.TH, d.TW, d.T);
     DENET_CHECK_LAUNCH("conv_wino transforms");
@@ -323,18 +338,22 @@ int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* b
 
 // dw = filter gradient of the 3x3 stride-1 pad-1 convolution; x:[N,H,W,C] dy:[N,H,W,K] dw:[K,3,3,C].
 // workspace (denet_conv_wino_workspace_bytes): dU | V | dM; split_ws: the split-K slices of the batched product.
-extern "C" int denet_conv_wino_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes,
-                                     float* split_ws, size_t split_ws_bytes, int tile, int N, int H, int W, int C, int K,
-                                     hipStream_t stream) {
+extern "C" int denet_conv_wino_wgrad(const float* x, const float* dy, const float* v_cached, float* dw, float* workspace,
+                                     size_t workspace_bytes, float* split_ws, size_t split_ws_bytes, int tile, int N, int H,
+                                     int W, int C, int K, hipStream_t stream) {
     DENET_CHECK_ARG(x && dy && dw && workspace, "conv_wino_wgrad: null pointer");
     WinoDims d;
     int rc = wino_dims(tile, N, H, W, C, K, &d);
     if (rc) return rc;
     DENET_CHECK_ARG(workspace_bytes >= (d.nU + d.nV + d.nM) * sizeof(float), "conv_wino_wgrad: workspace too small");
     float* dU = workspace;
-    float* V = dU + d.nU;
-    float* dM = V + d.nV;
-    WINO_LAUNCH(tile, wino_input_kernel, d.T * (C / 4), x, V, N, H, W, C, d.TH, d.TW, d.T);
+    const float* V = v_cached;
+    float* dM = dU + d.nU + d.nV;
+    if (!V) {      // v_cached: the transformed input the forward pass of this layer kept (same tile)
+        float* Vw = dU + d.nU;
+        WINO_LAUNCH(tile, wino_input_kernel, d.T * (C / 4), x, Vw, N, H, W, C, d.TH, d.TW, d.T);
+        V = Vw;
+    }
     WINO_LAUNCH(tile, wino_dout_kernel, d.T * (K / 4), dy, dM, N, H, W, K, d.TH, d.TW, d.T);
     DENET_CHECK_LAUNCH("conv_wino_wgrad transforms");
     rc = denet_wgrad_batched(V, dM, dU, split_ws, split_ws_bytes, d.NX, (int)d.T, C, K, stream);
@@ -370,15 +389,22 @@ extern "C" size_t denet_conv_wino_workspace_bytes(int tile, int N, int H, int W,
 }
 
 // y = conv3x3(x, w) stride 1 pad 1 (+ bias) (+ add); x:[N,H,W,C] w:[K,3,3,C] y:[N,H,W,K]; tile = 2: F(2x2,3x3), 4: F(4x4,3x3)
-extern "C" int denet_conv_wino_fwd(const float* x, const float* w, const float* bias, const float* add, float* y,
-                                   float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
-                                   hipStream_t stream) {
-    return wino_run(tile, false, x, w, bias, add, y, workspace, workspace_bytes, N, H, W, C, K, stream);
+extern "C" int denet_conv_wino_fwd(const float* x, const float* w, const float* u_cached, float* v_keep, const float* bias,
+                                   const float* add, float* y, float* workspace, size_t workspace_bytes, int tile, int N,
+                                   int H, int W, int C, int K, hipStream_t stream) {
+    return wino_run(tile, false, x, w, u_cached, v_keep, bias, add, y, workspace, workspace_bytes, N, H, W, C, K, stream);
+}
+
+// transformed filters of a layer, prepared ahead of its passes (e.g. for all layers on a side stream right after the
+// solver step): dgrad = 0: U[xi][K][C] for denet_conv_wino_fwd, 1: U'[xi][C][K] for denet_conv_wino_dgrad
+extern "C" int denet_conv_wino_filter(const float* w, float* u, int tile, int dgrad, int C, int K, hipStream_t stream) {
+    DENET_CHECK_ARG(w && u && (tile == 2 || tile == 4) && C > 0 && K > 0, "conv_wino_filter: bad arguments");
+    return wino_filter(tile, dgrad != 0, w, u, K, C, stream);
 }
 
 // dx = conv3x3_transposed(dy, w) (+ add); dy:[N,H,W,K] w:[K,3,3,C] dx:[N,H,W,C]
-extern "C" int denet_conv_wino_dgrad(const float* dy, const float* w, const float* add, float* dx, float* workspace,
-                                     size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
+extern "C" int denet_conv_wino_dgrad(const float* dy, const float* w, const float* u_cached, const float* add, float* dx,
+                                     float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
                                      hipStream_t stream) {
-    return wino_run(tile, true, dy, w, nullptr, add, dx, workspace, workspace_bytes, N, H, W, K, C, stream);
+    return wino_run(tile, true, dy, w, u_cached, nullptr, nullptr, add, dx, workspace, workspace_bytes, N, H, W, K, C, stream);
 }

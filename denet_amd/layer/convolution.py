@@ -141,11 +141,21 @@ class ConvLayer(AbstractLayer):
     def _logical(self):
         return (self.filter_shape[1], self.filter_shape[0])
 
+    def _cache(self):
+        """per-layer state of the Winograd passes (chosen tiles, transformed filters, kept input transform)"""
+        c = self.__dict__.get("_wino_cache")
+        if c is None:
+            c = self.__dict__["_wino_cache"] = {}
+        return c
+
     def forward(self, ctx, add=None):
+        from . import get_train
         x = self.input.data
+        cache = self._cache()
+        cache["train"] = bool(get_train()) and self.enabled and self.omega.grad is not None
         self.output.data = ops.conv_fwd(x, self._w(), bias=self.beta.dev if self.use_bias else None, add=add,
                                         stride=self.stride[0], pad=self.pad, s_real=self.filter_shape[3],
-                                        logical=self._logical())
+                                        logical=self._logical(), cache=cache)
 
     def backward(self, ctx):
         dy = self.output.grad
@@ -153,9 +163,9 @@ class ConvLayer(AbstractLayer):
         st, pad, sr = self.stride[0], self.pad, self.filter_shape[3]
         if self.enabled and self.omega.grad is not None:
             ops.conv_wgrad(x, dy, self.omega.dev_shape, stride=st, pad=pad, s_real=sr,
-                           out=self.omega.grad.view(self.omega.dev_shape), logical=self._logical())
+                           out=self.omega.grad.view(self.omega.dev_shape), logical=self._logical(), cache=self._cache())
             if self.use_bias:
                 ops.colsum(dy.view(-1, self.kp), out=self.beta.grad)
         if getattr(self.input, "requires_grad", True):
             self.input.grad = ops.conv_dgrad(dy, self._w(), tuple(x.shape), add=self.input.grad, stride=st, pad=pad,
-                                             s_real=sr, logical=self._logical())
+                                             s_real=sr, logical=self._logical(), cache=self._cache())

@@ -28,9 +28,10 @@ SIGNATURES = {
     "denet_conv_wgrad_workspace_bytes": (Z, [I] * 7),
     "denet_conv_wino_workspace_bytes": (Z, [I] * 6),
     "denet_conv_wino_tune": (I, [P, Z, P, Z] + [I] * 6 + [P]),
-    "denet_conv_wino_wgrad": (I, [P, P, P, P, Z, P, Z] + [I] * 6 + [P]),
-    "denet_conv_wino_fwd": (I, [P] * 6 + [Z] + [I] * 6 + [P]),
-    "denet_conv_wino_dgrad": (I, [P] * 5 + [Z] + [I] * 6 + [P]),
+    "denet_conv_wino_wgrad": (I, [P, P, P, P, P, Z, P, Z] + [I] * 6 + [P]),
+    "denet_conv_wino_filter": (I, [P, P, I, I, I, I, P]),
+    "denet_conv_wino_fwd": (I, [P] * 8 + [Z] + [I] * 6 + [P]),
+    "denet_conv_wino_dgrad": (I, [P] * 6 + [Z] + [I] * 6 + [P]),
     "denet_conv_tune": (I, [I, P, P, P, P, P, P, Z] + [I] * 12 + [P]),
     "denet_conv_tuned": (I, [I] * 11 + [P, P, P]),
     "denet_conv_last_config": (I, [P] * 5),

@@ -307,6 +307,14 @@ class ModelCNN:
             a.grad = None
         self._upload_input(data_x)
         ctx = StepContext(self)
+        if train:
+            # filters of the Winograd passes: transformed for all layers on a side stream while the stem runs
+            from .. import ops
+            convs = getattr(self, "_conv_layers", None)
+            if convs is None:
+                convs = self._conv_layers = [l for l in walk_layers(self.layers) if l.type_name == "conv" and
+                                             getattr(l, "enabled", True)]
+            ops.wino_prefetch_filters([(l._cache(), l._w()) for l in convs])
         if train and data_m is not None:
             for layer in self.layers[1:]:
                 layer.begin_step(data_m)

@@ -148,7 +148,7 @@ def _tune_first(mode, g, a, b, bias, add, out, ws):
     return True
 
 
-def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, logical=None):
+def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, logical=None, cache=None):
     g = conv_geom(x.shape, w.shape, stride, pad, s_real)
     N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
     y = out if out is not None else empty(N, OH, OW, K)
@@ -163,7 +163,20 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
     if tile:
         if PROFILE is not None:
             PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])     # the FLOPs its batched GEMM really executes
-        return conv_wino_fwd(x, w, bias, add, out=y, tile=tile)
+        u = v_keep = None
+        if cache is not None:
+            cache["fwd_tile"] = tile
+            u = _cached_u(cache, 0, tile)
+            # the filter gradient of this layer uses the same transformed input when it runs with the same tile
+            if cache.get("train") and _WINO.get((2, g)) == tile:
+                v_keep = cache.get("V")
+                nv = (tile + 2) * (tile + 2) * (N * (H // tile) * (W // tile)) * C
+                if v_keep is None or v_keep.numel() != nv:
+                    v_keep = cache["V"] = torch.empty(nv, dtype=torch.float32, device="cuda")
+                cache["V_tile"] = tile
+        return conv_wino_fwd(x, w, bias, add, out=y, tile=tile, u=u, v_keep=v_keep)
+    if cache is not None:
+        cache["fwd_tile"] = 0
     if PROFILE is not None:
         PROFILE.add(_conv_flops(g, logical))
     direct()
@@ -225,42 +238,92 @@ def _wino_tile(mode, g, direct, wino):
     return use
 
 
+def _cached_u(cache, dgrad, tile):
+    """transformed filters prepared ahead by wino_prefetch_filters (None: the call transforms them itself)"""
+    ent = cache.get(("u", dgrad))
+    if ent is None or ent[0] != tile or not ent[2]:
+        return None
+    wait_upload(cache.get("u_event"))
+    ent[2] = False                            # valid for one step: the solver changes the weights
+    return ent[1]
+
+
+def wino_prefetch_filters(caches_and_weights):
+    """For every convolution layer that runs Winograd passes: transform its filters for the forward and the data-gradient
+    pass on a side stream, right at the start of a training step (the ~60 small launches leave the critical path)."""
+    global _SIDE_FILTER
+    todo = [(c, w) for c, w in caches_and_weights if c.get("fwd_tile") or c.get("dgrad_tile")]
+    if not todo:
+        return
+    if _SIDE_FILTER is None:
+        _SIDE_FILTER = torch.cuda.Stream()
+    _SIDE_FILTER.wait_stream(torch.cuda.current_stream())        # the solver update of the weights
+    with torch.cuda.stream(_SIDE_FILTER):
+        for c, w in todo:
+            for dgrad, key in ((0, "fwd_tile"), (1, "dgrad_tile")):
+                tile = c.get(key)
+                if not tile:
+                    continue
+                ent = c.get(("u", dgrad))
+                if ent is None or ent[0] != tile:
+                    K, _, _, C = w.shape
+                    ent = c[("u", dgrad)] = [tile, torch.empty((tile + 2) * (tile + 2) * K * C, dtype=torch.float32, device="cuda"), False]
+                conv_wino_filter(w, tile, dgrad, out=ent[1])
+                ent[2] = True
+        ev = torch.cuda.Event()
+        ev.record(_SIDE_FILTER)
+    for c, _ in todo:
+        c["u_event"] = ev
+
+
+_SIDE_FILTER = None
+
+
 def _wino_ws(tile, N, H, W, C, K):
     return WS.get("wino", _L().denet_conv_wino_workspace_bytes(tile, N, H, W, C, K))
 
 
-def conv_wino_fwd(x, w, bias=None, add=None, out=None, tile=2):
+def conv_wino_fwd(x, w, bias=None, add=None, out=None, tile=2, u=None, v_keep=None):
     N, H, W, C = x.shape
     K = w.shape[0]
     y = out if out is not None else empty(N, H, W, K)
     ws = _wino_ws(tile, N, H, W, C, K)
-    check(_L().denet_conv_wino_fwd(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), ptr(ws), ws.numel(), tile, N, H, W, C, K,
-                                   stream_ptr()), "conv_wino_fwd")
+    check(_L().denet_conv_wino_fwd(ptr(x), ptr(w), ptr(u), ptr(v_keep), ptr(bias), ptr(add), ptr(y), ptr(ws), ws.numel(),
+                                   tile, N, H, W, C, K, stream_ptr()), "conv_wino_fwd")
     return y
 
 
-def conv_wino_dgrad(dy, w, add=None, out=None, tile=2):
+def conv_wino_dgrad(dy, w, add=None, out=None, tile=2, u=None):
     N, H, W, K = dy.shape
     C = w.shape[3]
     dx = out if out is not None else empty(N, H, W, C)
     ws = _wino_ws(tile, N, H, W, C, K)
-    check(_L().denet_conv_wino_dgrad(ptr(dy), ptr(w), ptr(add), ptr(dx), ptr(ws), ws.numel(), tile, N, H, W, C, K,
+    check(_L().denet_conv_wino_dgrad(ptr(dy), ptr(w), ptr(u), ptr(add), ptr(dx), ptr(ws), ws.numel(), tile, N, H, W, C, K,
                                      stream_ptr()), "conv_wino_dgrad")
     return dx
 
 
-def conv_wino_wgrad(x, dy, out=None, tile=2):
+def conv_wino_wgrad(x, dy, out=None, tile=2, v=None):
     N, H, W, C = x.shape
     K = dy.shape[3]
     dw = out if out is not None else empty(K, 3, 3, C)
     ws = _wino_ws(tile, N, H, W, C, K)
     sws = WS.get("wgrad", WGRAD_WS_BYTES)
-    check(_L().denet_conv_wino_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel(), ptr(sws), sws.numel(), tile, N, H, W,
-                                     C, K, stream_ptr()), "conv_wino_wgrad")
+    check(_L().denet_conv_wino_wgrad(ptr(x), ptr(dy), ptr(v), ptr(dw), ptr(ws), ws.numel(), ptr(sws), sws.numel(), tile, N, H,
+                                     W, C, K, stream_ptr()), "conv_wino_wgrad")
     return dw
 
 
-def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None, logical=None):
+def conv_wino_filter(w, tile, dgrad, out=None):
+    """transformed filters [(tile+2)^2, K, C] (dgrad: [.., C, K]) for the u= argument of conv_wino_fwd / _dgrad"""
+    K, _, _, C = w.shape
+    nx = (tile + 2) * (tile + 2)
+    u = out if out is not None else empty(nx, K, C)
+    check(_L().denet_conv_wino_filter(ptr(w), ptr(u), tile, int(dgrad), C, K, stream_ptr()), "conv_wino_filter")
+    return u
+
+
+def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None, logical=None, cache=None):
     g = conv_geom(x_shape, w.shape, stride, pad, s_real)
     assert tuple(dy.shape) == (g[0], g[10], g[11], g[4]), (dy.shape, g)
     dx = out if out is not None else empty(*x_shape)
@@ -273,14 +336,20 @@ def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None,
     if tile:
         if PROFILE is not None:
             PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])
-        return conv_wino_dgrad(dy, w, add, out=dx, tile=tile)
+        u = None
+        if cache is not None:
+            cache["dgrad_tile"] = tile
+            u = _cached_u(cache, 1, tile)
+        return conv_wino_dgrad(dy, w, add, out=dx, tile=tile, u=u)
+    if cache is not None:
+        cache["dgrad_tile"] = 0
     if PROFILE is not None:
         PROFILE.add(_conv_flops(g, logical))
     direct()
     return dx
 
 
-def conv_wgrad(x, dy, w_shape, stride=1, pad=0, s_real=None, out=None, logical=None):
+def conv_wgrad(x, dy, w_shape, stride=1, pad=0, s_real=None, out=None, logical=None, cache=None):
     g = conv_geom(x.shape, w_shape, stride, pad, s_real)
     assert tuple(dy.shape) == (g[0], g[10], g[11], g[4]), (dy.shape, g)
     dw = out if out is not None else empty(*w_shape)
@@ -294,7 +363,11 @@ def conv_wgrad(x, dy, w_shape, stride=1, pad=0, s_real=None, out=None, logical=N
     if tile:
         if PROFILE is not None:
             PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])
-        return conv_wino_wgrad(x, dy, out=dw, tile=tile)
+        v = None
+        if cache is not None and cache.get("V_tile") == tile:
+            v = cache.get("V")
+            cache["V_tile"] = None            # consumed: the next forward pass writes a fresh one
+        return conv_wino_wgrad(x, dy, out=dw, tile=tile, v=v)
     if PROFILE is not None:
         PROFILE.add(_conv_flops(g, logical))
     direct()

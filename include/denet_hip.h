@@ -76,13 +76,19 @@ size_t denet_conv_wgrad_workspace_bytes(int N, int C, int K, int R, int S, int O
 size_t denet_conv_wino_workspace_bytes(int tile, int N, int H, int W, int C, int K);
 int denet_conv_wino_tune(float* workspace, size_t workspace_bytes, float* split_ws, size_t split_ws_bytes, int tile, int N,
                          int H, int W, int C, int K, hipStream_t stream);
-int denet_conv_wino_fwd(const float* x, const float* w, const float* bias, const float* add, float* y, float* workspace,
-                        size_t workspace_bytes, int tile, int N, int H, int W, int C, int K, hipStream_t stream);
-int denet_conv_wino_dgrad(const float* dy, const float* w, const float* add, float* dx, float* workspace,
-                          size_t workspace_bytes, int tile, int N, int H, int W, int C, int K, hipStream_t stream);
-int denet_conv_wino_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes,
-                          float* split_ws, size_t split_ws_bytes, int tile, int N, int H, int W, int C, int K,
+/* u_cached: transformed filters from denet_conv_wino_filter (dgrad = 0 / 1), or NULL to transform inside the call;
+ * v_keep: [(m+2)^2 * tiles * C] buffer receiving the transformed input of the forward pass, v_cached: the same buffer
+ * handed to the filter gradient of that layer (same tile), or NULL.                                             */
+int denet_conv_wino_filter(const float* w, float* u, int tile, int dgrad, int C, int K, hipStream_t stream);
+int denet_conv_wino_fwd(const float* x, const float* w, const float* u_cached, float* v_keep, const float* bias,
+                        const float* add, float* y, float* workspace, size_t workspace_bytes, int tile, int N, int H, int W,
+                        int C, int K, hipStream_t stream);
+int denet_conv_wino_dgrad(const float* dy, const float* w, const float* u_cached, const float* add, float* dx,
+                          float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
                           hipStream_t stream);
+int denet_conv_wino_wgrad(const float* x, const float* dy, const float* v_cached, float* dw, float* workspace,
+                          size_t workspace_bytes, float* split_ws, size_t split_ws_bytes, int tile, int N, int H, int W, int C,
+                          int K, hipStream_t stream);
 /* measured launch configuration: times the candidate tile shapes / loop structures (wgrad: split-K round counts) of one
  * convolution pass on the caller's own buffers, remembers the fastest for this geometry and leaves the pass's result in
  * `out`. mode 0 = fwd (a = x, b = w), 1 = dgrad (a = dy, b = w), 2 = wgrad (a = x, b = dy, out = dw). This is the ONE
