@@ -307,21 +307,22 @@ class ModelCNN:
             a.grad = None
         self._upload_input(data_x)
         ctx = StepContext(self)
-        if train:
-            # filters of the Winograd passes: transformed for all layers on a side stream while the stem runs
-            from .. import ops
-            convs = getattr(self, "_conv_layers", None)
-            if convs is None:
-                convs = self._conv_layers = [l for l in walk_layers(self.layers) if l.type_name == "conv" and
-                                             getattr(l, "enabled", True)]
-            ops.wino_prefetch_filters([(l._cache(), l._w()) for l in convs])
         if train and data_m is not None:
             for layer in self.layers[1:]:
                 layer.begin_step(data_m)
-        for layer in self.layers[1:]:
+        for i, layer in enumerate(self.layers[1:]):
             if train and data_m is not None:
                 layer.prepare_target(ctx, self, data_x, data_m)
             layer.forward(ctx)
+            if train and i == 0:
+                # filters of the Winograd passes: transformed for all layers on a side stream while the stem runs (the
+                # ~60 launches are queued behind the first convolution so that the compute stream never waits for them)
+                from .. import ops
+                convs = getattr(self, "_conv_layers", None)
+                if convs is None:
+                    convs = self._conv_layers = [l for l in walk_layers(self.layers) if l.type_name == "conv" and
+                                                 getattr(l, "enabled", True)]
+                ops.wino_prefetch_filters([(l._cache(), l._w()) for l in convs])
         return ctx
 
     def backward(self, ctx):
