@@ -150,7 +150,12 @@ def main():
                                "MSCOCO, full train step (targets, fwd, bwd, nesterov), %s corner regime" % args.regime,
                    "global_batch": BATCH_PER_GPU * world, "batch_per_gpu": BATCH_PER_GPU, "classes": 80,
                    "rois_per_image": 576, "parallelism": "dp%d" % world, "solver": "nesterov",
+                   "conv_algorithms": "fp32 throughout; per layer and pass the faster of the direct implicit GEMM and "
+                                      "Winograd F(2x2,3x3)/F(4x4,3x3) is measured on the first step (DENET_WINOGRAD=0: "
+                                      "direct kernels only)",
                    "final_cost": round(float(cost), 5)},
+        # rate in FLOPs of the reference's direct algorithm (164.3 GFLOP per image and step); layers that run Winograd
+        # execute fewer, so this is an effective rate - the MFMA utilisation of the kernels is in `roofline`
         "step_tflops_algorithmic": round(value * FLOP_PER_IMAGE_STEP / 1e12, 2),
         "step_frac_of_fp32_mfma_peak": round(value * FLOP_PER_IMAGE_STEP / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
     }
