@@ -432,6 +432,194 @@ float run_il(const float* A, const float* B, float* C, int M, int N, int K, int 
     return ms / iters;
 }
 
+// ---- persistent variant of gemm_il: a workgroup walks tiles w, w+G, w+2G, ... and treats their K chunks as ONE stream:
+// the staging pipeline (LDS ring, register prefetch) never drains at a tile boundary, only the accumulators are stored
+template <int BM, int BN, int WM, int WN, int OCC, int NB>
+__global__ __launch_bounds__(256, OCC) void gemm_pers(const float* __restrict__ A, const float* __restrict__ B,
+                                                       float* __restrict__ C, int M, int N, int K) {
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int SZA = BM * LDK, SZB = BN * LDK;
+    constexpr int PA = BM / 32, PB = BN / 32;
+    static_assert(PA <= 4 && PB <= 4, "quarters");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;
+    float* sB = smem + NB * SZA;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
+    const int tiles_n = N / BN, ntiles = (M / BM) * tiles_n;
+    const int ksteps = K / BK;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (my_tiles <= 0) return;
+    const int total = my_tiles * ksteps;
+    const int q8 = tid & 7, row8 = tid >> 3;
+    // load cursor
+    int l_tile = blockIdx.x, l_k = 0;
+    const float* pa[PA];
+    const float* pb[PB];
+    auto set_ptrs = [&](int tile) {
+        const int tn = tile % tiles_n, tmm = tile / tiles_n;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) pa[i] = A + (long)(tmm * BM + row8 + 32 * i) * K + 4 * q8;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) pb[i] = B + (long)(tn * BN + row8 + 32 * i) * K + 4 * q8;
+    };
+    set_ptrs(l_tile);
+    auto advance_load = [&]() {
+        if (++l_k == ksteps) {
+            l_k = 0;
+            l_tile += gridDim.x;
+            if (l_tile < ntiles) set_ptrs(l_tile);
+        }
+    };
+    f32x4 ra[PA], rb[PB];
+    auto load_all = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) ra[i] = *(const f32x4*)(pa[i] + l_k * BK);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) rb[i] = *(const f32x4*)(pb[i] + l_k * BK);
+    };
+    auto store_all = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) *(f32x4*)(sA + buf * SZA + (row8 + 32 * i) * LDK + 4 * q8) = ra[i];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) *(f32x4*)(sB + buf * SZB + (row8 + 32 * i) * LDK + 4 * q8) = rb[i];
+    };
+    f32x16 acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    zero_acc();
+    const int fa = (wm * TM * 32 + li) * LDK + 4 * lh;
+    const int fb = (wn * TN * 32 + li) * LDK + 4 * lh;
+    auto load_frags = [&](int buf, int kb, float (&av)[TM][4], float (&bv)[TN][4]) {
+        const float* cA = sA + buf * SZA + fa;
+        const float* cB = sB + buf * SZB + fb;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const f32x4 t = *(const f32x4*)(cA + i * 32 * LDK + kb * 8);
+            av[i][0] = t[0]; av[i][1] = t[1]; av[i][2] = t[2]; av[i][3] = t[3];
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const f32x4 t = *(const f32x4*)(cB + j * 32 * LDK + kb * 8);
+            bv[j][0] = t[0]; bv[j][1] = t[1]; bv[j][2] = t[2]; bv[j][3] = t[3];
+        }
+    };
+    float av[2][TM][4], bv[2][TN][4];
+    constexpr int AH = NB - 1;
+    // prologue: chunks 0..AH-1 -> LDS, chunk AH -> registers
+    load_all(); advance_load(); store_all(0);
+    if (NB == 3 && total > 1) { load_all(); advance_load(); store_all(1); }
+    if (total > AH) { load_all(); advance_load(); }
+    __syncthreads();
+    load_frags(0, 0, av[0], bv[0]);
+    int cur = 0, c_tile = blockIdx.x, c_k = 0;
+    auto body = [&](auto WF, auto LF, auto NF) {
+        constexpr bool do_w = decltype(WF)::value, do_l = decltype(LF)::value, has_next = decltype(NF)::value;
+        const int nxt = (cur == NB - 1) ? 0 : cur + 1;
+        const int wbuf = (NB == 2) ? nxt : ((nxt == NB - 1) ? 0 : nxt + 1);
+        float* wA = sA + wbuf * SZA + row8 * LDK + 4 * q8;
+        float* wB = sB + wbuf * SZB + row8 * LDK + 4 * q8;
+        auto step = [&](auto KB) {
+            constexpr int kb = decltype(KB)::value;
+            if (kb < 3) load_frags(cur, kb + 1, av[(kb + 1) & 1], bv[(kb + 1) & 1]);
+            else if (NB == 3 && has_next) load_frags(nxt, 0, av[0], bv[0]);
+            if constexpr (kb < PA) {
+                if (do_w) *(f32x4*)(wA + 32 * kb * LDK) = ra[kb];
+                if (do_l) ra[kb] = *(const f32x4*)(pa[kb] + l_k * BK);
+            }
+            if constexpr (kb < PB) {
+                if (do_w) *(f32x4*)(wB + 32 * kb * LDK) = rb[kb];
+                if (do_l) rb[kb] = *(const f32x4*)(pb[kb] + l_k * BK);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb & 1][i][t], bv[kb & 1][j][t], acc[i][j], 0, 0, 0);
+            constexpr int NM = 4 * TM * TN;
+            constexpr int NR = (kb < 3 || (NB == 3 && has_next)) ? TM + TN : 0;
+            constexpr int NW = do_w ? ((kb < PA) ? 1 : 0) + ((kb < PB) ? 1 : 0) : 0;
+#pragma unroll
+            for (int g = 0; g < NR; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < NW; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                if (do_l) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+            if constexpr (NM - NR - NW > 0) __builtin_amdgcn_sched_group_barrier(0x008, NM - NR - NW, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
+        if (do_l) advance_load();
+        if (++c_k == ksteps) {          // tile finished: store and clear the accumulators, the staging keeps streaming
+            const int tn = c_tile % tiles_n, tmm = c_tile / tiles_n;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = tn * BN + (wn * TN + j) * 32 + li;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = tmm * BM + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        C[(long)m * N + n] = acc[i][j][r];
+                    }
+                }
+            zero_acc();
+            c_k = 0;
+            c_tile += gridDim.x;
+        }
+        __syncthreads();
+        if (NB == 2 && has_next) load_frags(nxt, 0, av[0], bv[0]);
+        cur = nxt;
+    };
+    {
+        using T = std::true_type; using F = std::false_type;
+        int s = 0;
+        for (; s + AH + 1 < total; ++s) body(T{}, T{}, T{});
+        for (; s + AH < total; ++s) body(T{}, F{}, T{});
+        for (; s + 1 < total; ++s) body(F{}, F{}, T{});
+        for (; s < total; ++s) body(F{}, F{}, F{});
+    }
+}
+
+template <int BM, int BN, int OCC, int NB>
+float run_pers(const float* A, const float* B, float* C, int M, int N, int K, int iters, int wgs_per_cu) {
+    constexpr size_t lds = NB * (size_t)(BM + BN) * LDK * sizeof(float);
+    CK(hipFuncSetAttribute((const void*)gemm_pers<BM, BN, 2, 2, OCC, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int ntiles = (M / BM) * (N / BN);
+    int g = 256 * wgs_per_cu; if (g > ntiles) g = ntiles;
+    dim3 grid(g);
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    gemm_pers<BM, BN, 2, 2, OCC, NB><<<grid, 256, lds>>>(A, B, C, M, N, K);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) gemm_pers<BM, BN, 2, 2, OCC, NB><<<grid, 256, lds>>>(A, B, C, M, N, K);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return ms / iters;
+}
+
 template <int BM, int BN, int WM, int WN, int NBUF, int VAR>
 float run(const float* A, const float* B, float* C, int M, int N, int K, int iters) {
     constexpr size_t lds = NBUF * (size_t)(BM + BN) * LDK * sizeof(float);
@@ -463,6 +651,18 @@ int main(int argc, char** argv) {
     { float ms = run_pipe<128, 128, 1, 1>(A, B, C, M, N, K, 10); printf("pipe3 128x128 pd1: %.3f ms %.1f TF\n", ms, flop / ms / 1e9); }
     { float ms = run_pipe<128, 128, 1, 2>(A, B, C, M, N, K, 10); printf("pipe3 128x128 pd2: %.3f ms %.1f TF\n", ms, flop / ms / 1e9); }
     { float ms = run_pipe<128, 64, 1, 2>(A, B, C, M, N, K, 10); printf("pipe3 128x64 pd2: %.3f ms %.1f TF\n", ms, flop / ms / 1e9); }
+#define RUNP(BM, BN, OCC, NB, W) { float ms = run_pers<BM, BN, OCC, NB>(A, B, C, M, N, K, 10, W); printf("pers %dx%d occ %d nb %d wg/cu %d : %.3f ms %.1f TF\n", BM, BN, OCC, NB, W, ms, flop / ms / 1e9); fflush(stdout); }
+    RUNP(128, 128, 2, 2, 2) RUNP(128, 128, 1, 3, 1) RUNP(128, 64, 2, 2, 2) RUNP(128, 64, 3, 2, 3) RUNP(128, 64, 2, 3, 2)
+    {
+        std::vector<float> c1((size_t)256 * N), c2((size_t)256 * N);
+        run<128, 128, 2, 2, 2, 0>(A, B, C, M, N, K, 1);
+        CK(hipMemcpy(c1.data(), C + (size_t)(M - 256) * N, c1.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemset(C, 0, (size_t)M * N * 4));
+        run_pers<128, 64, 2, 2>(A, B, C, M, N, K, 1, 2);
+        CK(hipMemcpy(c2.data(), C + (size_t)(M - 256) * N, c2.size() * 4, hipMemcpyDeviceToHost));
+        double md = 0; for (size_t i = 0; i < c1.size(); ++i) md = fmax(md, fabs((double)c1[i] - c2[i]));
+        printf("max |pers - base| (last rows) = %g\n", md);
+    }
 #define RUNIL(BM, BN, OCC, NB, IL) { float ms = run_il<BM, BN, OCC, NB, IL>(A, B, C, M, N, K, 10); printf("il %dx%d occ %d nb %d il %d : %.3f ms %.1f TF\n", BM, BN, OCC, NB, IL, ms, flop / ms / 1e9); fflush(stdout); }
     RUNIL(128, 128, 2, 2, 1) RUNIL(128, 128, 2, 2, 2) RUNIL(128, 128, 1, 3, 1) RUNIL(128, 128, 1, 3, 2) RUNIL(128, 64, 2, 2, 2) RUNIL(128, 64, 3, 2, 2)
     {
