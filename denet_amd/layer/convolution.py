@@ -162,10 +162,12 @@ class ConvLayer(AbstractLayer):
         x = self.input.data
         st, pad, sr = self.stride[0], self.pad, self.filter_shape[3]
         if self.enabled and self.omega.grad is not None:
-            ops.conv_wgrad(x, dy, self.omega.dev_shape, stride=st, pad=pad, s_real=sr,
-                           out=self.omega.grad.view(self.omega.dev_shape), logical=self._logical(), cache=self._cache())
-            if self.use_bias:
-                ops.colsum(dy.view(-1, self.kp), out=self.beta.grad)
+            with ops.wgrad_stream():        # independent of the data-gradient chain below
+                ops.conv_wgrad(x, dy, self.omega.dev_shape, stride=st, pad=pad, s_real=sr,
+                               out=self.omega.grad.view(self.omega.dev_shape), logical=self._logical(),
+                               cache=self._cache())
+                if self.use_bias:
+                    ops.colsum(dy.view(-1, self.kp), out=self.beta.grad)
         if getattr(self.input, "requires_grad", True):
             self.input.grad = ops.conv_dgrad(dy, self._w(), tuple(x.shape), add=self.input.grad, stride=st, pad=pad,
                                              s_real=sr, logical=self._logical(), cache=self._cache())

@@ -343,6 +343,7 @@ class ModelCNN:
             layer.backward(ctx)
             if dist is not None:
                 dist.layer_done(self, layer)
+        ops.join_wgrad_stream()           # filter / bias gradients (second stream) before all-reduce tail and solver
         if dist is not None:
             dist.finish_step(self)
 

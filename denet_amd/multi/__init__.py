@@ -80,7 +80,16 @@ class DataParallel:
         r = self._trigger.get(id(layer))
         if r is not None and (self.world_size > 1 or self.force_collectives):
             lo, hi = r
+            self._join_wgrad()
             self._pending.append(self.dist.all_reduce(model.G[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True))
+
+    @staticmethod
+    def _join_wgrad():
+        """the weight gradients of a bucket are produced on the wgrad stream (ops.wgrad_stream)"""
+        import torch
+        if torch.cuda.is_available():
+            from .. import ops
+            ops.join_wgrad_stream()
 
     def finish_step(self, model):
         if self.world_size > 1 or self.force_collectives:

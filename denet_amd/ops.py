@@ -279,8 +279,46 @@ def wino_prefetch_filters(caches_and_weights):
 _SIDE_FILTER = None
 
 
+_WGRAD_STREAM = None
+_ON_WGRAD_STREAM = False
+WGRAD_STREAM = os.environ.get("DENET_WGRAD_STREAM", "1") != "0"
+
+
+class wgrad_stream:
+    """context: filter-gradient work of a layer (wgrad, bias column sums) on a second stream, ordered after everything
+    queued so far on the compute stream. The data-gradient chain continues on the compute stream meanwhile: the
+    tails of the many short kernels of one chain overlap with the heads of the other, and the HBM-bound transforms of
+    one with the MFMA-bound products of the other. join_wgrad_stream() before the gradients are consumed."""
+
+    def __enter__(self):
+        global _WGRAD_STREAM, _ON_WGRAD_STREAM
+        self.active = WGRAD_STREAM and PROFILE is None
+        if not self.active:
+            return self
+        if _WGRAD_STREAM is None:
+            _WGRAD_STREAM = torch.cuda.Stream()
+        _WGRAD_STREAM.wait_stream(torch.cuda.current_stream())
+        self.ctx = torch.cuda.stream(_WGRAD_STREAM)
+        self.ctx.__enter__()
+        _ON_WGRAD_STREAM = True
+        return self
+
+    def __exit__(self, *a):
+        global _ON_WGRAD_STREAM
+        if self.active:
+            _ON_WGRAD_STREAM = False
+            self.ctx.__exit__(*a)
+        return False
+
+
+def join_wgrad_stream():
+    if _WGRAD_STREAM is not None:
+        torch.cuda.current_stream().wait_stream(_WGRAD_STREAM)
+
+
 def _wino_ws(tile, N, H, W, C, K):
-    return WS.get("wino", _L().denet_conv_wino_workspace_bytes(tile, N, H, W, C, K))
+    # the second stream has its own transform workspace (the two chains run concurrently)
+    return WS.get("wino_side" if _ON_WGRAD_STREAM else "wino", _L().denet_conv_wino_workspace_bytes(tile, N, H, W, C, K))
 
 
 def conv_wino_fwd(x, w, bias=None, add=None, out=None, tile=2, u=None, v_keep=None):
@@ -499,7 +537,7 @@ def colsum(x, out=None):
     C = x.shape[-1]
     M = x.numel() // C
     out = out if out is not None else empty(C)
-    ws = WS.get("colsum", _L().denet_colsum_workspace_bytes(M, C))
+    ws = WS.get("colsum_side" if _ON_WGRAD_STREAM else "colsum", _L().denet_colsum_workspace_bytes(M, C))
     check(_L().denet_colsum(ptr(x), ptr(out), ptr(ws), M, C, stream_ptr()), "colsum")
     return out
 
