@@ -224,7 +224,14 @@ __global__ __launch_bounds__(256) void sparse_bwd_kernel(const float* __restrict
         for (int c = 0; c < 4; ++c) tot[c] += __shfl(acc[c], f4 + k * F4, 64);
     }
     float* o = dfmap + cellg * CP;
-    if (lane < F4) *(f32x4*)(o + coff + lane * 4) = tot;
+    if (lane < F4) {
+        if ((coff & 3) == 0) {
+            *(f32x4*)(o + coff + lane * 4) = tot;
+        } else {      // DNC.C: five corner channels in front of the features, the slice is not 16-byte aligned
+            float* q = o + coff + lane * 4;
+            q[0] = tot[0]; q[1] = tot[1]; q[2] = tot[2]; q[3] = tot[3];
+        }
+    }
     // zero the physical padding channels of this cell
     for (int c = zero_from + lane; c < CP; c += 64) o[c] = 0.f;
 }
@@ -422,8 +429,8 @@ extern "C" int denet_sparse_bwd(const float* dy, const int* taps, unsigned* sort
     DENET_CHECK_ARG(dy && sorted_ws && dfmap, "sparse_bwd: null pointer");
     const int ntap = gs * gs;
     DENET_CHECK_ARG(H * W <= (1 << 17) - 1, "sparse_bwd: feature map too large for 17-bit cell keys");
-    DENET_CHECK_ARG(F % 4 == 0 && F / 4 <= 64 && coff % 4 == 0 && CP % 4 == 0 && KP % 4 == 0,
-                    "sparse_bwd: F/coff/CP/KP must be multiples of 4 and F <= 256");
+    DENET_CHECK_ARG(F % 4 == 0 && F / 4 <= 64 && CP % 4 == 0 && KP % 4 == 0,
+                    "sparse_bwd: F/CP/KP must be multiples of 4 and F <= 256");
     DENET_CHECK_ARG(zero_from >= coff + F && zero_from <= CP, "sparse_bwd: zero_from out of range");
     if (taps) {
         int rc = denet_sparse_sort(taps, sorted_ws, B, H, W, rois_per_image, gs, stream);

@@ -153,16 +153,26 @@ __device__ __forceinline__ void for_each_candidate(const PairCtx& c, int b, F&& 
     const int HW = c.H * c.W;
     const int* nc = c.ncorner + b * c.Cn;
     const int nTL = nc[0], nTR = nc[1], nBL = nc[2], nBR = nc[3];
+    const int nC = (c.Cn == 5) ? nc[4] : 0;
     const int* cTL = c.corners + ((long)b * c.Cn + 0) * c.max_corners;
     const int* cTR = c.corners + ((long)b * c.Cn + 1) * c.max_corners;
     const int* cBL = c.corners + ((long)b * c.Cn + 2) * c.max_corners;
     const int* cBR = c.corners + ((long)b * c.Cn + 3) * c.max_corners;
+    const int* cCC = c.corners + ((long)b * c.Cn + (c.Cn - 1)) * c.max_corners;     // centres (Cn == 5 only)
     const unsigned* bTL = c.bitmap + ((long)b * c.Cn + 0) * c.nwords;
+    const unsigned* bTR = c.bitmap + ((long)b * c.Cn + 1) * c.nwords;
+    const unsigned* bBL = c.bitmap + ((long)b * c.Cn + 2) * c.nwords;
     const unsigned* bBR = c.bitmap + ((long)b * c.Cn + 3) * c.nwords;
+    auto has = [&](const unsigned* bm, int y, int x) { const int q = y * c.W + x; return ((bm[q >> 5] >> (q & 31)) & 1u) != 0u; };
     const float* pf = c.pr + (long)(b * 2 + 0) * c.Cn * HW;
     const float* pt = c.pr + (long)(b * 2 + 1) * c.Cn * HW;
+    // generators in the reference's order (denet_sparse.cc:337-466): TLxBR, TRxBL, then centre x {TL, TR, BL, BR}.
+    // A box has ONE centre, so boxes of different centres never coincide and a box generated from centre c by a later
+    // corner type is a duplicate iff one of its earlier corner types is selected; all de-duplication is O(1) bitmap tests
     const unsigned P0 = (unsigned)nTL * (unsigned)nBR, P1 = (unsigned)nTR * (unsigned)nBL;
-    const unsigned total = P0 + P1;
+    const unsigned Q0 = (unsigned)nC * (unsigned)nTL, Q1 = (unsigned)nC * (unsigned)nTR, Q2 = (unsigned)nC * (unsigned)nBL,
+                   Q3 = (unsigned)nC * (unsigned)nBR;
+    const unsigned total = P0 + P1 + Q0 + Q1 + Q2 + Q3;
     for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
         int x0, y0, x1, y1;
         if (p < P0) {
@@ -171,7 +181,7 @@ __device__ __forceinline__ void for_each_candidate(const PairCtx& c, int b, F&& 
             y0 = tl / c.W; x0 = tl - y0 * c.W;
             y1 = br / c.W; x1 = br - y1 * c.W;
             if (x1 <= x0 || y1 <= y0) continue;
-        } else {
+        } else if (p < P0 + P1) {
             const unsigned q = p - P0;
             const unsigned i = q / (unsigned)nBL, j = q - i * (unsigned)nBL;
             const int tr = cTR[i], bl = cBL[j];
@@ -179,10 +189,27 @@ __device__ __forceinline__ void for_each_candidate(const PairCtx& c, int b, F&& 
             y1 = bl / c.W; x0 = bl - y1 * c.W;
             if (x1 <= x0 || y1 <= y0) continue;
             // already produced by the TLxBR pass?
-            const int ptl = y0 * c.W + x0, pbr = y1 * c.W + x1;
-            if (((bTL[ptl >> 5] >> (ptl & 31)) & 1u) && ((bBR[pbr >> 5] >> (pbr & 31)) & 1u)) continue;
+            if (has(bTL, y0, x0) && has(bBR, y1, x1)) continue;
+        } else {
+            unsigned q = p - P0 - P1;
+            int type = 0;
+            if (q >= Q0) { q -= Q0; type = 1; if (q >= Q1) { q -= Q1; type = 2; if (q >= Q2) { q -= Q2; type = 3; } } }
+            const unsigned nT = (type == 0) ? nTL : (type == 1) ? nTR : (type == 2) ? nBL : nBR;
+            const int* cT = (type == 0) ? cTL : (type == 1) ? cTR : (type == 2) ? cBL : cBR;
+            const unsigned i = q / nT, j = q - i * nT;       // centre i (outer), corner j (inner)
+            const int cc = cCC[i], ct = cT[j];
+            const int cy = cc / c.W, cx = cc - cy * c.W;
+            const int ty = ct / c.W, tx = ct - ty * c.W;
+            if (type == 0) { x0 = tx; y0 = ty; x1 = x0 + 2 * (cx - x0); y1 = y0 + 2 * (cy - y0); }
+            else if (type == 1) { x1 = tx; y0 = ty; x0 = x1 - 2 * (x1 - cx); y1 = y0 + 2 * (cy - y0); }
+            else if (type == 2) { x0 = tx; y1 = ty; x1 = x0 + 2 * (cx - x0); y0 = y1 - 2 * (y1 - cy); }
+            else { x1 = tx; y1 = ty; x0 = x1 - 2 * (x1 - cx); y0 = y1 - 2 * (y1 - cy); }
+            if (x0 < 0 || y0 < 0 || x1 >= c.W || y1 >= c.H || x1 <= x0 || y1 <= y0) continue;
+            const bool tl = has(bTL, y0, x0), tr = has(bTR, y0, x1), bl = has(bBL, y1, x0), br = has(bBR, y1, x1);
+            if ((tl && br) || (tr && bl)) continue;                       // produced by one of the corner-pair passes
+            if ((type >= 1 && tl) || (type >= 2 && tr) || (type >= 3 && bl)) continue;   // earlier type, same centre
         }
-        // denet_sparse.cc:276-294: sequential fp32 sums in the order TL, TR, BL, BR
+        // denet_sparse.cc:276-303: sequential fp32 sums in the order TL, TR, BL, BR (, centre)
         float sf = 0.f, st = 0.f;
         sf += pf[0 * HW + y0 * c.W + x0];
         sf += pf[1 * HW + y0 * c.W + x1];
@@ -192,6 +219,11 @@ __device__ __forceinline__ void for_each_candidate(const PairCtx& c, int b, F&& 
         st += pt[1 * HW + y0 * c.W + x1];
         st += pt[2 * HW + y1 * c.W + x0];
         st += pt[3 * HW + y1 * c.W + x1];
+        if (c.Cn == 5) {
+            const int mx = (x0 + x1) / 2, my = (y0 + y1) / 2;
+            sf += pf[4 * HW + my * c.W + mx];
+            st += pt[4 * HW + my * c.W + mx];
+        }
         const unsigned key = __float_as_uint(fabsf(sf - st));
         f(key, p, x0, y0, x1, y1);
     }
@@ -402,7 +434,7 @@ extern "C" int denet_build_samples(const float* corner_pr, int* out_box, float* 
                                    float corner_threshold, int sample_count, int max_corners, int local_max,
                                    hipStream_t stream) {
     DENET_CHECK_ARG(corner_pr && out_box && out_absd && out_count && workspace, "build_samples: null pointer");
-    DENET_CHECK_ARG(Cn == 4, "build_samples: only the 4-corner variant runs on the GPU (Cn=%d)", Cn);
+    DENET_CHECK_ARG(Cn == 4 || Cn == 5, "build_samples: Cn must be 4 or 5 (corner types + optional centre), got %d", Cn);
     DENET_CHECK_ARG(H > 0 && W > 0 && H <= 256 && W <= 256 && H * W <= 16384, "build_samples: map %dx%d unsupported", H, W);
     DENET_CHECK_ARG(max_corners > 0 && max_corners <= 1024, "build_samples: max_corners must be in 1..1024");
     DENET_CHECK_ARG(sample_count > 0 && sample_count <= 4096, "build_samples: sample_count must be in 1..4096");

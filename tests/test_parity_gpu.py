@@ -82,6 +82,16 @@ def test_build_samples_vs_oracle(hip, frac, lm):
         assert total > 0
 
 
+@pytest.mark.parametrize("frac,lm", [(0.004, 0), (0.01, 1), (0.05, 0), (0.3, 0)])
+def test_build_samples_center_variant_vs_oracle(hip, frac, lm):
+    """DNC.C: five maps (TL, TR, BL, BR, centre); every centre proposes the boxes that have it as mid-point and one
+    selected corner (denet_sparse.cc:374-466), the score adds the centre term (:296-303)"""
+    rng = np.random.RandomState(int(frac * 1000) + lm + 50)
+    pr_map = random_corner_map(rng, 3, 32, 48, frac, Cn=5)
+    n, nties = check_samples(pr_map, 0.01, 12, 1024, lm)
+    assert n > 0
+
+
 def test_build_samples_truncation_and_small_k(hip):
     rng = np.random.RandomState(9)
     pr = random_corner_map(rng, 2, 64, 64, 0.5)        # > 1024 corners per type -> top-1024 by log-probability
@@ -229,12 +239,13 @@ def _forced_step_check(model, om, x, metas, it, lr, mu, decay, solver, roi_lists
 def _warm_corner_head(model, bias, std, seed=3):
     """makes the corner detector fire: random corner filters + a lower bias (SURVEY §8d 'warm' regime)"""
     rng = np.random.RandomState(seed)
-    conv = [l for l in model.layers if l.type_name == "denet-corner"][0].layers[-1]
+    dnc = [l for l in model.layers if l.type_name == "denet-corner"][0]
+    conv, cn = dnc.layers[-1], dnc.corner_num
     w = conv.omega.get_value().copy()
-    w[:4] = rng.normal(0, std, w[:4].shape)
+    w[:cn] = rng.normal(0, std, w[:cn].shape)
     conv.omega.set_value(w)
     b = conv.beta.get_value().copy()
-    b[:4] = bias
+    b[:cn] = bias
     conv.beta.set_value(b)
 
 
@@ -483,6 +494,35 @@ def test_denet_head_variants_vs_oracle(hip, head, rule):
     assert np.array_equal(model.layers[31]._taps.cpu().numpy(), taps_ref)
     if "J" in head:
         assert model.layers[40].s0 == 401
+
+
+def test_denet_center_corner_variant_vs_oracle(hip):
+    """DNC.C (denet_corner.py:62-71 tag C): a fifth 'centre' map in the corner cost, the RoI proposal and its score"""
+    B, IMG = 2, 128
+    desc = zoo.DENET34_SKIP_DESC.replace("DNC[96,100]", "DNC.C[96,100]")
+    model = zoo.denet34(B, "skip", IMG, class_num=80, seed=1, head_desc=desc)
+    dnc = [l for l in model.layers if l.type_name == "denet-corner"][0]
+    dns = [l for l in model.layers if l.type_name == "denet-sparse"][0]
+    dnd = [l for l in model.layers if l.type_name == "denet-detect"][0]
+    assert dnc.corner_num == 5
+    rng = np.random.RandomState(5)
+    dconv = dnd.layers[0]
+    dconv.omega.set_value(rng.normal(0, 0.05, dconv.omega.value.shape))
+    _warm_corner_head(model, 4.0, 0.3)
+    x, metas = zoo.synthetic_batch(B, IMG, seed=3)
+    om = OM.OracleModel(model.export_json(), B)
+    model.build_train_func("nesterov")
+    random.seed(9)
+    cost, costs = model.train_step(x, metas, 0, 0, 0.05, [0.9], 1e-4)
+    roi_lists = dns.sample_bbox_list
+    # the proposal itself: exact against the C++ oracle on the product's own 5-map corner tensor
+    lists = OM.oracle_build_samples(dnc.corner_pr.cpu().numpy(), dns.corner_threshold, dns.sample_num, 1024, 0)
+    assert sum(len(l) for l in lists) > 0
+    random.seed(9)
+    ref_lists = OL.edit_samples(lists, metas, dns.sample_count, dns.random_sample, dns.sample_gt)
+    assert [[p for p, _ in l] for l in ref_lists] == [[p for p, _ in l] for l in roi_lists]
+    ocost, ocosts = _forced_step_check(model, om, x, metas, 0, 0.05, 0.9, 1e-4, "nesterov", roi_lists)
+    assert abs(cost - ocost) <= 1e-4 * abs(ocost), (cost, ocost)
 
 
 def test_denet101_wide_train_step_vs_oracle(hip):
