@@ -204,7 +204,7 @@ int denet_soft_nms_host(const float* score_host, const float* box_host, int n, f
 /* ---- corner selection + RoI proposal  (denet/layer/denet_sparse.cc:489-557 run_build_samples, :321-471
  *      search_corners, :271-308 get_sample; Python-facing wrapper build_samples :559-668, which the reference
  *      calls on the HOST with a D2H copy of the corner map, denet/layer/denet_sparse.py:129-139).
- *      corner_pr:[B,2,4,H,W] device. Per image the best `sample_count` candidate boxes, ranked exactly like
+ *      corner_pr:[B,2,Cn,H,W] device, Cn = 4 (TL,TR,BL,BR) or 5 (+ centre, DNC.C). Per image the best `sample_count` candidate boxes, ranked exactly like
  *      the reference (score descending == |pr_f-pr_t| ascending; equal scores ordered by generation index):
  *        out_box:[B,sample_count,4] int32 corner cells x0,y0,x1,y1;  out_absd:[B,sample_count] fp32 |pr_f-pr_t|;
  *        out_count:[B].
