@@ -80,16 +80,20 @@ class DataParallel:
         r = self._trigger.get(id(layer))
         if r is not None and (self.world_size > 1 or self.force_collectives):
             lo, hi = r
-            self._join_wgrad()
-            self._pending.append(self.dist.all_reduce(model.G[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True))
+            # the bucket holds convolution weight gradients only: they are produced on the wgrad stream, so the
+            # collective is ordered behind THAT stream and the data-gradient chain on the compute stream never waits
+            with self._wgrad_ctx():
+                self._pending.append(self.dist.all_reduce(model.G[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True))
 
     @staticmethod
-    def _join_wgrad():
-        """the weight gradients of a bucket are produced on the wgrad stream (ops.wgrad_stream)"""
+    def _wgrad_ctx():
+        """ops.wgrad_stream() on a GPU (the stream the weight gradients are produced on), a no-op context on CPU"""
+        import contextlib
         import torch
         if torch.cuda.is_available():
             from .. import ops
-            ops.join_wgrad_stream()
+            return ops.wgrad_stream()
+        return contextlib.nullcontext()
 
     def finish_step(self, model):
         if self.world_size > 1 or self.force_collectives:
