@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(const float* __restr
                                                             const float* __restrict__ roi, float* __restrict__ det_pr,
                                                             float* __restrict__ fitness, float* __restrict__ bbox, int M,
                                                             int CP, int class_num, int fit_num, int jointfit, int nreg,
-                                                            float t0) {
+                                                            float t0, int nfit) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
@@ -60,6 +60,24 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(const float* __restr
             dp[class_num] = lp;
             fp[class_num] = lp;
         }
+    }
+    if (nfit > 0) {
+        // independent fitness head (denet_detect.py:396-401): fitness += log( sum_f P(f) * val[f] ),
+        // val = [0, t0 + i*(1-t0)/(nfit-1)], the expectation in double, cast to float32, log in float32
+        const float* zf = z + s0 + nreg;
+        const float zv = lane < nfit ? zf[lane] : -INFINITY;
+        float fm = zv;
+        for (int o = 32; o > 0; o >>= 1) fm = fmaxf(fm, __shfl_xor(fm, o, 64));
+        float fe = lane < nfit ? expf(zv - fm) : 0.f;
+        float fse = fe;
+        for (int o = 32; o > 0; o >>= 1) fse += __shfl_xor(fse, o, 64);
+        const float lp = (zv - fm) - logf(fse);
+        double term = 0.0;
+        if (lane >= 1 && lane < nfit)
+            term = (double)expf(lp) * ((double)t0 + (double)(lane - 1) * (1.0 - (double)t0) / (double)(nfit - 1));
+        for (int o = 32; o > 0; o >>= 1) term += __shfl_xor(term, o, 64);
+        const float add = logf((float)term);
+        for (int c = lane; c < class_num + 1; c += 64) fp[c] += add;
     }
     if (lane == 0) {
         const float x0 = roi[m * 4 + 0], y0 = roi[m * 4 + 1], x1 = roi[m * 4 + 2], y1 = roi[m * 4 + 3];
@@ -155,15 +173,16 @@ __global__ __launch_bounds__(256) void detect_nms_kernel(const float* __restrict
 }  // namespace
 
 extern "C" int denet_detect_decode(const float* logits, const float* roi_bbox, float* det_pr, float* fitness,
-                                   float* bbox, int M, int CP, int class_num, int jointfit, int nreg,
+                                   float* bbox, int M, int CP, int class_num, int jointfit, int nreg, int nfit,
                                    float overlap_threshold, hipStream_t stream) {
     DENET_CHECK_ARG(logits && roi_bbox && det_pr && fitness && bbox, "detect_decode: null pointer");
     DENET_CHECK_ARG(nreg == 0 || nreg == 4, "detect_decode: nreg must be 0 or 4");
     const int fit_num = 5;
     const int s0 = jointfit ? class_num * fit_num + 1 : class_num + 1;
-    DENET_CHECK_ARG(s0 + nreg <= CP, "detect_decode: CP too small");
+    DENET_CHECK_ARG(nfit >= 0 && nfit <= 64 && !(nfit > 0 && jointfit), "detect_decode: bad independent-fitness size");
+    DENET_CHECK_ARG(s0 + nreg + nfit <= CP, "detect_decode: CP too small");
     hipLaunchKernelGGL(detect_decode_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, logits, roi_bbox, det_pr, fitness,
-                       bbox, M, CP, class_num, fit_num, jointfit, nreg, overlap_threshold);
+                       bbox, M, CP, class_num, fit_num, jointfit, nreg, overlap_threshold, nfit);
     DENET_CHECK_LAUNCH("detect_decode");
     return DENET_OK;
 }

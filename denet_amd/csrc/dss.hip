@@ -248,7 +248,9 @@ __global__ __launch_bounds__(256) void detect_loss_kernel(const float* __restric
                                                           double* __restrict__ partial, int M, int CP, int ncls,
                                                           int nreg, float det_scale, float bbox_factor,
                                                           float bbox_scale, int bounded_iou,
-                                                          const float* __restrict__ roi_bbox) {
+                                                          const float* __restrict__ roi_bbox,
+                                                          const float* __restrict__ fit_t, int nfit, float fit_factor,
+                                                          float fit_scale) {
     __shared__ double red[2][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int m = blockIdx.x * 4 + wv;
@@ -336,10 +338,32 @@ __global__ __launch_bounds__(256) void detect_loss_kernel(const float* __restric
                 sl *= valid;
             }
             for (int o = 2; o > 0; o >>= 1) sl += __shfl_xor(sl, o, 64);
-            berr = (double)bbox_factor * (double)sl;
+            berr = (double)bbox_factor * (double)bbox_factor * (double)sl;     // factor of get_errors :295 and of cost :310
+        }
+        if (nfit > 0) {
+            // independent fitness distribution (denet_detect.py:103-108, 298-301): a second soft-target cross entropy
+            // over the nfit logits behind the box regressors
+            const float* zf = z + ncls + nreg;
+            const float* tf = fit_t + (long)m * nfit;
+            const float zv = lane < nfit ? zf[lane] : -INFINITY;
+            float fm = zv;
+            for (int o = 32; o > 0; o >>= 1) fm = fmaxf(fm, __shfl_xor(fm, o, 64));
+            float fe = lane < nfit ? expf(zv - fm) : 0.f, ft = lane < nfit ? tf[lane] : 0.f;
+            float fse = fe, fts = ft;
+            for (int o = 32; o > 0; o >>= 1) {
+                fse += __shfl_xor(fse, o, 64);
+                fts += __shfl_xor(fts, o, 64);
+            }
+            const float flse = logf(fse);
+            const float finv = (float)(1.0 / log((double)nfit));
+            const float flp = lane < nfit ? (zv - fm) - flse : 0.f;
+            float fsum = ft * flp;
+            if (dz && lane < nfit) dz[ncls + nreg + lane] = fit_scale * finv * (fts * expf(flp) - ft);
+            for (int o = 32; o > 0; o >>= 1) fsum += __shfl_xor(fsum, o, 64);
+            berr += (double)fit_factor * (-(double)fsum * (double)finv);
         }
         if (dz) {
-            for (int c = ncls + nreg + lane; c < CP; c += 64) dz[c] = 0.f;
+            for (int c = ncls + nreg + nfit + lane; c < CP; c += 64) dz[c] = 0.f;
         }
     }
     if (lane == 0) {
@@ -444,14 +468,16 @@ extern "C" int denet_sparse_bwd(const float* dy, const int* taps, unsigned* sort
 }
 
 extern "C" int denet_detect_loss(const float* logits, const float* det_target, const float* bbox_valid,
-                                 const float* bbox_target, const float* roi_bbox, float* dlogits, float* costs,
-                                 void* workspace, int M, int batch, int CP, int ncls, int nreg, float cost_factor,
-                                 float bbox_factor, int bounded_iou, hipStream_t stream) {
+                                 const float* bbox_target, const float* roi_bbox, const float* fit_target, float* dlogits,
+                                 float* costs, void* workspace, int M, int batch, int CP, int ncls, int nreg, int nfit,
+                                 float cost_factor, float bbox_factor, float fit_factor, int bounded_iou,
+                                 hipStream_t stream) {
     DENET_CHECK_ARG(logits && det_target && costs && workspace, "detect_loss: null pointer");
     DENET_CHECK_ARG(nreg == 0 || nreg == 4, "detect_loss: nreg must be 0 or 4");
     DENET_CHECK_ARG(nreg == 0 || (bbox_valid && bbox_target), "detect_loss: bbox targets missing");
     DENET_CHECK_ARG(!bounded_iou || roi_bbox, "detect_loss: bounded IoU needs the RoI boxes");
-    DENET_CHECK_ARG(ncls + nreg <= CP, "detect_loss: CP too small");
+    DENET_CHECK_ARG(nfit >= 0 && nfit <= 64 && (nfit == 0 || fit_target), "detect_loss: fitness targets missing / nfit > 64");
+    DENET_CHECK_ARG(ncls + nreg + nfit <= CP, "detect_loss: CP too small");
     const int g = (M + 3) / 4;
     DENET_CHECK_ARG(g <= 65536, "detect_loss: too many RoIs (%d)", M);
     const float det_scale = cost_factor / (float)batch;
@@ -459,11 +485,12 @@ extern "C" int denet_detect_loss(const float* logits, const float* det_target, c
     const float bbox_scale = bbox_factor * bbox_factor / (float)batch;
     hipLaunchKernelGGL(detect_loss_kernel, dim3(g), dim3(256), 0, stream, logits, det_target, bbox_valid, bbox_target,
                        dlogits, (double*)workspace, M, CP, ncls, nreg, det_scale, bbox_factor, bbox_scale, bounded_iou,
-                       roi_bbox);
+                       roi_bbox, fit_target, nfit, fit_factor, fit_factor / (float)batch);
     hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, stream, (const double*)workspace, g,
                        (double)cost_factor / (double)batch, costs);
+    // costs[1] = box cost + independent-fitness cost (both already carry their factors)
     hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, stream, (const double*)workspace + g, g,
-                       (double)bbox_factor / (double)batch, costs + 1);
+                       1.0 / (double)batch, costs + 1);
     DENET_CHECK_LAUNCH("detect_loss");
     return DENET_OK;
 }

@@ -169,11 +169,12 @@ extern "C" int denet_host_edit_samples(uint32_t* mt, int* pos, const float* det,
 // float32 IoU) and clears the null class; per RoI the arg-max GT gives the box-regression target if IoU > t1
 // (:194-213, double arithmetic, stored as float32); rows are normalised to sum 1 and divided by S (:216-226).
 // gt: concatenated [n,4] doubles, gt_off [B+1], gt_class [n]; roi [B,S,4] doubles (the edited RoI list).
-// det [B*S,s0], valid [B*S] (or null), reg [B*S,8] (or null). Pure host code.
+// det [B*S,s0], valid [B*S] (or null), reg [B*S,8] (or null), indfit [B*S,fitness_num] (or null: no independent
+// fitness head). Pure host code.
 // ---------------------------------------------------------------------------------------------------------
 extern "C" int denet_host_detect_targets(const double* gt, const int* gt_off, const int* gt_class, const double* roi,
                                          int B, int S, int s0, int null_class, int fitness_num, int jointfit,
-                                         double t0, double t1, float* det, float* valid, float* reg) {
+                                         double t0, double t1, float* det, float* valid, float* reg, float* indfit) {
 #pragma clang fp contract(off)
     DENET_CHECK_ARG(gt_off && roi && det && B > 0 && S > 0 && s0 > 0, "detect_targets: bad arguments");
     DENET_CHECK_ARG(null_class >= 0 && null_class < s0, "detect_targets: null class out of range");
@@ -202,8 +203,15 @@ extern "C" int denet_host_detect_targets(const double* gt, const int* gt_off, co
                 r[2] = r[3] = r[6] = r[7] = 1.f;
                 valid[row] = 0.f;
             }
+            // independent fitness target (:188-192, :219-226): bin 0 = background, matched RoIs mark bins 1..n-1
+            float* fi = indfit ? indfit + row * fitness_num : nullptr;
+            if (fi) {
+                for (int c = 0; c < fitness_num; ++c) fi[c] = 0.f;
+                fi[0] = 1.f;
+            }
             if (ng == 0) {
                 d[null_class] = inv_s;      // (1 / 1) / S
+                if (fi) fi[0] = inv_s;
                 continue;
             }
             const double* yd = roi + row * 4;
@@ -235,7 +243,20 @@ extern "C" int denet_host_detect_targets(const double* gt, const int* gt_off, co
                     DENET_CHECK_ARG(col >= 0 && col < s0, "detect_targets: class column %d out of range", col);
                     d[col] = 1.f;
                     d[null_class] = 0.f;
+                    if (fi) {
+                        const double sf = ((double)v - t0) / (1.0 - t0);
+                        long f = 1 + (long)floor((double)(fitness_num - 1) * sf);
+                        f = f < 1 ? 1 : (f > fitness_num - 1 ? fitness_num - 1 : f);
+                        fi[0] = 0.f;
+                        fi[f] = 1.f;
+                    }
                 }
+            }
+            if (fi) {
+                float fs = 0.f;
+                for (int c = 0; c < fitness_num; ++c) fs += fi[c];
+                for (int c = 0; c < fitness_num; ++c)
+                    if (fi[c] != 0.f) fi[c] = (fi[c] / fs) / Sf;
             }
             float sum = 0.f;
             for (int c = 0; c < s0; ++c) sum += d[c];

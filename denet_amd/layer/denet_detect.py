@@ -33,8 +33,6 @@ class DeNetDetectLayer(AbstractLayer):
         self.indfit_factor = json_param.get("fitnessFactor", indfit_factor)
         self.use_indfit = (self.indfit_factor > 0.0)
         assert not (self.use_indfit and self.use_jointfit), "Cannot enable both fitness methods at once!"
-        if self.use_indfit:
-            raise NotImplementedError("independent fitness head (indfit_factor > 0) is outside the hot path")
 
         self.sparse_layer = common.find_layers(layers, "denet-sparse", False)
         assert self.sparse_layer is not None, "Error: Requires denet-sparse layer to be specified before denet-detect layer!"
@@ -50,9 +48,12 @@ class DeNetDetectLayer(AbstractLayer):
             self.null_class = self.class_num
             s0 = self.class_num + 1
         s1 = 4 if self.use_bbox_reg else 0
-        self.s0, self.s1 = s0, s1
-        self.layers = [ConvLayer([InitialLayer(self.input, self.input_shape)], (s0 + s1, self.input_shape[1], 1, 1),
+        s2 = self.fitness_num if self.use_indfit else 0       # independent fitness distribution (:103-108)
+        self.s0, self.s1, self.s2 = s0, s1, s2
+        self.layers = [ConvLayer([InitialLayer(self.input, self.input_shape)], (s0 + s1 + s2, self.input_shape[1], 1, 1),
                                  (1, 1), True, "valid", 0.0)]
+        if self.use_indfit:
+            self.indfit_shape = (self.batch_size, s2, self.sample_num, self.sample_num)
         self.det_shape = (self.batch_size, s0, self.sample_num, self.sample_num)
         if self.use_bbox_reg:
             self.bbox_shape = (self.batch_size, s1, self.sample_num, self.sample_num)
@@ -122,11 +123,13 @@ class DeNetDetectLayer(AbstractLayer):
         if self.use_bbox_reg:
             valid = self._buf("valid", (B * S,))
             reg = self._buf("reg", (B * S, 8))
+        fit = self._buf("indfit", (B * S, self.s2)) if self.use_indfit else None
         _lib.check(_lib.load().denet_host_detect_targets(
             gt.ctypes.data, off.ctypes.data, cls.ctypes.data, roi.ctypes.data, B, S, self.s0, self.null_class,
             self.fitness_num, int(bool(self.use_jointfit)), float(t0), float(t1), det.ctypes.data,
-            valid.ctypes.data if valid is not None else None, reg.ctypes.data if reg is not None else None),
-            "detect_targets")
+            valid.ctypes.data if valid is not None else None, reg.ctypes.data if reg is not None else None,
+            fit.ctypes.data if fit is not None else None), "detect_targets")
+        self._fit_target = fit
         return det, valid, reg
 
     def build_targets_numpy(self, metas):
@@ -149,6 +152,11 @@ class DeNetDetectLayer(AbstractLayer):
             valid.fill(0.0)
             reg.fill(0.0)
             reg[:, [2, 3, 6, 7]] = 1.0
+        fit = None
+        if self.use_indfit:
+            fit = self._buf("indfit", (B * S, self.s2))
+            fit.fill(0.0)
+            fit[:, 0] = 1.0
 
         for b, meta in enumerate(metas):
             boxes = sp.sample_boxes[b]
@@ -167,6 +175,13 @@ class DeNetDetectLayer(AbstractLayer):
                 else:
                     det[rows, cls] = 1.0
                 det[rows, self.null_class] = 0.0
+                if self.use_indfit:
+                    # f = clip(1 + floor((n-1) * sample_f), 1, n-1) on the float64 value of the float32 IoU (:188-192)
+                    sample_f = (overlap[bbox_indexs, sample_indexs].astype(numpy.float64) - t0) / (1.0 - t0)
+                    f = numpy.clip(1 + numpy.floor((self.fitness_num - 1) * sample_f).astype(numpy.int64), 1,
+                                   self.fitness_num - 1)
+                    fit[rows, 0] = 0.0
+                    fit[rows, f] = 1.0
             if self.use_bbox_reg:
                 overlap_max = overlap.argmax(axis=0)
                 idx = numpy.arange(len(boxes))
@@ -189,6 +204,10 @@ class DeNetDetectLayer(AbstractLayer):
         det /= S
         if self.use_bbox_reg:
             valid /= S
+        if self.use_indfit:
+            fit /= fit.sum(axis=1, keepdims=True)
+            fit /= S
+        self._fit_target = fit
         return det, valid, reg
 
     def get_target(self, model, samples, metas):
@@ -199,6 +218,9 @@ class DeNetDetectLayer(AbstractLayer):
         if self.use_bbox_reg:
             yt_value = numpy.concatenate((yt_value, valid.flatten(),
                                           reg.reshape(B, sn, sn, 8).transpose(0, 3, 1, 2).flatten()))
+        if self.use_indfit:
+            yt_value = numpy.concatenate((yt_value,
+                                          self._fit_target.reshape(B, sn, sn, self.s2).transpose(0, 3, 1, 2).flatten()))
         return numpy.array([], dtype=numpy.int64), yt_value
 
     def cost(self, yt_index, yt_value):
@@ -213,12 +235,14 @@ class DeNetDetectLayer(AbstractLayer):
         import torch
         det, valid, reg = self.build_targets(metas)
         b = self._bufs
-        t = {"valid": None, "reg": None}
+        t = {"valid": None, "reg": None, "fit": None}
         t["det"], ev = ops.upload_async(b["det"])
         if self.use_bbox_reg:
             t["valid"], _ = ops.upload_async(b["valid"])
             t["reg"], ev = ops.upload_async(b["reg"])
-        t["event"] = ev           # the copies are ordered on the copy stream: the last event covers all three
+        if self.use_indfit:
+            t["fit"], ev = ops.upload_async(b["indfit"])
+        t["event"] = ev           # the copies are ordered on the copy stream: the last event covers all of them
         self._targets = t
 
     def set_target(self, ctx, yt_index, yt_value):
@@ -228,12 +252,16 @@ class DeNetDetectLayer(AbstractLayer):
         shapes = [self.det_shape]
         if self.use_bbox_reg:
             shapes += [(B, sn, sn), (B, 8, sn, sn)]
+        if self.use_indfit:
+            shapes += [self.indfit_shape]
         v = common.ndarray_unpack(numpy.asarray(yt_value, dtype=numpy.float32), shapes)
         det = numpy.ascontiguousarray(v[0].transpose(0, 2, 3, 1).reshape(B * sn * sn, self.s0))
-        t = {"det": torch.from_numpy(det).cuda(), "valid": None, "reg": None}
+        t = {"det": torch.from_numpy(det).cuda(), "valid": None, "reg": None, "fit": None}
         if self.use_bbox_reg:
             t["valid"] = torch.from_numpy(numpy.ascontiguousarray(v[1].reshape(-1))).cuda()
             t["reg"] = torch.from_numpy(numpy.ascontiguousarray(v[2].transpose(0, 2, 3, 1).reshape(-1, 8))).cuda()
+        if self.use_indfit:
+            t["fit"] = torch.from_numpy(numpy.ascontiguousarray(v[-1].transpose(0, 2, 3, 1).reshape(-1, self.s2))).cuda()
         self._targets = t
 
     def forward(self, ctx):
@@ -249,7 +277,8 @@ class DeNetDetectLayer(AbstractLayer):
         ops.wait_upload(t.get("event"))
         ops.detect_loss(lg, t["det"], t["valid"], t["reg"], self.sparse_layer.sample_bbox, dl, cost_out,
                         self.batch_size, self.s0, self.s1, float(self.cost_factor), float(self.bbox_factor),
-                        bool(self.use_bounded_iou))
+                        bool(self.use_bounded_iou), fit_target=t.get("fit"), nfit=self.s2,
+                        fit_factor=float(self.indfit_factor))
         if want_grad:
             self.conv.output.grad = dl.view(logits.shape)
 
@@ -278,7 +307,7 @@ class DeNetDetectLayer(AbstractLayer):
         B, S = self.batch_size, self.sample_num * self.sample_num
         logits = self.conv.output.data.view(B * S, self.conv.kp)
         t0, _ = self._thresholds()
-        det_pr, fitness, bbox = ops.detect_decode(logits, sp.sample_bbox, self.class_num, self.use_jointfit, self.s1, t0)
+        det_pr, fitness, bbox = ops.detect_decode(logits, sp.sample_bbox, self.class_num, self.use_jointfit, self.s1, t0, nfit=self.s2)
         counts = numpy.array([len(bx) for bx in sp.sample_boxes], dtype=numpy.int32)
         self.last_outputs = (det_pr, fitness, bbox, counts)
         results = []

@@ -22,7 +22,7 @@ SIGNATURES = {
     "denet_device_info": (I, [I, P, P, P, I]),
     "denet_host_py_random_sample": (I, [P, P, I, I, P, P]),
     "denet_host_edit_samples": (I, [P, P, P, P, I, I, I, P, P, I, P, P, P, P]),
-    "denet_host_detect_targets": (I, [P, P, P, P, I, I, I, I, I, I, ctypes.c_double, ctypes.c_double, P, P, P]),
+    "denet_host_detect_targets": (I, [P, P, P, P, I, I, I, I, I, I, ctypes.c_double, ctypes.c_double, P, P, P, P]),
     "denet_conv_fwd": (I, [P, P, P, P, P] + [I] * 12 + [P]),
     "denet_conv_dgrad": (I, [P, P, P, P] + [I] * 12 + [P]),
     "denet_conv_wgrad_workspace_bytes": (Z, [I] * 7),
@@ -65,8 +65,8 @@ SIGNATURES = {
     "denet_sparse_fwd": (I, [P, P, P, P] + [I] * 10 + [P]),
     "denet_sparse_sort": (I, [P, P] + [I] * 5 + [P]),
     "denet_sparse_bwd": (I, [P, P, P, P] + [I] * 10 + [P]),
-    "denet_detect_loss": (I, [P] * 8 + [I] * 5 + [F, F, I, P]),
-    "denet_detect_decode": (I, [P] * 5 + [I] * 5 + [F, P]),
+    "denet_detect_loss": (I, [P] * 9 + [I] * 6 + [F, F, F, I, P]),
+    "denet_detect_decode": (I, [P] * 5 + [I] * 6 + [F, P]),
     "denet_detect_nms": (I, [P] * 5 + [I, I, I, F, F, P]),
     "denet_soft_nms_host": (I, [P, P, I, F, P, P, P]),
     "denet_build_samples_workspace_bytes": (Z, [I] * 6),

@@ -610,11 +610,12 @@ def sparse_bwd(dy, taps, dfmap, coff, F, rois_per_image, gs, zero_from, presorte
 
 
 def detect_loss(logits, det_target, bbox_valid, bbox_target, roi_bbox, dlogits, costs, batch, ncls, nreg,
-                cost_factor, bbox_factor, bounded_iou=False):
+                cost_factor, bbox_factor, bounded_iou=False, fit_target=None, nfit=0, fit_factor=0.0):
     M, CP = logits.shape
     check(_L().denet_detect_loss(ptr(logits), ptr(det_target), ptr(bbox_valid), ptr(bbox_target), ptr(roi_bbox),
-                                 ptr(dlogits), ptr(costs), ptr(_loss_ws()), M, batch, CP, ncls, nreg, cost_factor,
-                                 bbox_factor, int(bounded_iou), stream_ptr()), "detect_loss")
+                                 ptr(fit_target), ptr(dlogits), ptr(costs), ptr(_loss_ws()), M, batch, CP, ncls, nreg,
+                                 int(nfit), cost_factor, bbox_factor, float(fit_factor), int(bounded_iou), stream_ptr()),
+          "detect_loss")
 
 
 def build_samples(corner_pr, corner_threshold, sample_count, max_corners=1024, local_max=0, out=None):
@@ -643,11 +644,11 @@ def samples_finish_host(box, absd, count, H, W):
     return out
 
 
-def detect_decode(logits, roi_bbox, class_num, jointfit, nreg, overlap_threshold):
+def detect_decode(logits, roi_bbox, class_num, jointfit, nreg, overlap_threshold, nfit=0):
     M, CP = logits.shape
     det_pr, fitness, bbox = empty(M, class_num + 1), empty(M, class_num + 1), empty(M, 4)
     check(_L().denet_detect_decode(ptr(logits), ptr(roi_bbox), ptr(det_pr), ptr(fitness), ptr(bbox), M, CP, class_num,
-                                   int(jointfit), nreg, float(overlap_threshold), stream_ptr()), "detect_decode")
+                                   int(jointfit), nreg, int(nfit), float(overlap_threshold), stream_ptr()), "detect_decode")
     return det_pr, fitness, bbox
 
 

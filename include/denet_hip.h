@@ -55,7 +55,8 @@ int denet_host_edit_samples(unsigned* mt_host, int* pos_host, const float* det_h
  * gt_off:[B+1], gt_class:[n]; roi:[B,S,4] doubles; det:[B*S,s0]; valid:[B*S] and reg:[B*S,8] or both NULL.      */
 int denet_host_detect_targets(const double* gt_host, const int* gt_off_host, const int* gt_class_host,
                               const double* roi_host, int B, int S, int s0, int null_class, int fitness_num,
-                              int jointfit, double t0, double t1, float* det_host, float* valid_host, float* reg_host);
+                              int jointfit, double t0, double t1, float* det_host, float* valid_host, float* reg_host,
+                              float* indfit_host /* [B*S,fitness_num] or NULL */);
 
 /* ---- convolution  (denet/layer/convolution.py:80-83 -> cuDNN conv fwd; model_cnn.py:318 tensor.grad ->
  *      cuDNN bwd-data / bwd-filter).  x:[N,H,W,C]  w:[K,R,S,C]  y:[N,OH,OW,K]; `S` may be padded beyond the
@@ -182,11 +183,13 @@ int denet_sparse_bwd(const float* dy, const int* taps, unsigned* sorted_ws, floa
                      int coff, int F, int rois_per_image, int gs, int KP, int zero_from, hipStream_t stream);
 
 /* ---- detection cost  (denet/layer/denet_detect.py:238-313 get_errors/cost; theano_util.py:27-34)
- *      logits:[M,CP] (ncls class logits then nreg box regressors); det_target:[M,ncls]; bbox_valid:[M];
- *      bbox_target:[M,8] = target cx,cy,w,h, sample cx,cy,w,h; costs[0] = DET cost, costs[1] = BBOX cost.  */
+ *      logits:[M,CP] (ncls class logits, nreg box regressors, nfit independent-fitness logits); det_target:[M,ncls];
+ *      bbox_valid:[M]; bbox_target:[M,8] = target cx,cy,w,h, sample cx,cy,w,h; fit_target:[M,nfit] or NULL (:103-108,
+ *      :298-301); costs[0] = DET cost, costs[1] = BBOX cost + independent-fitness cost.                      */
 int denet_detect_loss(const float* logits, const float* det_target, const float* bbox_valid, const float* bbox_target,
-                      const float* roi_bbox, float* dlogits, float* costs, void* workspace, int M, int batch, int CP,
-                      int ncls, int nreg, float cost_factor, float bbox_factor, int bounded_iou, hipStream_t stream);
+                      const float* roi_bbox, const float* fit_target, float* dlogits, float* costs, void* workspace, int M,
+                      int batch, int CP, int ncls, int nreg, int nfit, float cost_factor, float bbox_factor,
+                      float fit_factor, int bounded_iou, hipStream_t stream);
 
 /* ---- inference tail  (denet/layer/denet_detect.py:76-100 class log-softmax + box decoding, :330-349
  *      joint-fitness marginalisation; denet/layer/denet_detect.cc:99-173 build_detections_nms, :73-97 hard NMS,
@@ -194,7 +197,8 @@ int denet_detect_loss(const float* logits, const float* det_target, const float*
  *      count:[B] valid RoIs per image; keep:[B,class_num,S] bytes (1 = surviving detection). The soft-NMS variant is
  *      sequential by construction and runs on the host over one class' candidates.                           */
 int denet_detect_decode(const float* logits, const float* roi_bbox, float* det_pr, float* fitness, float* bbox, int M,
-                        int CP, int class_num, int jointfit, int nreg, float overlap_threshold, hipStream_t stream);
+                        int CP, int class_num, int jointfit, int nreg, int nfit /* independent-fitness logits, :396-401 */,
+                        float overlap_threshold, hipStream_t stream);
 int denet_detect_nms(const float* det_pr, const float* fitness, const float* bbox, const int* count,
                      unsigned char* keep, int B, int S, int class_num, float pr_threshold, float nms_threshold,
                      hipStream_t stream);

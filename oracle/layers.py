@@ -349,8 +349,9 @@ def overlap_iou(obj_bboxs, sample_bboxs):
 
 
 def detect_target(metas, sample_bbox_list, batch_size, sample_num, class_num, thresholds, use_bbox_reg=True,
-                  use_jointfit=False):
-    """denet/layer/denet_detect.py:147-235, loop for loop"""
+                  use_jointfit=False, use_indfit=False):
+    """denet/layer/denet_detect.py:147-235, loop for loop; with use_indfit a fourth array, the independent fitness
+    target (B, 6, sn, sn) of :188-192 / :219-226, is returned as well"""
     t0, t1 = thresholds
     fitness_num = 5 if use_jointfit else 6
     null_class = class_num * fitness_num if use_jointfit else class_num
@@ -363,6 +364,8 @@ def detect_target(metas, sample_bbox_list, batch_size, sample_num, class_num, th
     bbox_reg[:, 3, ...] = 1.0
     bbox_reg[:, 6, ...] = 1.0
     bbox_reg[:, 7, ...] = 1.0
+    indfit_pr = np.zeros((batch_size, fitness_num, sample_num, sample_num), dtype=F32)
+    indfit_pr[:, 0, ...] = 1.0
     for b, meta in enumerate(metas):
         samples = [bbox for _, bbox in sample_bbox_list[b]]
         if len(meta["bbox"]) > 0 and len(samples) > 0:
@@ -379,6 +382,11 @@ def detect_target(metas, sample_bbox_list, batch_size, sample_num, class_num, th
                 else:
                     det_pr[b, sample_cls, sample_j, sample_i] = 1.0
                 det_pr[b, null_class, sample_j, sample_i] = 0.0
+                if use_indfit:
+                    f = 1 + int(math.floor((fitness_num - 1) * sample_f))
+                    f = max(1, min(f, fitness_num - 1))
+                    indfit_pr[b, 0, sample_j, sample_i] = 0.0
+                    indfit_pr[b, f, sample_j, sample_i] = 1.0
             if use_bbox_reg:
                 overlap_max = overlap.argmax(axis=0)
                 for index in range(len(samples)):
@@ -401,6 +409,10 @@ def detect_target(metas, sample_bbox_list, batch_size, sample_num, class_num, th
     nfactor = sample_num * sample_num
     det_pr /= nfactor
     bbox_valid /= nfactor
+    if use_indfit:
+        indfit_pr /= indfit_pr.sum(axis=1)[:, None, ...]
+        indfit_pr /= nfactor
+        return det_pr, bbox_valid, bbox_reg, indfit_pr
     return det_pr, bbox_valid, bbox_reg
 
 
@@ -466,6 +478,21 @@ def detect_cost(out, det_t, bbox_valid, bbox_reg_t, sample_bbox, class_outputs, 
     return float(det_cost), float(bbox_cost), d_out.astype(F32)
 
 
+def indfit_cost(out, indfit_t, offset, indfit_factor):
+    """independent fitness cost (denet_detect.py:103-108 log-softmax of the logits behind the box regressors, :298-301,
+    :311-312): -sum(target * logp) / ln(n), x factor / batch. returns (cost, d_out with only its slice filled)"""
+    B = out.shape[0]
+    n = indfit_t.shape[1]
+    o = out.astype(np.float64)
+    lp = log_softmax(o[:, offset:offset + n], axis=1)
+    err = -(indfit_t * lp).sum(axis=1) / math.log(n)
+    cost = indfit_factor * err.sum() / B
+    d_out = np.zeros_like(o)
+    T = indfit_t.sum(axis=1, keepdims=True)
+    d_out[:, offset:offset + n] = (indfit_factor / B / math.log(n)) * (T * np.exp(lp) - indfit_t)
+    return float(cost), d_out.astype(F32)
+
+
 def regression_cost(logits, classes, want_grad=True):
     """denet/layer/regression.py:97-98: -mean(log_softmax(x)[b, cls]) for x (B, C, 1, 1)"""
     B, C = logits.shape[0], logits.shape[1]
@@ -514,7 +541,7 @@ def solver_update(p, m, g, lr, momentum, iteration, decay, is_weight, mode="nest
 # ---------------------------------------------------------------------------------------------------------
 # inference decode: denet/layer/denet_detect.py:76-100 (det_pr, bbox_predict), :330-349 (joint fitness)
 # ---------------------------------------------------------------------------------------------------------
-def detect_outputs(out, sample_bbox, class_num, jointfit, t0, use_bbox_reg=True):
+def detect_outputs(out, sample_bbox, class_num, jointfit, t0, use_bbox_reg=True, nfit=0):
     """out (B, s0[+4], sn, sn) -> det_pr (B,C+1,sn,sn), fitness (B,C+1,sn,sn), bbox (B,sn,sn,4)"""
     B, _, sn, _ = out.shape
     fit = 5
@@ -543,4 +570,11 @@ def detect_outputs(out, sample_bbox, class_num, jointfit, t0, use_bbox_reg=True)
         bbox = np.stack([pcx - pw * F32(0.5), pcy - ph * F32(0.5), pcx + pw * F32(0.5), pcy + ph * F32(0.5)], axis=-1)
     else:
         bbox = sample_bbox
-    return det_pr, fitness, bbox.astype(F32)
+    if nfit > 0:
+        # denet_detect.py:396-401: fitness += log(sum_f indfit_pr[f] * val[f]) (expectation in double, cast to float32)
+        off = s0 + (4 if use_bbox_reg else 0)
+        ip = np.exp(log_softmax(o[:, off:off + nfit], axis=1).astype(F32))
+        val = np.array([0.0] + [t0 + i * (1.0 - t0) / (nfit - 1) for i in range(nfit - 1)])
+        fexp = np.sum(ip * val[None, :, None, None], axis=1).astype(F32)
+        fitness = fitness + np.log(fexp)[:, None, :, :]
+    return det_pr, fitness.astype(F32), bbox.astype(F32)

@@ -221,7 +221,7 @@ class OracleModel:
             ot = j["overlapThreshold"]
             ot = (float(ot[0]), float(ot[1])) if isinstance(ot, (list, tuple)) else (float(ot), float(ot))
             n.update(cost_factor=j["costFactor"], bbox_factor=j["bboxFactor"], class_num=j["classNum"], thresholds=ot,
-                     jointfit=j["useJointFitness"], bounded=j["useBoundedIoU"])
+                     jointfit=j["useJointFitness"], bounded=j["useBoundedIoU"], indfit_factor=j.get("fitnessFactor", 0.0))
             n["conv"] = self._build([s for s in j["layers"] if s["type"] == "conv"][0])
         elif t in ("regression", "split", "identity"):
             pass
@@ -373,11 +373,17 @@ class OracleModel:
                     fit = 5 if n["jointfit"] else 6
                     s0 = (n["class_num"] * fit + 1) if n["jointfit"] else n["class_num"] + 1
                     use_reg = n["bbox_factor"] > 0.0
-                    det_t, valid, reg_t = L.detect_target(metas, self.sample_bbox_list, B, sn, n["class_num"],
-                                                          n["thresholds"], use_reg, n["jointfit"])
+                    use_indfit = n["indfit_factor"] > 0.0
+                    tg = L.detect_target(metas, self.sample_bbox_list, B, sn, n["class_num"], n["thresholds"], use_reg,
+                                         n["jointfit"], use_indfit)
+                    det_t, valid, reg_t = tg[:3]
                     self.detect_target = (det_t, valid, reg_t)
                     dc, bc, g = L.detect_cost(out.v, det_t, valid, reg_t, self.sample_bbox, s0, n["cost_factor"],
                                               n["bbox_factor"], n["bounded"])
+                    if use_indfit:
+                        fc, fg = L.indfit_cost(out.v, tg[3], s0 + (4 if use_reg else 0), n["indfit_factor"])
+                        bc += fc
+                        g = g + fg
                     self.costs.append(("denet-detect", dc + bc))
                     self.detect_cost_terms = (dc, bc)
                     out.add_grad(g)

@@ -174,9 +174,13 @@ def test_native_roi_editing_matches_reference_loop(denet_small, random_sample):
         dns.random_sample = old
 
 
-@pytest.mark.parametrize("jointfit", [False, True])
+@pytest.mark.parametrize("jointfit", [False, True, "indfit"])
 def test_detect_and_corner_targets_match_reference_loops(jointfit):
+    indfit = jointfit == "indfit"
+    jointfit = jointfit is True
     head = zoo.DENET34_SKIP_DESC.replace("DND[0.5,1,1]", "DND.J[0.5,1,1]") if jointfit else None
+    if indfit:
+        head = zoo.DENET34_SKIP_DESC.replace("DND[0.5,1,1]", "DND[0.5,1,1,0.5]")
     m = zoo.denet34(2, "skip", 128, head_desc=head)
     dns, dnd, dnc = m.layers[31], m.layers[40], m.layers[30]
     _, metas = zoo.synthetic_batch(2, 128, seed=5)
@@ -193,12 +197,16 @@ def test_detect_and_corner_targets_match_reference_loops(jointfit):
             dns.sample_boxes[b][k] = np.clip(g + rng.normal(0, 0.04 * (1 + k % 5), 4), 0, 1)
     n_det, n_valid, n_reg = dnd.build_targets_numpy(metas)
     n_det, n_valid, n_reg = n_det.copy(), n_valid.copy(), n_reg.copy()
+    n_fit = dnd._fit_target.copy() if indfit else None
     d_det, d_valid, d_reg = dnd.build_targets(metas)                       # native host path
     assert np.array_equal(n_det, d_det) and np.array_equal(n_valid, d_valid) and np.array_equal(n_reg, d_reg)
+    if indfit:
+        assert dnd.s2 == 6 and np.array_equal(n_fit, dnd._fit_target) and (n_fit[:, 1:] > 0).sum() > 100
     assert (d_det[:, :-1] > 0).sum() > 100
     idx, val = dnd.get_target(m, None, metas)
-    det_t, valid, reg_t = OL.detect_target(metas, dns.sample_bbox_list, 2, 24, 80, (0.5, 0.5), True, jointfit)
-    ref = np.concatenate([det_t.flatten(), valid.flatten(), reg_t.flatten()])
+    tg = OL.detect_target(metas, dns.sample_bbox_list, 2, 24, 80, (0.5, 0.5), True, jointfit, indfit)
+    det_t, valid, reg_t = tg[:3]
+    ref = np.concatenate([det_t.flatten(), valid.flatten(), reg_t.flatten()] + ([tg[3].flatten()] if indfit else []))
     assert idx.size == 0 and val.dtype == np.float32
     np.testing.assert_array_equal(val, ref)
     assert (det_t.sum(axis=1) > 0).all() and valid.sum() > 0

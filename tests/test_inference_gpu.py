@@ -86,6 +86,28 @@ def test_detect_decode_and_nms_vs_oracle(hip, jointfit, sn):
     assert len(got[2]) == 0
 
 
+@pytest.mark.parametrize("nreg", [4, 0])
+def test_detect_decode_independent_fitness_vs_oracle(hip, nreg):
+    """independent fitness head at inference (denet_detect.py:396-401): fitness += log E[val]"""
+    rng = np.random.RandomState(21 + nreg)
+    B, C, sn = 2, 7, 6
+    S, s0, nfit, t0 = sn * sn, C + 1, 6, 0.5
+    CP = 32
+    logits = np.zeros((B * S, CP), np.float32)
+    logits[:, :s0] = rng.normal(0, 2.0, (B * S, s0))
+    logits[:, s0:s0 + nreg] = rng.normal(0, 0.2, (B * S, nreg))
+    logits[:, s0 + nreg:s0 + nreg + nfit] = rng.normal(0, 1.5, (B * S, nfit))
+    roi = _clustered_boxes(rng, B, S).reshape(B * S, 4)
+    det_pr, fitness, bbox = ops.detect_decode(torch.from_numpy(logits).cuda(), torch.from_numpy(roi).cuda(), C, 0, nreg, t0,
+                                              nfit=nfit)
+    out_nchw = logits[:, :s0 + nreg + nfit].reshape(B, sn, sn, -1).transpose(0, 3, 1, 2)
+    o_det, o_fit, o_box = OL.detect_outputs(out_nchw, roi.reshape(B, sn, sn, 4), C, False, t0, use_bbox_reg=nreg == 4,
+                                            nfit=nfit)
+    np.testing.assert_allclose(det_pr.cpu().numpy().reshape(B, sn, sn, C + 1).transpose(0, 3, 1, 2), o_det, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(fitness.cpu().numpy().reshape(B, sn, sn, C + 1).transpose(0, 3, 1, 2), o_fit, rtol=1e-5, atol=4e-6)
+    assert float(np.abs(o_fit - o_det).max()) > 0.1      # the fitness term is really there
+
+
 def test_soft_nms_host_vs_oracle(hip):
     rng = np.random.RandomState(3)
     B, sn, C = 1, 12, 1

@@ -468,7 +468,8 @@ def test_skip_projection_vs_oracle(hip):
     assert len(skip.layers) == 2 and skip.layers[1].filter_shape == (64, 32, 1, 1)
 
 
-@pytest.mark.parametrize("head,rule", [("DND.JB[0.5,1,1]", 0), ("DND.B[0.4,2,0.5]", 1), ("DND[0.5,1,1]", 1)])
+@pytest.mark.parametrize("head,rule", [("DND.JB[0.5,1,1]", 0), ("DND.B[0.4,2,0.5]", 1), ("DND[0.5,1,1]", 1),
+                                       ("DND[0.5,1,1,0.7]", 0), ("DND[0.5,1,0,0.7]", 0)])
 def test_denet_head_variants_vs_oracle(hip, head, rule):
     """joint-fitness classes + bounded-IoU box cost (denet_detect.py:180-183, 266-286) and the CUDA tap rule"""
     B, IMG = 2, 128
@@ -494,6 +495,8 @@ def test_denet_head_variants_vs_oracle(hip, head, rule):
     assert np.array_equal(model.layers[31]._taps.cpu().numpy(), taps_ref)
     if "J" in head:
         assert model.layers[40].s0 == 401
+    if head.endswith("0.7]"):       # independent fitness head (4th argument = its cost factor)
+        assert model.layers[40].s2 == 6 and model.layers[40].layers[0].filter_shape[0] == 81 + model.layers[40].s1 + 6
 
 
 def test_denet_center_corner_variant_vs_oracle(hip):
