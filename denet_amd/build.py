@@ -11,9 +11,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libdenet_hip.so")
 
-SOURCES = ["runtime.hip", "igemm.hip", "bn.hip", "pool.hip", "elementwise.hip", "dss.hip", "samples.hip", "detect.hip", "winograd.hip"]
+SOURCES = ["runtime.hip", "igemm.hip", "bn.hip", "pool.hip", "elementwise.hip", "dss.hip", "samples.hip", "detect.hip", "winograd.hip",
+           "augment.hip"]
 # files whose integer results must not depend on FMA contraction
-NO_CONTRACT = {"dss.hip", "samples.hip", "detect.hip"}
+NO_CONTRACT = {"dss.hip", "samples.hip", "detect.hip", "augment.hip"}
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -7,7 +7,7 @@ into the model's flat device buffers in the kernel layout).
 import numpy
 
 # ---- global training state (reference: layer_train_enable / layer_train_epoch / layer_train_it) ----------
-_state = {"train": True, "epoch": 0, "iteration": 0}
+_state = {"train": True, "epoch": 0, "iteration": 0, "rng_seed": 0}
 
 
 def get_train():
@@ -32,6 +32,16 @@ def get_iteration():
 
 def set_iteration(v):
     _state["iteration"] = v
+
+
+def set_rng_seed(v):
+    """reference: seeds the MRG stream of the `D` / `CM` layers (layer/__init__.py:14-16); here: the base key of
+    their counter-based generator"""
+    _state["rng_seed"] = int(v)
+
+
+def get_rng_seed():
+    return _state["rng_seed"]
 
 
 def round_up(v, m):

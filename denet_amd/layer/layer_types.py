@@ -10,9 +10,15 @@ from .resnet import ResnetLayer
 from .regression import RegressionLayer
 from .split import SplitLayer
 from .skip import SkipLayer, SkipSrcLayer
+from .deconvolution import DeconvLayer
+from .dropout import DropoutLayer
+from .crop_mirror import CropMirrorLayer
+from .border import BorderLayer
 
-layer_types = [IdentityLayer, ConvLayer, PoolLayer, PoolInvLayer, RegressionLayer, ActivationLayer, BatchNormLayer,
-               BatchNormReluLayer, ResnetLayer, SplitLayer, SkipLayer, SkipSrcLayer]
+# same order as the reference list
+layer_types = [IdentityLayer, DropoutLayer, BorderLayer, ConvLayer, PoolLayer, PoolInvLayer, RegressionLayer,
+               CropMirrorLayer, ActivationLayer, BatchNormLayer, BatchNormReluLayer, ResnetLayer, DeconvLayer,
+               SplitLayer, SkipLayer, SkipSrcLayer]
 
 from .denet_corner import DeNetCornerLayer
 from .denet_sparse import DeNetSparseLayer

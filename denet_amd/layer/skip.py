@@ -59,11 +59,13 @@ class SkipLayer(AbstractLayer):
             if self.y_shape[1] != self.x_shape[1]:
                 self.layers = [InitialLayer(self.y, self.y_shape)]
                 self.layers.append(ConvLayer(self.layers, filter_shape=(self.x_shape[1], self.y_shape[1], 1, 1)))
+            self.output = Act(self.output_shape, self.x.cp, "skip%i" % self.layer_index)
         elif self.combine_mode == "concat":
-            raise NotImplementedError("SKIP combine mode 'concat' is only reachable through JSON and outside the hot path")
+            # skip.py:93-96 (only reachable through the JSON key "combineMode"): channels of x, then of the tap
+            self.output_shape = (self.x_shape[0], self.x_shape[1] + self.y_shape[1], self.x_shape[2], self.x_shape[3])
+            self.output = Act(self.output_shape, None, "skip%i" % self.layer_index)
         else:
             raise Exception("Unknown combine mode: %s" % self.combine_mode)
-        self.output = Act(self.output_shape, self.x.cp, "skip%i" % self.layer_index)
 
     def export_json(self):
         j = super().export_json()
@@ -78,7 +80,9 @@ class SkipLayer(AbstractLayer):
         return True
 
     def forward(self, ctx):
-        if len(self.layers) > 1:
+        if self.combine_mode == "concat":
+            self.output.data = ops.concat_fwd(self.x.data, self.y.data, self.x_shape[1], self.y_shape[1], self.output.cp)
+        elif len(self.layers) > 1:
             # 1x1 projection of the tap with the add fused in its epilogue
             self.layers[1].forward(ctx, add=self.x.data)
             self.output.data = self.layers[1].output.data
@@ -87,6 +91,11 @@ class SkipLayer(AbstractLayer):
 
     def backward(self, ctx):
         g = self.output.grad
+        if self.combine_mode == "concat":
+            gx, gy = ops.concat_bwd(g, self.x_shape[1], self.x.cp, self.y_shape[1], self.y.cp)
+            self.x.add_grad(gx)
+            self.y.add_grad(gy)
+            return
         self.x.add_grad(g)
         if len(self.layers) > 1:
             self.layers[1].output.grad = g

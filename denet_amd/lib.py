@@ -14,6 +14,7 @@ I = ctypes.c_int
 L = ctypes.c_long
 F = ctypes.c_float
 Z = ctypes.c_size_t
+U64 = ctypes.c_uint64
 
 # name -> (restype, argtypes); mirrors include/denet_hip.h declaration by declaration
 SIGNATURES = {
@@ -49,6 +50,14 @@ SIGNATURES = {
     "denet_avgpool_bwd": (I, [P, P] + [I] * 9 + [P]),
     "denet_pool_inv_fwd": (I, [P, P] + [I] * 6 + [P]),
     "denet_pool_inv_bwd": (I, [P, P] + [I] * 6 + [P]),
+    "denet_border_fwd": (I, [P, P] + [I] * 8 + [P]),
+    "denet_border_bwd": (I, [P, P] + [I] * 8 + [P]),
+    "denet_crop_mirror_fwd": (I, [P, P] + [I] * 6 + [F, F, I, U64, P]),
+    "denet_crop_mirror_bwd": (I, [P, P] + [I] * 6 + [F, F, I, U64, P]),
+    "denet_dropout": (I, [P, P, I, I, I, I, F, U64, P]),
+    "denet_concat_fwd": (I, [P, P, P, L] + [I] * 5 + [P]),
+    "denet_concat_bwd": (I, [P, P, P, L] + [I] * 5 + [P]),
+    "denet_add_bias": (I, [P, P, P, L, I, P]),
     "denet_nchw_to_nhwc": (I, [P, P] + [I] * 5 + [P]),
     "denet_nhwc_to_nchw": (I, [P, P] + [I] * 5 + [P]),
     "denet_add": (I, [P, P, P, L, I, P]),

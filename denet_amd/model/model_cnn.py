@@ -96,6 +96,7 @@ class ModelCNN:
         self.data_shape = None
         self.class_num = 0
         self.rng_seed = random.randint(1, 9999)
+        layer_mod.set_rng_seed(self.rng_seed)
         self.gradient_clip = 0.0
         self.skip_layer_updates = []
         self.bias_decay = False
@@ -380,6 +381,7 @@ class ModelCNN:
         """same signature and return value as the reference (model_cnn.py:407-445)"""
         layer_mod.set_iteration(it)
         layer_mod.set_epoch(epoch)
+        layer_mod.set_rng_seed(self.rng_seed)      # several models may live in one process
         momentum = numpy.array(momentum, dtype=numpy.float32).reshape(-1)
         costs = self.func["train_step"](epoch, it, learning_rate, momentum, decay, data_x, data_m, fetch_cost)
         if costs is None:

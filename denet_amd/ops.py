@@ -501,6 +501,81 @@ def pool_inv_bwd(dy, fy, fx):
     return dx
 
 
+# ---- shape / stochastic layers (csrc/augment.hip) -----------------------------------------------------------
+def border_fwd(x, border):
+    """border = (left, right, top, bottom) (denet/layer/border.py:18)"""
+    N, H, W, C = x.shape
+    l, r, t, b = (int(v) for v in border)
+    y = empty(N, H + t + b, W + l + r, C)
+    check(_L().denet_border_fwd(ptr(x), ptr(y), N, H, W, C, l, r, t, b, stream_ptr()), "border_fwd")
+    return y
+
+
+def border_bwd(dy, border):
+    N, OH, OW, C = dy.shape
+    l, r, t, b = (int(v) for v in border)
+    dx = empty(N, OH - t - b, OW - l - r, C)
+    check(_L().denet_border_bwd(ptr(dy), ptr(dx), N, OH - t - b, OW - l - r, C, l, r, t, b, stream_ptr()), "border_bwd")
+    return dx
+
+
+def crop_mirror_fwd(x, crop, mirror_pr, flip_pr, train, seed):
+    """crop = (rows, cols); seed: 64-bit counter key of this (layer, iteration)"""
+    N, H, W, C = x.shape
+    y = empty(N, int(crop[0]), int(crop[1]), C)
+    check(_L().denet_crop_mirror_fwd(ptr(x), ptr(y), N, H, W, C, int(crop[0]), int(crop[1]), float(mirror_pr),
+                                     float(flip_pr), int(bool(train)), int(seed), stream_ptr()), "crop_mirror_fwd")
+    return y
+
+
+def crop_mirror_bwd(dy, x_shape, mirror_pr, flip_pr, train, seed):
+    N, H, W, C = x_shape
+    dx = empty(N, H, W, C)
+    check(_L().denet_crop_mirror_bwd(ptr(dy), ptr(dx), N, H, W, C, dy.shape[1], dy.shape[2], float(mirror_pr),
+                                     float(flip_pr), int(bool(train)), int(seed), stream_ptr()), "crop_mirror_bwd")
+    return dx
+
+
+def dropout(x, c_logical, rate, seed):
+    """y = x * mask(seed) / (1 - rate); apply to dy with the same seed for the gradient"""
+    N, C = x.shape[0], x.shape[-1]
+    y = torch.empty_like(x)
+    check(_L().denet_dropout(ptr(x), ptr(y), N, x.numel() // (N * C), C, int(c_logical), float(rate), int(seed),
+                             stream_ptr()), "dropout")
+    return y
+
+
+def concat_fwd(a, b, ca, cb, cyp):
+    """logical channel concatenation of two channel-padded NHWC buffers"""
+    rows = a.numel() // a.shape[-1]
+    y = empty(*a.shape[:-1], cyp)
+    check(_L().denet_concat_fwd(ptr(a), ptr(b), ptr(y), rows, int(ca), a.shape[-1], int(cb), b.shape[-1], int(cyp),
+                                stream_ptr()), "concat_fwd")
+    return y
+
+
+def concat_bwd(dy, ca, cap, cb, cbp):
+    rows = dy.numel() // dy.shape[-1]
+    da = empty(*dy.shape[:-1], cap)
+    db = empty(*dy.shape[:-1], cbp)
+    check(_L().denet_concat_bwd(ptr(dy), ptr(da), ptr(db), rows, int(ca), int(cap), int(cb), int(cbp), dy.shape[-1],
+                                stream_ptr()), "concat_bwd")
+    return da, db
+
+
+def add_bias(x, bias, out=None):
+    y = out if out is not None else torch.empty_like(x)
+    C = x.shape[-1]
+    check(_L().denet_add_bias(ptr(x), ptr(bias), ptr(y), x.numel() // C, C, stream_ptr()), "add_bias")
+    return y
+
+
+def layer_seed(base, layer_index, iteration):
+    """64-bit counter key of one stochastic layer at one training iteration"""
+    return (int(base) * 0x9E3779B97F4A7C15 + (int(layer_index) + 1) * 0xD1B54A32D192ED03
+            + (int(iteration) + 1) * 0x8CB92BA72F3D8DD7) & 0xFFFFFFFFFFFFFFFF
+
+
 def nchw_to_nhwc(x, cp):
     N, C, H, W = x.shape
     y = empty(N, H, W, cp)

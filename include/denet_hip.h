@@ -18,14 +18,15 @@
 #define DENET_HIP_H
 
 #include <stddef.h>
+#include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#ifndef __HIP_PLATFORM_AMD__
+/* the HIP stream handle, declared here so a plain-C host can include this file without the HIP headers (an
+ * identical re-declaration of hip_runtime_api.h's typedef, which C11 and C++ both allow) */
 typedef struct ihipStream_t* hipStream_t;
-#endif
 
 #define DENET_ERR_ARG (-1000)
 #define DENET_TAP_THEANO 0 /* denet/layer/denet_sparse.py:72-84  (i*extent)/(gs-1), round half to even */
@@ -139,6 +140,33 @@ int denet_avgpool_bwd(const float* dy, float* dx, int N, int H, int W, int C, in
                       int pad, hipStream_t stream);
 int denet_pool_inv_fwd(const float* x, float* y, int N, int H, int W, int C, int fy, int fx, hipStream_t stream);
 int denet_pool_inv_bwd(const float* dy, float* dx, int N, int H, int W, int C, int fy, int fx, hipStream_t stream);
+
+/* ---- shape / stochastic layers of the operator surface (csrc/augment.hip), NHWC fp32, C % 4 == 0
+ *      B    zero border, (left, right, top, bottom)              denet/layer/border.py:18-33
+ *      CM   per-image random crop + column mirror + row flip     denet/layer/crop_mirror.py:26-56 (train=0: centre
+ *           crop, no mirror / flip)
+ *      D    dropout, y = x * mask / (1 - rate)                   denet/layer/dropout.py:20-24 (call again with dy
+ *           and the same seed for the gradient)
+ *      SKIP "concat" combine mode: channel concatenation         denet/layer/skip.py:93-96
+ *      DC   bias epilogue of the deconvolution                   denet/layer/deconvolution.py:66-67
+ *    The reference's random stream is Theano's MRG_RandomStreams (third party, not reproducible here); the masks
+ *    and crop geometry are a pure function of `seed` and the LOGICAL element / image index instead (splitmix64
+ *    finaliser, restated in oracle/layers.py), so nothing is stored between the forward and backward pass.  */
+int denet_border_fwd(const float* x, float* y, int N, int H, int W, int C, int left, int right, int top, int bottom,
+                     hipStream_t stream);
+int denet_border_bwd(const float* dy, float* dx, int N, int H, int W, int C, int left, int right, int top, int bottom,
+                     hipStream_t stream);
+int denet_crop_mirror_fwd(const float* x, float* y, int N, int H, int W, int C, int crop_h, int crop_w, float mirror_pr,
+                          float flip_pr, int train, uint64_t seed, hipStream_t stream);
+int denet_crop_mirror_bwd(const float* dy, float* dx, int N, int H, int W, int C, int crop_h, int crop_w,
+                          float mirror_pr, float flip_pr, int train, uint64_t seed, hipStream_t stream);
+int denet_dropout(const float* x, float* y, int N, int HW, int C, int C_logical, float rate, uint64_t seed,
+                  hipStream_t stream);
+int denet_concat_fwd(const float* a, const float* b, float* y, long rows, int CA, int CAP, int CB, int CBP, int CYP,
+                     hipStream_t stream);
+int denet_concat_bwd(const float* dy, float* da, float* db, long rows, int CA, int CAP, int CB, int CBP, int CYP,
+                     hipStream_t stream);
+int denet_add_bias(const float* x, const float* bias, float* y, long rows, int C, hipStream_t stream);
 
 /* ---- element-wise / boundary helpers
  *      layout conversion of the NCHW batches handed to ModelCNN.train_step (denet/model/model_cnn.py:407),

@@ -73,6 +73,118 @@ def conv2d_grad(x, w, dy, stride=1, pad=0, need_dx=True):
     return dx, np.ascontiguousarray(dw), db
 
 
+def deconv2d(x, w, b=None, stride=1, pad=0):
+    """`DC`: denet/layer/deconvolution.py:54-67. w is omega (C_out, C_in, kh, kw); the output is the gradient of the
+    true convolution F (filters omega with the first two axes swapped, i.e. (C_in, C_out, kh, kw)) w.r.t. its input
+    of shape (N, C_out, h, w), h = H*s - 2p + k - 1, evaluated at output-gradient x"""
+    O, I, R, S = w.shape
+    N, C, H, W = x.shape
+    assert C == I
+    h = H * stride - 2 * pad + R - 1
+    wd = W * stride - 2 * pad + S - 1
+    wt = np.ascontiguousarray(w.transpose(1, 0, 2, 3))          # F's filters (K = C_in, C = C_out)
+    wf = wt[:, :, ::-1, ::-1].reshape(I, O * R * S)
+    dcols = np.matmul(wf.T[None], x.reshape(N, I, H * W))
+    y = _col2im(dcols, (N, O, h, wd), R, S, stride, pad, H, W)
+    if b is not None:
+        y = y + b[None, :, None, None]
+    return y.astype(x.dtype)
+
+
+def deconv2d_grad(x, w, dy, stride=1, pad=0, need_dx=True):
+    """gradients of deconv2d w.r.t. x, omega, bias: dx = F(dy); d_omega = (filter gradient of F with input dy and
+    output-gradient x), axes swapped back"""
+    wt = np.ascontiguousarray(w.transpose(1, 0, 2, 3))
+    dx = conv2d(dy, wt, None, stride, pad) if need_dx else None
+    _, dwt, _ = conv2d_grad(dy, wt, x, stride, pad, need_dx=False)
+    return dx, np.ascontiguousarray(dwt.transpose(1, 0, 2, 3)), dy.sum(axis=(0, 2, 3))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# `B` / `D` / `CM` (denet/layer/border.py:18-33, dropout.py:20-24, crop_mirror.py:26-56). The reference's random
+# stream is Theano's MRG_RandomStreams (third party, not under /root/reference): parity with it is UNPINNED. The
+# build defines its masks by a counter-based generator (csrc/augment.hip); this is its restatement.
+# ---------------------------------------------------------------------------------------------------------
+_M64 = (1 << 64) - 1
+
+
+def mix64(seed, idx):
+    """splitmix64 finaliser of seed + idx * golden; idx: uint64 array"""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed & _M64) + np.asarray(idx, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def u24(seed, idx):
+    return (mix64(seed, idx) >> np.uint64(40)).astype(np.int64)
+
+
+def thr24(p):
+    return 0 if p <= 0.0 else (1 << 24) if p >= 1.0 else int(p * 16777216.0)
+
+
+def layer_seed(base, layer_index, iteration):
+    return (int(base) * 0x9E3779B97F4A7C15 + (int(layer_index) + 1) * 0xD1B54A32D192ED03
+            + (int(iteration) + 1) * 0x8CB92BA72F3D8DD7) & _M64
+
+
+def dropout_mask(shape, rate, seed):
+    """mask * 1/(1-rate) over a logical NCHW shape; rate is rounded to fp32 like the C-ABI argument"""
+    rate = float(np.float32(rate))
+    keep = u24(seed, np.arange(int(np.prod(shape)), dtype=np.uint64)) < thr24(1.0 - rate)
+    return (keep.astype(F32) * F32(1.0 / (1.0 - rate))).reshape(shape)
+
+
+def crop_mirror_geom(N, H, W, CH, CW, mirror_pr, flip_pr, train, seed):
+    """per-image (off_r, off_c, flip, mirror)"""
+    if not train:
+        return [((H - CH) // 2, (W - CW) // 2, False, False)] * N
+    n4 = np.arange(N, dtype=np.uint64) * np.uint64(4)
+    mirror = u24(seed, n4) > thr24(1.0 - float(np.float32(mirror_pr)))
+    flip = u24(seed, n4 + np.uint64(1)) > thr24(1.0 - float(np.float32(flip_pr)))
+    off_r = (u24(seed, n4 + np.uint64(2)) * (H - CH + 1)) >> 24
+    off_c = (u24(seed, n4 + np.uint64(3)) * (W - CW + 1)) >> 24
+    return [(int(off_r[n]), int(off_c[n]), bool(flip[n]), bool(mirror[n])) for n in range(N)]
+
+
+def crop_mirror(x, crop, geom):
+    N, C, H, W = x.shape
+    y = np.empty((N, C, crop[0], crop[1]), dtype=x.dtype)
+    for n, (r0, c0, flip, mirror) in enumerate(geom):
+        v = x[n, :, r0:r0 + crop[0], c0:c0 + crop[1]]
+        if flip:
+            v = v[:, ::-1, :]
+        if mirror:
+            v = v[:, :, ::-1]
+        y[n] = v
+    return y
+
+
+def crop_mirror_grad(dy, x_shape, geom):
+    dx = np.zeros(x_shape, dtype=dy.dtype)
+    CH, CW = dy.shape[2], dy.shape[3]
+    for n, (r0, c0, flip, mirror) in enumerate(geom):
+        v = dy[n]
+        if flip:
+            v = v[:, ::-1, :]
+        if mirror:
+            v = v[:, :, ::-1]
+        dx[n, :, r0:r0 + CH, c0:c0 + CW] = v
+    return dx
+
+
+def border(x, b):
+    """b = (left, right, top, bottom)"""
+    return np.pad(x, ((0, 0), (0, 0), (b[2], b[3]), (b[0], b[1])))
+
+
+def border_grad(dy, b):
+    H, W = dy.shape[2], dy.shape[3]
+    return np.ascontiguousarray(dy[:, :, b[2]:H - b[3], b[0]:W - b[1]])
+
+
 # ---------------------------------------------------------------------------------------------------------
 # batch normalisation: denet/layer/batch_norm.py:50-79 (cuDNN spatial BN: biased variance, eps inside the
 # sqrt; running mean / running INVERSE std with momentum; test path feeds var=(1/stdinv)^2 and cuDNN adds eps

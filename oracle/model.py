@@ -145,6 +145,43 @@ def op_pool(x, mode, k, s, p):
     return T(y, (x,), lambda g: x.add_grad(L.pool_avg_grad(g, x.v.shape, k, s, p)))
 
 
+def op_deconv(x, w, b, stride, pad, need_dx=True):
+    y = L.deconv2d(x.v, w.v, None if b is None else b.v, stride, pad)
+
+    def bw(g):
+        dx, dw, db = L.deconv2d_grad(x.v, w.v, g, stride, pad, need_dx)
+        w.g = dw if w.g is None else w.g + dw
+        if b is not None:
+            b.g = db.astype(F32) if b.g is None else b.g + db
+        if need_dx:
+            x.add_grad(dx)
+
+    return T(y, (x,), bw)
+
+
+def op_border(x, b):
+    return T(L.border(x.v, b), (x,), lambda g: x.add_grad(L.border_grad(g, b)))
+
+
+def op_dropout(x, rate, seed):
+    m = L.dropout_mask(x.v.shape, rate, seed)
+    return T((x.v * m).astype(F32), (x,), lambda g: x.add_grad((g * m).astype(F32)))
+
+
+def op_crop_mirror(x, crop, geom):
+    return T(L.crop_mirror(x.v, crop, geom), (x,), lambda g: x.add_grad(L.crop_mirror_grad(g, x.v.shape, geom)))
+
+
+def op_concat(a, b):
+    ca = a.v.shape[1]
+
+    def bw(g):
+        a.add_grad(np.ascontiguousarray(g[:, :ca]))
+        b.add_grad(np.ascontiguousarray(g[:, ca:]))
+
+    return T(np.concatenate([a.v, b.v], axis=1), (a, b), bw)
+
+
 def op_pool_inv(x, size):
     return T(L.pool_inv(x.v, size), (x,), lambda g: x.add_grad(L.pool_inv_grad(g, size)))
 
@@ -165,10 +202,12 @@ def _conv_node(j):
 
 
 class OracleModel:
-    def __init__(self, json_obj, batch_size, tap_rule=0):
+    def __init__(self, json_obj, batch_size, tap_rule=0, rng_seed=0):
         self.batch_size = batch_size
         self.class_num = json_obj["classNum"]
         self.tap_rule = tap_rule
+        self.rng_seed = rng_seed   # base key of the `D` / `CM` counter generator (ModelCNN.rng_seed)
+        self.iteration = 0
         self.nodes = [self._build(j) for j in json_obj["layers"]]
         self.acts = {}
         self.sample_bbox_list = None
@@ -208,8 +247,18 @@ class OracleModel:
         elif t == "resnet":
             n.update(version=j["version"], bottleneck=j["bottleneck"], activation=j["activation"])
             n["layers"] = [self._build(s) for s in j["layers"] if s["type"] not in ("initial", "identity")]
+        elif t == "deconv":
+            n.update(w=P(j["weight"], True), b=P(j["bias"], False) if j["useBias"] else None,
+                     stride=int(j["stride"][0]), pad=int(j["shape"][2]) // 2)
+        elif t == "border":
+            n["border"] = tuple(int(v) for v in j["border"])
+        elif t == "dropout":
+            n["rate"] = float(j["dropoutRate"])
+        elif t == "crop-mirror":
+            n.update(crop=tuple(j["crop"]), mirror=float(j["mirror"]), flip=float(j["flip"]))
         elif t in ("skip-src", "skip"):
             n["index"] = j["index"]
+            n["mode"] = j.get("combineMode", "proj-add")
             n["layers"] = [self._build(s) for s in j.get("layers", []) if s["type"] != "initial"]
         elif t == "denet-corner":
             n.update(sample_feat=j["sampleFeat"], cost_factor=j["costFactor"], use_center=j["useCenter"])
@@ -234,7 +283,7 @@ class OracleModel:
         out = []
 
         def rec(n):
-            if n["type"] == "conv" and n["enabled"]:
+            if n["type"] == "deconv" or (n["type"] == "conv" and n["enabled"]):
                 out.append(n["w"])
                 if n["b"] is not None:
                     out.append(n["b"])
@@ -286,8 +335,21 @@ class OracleModel:
             y = op_relu(y)
         return self._forced(y, "resnet-out")
 
-    def _apply(self, n, x, train):
+    def _apply(self, n, x, train, li=0):
         t = n["type"]
+        if t == "deconv":
+            return self._forced(op_deconv(x, n["w"], n["b"], n["stride"], n["pad"], need_dx=x is not self.x_in), t)
+        if t == "border":
+            return self._forced(op_border(x, n["border"]), t)
+        if t == "dropout":
+            if not train:
+                return x
+            return self._forced(op_dropout(x, n["rate"], L.layer_seed(self.rng_seed, li, self.iteration)), t)
+        if t == "crop-mirror":
+            N, _, H, W = x.v.shape
+            geom = L.crop_mirror_geom(N, H, W, n["crop"][0], n["crop"][1], n["mirror"], n["flip"], train,
+                                      L.layer_seed(self.rng_seed, li, self.iteration))
+            return self._forced(op_crop_mirror(x, n["crop"], geom), t)
         if t == "conv":
             return self._forced(op_conv(x, n["w"], n["b"], n["stride"], n["pad"], need_dx=x is not self.x_in), t)
         if t == "batchnorm":
@@ -324,6 +386,10 @@ class OracleModel:
                 taps_src[n["index"]] = h
             elif t == "skip":
                 tap = taps_src[n["index"]]
+                if n["mode"] == "concat":
+                    h = self._forced(op_concat(h, tap), "skip")
+                    self.acts[li] = h.v
+                    continue
                 if n["layers"]:
                     tap = self._apply(n["layers"][0], tap, train)
                 h = self._forced(op_add(h, tap), "skip")
@@ -396,7 +462,7 @@ class OracleModel:
                     h.add_grad(g)
                     self.cost_roots.append(h)
             else:
-                h = self._apply(n, h, train)
+                h = self._apply(n, h, train, li)
             self.acts[li] = h.v
         self.out = h
         return self.costs
@@ -405,6 +471,7 @@ class OracleModel:
         """denet/model/model_cnn.py:407-445 + the solver updates of :282-331"""
         for p in self.params():
             p.g = None
+        self.iteration = iteration
         costs = self.forward(x_nchw, metas, True, sample_override)
         backprop(self.cost_roots)
         for p in self.params():

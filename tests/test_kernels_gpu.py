@@ -219,6 +219,70 @@ def test_pool_inv(hip):
     _close(_nchw(dx), ref, rtol=1e-6)
 
 
+def test_border_crop_dropout_concat_kernels_vs_oracle(hip):
+    """csrc/augment.hip against the oracle restatements, bit-exact (pure copies / one multiply by a constant)"""
+    from denet_amd import ops
+    from oracle import layers as L
+    rng = np.random.RandomState(4)
+    N, C, CP, H, W = 3, 40, 64, 9, 11
+    x = rng.randn(N, C, H, W).astype(np.float32)
+    xd = ops.nchw_to_nhwc(torch.from_numpy(x).cuda(), CP)
+
+    def back(t, c=C):
+        return ops.nhwc_to_nchw(t, c).cpu().numpy()
+
+    # B
+    b = (2, 1, 0, 3)
+    y = ops.border_fwd(xd, b)
+    assert np.array_equal(back(y), L.border(x, b))
+    assert np.array_equal(back(ops.border_bwd(y, b)), x)
+    # CM: training geometry per image from the counter generator, centre crop at test time
+    for train in (True, False):
+        for it in range(4):
+            seed = L.layer_seed(77, 1, it)
+            geom = L.crop_mirror_geom(N, H, W, 5, 6, 0.5, 0.5, train, seed)
+            y = ops.crop_mirror_fwd(xd, (5, 6), 0.5, 0.5, train, seed)
+            ref = L.crop_mirror(x, (5, 6), geom)
+            assert np.array_equal(back(y), ref)
+            dy = rng.randn(*ref.shape).astype(np.float32)
+            dx = ops.crop_mirror_bwd(ops.nchw_to_nhwc(torch.from_numpy(dy).cuda(), CP), (N, H, W, CP), 0.5, 0.5, train, seed)
+            assert np.array_equal(back(dx), L.crop_mirror_grad(dy, x.shape, geom))
+    # D: mask is a function of the LOGICAL NCHW index (independent of the channel padding), padding stays zero
+    for rate in (0.0, 0.3, 0.5):
+        seed = L.layer_seed(5, 2, 9)
+        y = ops.dropout(xd, C, rate, seed)
+        assert np.array_equal(back(y), x * L.dropout_mask(x.shape, rate, seed))
+        assert float(y[..., C:].abs().max()) == 0.0
+        y32 = ops.dropout(ops.nchw_to_nhwc(torch.from_numpy(x[:, :32].copy()).cuda(), 32), 32, rate, seed)
+        assert np.array_equal(back(y32, 32), x[:, :32] * L.dropout_mask((N, 32, H, W), rate, seed))
+    # SKIP concat of two channel-padded buffers and its split gradient
+    z = rng.randn(N, 24, H, W).astype(np.float32)
+    zd = ops.nchw_to_nhwc(torch.from_numpy(z).cuda(), 32)
+    y = ops.concat_fwd(xd, zd, C, 24, 64)
+    assert y.shape[-1] == 64 and np.array_equal(back(y, 64), np.concatenate([x, z], axis=1))
+    y96 = ops.concat_fwd(xd, zd, C, 24, 96)
+    assert float(y96[..., 64:].abs().max()) == 0.0
+    da, db = ops.concat_bwd(y, C, CP, 24, 32)
+    assert np.array_equal(back(da, CP)[:, :C], x) and float(da[..., C:].abs().max()) == 0.0
+    assert np.array_equal(back(db, 32)[:, :24], z) and float(db[..., 24:].abs().max()) == 0.0
+    # bias epilogue of DC
+    bias = torch.from_numpy(rng.randn(CP).astype(np.float32)).cuda()
+    yb = ops.add_bias(xd, bias)
+    assert torch.equal(yb, xd + bias)
+
+
+def test_dropout_full_size_statistics(hip):
+    """a hot-path-sized activation (32 x 64 x 128 x 128): keep rate, mean preservation, forward/backward masks equal"""
+    from denet_amd import ops
+    x = torch.ones(32, 128, 128, 64, device="cuda")
+    y = ops.dropout(x, 64, 0.25, 12345)
+    keep = (y > 0).float().mean().item()
+    assert abs(keep - 0.75) < 1e-3
+    assert abs(y.mean().item() - 1.0) < 2e-3
+    assert torch.equal(y, ops.dropout(x, 64, 0.25, 12345))
+    assert not torch.equal(y, ops.dropout(x, 64, 0.25, 12346))
+
+
 def test_elementwise_and_solver(hip):
     from denet_amd import ops
     g = torch.Generator().manual_seed(9)

@@ -76,6 +76,68 @@ def test_conv_vs_torch(k, stride, pad):
     np.testing.assert_allclose(db, tb.grad.numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("k,stride", [(3, 1), (3, 2), (4, 2), (1, 1), (5, 3)])
+def test_deconv_vs_torch(k, stride):
+    """`DC` = gradient of the true convolution w.r.t. its input (denet/layer/deconvolution.py:54-67): second
+    implementation = torch conv_transpose2d on the flipped, axis-swapped filters, output_padding = stride - 1"""
+    rng = np.random.RandomState(k * 10 + stride)
+    pad = k // 2
+    x = rng.randn(2, 5, 6, 7).astype(np.float32)
+    w = rng.randn(4, 5, k, k).astype(np.float32)           # omega (C_out, C_in, kh, kw)
+    b = rng.randn(4).astype(np.float32)
+    tx, tw, tb = _t(x, True), _t(w, True), _t(b, True)
+    wt = torch.flip(tw.permute(1, 0, 2, 3), [2, 3])        # correlation filters of F, (C_in, C_out, kh, kw)
+    ty = Fn.conv_transpose2d(tx, wt, tb, stride=stride, padding=pad, output_padding=stride - 1)
+    y = L.deconv2d(x, w, b, stride, pad)
+    assert y.shape == (2, 4, 6 * stride - 2 * pad + k - 1, 7 * stride - 2 * pad + k - 1)
+    np.testing.assert_allclose(y, ty.detach().numpy(), rtol=1e-4, atol=1e-4)
+    dy = rng.randn(*y.shape).astype(np.float32)
+    ty.backward(_t(dy))
+    dx, dw, db = L.deconv2d_grad(x, w, dy, stride, pad)
+    np.testing.assert_allclose(dx, tx.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dw, tw.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(db, tb.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_border_crop_dropout_restatements():
+    """`B` (border.py:30-33), `CM` (crop_mirror.py:26-56) and `D` (dropout.py:20-24): shapes, adjoints and the
+    statistics of the counter-based generator that replaces the (third-party, unpinned) Theano MRG stream"""
+    rng = np.random.RandomState(2)
+    x = rng.randn(3, 2, 5, 6).astype(np.float32)
+    y = L.border(x, (1, 2, 3, 0))                         # (left, right, top, bottom)
+    assert y.shape == (3, 2, 8, 9) and np.array_equal(y[:, :, 3:8, 1:7], x) and y.sum() == pytest.approx(x.sum(), rel=1e-5)
+    assert np.array_equal(L.border_grad(y, (1, 2, 3, 0)), x)
+
+    # crop-mirror: test mode = centre crop; train mode = a permutation of a window, adjoint identity <Ax,y> = <x,A'y>
+    g0 = L.crop_mirror_geom(3, 5, 6, 3, 4, 0.5, 0.5, False, 123)
+    assert g0 == [(1, 1, False, False)] * 3
+    assert np.array_equal(L.crop_mirror(x, (3, 4), g0), x[:, :, 1:4, 1:5])
+    seen = set()
+    for seed in range(200):
+        g = L.crop_mirror_geom(3, 5, 6, 3, 4, 0.5, 0.25, True, L.layer_seed(7, 1, seed))
+        for r0, c0, flip, mirror in g:
+            assert 0 <= r0 <= 2 and 0 <= c0 <= 2
+            seen.add((r0, c0, flip, mirror))
+        ycm = L.crop_mirror(x, (3, 4), g)
+        dy = rng.randn(*ycm.shape).astype(np.float32)
+        assert np.vdot(ycm, dy) == pytest.approx(np.vdot(x, L.crop_mirror_grad(dy, x.shape, g)), rel=1e-4, abs=1e-4)
+    assert len(seen) == 3 * 3 * 2 * 2                      # every offset / flip / mirror combination occurs
+    one = L.crop_mirror(x[:1], (3, 4), [(2, 1, True, True)])
+    assert np.array_equal(one[0], x[0, :, 2:5, 1:5][:, ::-1, ::-1])
+
+    # dropout: keep probability 1 - rate, scale 1/(1 - rate), different per (layer, iteration), reproducible
+    m = L.dropout_mask((8, 16, 32, 32), 0.3, L.layer_seed(5, 2, 0))
+    assert set(np.unique(m).tolist()) == {0.0, float(np.float32(1.0 / (1.0 - float(np.float32(0.3)))))}
+    assert abs((m > 0).mean() - 0.7) < 5e-3
+    assert abs(m.mean() - 1.0) < 1e-2
+    assert np.array_equal(m, L.dropout_mask((8, 16, 32, 32), 0.3, L.layer_seed(5, 2, 0)))
+    assert (m != L.dropout_mask((8, 16, 32, 32), 0.3, L.layer_seed(5, 2, 1))).mean() > 0.3
+    assert (m != L.dropout_mask((8, 16, 32, 32), 0.3, L.layer_seed(5, 3, 0))).mean() > 0.3
+    assert abs(np.corrcoef(m[:, :, :, :-1].ravel(), m[:, :, :, 1:].ravel())[0, 1]) < 5e-3   # neighbours independent
+    assert L.u24(0, np.array([0], dtype=np.uint64))[0] == (0 >> 40)      # mix64(0) == 0: the finaliser's fixed point
+    assert int(L.mix64(1, np.array([0], dtype=np.uint64))[0]) == 0x5692161D100B05E5        # splitmix64 known answer
+
+
 def test_bn_grad_and_test_mode_vs_torch():
     rng = np.random.RandomState(3)
     x = (rng.randn(4, 6, 5, 5) * 2 + 1).astype(np.float32)

@@ -137,8 +137,10 @@ def _force_list(model):
     out = []
     for layer in model.layers[1:]:
         t = layer.type_name
-        if t in ("conv", "batchnorm", "batchnorm-relu", "pool", "pool-inv"):
+        if t in ("conv", "batchnorm", "batchnorm-relu", "pool", "pool-inv", "deconv", "border", "crop-mirror"):
             out.append(nchw(layer.output))
+        elif t == "dropout":
+            out.append(nchw(layer.output))        # parity runs are training steps (the test path is an identity)
         elif t == "activation":
             if layer.activation != "none":
                 out.append(nchw(layer.output))
@@ -167,7 +169,7 @@ def _param_pairs(model, om):
     def walk(layers):
         out = []
         for l in layers:
-            if l.type_name == "conv" and l.enabled:
+            if l.type_name == "deconv" or (l.type_name == "conv" and l.enabled):
                 out.append(l.omega)
                 if l.use_bias:
                     out.append(l.beta)
@@ -182,7 +184,7 @@ def _param_pairs(model, om):
         assert a.value.shape == b.v.shape
     # a conv bias directly in front of a batch norm has an analytically zero gradient
     for l, nxt in zip(model.layers[1:-1], model.layers[2:]):
-        if l.type_name == "conv" and l.use_bias and nxt.type_name in ("batchnorm", "batchnorm-relu"):
+        if l.type_name in ("conv", "deconv") and l.use_bias and nxt.type_name in ("batchnorm", "batchnorm-relu"):
             l.beta.zero_grad_expected = l.omega
     return list(zip(pp, op))
 
@@ -391,8 +393,8 @@ def _generic_step_check(desc, data_shape, B, solver="nesterov", steps=2, convert
             p.set_value(p.value + rng.normal(0, 0.1, p.value.shape).astype(np.float32))
     rconv = model.layers[-2]
     rconv.omega.set_value(rng.normal(0, 0.05, rconv.omega.value.shape))
-    om = OM.OracleModel(model.export_json(), B)
-    om_free = OM.OracleModel(model.export_json(), B)
+    om = OM.OracleModel(model.export_json(), B, rng_seed=model.rng_seed)
+    om_free = OM.OracleModel(model.export_json(), B, rng_seed=model.rng_seed)
     model.build_train_func(solver)
     mom = [0.9, 0.999] if solver == "adam" else [0.9]
     omom = mom if solver == "adam" else mom[0]
@@ -458,6 +460,64 @@ def test_direct_and_measured_paths_agree(hip):
 def test_adam_solver_vs_oracle(hip):
     """adam updates (denet/model/model_cnn.py:296-305): first / second moments, bias correction, L2 on weights only"""
     _generic_step_check("C.B[32,3] BN A nRSN.O[2,32,3] P.A[16] R", (3, 16, 16), 4, solver="adam", steps=3)
+
+
+def test_augment_and_deconv_layers_vs_oracle(hip):
+    """the remaining desc tokens of the operator surface in one training graph: CM (random crop / mirror / flip,
+    crop_mirror.py:26-56), B (zero border, border.py:30-33), D (dropout, dropout.py:20-24) and DC (transposed
+    convolution with bias, stride 2 and stride 1, deconvolution.py:54-67), forward, gradients and solver update"""
+    desc = "CM[14,0.5,0.5] B[1] C.B[32,3] BN A P[2] D[0.3] DC[64,3,2] BNA DC.B[32,3] BNA D[0.5] P.A[16] R"
+    model = _generic_step_check(desc, (3, 18, 18), 4, steps=3)
+    types = [l.type_name for l in model.layers]
+    assert [t for t in types if t in ("crop-mirror", "border", "dropout", "deconv")] == \
+        ["crop-mirror", "border", "dropout", "deconv", "deconv", "dropout"]
+    dcs = [l for l in model.layers if l.type_name == "deconv"]
+    assert dcs[0].output_shape == (4, 64, 16, 16) and dcs[0].use_bias and not dcs[1].use_bias
+    # test mode: dropout is the identity, CM takes the centre crop without mirroring
+    x = np.random.RandomState(0).uniform(0, 1, (4, 3, 18, 18)).astype(np.float32)
+    model.forward(x, None, train=False)
+    drop = [l for l in model.layers if l.type_name == "dropout"][0]
+    assert drop.output.data is drop.input.data
+    cm = model.layers[1]
+    got = ops.nhwc_to_nchw(cm.output.data, 3).cpu().numpy()
+    assert np.array_equal(got, x[:, :, 2:16, 2:16])
+    # JSON surface round trip (deconvolution.py:105-113, dropout.py:36-39, border.py:43-46, crop_mirror.py:72-75)
+    j = model.export_json()
+    keys = {l["type"]: set(l.keys()) for l in j["layers"]}
+    assert {"shape", "stride", "border", "useBias", "bias", "weight"} <= keys["deconv"]
+    assert "dropoutRate" in keys["dropout"] and "border" in keys["border"] and {"crop", "mirror", "flip"} <= keys["crop-mirror"]
+
+
+def test_skip_concat_vs_oracle(hip):
+    """SKIP combine mode "concat" (only reachable through the JSON key combineMode, skip.py:93-96)"""
+    from denet_amd.model import model_cnn
+    B = 4
+    np.random.seed(5)
+    model = model_cnn.ModelCNN()
+    model.batch_size = B
+    model.class_num = 10
+    model.build("C[32,3] BNA C.B[24,3] A SKIPSRC[0] C.B[40,3] A SKIP[0] C[32,1] BNA P.A[16] R", (3, 16, 16), "relu", "half",
+                ["he-backward"])
+    j = model.export_json()
+    rng = np.random.RandomState(6)
+    for i, l in enumerate(j["layers"]):
+        if l["type"] == "skip":
+            l["combineMode"] = "concat"
+            l["layers"] = []
+            nxt = j["layers"][i + 1]
+            nxt["shape"] = (32, 64, 1, 1)
+            nxt["weight"] = rng.normal(0, 0.2, (32, 64, 1, 1)).astype(np.float32)
+    model2 = model_cnn.load_from_json(j, B)
+    skip = [l for l in model2.layers if l.type_name == "skip"][0]
+    assert skip.combine_mode == "concat" and skip.output_shape == (B, 64, 16, 16)
+    x = rng.uniform(0, 1, (B, 3, 16, 16)).astype(np.float32)
+    metas = [{"image_class": int(rng.randint(0, 10)), "bbox": [], "class": []} for _ in range(B)]
+    om = OM.OracleModel(model2.export_json(), B)
+    model2.build_train_func("nesterov")
+    for it in range(2):
+        cost, _ = model2.train_step(x, metas, 0, it, 0.05, [0.9], 1e-4)
+        ocost, _ = _forced_step_check(model2, om, x, metas, it, 0.05, 0.9, 1e-4, "nesterov", None)
+        assert abs(cost - ocost) <= 1e-4 * abs(ocost), (cost, ocost)
 
 
 def test_skip_projection_vs_oracle(hip):
