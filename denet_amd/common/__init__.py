@@ -4,6 +4,8 @@ import time
 
 import numpy
 
+from .json_util import json_from_file, json_to_file  # noqa: F401 (denet.common re-exports them)
+
 
 class Timer:
     """wall-clock marks, same phase bookkeeping as the reference Timer (denet/common/__init__.py:16-46)"""
@@ -69,6 +71,15 @@ def overlap_iou(bbox0, bbox1=(0, 0, 1, 1)):
     a1 = (bbox1[2] - bbox1[0]) * (bbox1[3] - bbox1[1])
     ai = overlap(bbox0, bbox1)
     return ai / (a0 + a1 - ai)
+
+
+def clip(x, x_min=None, x_max=None):
+    """denet/common/__init__.py:112-118"""
+    if x_min is None:
+        return min(x, x_max)
+    if x_max is None:
+        return max(x, x_min)
+    return min(x_max, max(x, x_min))
 
 
 def ndarray_unpack(v, shapes):

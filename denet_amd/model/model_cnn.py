@@ -402,6 +402,20 @@ class ModelCNN:
             self.iteration += 1
         return total_cost
 
+    def predict_output(self, dataset):
+        """last-layer output for every sample of the loaded subset, padding of the last batch cropped
+        (reference model_cnn.py:484-508)"""
+        dataset_x, _, dataset_size = dataset.export(self.batch_size)
+        n = math.ceil(dataset_size / self.batch_size)
+        pr = numpy.concatenate([self.predict_output_step(dataset_x[i * self.batch_size:(i + 1) * self.batch_size])
+                                for i in range(n)], axis=0)
+        return pr[:dataset_size]
+
+    def predict_label(self, dataset):
+        pr = self.predict_output(dataset)
+        assert pr.ndim == 2
+        return [int(numpy.argmax(pr[i, ...])) for i in range(pr.shape[0])]
+
     def predict_output_step(self, data_x):
         """inference forward (BN in test mode); returns the last layer's output as a numpy array in the reference's
         NCHW convention (class probabilities for a regression head)"""

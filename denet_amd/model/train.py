@@ -68,11 +68,13 @@ class SyntheticDataset(ArrayDataset):
         super().__init__(x, m, class_num)
 
 
-def load_dataset(spec, seed):
+def load_dataset(spec, seed, extension="ppm", is_training=True, thread_num=1, class_labels=None):
+    """`synthetic[,samples=N,image=S,classes=C]` (there is no network for the real datasets), or a directory read by
+    denet_amd.dataset.load with the reference's format string (`--extension mscoco,2014-train,crop=512,...`)"""
     parts = spec.split(",")
     if parts[0] != "synthetic":
-        raise NotImplementedError("only `synthetic[,samples=N,image=S,classes=C]` data is provided: the reference's "
-                                  "dataset loaders are outside the hot path")
+        from .. import dataset
+        return dataset.load(spec, extension, is_training=is_training, thread_num=thread_num, class_labels=class_labels)
     kw = {}
     for p in parts[1:]:
         k, v = p.split("=")
@@ -84,7 +86,14 @@ def build_parser():
     parser = argparse.ArgumentParser(description="Train a convolutional network (MI355X hot path of lachlants/denet)")
     parser.add_argument("--model", required=False, default=None, help="Model (.mdl.gz) to continue training.")
     parser.add_argument("--cost-factors", default=[], nargs="+", help="Multiplicative factors for model costs")
-    parser.add_argument("--train", default="synthetic", help="training data: synthetic[,samples=N,image=S,classes=C]")
+    parser.add_argument("--train", default="synthetic",
+                        help="training data folder, or synthetic[,samples=N,image=S,classes=C]")
+    parser.add_argument("--test", default=None, help="The folder with testing data (optional)")
+    parser.add_argument("--test-epochs", type=int, default=1, help="Epochs between each test evaluation")
+    parser.add_argument("--extension", default="ppm", help="Image file extension / dataset format string")
+    parser.add_argument("--thread-num", type=int, default=1, help="Worker processes for loading / augmenting data")
+    parser.add_argument("--max-samples", type=int, default=None, help="Maximum samples to load from training set")
+    parser.add_argument("--augment-mirror", default=False, action="store_true")
     parser.add_argument("--border-mode", default="valid")
     parser.add_argument("--output-prefix", default="./model")
     parser.add_argument("--activation", default="relu")
@@ -105,7 +114,31 @@ def build_parser():
     return parser
 
 
-def train(args, train_data, log=print):
+def compute_error(data, model):
+    """per-class top-1 error of a classifier over all subsets (train.py:18-39) -> (error %, [(class, error %, samples)])"""
+    class_errors = [0] * model.class_num
+    class_samples = [0] * model.class_num
+    for subset in range(data.subset_num):
+        data.load_from_subset(subset)
+        predicted = model.predict_label(data)
+        labels = data.get_labels()
+        for i in range(len(data)):
+            class_samples[labels[i]] += 1
+            if predicted[i] != labels[i]:
+                class_errors[labels[i]] += 1
+    error = 100.0 * sum(class_errors) / sum(class_samples)
+    return error, [(i, 100.0 * class_errors[i] / class_samples[i] if class_samples[i] else 0.0, class_samples[i])
+                   for i in range(model.class_num)]
+
+
+def save_results(fname, error, class_errors):
+    with open(fname, "w") as f:
+        print("Overall Error=%.2f%%" % error, file=f)
+        for d in class_errors:
+            print("Class %i=%.2f%% (%i samples)" % (d[0], d[1], d[2] * d[1] / 100), file=f)
+
+
+def train(args, train_data, log=print, test_data=None):
     """the epoch loop of train.py:117-151 (shuffle, train_epoch, learning-rate annealing, checkpoint per epoch)"""
     model = model_cnn.initialize(args, train_data.get_data_shape(), train_data.class_labels, train_data.get_class_num())
     model.build_train_func(args.solver, args.cost_factors)
@@ -120,6 +153,10 @@ def train(args, train_data, log=print):
             log("epoch %i subset %i - cost: %.4f (lr %g)" % (epoch, subset, cost, learn_rate))
         if len(args.learn_anneal_epochs) == 0 or (epoch + 1) in args.learn_anneal_epochs:
             learn_rate *= args.learn_anneal
+        if test_data is not None and ((epoch % getattr(args, "test_epochs", 1)) == 0 or epoch == (args.epochs - 1)):
+            test_error, test_class_errors = compute_error(test_data, model)
+            log("epoch %i test error: %.2f%%" % (epoch, test_error))
+            save_results(args.output_prefix + "_epoch%03i.test" % epoch, test_error, test_class_errors)
         if not args.disable_intermediate:
             model_cnn.save_to_file(model, args.output_prefix + "_epoch%03i.mdl.gz" % epoch)
     model_cnn.save_to_file(model, args.output_prefix + "_epoch%03i_final.mdl.gz" % (args.epochs - 1))
@@ -130,8 +167,15 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     random.seed(args.seed)
     numpy.random.seed(args.seed)
-    train_data = load_dataset(args.train, args.seed)
-    train(args, train_data)
+    train_data = load_dataset(args.train, args.seed, args.extension, True, args.thread_num)
+    if args.max_samples is not None:
+        train_data.data = random.sample(train_data.data, args.max_samples)
+    if args.augment_mirror:
+        train_data.augment_mirror()
+    test_data = None
+    if args.test:
+        test_data = load_dataset(args.test, args.seed, args.extension, False, args.thread_num, train_data.class_labels)
+    train(args, train_data, test_data=test_data)
     return 0
 
 
