@@ -13,6 +13,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32, LDK = 36;
 
 // VAR: 0 baseline, 1 no global loads in loop, 2 also no LDS writes, 3 also no barriers, 4 MFMA only
+// 5: 4 without the prologue chunk load, 6: 4 without the epilogue stores, 7: neither (pure MFMA + launch)
 template <int BM, int BN, int WM, int WN, int NBUF, int VAR>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                       float* __restrict__ C, int M, int N, int K) {
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float* __restrict__ 
         }
     };
     float cav[TM][4], cbv[TN][4];
-    if (VAR == 4) {
+    if (VAR >= 4) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) for (int t = 0; t < 4; ++t) cav[i][t] = A[lane + i + t];
 #pragma unroll
@@ -79,10 +80,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float* __restrict__ 
         const float* cA = sA + buf * SZA + fa;
         const float* cB = sB + buf * SZB + fb;
         float av[2][TM][4], bv[2][TN][4];
-        if (VAR != 4) load_frags(cA, cB, 0, av[0], bv[0]);
+        if (VAR < 4) load_frags(cA, cB, 0, av[0], bv[0]);
 #pragma unroll
         for (int kb = 0; kb < BK / 8; ++kb) {
-            if (VAR != 4) {
+            if (VAR < 4) {
                 if (kb + 1 < BK / 8) load_frags(cA, cB, kb + 1, av[(kb + 1) & 1], bv[(kb + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -92,14 +93,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float* __restrict__ 
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(VAR == 4 ? cav[i][t] : av[kb & 1][i][t],
-                                                                         VAR == 4 ? cbv[j][t] : bv[kb & 1][j][t], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(VAR >= 4 ? cav[i][t] : av[kb & 1][i][t],
+                                                                         VAR >= 4 ? cbv[j][t] : bv[kb & 1][j][t], acc[i][j], 0, 0, 0);
         }
     };
     const int nsteps = K / BK;
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
+    if (VAR != 5 && VAR != 7) {
+        load_chunk(0);
+        store_chunk(0);
+        __syncthreads();
+    }
     for (int s = 0; s < nsteps; ++s) {
         const bool more = (s + 1 < nsteps);
         if (VAR == 0 && more) load_chunk(s + 1);
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                C[(long)m * N + n] = acc[i][j][r];
+                if ((VAR != 6 && VAR != 7) || acc[i][j][r] == 123.456f) C[(long)m * N + n] = acc[i][j][r];
             }
         }
 }
@@ -687,6 +690,7 @@ int main(int argc, char** argv) {
         printf("max |pipe - base| = %g (ref %g)\n", md, (double)c1[5]);
     }
     RUN(128, 128, 2, 0) RUN(128, 128, 2, 1) RUN(128, 128, 2, 2) RUN(128, 128, 2, 3) RUN(128, 128, 2, 4)
+    RUN(128, 128, 2, 5) RUN(128, 128, 2, 6) RUN(128, 128, 2, 7) RUN(128, 64, 2, 4) RUN(128, 64, 2, 5) RUN(128, 64, 2, 6) RUN(128, 64, 2, 7)
     RUN(128, 128, 1, 0) RUN(128, 128, 1, 1) RUN(128, 128, 1, 2)
     return 0;
 }
