@@ -305,6 +305,56 @@ def test_denet34_skip_train_step_vs_oracle(hip, regime):
         assert np.array_equal(dns._taps.cpu().numpy(), taps_ref)
 
 
+def test_denet34_edge_case_ground_truth_vs_oracle(hip):
+    """ragged ground truth through the whole step: an image without objects, a crowded image (39 boxes, more than any
+    MSCOCO-like batch of the synthetic generator), a sliver box, boxes partly / completely off screen and an exact
+    duplicate - corner targets (denet_corner.py:81-123), RoI editing + GT injection (denet_sparse.py:184-201),
+    detection targets (denet_detect.py:147-235) and both costs, op by op against the oracle"""
+    B, IMG = 2, 128
+    model = zoo.denet34(B, "skip", IMG, class_num=80, seed=1)
+    rng = np.random.RandomState(9)
+    dconv = model.layers[40].layers[0]
+    dconv.omega.set_value(rng.normal(0, 0.05, dconv.omega.value.shape))
+    _warm_corner_head(model, 4.0, 0.3)
+    x, _ = zoo.synthetic_batch(B, IMG, seed=4)
+    crowd, cls = [], []
+    for k in range(34):
+        cx, cy, w, h = rng.uniform(0.1, 0.9), rng.uniform(0.1, 0.9), rng.uniform(0.02, 0.5), rng.uniform(0.02, 0.5)
+        crowd.append((float(max(cx - w / 2, 0)), float(max(cy - h / 2, 0)), float(min(cx + w / 2, 1)), float(min(cy + h / 2, 1))))
+        cls.append(int(rng.randint(0, 80)))
+    # (zero-area boxes are not part of the contract: the reference's IoU is 0/0 = NaN for them and its cost turns NaN,
+    # which train_epoch treats as fatal, model_cnn.py:462; the loader never emits them, image_loader.py:128)
+    crowd += [(0.3, 0.3, 0.30001, 0.6),                             # a sliver, narrower than one feature cell
+              (-0.2, 0.1, 0.25, 0.4), (0.8, 0.7, 1.3, 1.2),         # partly off screen
+              (1.1, 1.1, 1.4, 1.5),                                 # completely off screen
+              crowd[0]]                                             # exact duplicate (other class)
+    cls += [3, 5, 6, 7, (cls[0] + 1) % 80]
+    metas = [{"bbox": [], "class": []}, {"bbox": crowd, "class": cls}]
+    om_free = OM.OracleModel(model.export_json(), B)
+    om = OM.OracleModel(model.export_json(), B)
+    model.build_train_func("nesterov")
+    lr, mu, decay = 0.05, 0.9, 1e-4
+    for it in range(2):
+        random.seed(300 + it)
+        cost, costs = model.train_step(x, metas, 0, it, lr, [mu], decay)
+        assert np.isfinite(cost)
+        dns, cl = model.layers[31], model.layers[30]
+        roi_lists = dns.sample_bbox_list
+        lists = OM.oracle_build_samples(cl.corner_pr.cpu().numpy(), dns.corner_threshold, dns.sample_num, 1024, 0)
+        random.seed(300 + it)
+        ref_lists = OL.edit_samples(lists, metas, dns.sample_count, dns.random_sample, dns.sample_gt)
+        assert ref_lists == roi_lists, "RoI lists differ from the oracle on the same corner map"
+        assert [r for r in roi_lists[1][-len(crowd):]] == [(1.0, b) for b in crowd[::-1]]     # GT injection, reversed
+        if it == 0:
+            random.seed(300 + it)
+            fcost, fcosts = om_free.train_step(x, metas, it, lr, mu, decay, "nesterov", sample_override=roi_lists)
+            assert abs(cost - fcost) <= 1e-3 * abs(fcost), (cost, fcost)
+            for c, oc in zip(costs, fcosts):
+                assert abs(c - oc) <= 1e-3 * max(abs(oc), 1e-6), (costs, fcosts)
+        ocost, _ = _forced_step_check(model, om, x, metas, it, lr, mu, decay, "nesterov", roi_lists)
+        assert abs(cost - ocost) <= 1e-4 * abs(ocost), (cost, ocost)
+
+
 def test_cifar3_train_step_vs_oracle(hip):
     """BASELINE config 1 (README.md:52 three-layer CNN): unfused BN / A / P / P.A / R path"""
     B = 8
