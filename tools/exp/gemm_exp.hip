@@ -641,6 +641,137 @@ float run(const float* A, const float* B, float* C, int M, int N, int K, int ite
     return ms / iters;
 }
 
+// ---- direct-to-LDS variant (gfx950 global_load_lds_dwordx4): no staging VGPRs, no ds_write. LDS rows are 128 B, unpadded
+// (the DMA writes wave-linear: 64 lanes x 16 B = 8 rows); bank conflicts are avoided by an XOR swizzle of the 16-byte chunk
+// index with (row & 7), applied to the per-lane GLOBAL source address and to the fragment read address.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+template <int BM, int BN, int OCC, int NB>
+__global__ __launch_bounds__(256, OCC) void gemm_glds(const float* __restrict__ A, const float* __restrict__ B,
+                                                       float* __restrict__ C, int M, int N, int K) {
+    constexpr int WM = 2, WN = 2;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int SZA = BM * 32, SZB = BN * 32, SZ = SZA + SZB;
+    constexpr int IA = BM / 32, IB = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
+    const int tiles_n = N / BN;
+    const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int lr = lane >> 3, lj = lane & 7;
+    const float* ga[IA];
+    const float* gb[IB];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+        const int row = wave * (BM / 4) + i * 8 + lr;
+        ga[i] = A + (long)(m0 + row) * K + ((lj ^ (row & 7)) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+        const int row = wave * (BN / 4) + i * 8 + lr;
+        gb[i] = B + (long)(n0 + row) * K + ((lj ^ (row & 7)) * 4);
+    }
+    auto stage = [&](int buf, int kc) {
+        float* sa = smem + buf * SZ;
+        float* sb = sa + SZA;
+#pragma unroll
+        for (int i = 0; i < IA; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ga[i] + kc * 32), (lds_ptr_t)(sa + (wave * (BM / 4) + i * 8) * 32), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < IB; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gb[i] + kc * 32), (lds_ptr_t)(sb + (wave * (BN / 4) + i * 8) * 32), 16, 0, 0);
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int swz = li & 7;
+    const int fa = (wm * TM * 32 + li) * 32, fb = (wn * TN * 32 + li) * 32;
+    auto load_frags = [&](const float* sa, const float* sb, int kb, f32x4 (&av)[TM], f32x4 (&bv)[TN]) {
+        const int off = ((kb * 2 + lh) ^ swz) * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[i] = *(const f32x4*)(sa + fa + i * 32 * 32 + off);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[j] = *(const f32x4*)(sb + fb + j * 32 * 32 + off);
+    };
+    auto compute = [&](int buf) {
+        const float* sa = smem + buf * SZ;
+        const float* sb = sa + SZA;
+        f32x4 av[2][TM], bv[2][TN];
+        load_frags(sa, sb, 0, av[0], bv[0]);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            if (kb + 1 < 4) load_frags(sa, sb, kb + 1, av[(kb + 1) & 1], bv[(kb + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb & 1][i][t], bv[kb & 1][j][t], acc[i][j], 0, 0, 0);
+        }
+    };
+    const int nsteps = K / 32;
+    if (NB == 2) {
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            if (s + 1 < nsteps) stage((s + 1) & 1, s + 1);
+            compute(s & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        stage(0, 0);
+        if (nsteps > 1) stage(1, 1);
+        int cur = 0, nxt = 2;
+        for (int s = 0; s < nsteps; ++s) {
+            if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IA + IB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (s + 2 < nsteps) stage(nxt, s + 2);
+            compute(cur);
+            cur = cur == 2 ? 0 : cur + 1;
+            nxt = nxt == 2 ? 0 : nxt + 1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                C[(long)m * N + n] = acc[i][j][r];
+            }
+        }
+}
+
+template <int BM, int BN, int OCC, int NB>
+float run_glds(const float* A, const float* B, float* C, int M, int N, int K, int iters) {
+    constexpr size_t lds = NB * (size_t)(BM + BN) * 32 * sizeof(float);
+    CK(hipFuncSetAttribute((const void*)gemm_glds<BM, BN, OCC, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((M / BM) * (N / BN));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    gemm_glds<BM, BN, OCC, NB><<<grid, 256, lds>>>(A, B, C, M, N, K);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) gemm_glds<BM, BN, OCC, NB><<<grid, 256, lds>>>(A, B, C, M, N, K);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return ms / iters;
+}
+
 int main(int argc, char** argv) {
     int M = argc > 1 ? atoi(argv[1]) : 18432, K = argc > 2 ? atoi(argv[2]) : 1536, N = argc > 3 ? atoi(argv[3]) : 1024;
     float *A, *B, *C;
@@ -650,6 +781,38 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(B, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice));
     const double flop = 2.0 * M * N * K;
+#define RUNG(BM, BN, OCC, NB) { float ms = run_glds<BM, BN, OCC, NB>(A, B, C, M, N, K, 10); printf("glds %dx%d occ %d nb %d : %.3f ms %.1f TF\n", BM, BN, OCC, NB, ms, flop / ms / 1e9); fflush(stdout); }
+    if (N % 128 == 0) { RUNG(128, 128, 2, 2) RUNG(128, 128, 1, 3) RUNG(128, 128, 1, 2) }
+    RUNG(128, 64, 2, 2) RUNG(128, 64, 3, 2) RUNG(128, 64, 2, 3)
+    if (N % 128 == 0) {
+        std::vector<float> c1((size_t)256 * N), c2((size_t)256 * N);
+        run<128, 128, 2, 2, 1, 0>(A, B, C, M, N, K, 1);
+        CK(hipMemcpy(c1.data(), C + (size_t)(M - 256) * N, c1.size() * 4, hipMemcpyDeviceToHost));
+        for (int v = 0; v < 2; ++v) {
+            CK(hipMemset(C, 0, (size_t)M * N * 4));
+            if (v == 0) run_glds<128, 128, 2, 2>(A, B, C, M, N, K, 1); else run_glds<128, 64, 2, 3>(A, B, C, M, N, K, 1);
+            CK(hipMemcpy(c2.data(), C + (size_t)(M - 256) * N, c2.size() * 4, hipMemcpyDeviceToHost));
+            double md = 0; for (size_t i = 0; i < c1.size(); ++i) md = fmax(md, fabs((double)c1[i] - c2[i]));
+            printf("max |glds%d - base| (last rows) = %g (ref %g)\n", v, md, (double)c1[7]);
+        }
+    }
+    if (getenv("GLDS_ONLY")) return 0;
+#define RUNG(BM, BN, OCC, NB) { float ms = run_glds<BM, BN, OCC, NB>(A, B, C, M, N, K, 10); printf("glds %dx%d occ %d nb %d : %.3f ms %.1f TF\n", BM, BN, OCC, NB, ms, flop / ms / 1e9); fflush(stdout); }
+    if (N % 128 == 0) { RUNG(128, 128, 2, 2) RUNG(128, 128, 1, 3) RUNG(128, 128, 1, 2) }
+    RUNG(128, 64, 2, 2) RUNG(128, 64, 3, 2) RUNG(128, 64, 2, 3)
+    if (N % 128 == 0) {
+        std::vector<float> c1((size_t)256 * N), c2((size_t)256 * N);
+        run<128, 128, 2, 2, 1, 0>(A, B, C, M, N, K, 1);
+        CK(hipMemcpy(c1.data(), C + (size_t)(M - 256) * N, c1.size() * 4, hipMemcpyDeviceToHost));
+        for (int v = 0; v < 2; ++v) {
+            CK(hipMemset(C, 0, (size_t)M * N * 4));
+            if (v == 0) run_glds<128, 128, 2, 2>(A, B, C, M, N, K, 1); else run_glds<128, 64, 2, 3>(A, B, C, M, N, K, 1);
+            CK(hipMemcpy(c2.data(), C + (size_t)(M - 256) * N, c2.size() * 4, hipMemcpyDeviceToHost));
+            double md = 0; for (size_t i = 0; i < c1.size(); ++i) md = fmax(md, fabs((double)c1[i] - c2[i]));
+            printf("max |glds%d - base| (last rows) = %g (ref %g)\n", v, md, (double)c1[7]);
+        }
+    }
+    if (getenv("GLDS_ONLY")) return 0;
 #define RUN(BM, BN, NB, V) { float ms = run<BM, BN, 2, 2, NB, V>(A, B, C, M, N, K, 10); printf("tile %dx%d nbuf %d var %d : %.3f ms %.1f TF\n", BM, BN, NB, V, ms, flop / ms / 1e9); fflush(stdout); }
     { float ms = run_pipe<128, 128, 1, 1>(A, B, C, M, N, K, 10); printf("pipe3 128x128 pd1: %.3f ms %.1f TF\n", ms, flop / ms / 1e9); }
     { float ms = run_pipe<128, 128, 1, 2>(A, B, C, M, N, K, 10); printf("pipe3 128x128 pd2: %.3f ms %.1f TF\n", ms, flop / ms / 1e9); }
