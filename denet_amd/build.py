@@ -12,9 +12,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libdenet_hip.so")
 
 SOURCES = ["runtime.hip", "igemm.hip", "bn.hip", "pool.hip", "elementwise.hip", "dss.hip", "samples.hip", "detect.hip", "winograd.hip",
-           "augment.hip"]
+           "augment.hip", "image.hip"]
 # files whose integer results must not depend on FMA contraction
-NO_CONTRACT = {"dss.hip", "samples.hip", "detect.hip", "augment.hip"}
+NO_CONTRACT = {"dss.hip", "samples.hip", "detect.hip", "augment.hip", "image.hip"}
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

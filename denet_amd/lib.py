@@ -15,6 +15,7 @@ L = ctypes.c_long
 F = ctypes.c_float
 Z = ctypes.c_size_t
 U64 = ctypes.c_uint64
+D = ctypes.c_double
 
 # name -> (restype, argtypes); mirrors include/denet_hip.h declaration by declaration
 SIGNATURES = {
@@ -50,6 +51,10 @@ SIGNATURES = {
     "denet_avgpool_bwd": (I, [P, P] + [I] * 9 + [P]),
     "denet_pool_inv_fwd": (I, [P, P] + [I] * 6 + [P]),
     "denet_pool_inv_bwd": (I, [P, P] + [I] * 6 + [P]),
+    "denet_host_resample_coeffs": (I, [I, D, D, I, I, P, P, L]),
+    "denet_image_crop": (I, [P, P] + [I] * 9 + [P]),
+    "denet_image_resample_pass": (I, [P, P, I, I, I, I, P, P, I, P]),
+    "denet_image_finish": (I, [P, P, I, I, I, I, P, P, P, P, I, P, P]),
     "denet_border_fwd": (I, [P, P] + [I] * 8 + [P]),
     "denet_border_bwd": (I, [P, P] + [I] * 8 + [P]),
     "denet_crop_mirror_fwd": (I, [P, P] + [I] * 6 + [F, F, I, U64, P]),

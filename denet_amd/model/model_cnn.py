@@ -291,6 +291,11 @@ class ModelCNN:
     def _upload_input(self, data_x):
         import torch
         from .. import ops
+        if isinstance(data_x, torch.Tensor) and data_x.is_cuda and tuple(data_x.shape) == self.input.phys_shape() \
+                and tuple(data_x.shape) != self.get_input_shape():
+            # a batch rendered on the device (denet_amd/dataset/device_render.py): already NHWC with padded channels
+            self.input.data = data_x if data_x.is_contiguous() else data_x.contiguous()
+            return
         if isinstance(data_x, torch.Tensor):
             x = data_x if data_x.is_cuda else data_x.cuda(non_blocking=True)
         else:

@@ -141,6 +141,23 @@ int denet_avgpool_bwd(const float* dy, float* dx, int N, int H, int W, int C, in
 int denet_pool_inv_fwd(const float* x, float* y, int N, int H, int W, int C, int fy, int fx, hipStream_t stream);
 int denet_pool_inv_bwd(const float* dy, float* dx, int N, int H, int W, int C, int fy, int fx, hipStream_t stream);
 
+/* ---- device-side rendering of the data pipeline's augmentation plan (csrc/image.hip)
+ *      Replaces the pixel work of denet/dataset/augment.py (add_border :51-61, crop, scale :21-47 = Pillow thumbnail /
+ *      resize, image_to_array :9-17, photometric :271-285, colorspace :288-293) and of
+ *      denet/dataset/image_loader.py:71-105 (mean/std, mirror); the random decisions stay on the host
+ *      (denet_amd/dataset/augment.py plan_*). Resampling is Pillow's two-pass fixed-point convolution
+ *      (src/libImaging/Resample.c, Pillow 12.2.0), bit for bit: coefficient tables from the host, integer passes on
+ *      the device. Images are RGBX u8 between the steps; the result is one fp32 NHWC image of the training batch.   */
+int denet_host_resample_coeffs(int in_size, double in0, double in1, int out_size, int filter, int* bounds_host,
+                               int* kk_host, long kk_capacity);
+int denet_image_crop(const unsigned char* src, unsigned char* dst_rgbx, int sw, int sh, int src_bpp, int px, int py, int x0,
+                     int y0, int w, int h, hipStream_t stream);
+int denet_image_resample_pass(const unsigned char* in_rgbx, unsigned char* out_rgbx, int in_w, int in_h, int out_n,
+                              int horizontal, const int* bounds_dev, const int* kk_dev, int ksize, hipStream_t stream);
+int denet_image_finish(const unsigned char* img_rgbx, float* out_nhwc, int w, int h, int cp, int n_ops,
+                       const int* ops_host, const double* alphas_host, const double* noise_host,
+                       const float* mean_std_host, int mirror, unsigned long long* sums_ws, hipStream_t stream);
+
 /* ---- shape / stochastic layers of the operator surface (csrc/augment.hip), NHWC fp32, C % 4 == 0
  *      B    zero border, (left, right, top, bottom)              denet/layer/border.py:18-33
  *      CM   per-image random crop + column mirror + row flip     denet/layer/crop_mirror.py:26-56 (train=0: centre

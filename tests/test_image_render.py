@@ -1,0 +1,195 @@
+"""Rendering of augmentation plans: Pillow's resampling restated (oracle/pil_resample.py) and pinned against Pillow
+itself, the native coefficient tables, plan == load_sample_proc on the host, and (GPU) the device renderer against the
+host path - bit-exact u8 resampling, bit-exact fp32 batch except under the `contrast` jitter (1e-6)."""
+import ctypes
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from oracle import pil_resample as PR
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+sys.path.insert(0, GOLDEN)
+import dataset_scenarios as S  # noqa: E402
+
+from denet_amd import lib as dlib  # noqa: E402
+from denet_amd.dataset import image_loader as IL, mscoco, plan as P  # noqa: E402
+
+PIL_FILTER = {PR.LANCZOS: Image.LANCZOS, PR.BILINEAR: Image.BILINEAR, PR.BICUBIC: Image.BICUBIC}
+EV = [0.2175, 0.0188, 0.0045]
+EVEC = [[-0.5675, 0.7192, 0.4009], [-0.5808, -0.0045, -0.8140], [-0.5836, -0.6948, 0.4203]]
+BASE = {"isTraining": True, "scale": 56, "crop": 48, "rgbMean": [0.485, 0.456, 0.406], "rgbStd": [0.229, 0.224, 0.225],
+        "rgbEigenVal": EV, "rgbEigenVec": EVEC}
+VARIANTS = [
+    {"cropMode": "denet", "augmentMirror": True, "checkOnscreen": 0.5},
+    {"cropMode": "denet", "augmentMirror": True, "augmentPhoto": True, "augmentColor": True, "subtractMean": True,
+     "checkOnscreen": 0.5, "checkCenter": True, "aspectFactor": 0.75},
+    {"cropMode": "denet", "aspectFactor": 1, "maxTrials": 0},                  # fallback: whole bordered image
+    {"cropMode": "denet", "augmentPhoto": True, "crop": 96},                   # up-sampling crops
+    {"cropMode": "default", "augmentMirror": True, "scaleMode": "small"},
+    {"cropMode": "center", "scaleMode": "large"},
+    {"cropMode": "default", "scale": 30, "crop": 48},                          # border after scaling
+    {"cropMode": "lenet", "augmentMirror": True, "areaMin": 0.2, "augmentColor": True},
+    {"cropMode": "lenet", "maxTrials": 0},
+    {"isTraining": False},
+    {"isTraining": False, "scale": 30, "subtractMean": True},
+]
+
+
+def test_oracle_resample_equals_pillow():
+    """the restated Resample.c arithmetic against Pillow: every filter, up- and down-sampling, odd sizes"""
+    rng = np.random.RandomState(0)
+    for trial in range(45):
+        W, H = rng.randint(5, 200), rng.randint(5, 200)
+        ow, oh = rng.randint(4, 200), rng.randint(4, 200)
+        if trial % 5 == 0:
+            ow = W                                                              # one axis untouched
+        a = rng.randint(0, 256, (H, W, 3)).astype(np.uint8)
+        flt = [PR.LANCZOS, PR.BILINEAR, PR.BICUBIC][trial % 3]
+        ref = np.array(Image.fromarray(a, "RGB").resize((ow, oh), PIL_FILTER[flt]))
+        assert np.array_equal(PR.resize(a, ow, oh, flt), ref), (trial, W, H, ow, oh, flt)
+    for W, H, s in [(295, 230, 160), (120, 97, 64), (64, 97, 60), (80, 80, 50), (150, 40, 30), (33, 120, 33), (50, 50, 64)]:
+        im = Image.fromarray(rng.randint(0, 256, (H, W, 3)).astype(np.uint8), "RGB")
+        t = PR.thumbnail_size(W, H, s)
+        assert t == P.thumbnail_size(W, H, s)
+        im.thumbnail((s, s), Image.LANCZOS)
+        assert im.size == (t if t is not None else (W, H))
+
+
+def test_native_coefficient_tables_equal_oracle():
+    L = dlib.load()
+    rng = np.random.RandomState(1)
+    for trial in range(60):
+        n_in, n_out = int(rng.randint(3, 700)), int(rng.randint(2, 600))
+        flt = [PR.LANCZOS, PR.BILINEAR, PR.BICUBIC][trial % 3]
+        b_ref, k_ref = PR.coeffs(n_in, 0, n_in, n_out, flt)
+        cap = n_out * k_ref.shape[1]
+        bounds = np.empty(2 * n_out, dtype=np.int32)
+        kk = np.empty(cap, dtype=np.int32)
+        ks = L.denet_host_resample_coeffs(n_in, 0.0, float(n_in), n_out, flt, bounds.ctypes.data_as(ctypes.c_void_p),
+                                          kk.ctypes.data_as(ctypes.c_void_p), cap)
+        assert ks == k_ref.shape[1]
+        assert np.array_equal(bounds.reshape(-1, 2), b_ref) and np.array_equal(kk.reshape(n_out, ks), k_ref)
+    # argument validation
+    assert L.denet_host_resample_coeffs(10, 0.0, 10.0, 5, 0, bounds.ctypes.data_as(ctypes.c_void_p),
+                                        kk.ctypes.data_as(ctypes.c_void_p), 4) == -1000
+
+
+@pytest.fixture(scope="module")
+def coco(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp("render"))
+    S.build_dataset(root)
+    ds = mscoco.DatasetMSCOCO()
+    ds.load(os.path.join(root, "coco"), "mscoco,2014-train,2014-val,crop=48,crop_mode=denet", True, 1)
+    return ds
+
+
+def _args(var, image, seed):
+    a = dict(BASE)
+    a.update(var)
+    a.update({"image": image, "seed": seed})
+    return a
+
+
+def test_plan_with_pillow_equals_load_sample_proc(coco, capsys):
+    """the plan layer draws the same random numbers and renders the same pixels as the (reference-pinned) loader"""
+    n = 0
+    for vi, var in enumerate(VARIANTS):
+        for ii, image in enumerate(coco.images):
+            args = _args(var, image, 31 * vi + 7 * ii)
+            (f, x, m), = IL.load_sample_proc(args)
+            s1, n1 = random.random(), np.random.random()
+            pl = P.plan_sample(args)
+            s2, n2 = random.random(), np.random.random()
+            assert (s1, n1) == (s2, n2), "random streams diverge"
+            assert m == pl["meta"]
+            assert np.array_equal(x, P.render_pil(pl)), (vi, ii)
+            n += 1
+    assert n == len(VARIANTS) * 12
+    with pytest.raises(Exception):
+        P.plan_sample(_args({"cropMode": "ssd"}, coco.images[0], 0))
+
+
+@pytest.mark.gpu
+def test_device_render_equals_host_path(hip, coco):
+    import torch
+    from denet_amd import ops
+    from denet_amd.dataset.device_render import DeviceRenderer
+    worst = 0.0
+    for vi, var in enumerate(VARIANTS):
+        crop = var.get("crop", BASE["crop"])
+        r = DeviceRenderer(crop, cp=4)
+        plans = [P.plan_sample(_args(var, image, 31 * vi + 7 * ii)) for ii, image in enumerate(coco.images)]
+        out = r.render_batch(plans)
+        assert tuple(out.shape) == (len(plans), crop, crop, 4)
+        got = ops.nhwc_to_nchw(out, 3).cpu().numpy()
+        assert float(out[..., 3].abs().max()) == 0.0
+        for b, pl in enumerate(plans):
+            ref = P.render_pil(pl)
+            if any(op == 1 for op, _ in pl["photo"]):       # contrast: grey mean from exact sums vs numpy's fp32 mean
+                err = float(np.abs(got[b] - ref).max())
+                worst = max(worst, err)
+                assert err <= 2e-6 * max(1.0, float(np.abs(ref).max())), (vi, b, err)
+            else:
+                assert np.array_equal(got[b], ref), (vi, b, float(np.abs(got[b] - ref).max()))
+    # a shrink by 4x or more goes through Pillow's reduce() pre-pass in Image.thumbnail: not rendered on the device
+    with pytest.raises(NotImplementedError):
+        DeviceRenderer(48).render_batch([P.plan_sample(_args({"isTraining": False, "scale": 20}, coco.images[2], 0))])
+
+
+@pytest.mark.gpu
+def test_device_render_headline_geometry(hip, tmp_path):
+    """MSCOCO-sized images (640x480 and 480x640, JPEG) to the 512x512 training batch: u8-exact against Pillow for the
+    denet crop (Lanczos, thumbnail + resize, bordered canvas), then through a training step of the network input path"""
+    from denet_amd import ops
+    from denet_amd.dataset.device_render import DeviceRenderer
+    images = []
+    for i, (w, h) in enumerate([(640, 480), (480, 640), (500, 375), (640, 427)]):
+        f = str(tmp_path / ("im%d.jpg" % i))
+        S.synth_image(40 + i, w, h).save(f, format="JPEG", quality=92)
+        images.append({"fname": f, "bboxs": S.synth_boxes(40 + i, w, h, 5, 80), "id": i})
+    var = {"cropMode": "denet", "crop": 512, "augmentMirror": True, "checkOnscreen": 0.5, "aspectFactor": 0.75}
+    plans = [P.plan_sample(_args(var, images[i % 4], 100 + i)) for i in range(8)]
+    r = DeviceRenderer(512, cp=4)
+    out = r.render_batch(plans)
+    got = ops.nhwc_to_nchw(out, 3).cpu().numpy()
+    for b, pl in enumerate(plans):
+        assert np.array_equal(got[b], P.render_pil(pl)), b
+    out2 = r.render_batch(plans)                      # buffers reused: same result
+    assert bool((out == out2).all())
+
+
+@pytest.mark.gpu
+def test_device_loader_feeds_training_like_host_loader(hip, coco):
+    """DeviceImageLoader: same seeds, metas and pixels as ImageLoader under the same parent random state, and a training
+    step consumes the device batch directly with the same cost as the host batch"""
+    import torch
+    from denet_amd import ops
+    from denet_amd.dataset.device_render import DeviceImageLoader
+    from denet_amd.model import zoo
+    fp = {"crop": 128, "crop_mode": "denet", "check_center": True, "augment_photo": False}
+    images = [im for im in coco.images if len(im["bboxs"]) > 0][:4]
+    random.seed(77)
+    host = IL.ImageLoader(1, True, fp).load(images)
+    after_host = random.random()
+    random.seed(77)
+    dev = DeviceImageLoader(2, True, fp)
+    x_dev, metas = dev.load_batch(images)
+    assert random.random() == after_host, "the two loaders consume the parent stream differently"
+    assert [m for _, _, m in host] == metas
+    x_host = np.stack([x for _, x, _ in host])
+    assert np.array_equal(ops.nhwc_to_nchw(x_dev, 3).cpu().numpy(), x_host)
+    B = 4
+    model = zoo.denet34(B, "skip", 128, class_num=3, seed=1)
+    model.build_train_func("nesterov")
+    state = (model.P.clone(), model.M.clone(), model.S.clone())
+    random.seed(5)
+    c_host, _ = model.train_step(x_host, metas, 0, 0, 0.01, [0.9], 1e-4)
+    model.P.copy_(state[0]); model.M.copy_(state[1]); model.S.copy_(state[2])
+    random.seed(5)
+    c_dev, _ = model.train_step(x_dev, metas, 0, 0, 0.01, [0.9], 1e-4)
+    assert c_host == c_dev and np.isfinite(c_dev)
