@@ -87,6 +87,30 @@ __global__ __launch_bounds__(256) void image_resample_kernel(const uchar4* __res
     }
 }
 
+// Pillow's Image.reduce((fx, fy)) for 8-bit pixels (src/libImaging/Reduce.c): box average in fixed point,
+// out = ((sum + n/2) * (2^24 / n)) >> 24 with n the pixels of the block (partial blocks at the right / bottom edge are
+// averaged over the pixels they have); output size = ceil(in / f)
+__global__ __launch_bounds__(256) void image_reduce_kernel(const uchar4* __restrict__ in, uchar4* __restrict__ out, int in_w,
+                                                           int in_h, int out_w, int out_h, int fx, int fy) {
+    const long total = (long)out_w * out_h;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % out_w), y = (int)(i / out_w);
+        const int x1 = min((x + 1) * fx, in_w), y1 = min((y + 1) * fy, in_h);
+        unsigned s0 = 0, s1 = 0, s2 = 0;
+        for (int yy = y * fy; yy < y1; ++yy)
+            for (int xx = x * fx; xx < x1; ++xx) {
+                const uchar4 p = in[(long)yy * in_w + xx];
+                s0 += p.x;
+                s1 += p.y;
+                s2 += p.z;
+            }
+        const unsigned n = (unsigned)((x1 - x * fx) * (y1 - y * fy));
+        const unsigned long long m = (1u << 24) / n, amend = n / 2;
+        out[i] = make_uchar4((unsigned char)(((s0 + amend) * m) >> 24), (unsigned char)(((s1 + amend) * m) >> 24),
+                             (unsigned char)(((s2 + amend) * m) >> 24), 0);
+    }
+}
+
 // exact per-channel sums of an RGBX image (for the grey mean of the "contrast" jitter): integer atomics, order free
 __global__ __launch_bounds__(256) void image_sum_kernel(const uchar4* __restrict__ img, long n,
                                                         unsigned long long* __restrict__ sums) {
@@ -250,6 +274,19 @@ extern "C" int denet_image_crop(const unsigned char* src, unsigned char* dst_rgb
     hipLaunchKernelGGL(image_crop_kernel, dim3(grid_for((long)w * h)), dim3(256), 0, stream, src, (uchar4*)dst_rgbx, sw, sh,
                        src_bpp, px, py, x0, y0, w, h);
     DENET_CHECK_LAUNCH("image_crop");
+    return DENET_OK;
+}
+
+// Image.reduce((fx, fy)) of an RGBX image: (in_w x in_h) -> (ceil(in_w / fx) x ceil(in_h / fy)); the box pre-pass
+// Image.thumbnail / resize(reducing_gap=2) insert before the convolution when the shrink factor reaches 4
+extern "C" int denet_image_reduce(const unsigned char* in_rgbx, unsigned char* out_rgbx, int in_w, int in_h, int fx, int fy,
+                                  hipStream_t stream) {
+    DENET_CHECK_ARG(in_rgbx && out_rgbx, "image_reduce: null pointer");
+    DENET_CHECK_ARG(in_w > 0 && in_h > 0 && fx > 0 && fy > 0 && fx * fy <= 65536, "image_reduce: bad sizes");
+    const int ow = (in_w + fx - 1) / fx, oh = (in_h + fy - 1) / fy;
+    hipLaunchKernelGGL(image_reduce_kernel, dim3(grid_for((long)ow * oh)), dim3(256), 0, stream, (const uchar4*)in_rgbx,
+                       (uchar4*)out_rgbx, in_w, in_h, ow, oh, fx, fy);
+    DENET_CHECK_LAUNCH("image_reduce");
     return DENET_OK;
 }
 

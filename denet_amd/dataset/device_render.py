@@ -39,16 +39,17 @@ class DeviceRenderer:
             return numpy.ascontiguousarray(numpy.asarray(im.convert("RGB"), dtype=numpy.uint8))
 
     @staticmethod
-    def _coeffs(in_size, out_size, filt):
+    def _coeffs(in_size, out_size, filt, in1=None):
         L = lib.load()
         fid = FILTER_ID.get(int(filt))
         if fid is None:
             raise NotImplementedError("device rendering supports the LANCZOS / BILINEAR / BICUBIC filters only")
-        scale = max(in_size / out_size, 1.0)
+        in1 = float(in_size) if in1 is None else float(in1)
+        scale = max(in1 / out_size, 1.0)
         cap = out_size * (int(numpy.ceil(3.0 * scale)) * 2 + 1)
         bounds = numpy.empty(2 * out_size, dtype=numpy.int32)
         kk = numpy.empty(cap, dtype=numpy.int32)
-        ks = L.denet_host_resample_coeffs(in_size, 0.0, float(in_size), out_size, fid,
+        ks = L.denet_host_resample_coeffs(in_size, 0.0, in1, out_size, fid,
                                           bounds.ctypes.data_as(ctypes.c_void_p), kk.ctypes.data_as(ctypes.c_void_p), cap)
         if ks <= 0:
             raise lib.DenetHipError("resample_coeffs: " + L.denet_last_error().decode())
@@ -56,7 +57,7 @@ class DeviceRenderer:
 
     def _expand(self, size, steps):
         """plan steps -> device ops with sizes: ("crop", ...) | ("pass", horizontal, in_w, in_h, out_n, tables)"""
-        ops, cur, need = [], tuple(size), 0
+        ops, cur, need = [], tuple(size), size[0] * size[1]
         for st in steps:
             if st[0] == "crop":
                 _, x0, y0, x1, y1, px, py, cw, ch = st
@@ -67,18 +68,26 @@ class DeviceRenderer:
                     t = planmod.thumbnail_size(cur[0], cur[1], st[1])
                     if t is None or t == cur:
                         continue
-                    # Image.thumbnail resizes with reducing_gap=2.0: a box-filter reduce() precedes the convolution
-                    # when the shrink factor reaches 4 - not needed for dataset images, not implemented
-                    if int(cur[0] / t[0] / 2.0) > 1 or int(cur[1] / t[1] / 2.0) > 1:
-                        raise NotImplementedError("shrink by %dx%d -> %dx%d needs Pillow's reduce() pre-pass" % (cur + t))
                     new, filt = t, st[2]
+                    # Image.thumbnail resizes with reducing_gap=2.0: when the shrink factor reaches 4 a box-filter
+                    # reduce() comes first and the convolution maps the fractional box (w / fx, h / fy), which Pillow
+                    # hands to its C code as float32
+                    fx, fy = int(cur[0] / t[0] / 2.0) or 1, int(cur[1] / t[1] / 2.0) or 1
+                    box = (float(cur[0]), float(cur[1]))
+                    if fx > 1 or fy > 1:
+                        ops.append(("reduce", cur[0], cur[1], fx, fy))
+                        box = (float(numpy.float32(cur[0] / fx)), float(numpy.float32(cur[1] / fy)))
+                        cur = ((cur[0] + fx - 1) // fx, (cur[1] + fy - 1) // fy)
+                        need = max(need, cur[0] * cur[1])
                 else:
                     new, filt = (st[1], st[2]), st[3]
-                if new[0] != cur[0]:
-                    ops.append(("pass", 1, cur[0], cur[1], new[0], self._coeffs(cur[0], new[0], filt)))
+                    box = (float(cur[0]), float(cur[1]))
+                if new[0] != cur[0] or box[0] != cur[0]:
+                    ops.append(("pass", 1, cur[0], cur[1], new[0], self._coeffs(cur[0], new[0], filt, box[0])))
                     cur = (new[0], cur[1])
-                if new[1] != cur[1]:
-                    ops.append(("pass", 0, cur[0], cur[1], new[1], self._coeffs(cur[1], new[1], filt)))
+                    need = max(need, cur[0] * cur[1])
+                if new[1] != cur[1] or box[1] != cur[1]:
+                    ops.append(("pass", 0, cur[0], cur[1], new[1], self._coeffs(cur[1], new[1], filt, box[1])))
                     cur = (cur[0], new[1])
             need = max(need, cur[0] * cur[1])
         if cur != (self.crop, self.crop):
@@ -139,11 +148,15 @@ class DeviceRenderer:
                     dops.check(L.denet_image_crop(cur_ptr, dst, sw, sh, 3 if cur_is_src else 4, px, py, x0, y0, w, h, stream),
                                "image_crop")
                 else:
-                    _, horizontal, in_w, in_h, out_n, (bounds, kk, ks) = o
+                    in_w, in_h = (o[1], o[2]) if o[0] == "reduce" else (o[2], o[3])
                     if cur_is_src:      # the first step is a resampling of the whole image: bring it to RGBX first
                         dops.check(L.denet_image_crop(cur_ptr, dst, in_w, in_h, 3, 0, 0, 0, 0, in_w, in_h, stream), "image_crop")
                         cur_ptr, cur_is_src, flip = dst, False, flip ^ 1
                         dst = self._scratch[flip].data_ptr()
+                if o[0] == "reduce":
+                    dops.check(L.denet_image_reduce(cur_ptr, dst, o[1], o[2], o[3], o[4], stream), "image_reduce")
+                elif o[0] == "pass":
+                    _, horizontal, in_w, in_h, out_n, (bounds, kk, ks) = o
                     dops.check(L.denet_image_resample_pass(cur_ptr, dst, in_w, in_h, out_n, horizontal, base + tab[0],
                                                            base + tab[1], ks, stream), "image_resample_pass")
                 cur_ptr, cur_is_src, flip = dst, False, flip ^ 1

@@ -53,6 +53,7 @@ SIGNATURES = {
     "denet_pool_inv_bwd": (I, [P, P] + [I] * 6 + [P]),
     "denet_host_resample_coeffs": (I, [I, D, D, I, I, P, P, L]),
     "denet_image_crop": (I, [P, P] + [I] * 9 + [P]),
+    "denet_image_reduce": (I, [P, P, I, I, I, I, P]),
     "denet_image_resample_pass": (I, [P, P, I, I, I, I, P, P, I, P]),
     "denet_image_finish": (I, [P, P, I, I, I, I, P, P, P, P, I, P, P]),
     "denet_border_fwd": (I, [P, P] + [I] * 8 + [P]),

@@ -152,6 +152,8 @@ int denet_host_resample_coeffs(int in_size, double in0, double in1, int out_size
                                int* kk_host, long kk_capacity);
 int denet_image_crop(const unsigned char* src, unsigned char* dst_rgbx, int sw, int sh, int src_bpp, int px, int py, int x0,
                      int y0, int w, int h, hipStream_t stream);
+int denet_image_reduce(const unsigned char* in_rgbx, unsigned char* out_rgbx, int in_w, int in_h, int fx, int fy,
+                       hipStream_t stream);
 int denet_image_resample_pass(const unsigned char* in_rgbx, unsigned char* out_rgbx, int in_w, int in_h, int out_n,
                               int horizontal, const int* bounds_dev, const int* kk_dev, int ksize, hipStream_t stream);
 int denet_image_finish(const unsigned char* img_rgbx, float* out_nhwc, int w, int h, int cp, int n_ops,

@@ -86,17 +86,49 @@ def _pass(cur, out_n, b, kk, axis):
     return out
 
 
-def resize(a, out_w, out_h, flt):
-    """a: uint8 (H, W, 3) -> uint8 (out_h, out_w, 3), Image.resize((out_w, out_h), flt) with the default box"""
+def reduce(a, fx, fy):
+    """Image.reduce((fx, fy)) (src/libImaging/Reduce.c, 8-bit): out = ((sum + n//2) * (2**24 // n)) >> 24 over the block's
+    n pixels, partial blocks at the right / bottom edge averaged over what they have; size = ceil(in / f)"""
+    H, W, _ = a.shape
+    oh, ow = (H + fy - 1) // fy, (W + fx - 1) // fx
+    out = np.zeros((oh, ow, 3), np.uint8)
+    for y in range(oh):
+        for x in range(ow):
+            blk = a[y * fy:min((y + 1) * fy, H), x * fx:min((x + 1) * fx, W)].astype(np.int64)
+            n = blk.shape[0] * blk.shape[1]
+            out[y, x] = ((blk.sum(axis=(0, 1)) + n // 2) * ((1 << 24) // n)) >> 24
+    return out
+
+
+def resize(a, out_w, out_h, flt, reducing_gap=None):
+    """a: uint8 (H, W, 3) -> uint8 (out_h, out_w, 3): Image.resize((out_w, out_h), flt, reducing_gap=...) with the default
+    box. With a reducing gap g, a shrink by int(in / out / g) > 1 per axis is first done by reduce(); the convolution then
+    maps the fractional box (0, 0, W / fx, H / fy) - passed to the C code as float32 - to the output"""
     H, W, _ = a.shape
     cur = a
-    if out_w != W:
-        b, kk = coeffs(W, 0, W, out_w, flt)
+    bw, bh = float(W), float(H)
+    if reducing_gap is not None:
+        fx = int(W / out_w / reducing_gap) or 1
+        fy = int(H / out_h / reducing_gap) or 1
+        if fx > 1 or fy > 1:
+            cur = reduce(a, fx, fy)
+            bw, bh = float(np.float32(W / fx)), float(np.float32(H / fy))
+    h2, w2, _ = cur.shape
+    if out_w != w2 or bw != w2:
+        b, kk = coeffs(w2, 0.0, bw, out_w, flt)
         cur = _pass(cur, out_w, b, kk, 1)
-    if out_h != H:
-        b, kk = coeffs(H, 0, H, out_h, flt)
+    if out_h != h2 or bh != h2:
+        b, kk = coeffs(h2, 0.0, bh, out_h, flt)
         cur = _pass(cur, out_h, b, kk, 0)
     return cur
+
+
+def thumbnail(a, s, flt):
+    """Image.thumbnail((s, s), flt): aspect-preserving shrink with reducing_gap = 2.0"""
+    t = thumbnail_size(a.shape[1], a.shape[0], s)
+    if t is None or t == (a.shape[1], a.shape[0]):
+        return a
+    return resize(a, t[0], t[1], flt, reducing_gap=2.0)
 
 
 def thumbnail_size(w, h, s):

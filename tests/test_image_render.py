@@ -52,12 +52,21 @@ def test_oracle_resample_equals_pillow():
         flt = [PR.LANCZOS, PR.BILINEAR, PR.BICUBIC][trial % 3]
         ref = np.array(Image.fromarray(a, "RGB").resize((ow, oh), PIL_FILTER[flt]))
         assert np.array_equal(PR.resize(a, ow, oh, flt), ref), (trial, W, H, ow, oh, flt)
-    for W, H, s in [(295, 230, 160), (120, 97, 64), (64, 97, 60), (80, 80, 50), (150, 40, 30), (33, 120, 33), (50, 50, 64)]:
-        im = Image.fromarray(rng.randint(0, 256, (H, W, 3)).astype(np.uint8), "RGB")
+    # Image.thumbnail: aspect-preserving size, and for shrinks >= 4x the reduce() pre-pass + fractional-box convolution
+    for W, H, s in [(295, 230, 160), (120, 97, 64), (64, 97, 60), (80, 80, 50), (150, 40, 30), (33, 120, 33), (50, 50, 64),
+                    (347, 222, 48), (500, 375, 40), (97, 411, 30), (640, 480, 17), (256, 256, 31)]:
+        a = rng.randint(0, 256, (H, W, 3)).astype(np.uint8)
+        im = Image.fromarray(a, "RGB")
         t = PR.thumbnail_size(W, H, s)
         assert t == P.thumbnail_size(W, H, s)
         im.thumbnail((s, s), Image.LANCZOS)
         assert im.size == (t if t is not None else (W, H))
+        assert np.array_equal(PR.thumbnail(a, s, PR.LANCZOS), np.array(im)), (W, H, s)
+    for trial in range(40):
+        W, H = rng.randint(3, 90), rng.randint(3, 90)
+        fx, fy = int(rng.randint(1, 8)), int(rng.randint(1, 8))
+        a = rng.randint(0, 256, (H, W, 3)).astype(np.uint8)
+        assert np.array_equal(PR.reduce(a, fx, fy), np.array(Image.fromarray(a, "RGB").reduce((fx, fy)))), (W, H, fx, fy)
 
 
 def test_native_coefficient_tables_equal_oracle():
@@ -136,9 +145,28 @@ def test_device_render_equals_host_path(hip, coco):
                 assert err <= 2e-6 * max(1.0, float(np.abs(ref).max())), (vi, b, err)
             else:
                 assert np.array_equal(got[b], ref), (vi, b, float(np.abs(got[b] - ref).max()))
-    # a shrink by 4x or more goes through Pillow's reduce() pre-pass in Image.thumbnail: not rendered on the device
-    with pytest.raises(NotImplementedError):
-        DeviceRenderer(48).render_batch([P.plan_sample(_args({"isTraining": False, "scale": 20}, coco.images[2], 0))])
+
+
+@pytest.mark.gpu
+def test_device_render_large_shrink_uses_reduce(hip, tmp_path):
+    """photo-sized sources (ImageNet-like, 1900x1400 and 1333x2000) scaled to 256 then centre-cropped to 224, and a 4.6x
+    shrink of a denet window: Image.thumbnail's reduce() box pre-pass + fractional-box convolution, bit-exact"""
+    from denet_amd import ops
+    from denet_amd.dataset.device_render import DeviceRenderer
+    images = []
+    for i, (w, h) in enumerate([(1900, 1400), (1333, 2000), (1024, 1024)]):
+        f = str(tmp_path / ("big%d.png" % i))
+        S.synth_image(60 + i, w, h).save(f)
+        images.append({"fname": f, "bboxs": S.synth_boxes(60 + i, w, h, 4, 10), "id": i, "class": i})
+    for var in ({"isTraining": False, "scale": 256, "crop": 224, "subtractMean": True},
+                {"cropMode": "default", "scale": 256, "crop": 224, "augmentMirror": True},
+                {"cropMode": "denet", "crop": 128, "areaMin": 0.6, "aspectFactor": 1}):
+        plans = [P.plan_sample(_args(var, im, 9 + k)) for k, im in enumerate(images)]
+        assert any(st[0] == "thumbnail" for pl in plans for st in pl["steps"])
+        out = DeviceRenderer(var["crop"]).render_batch(plans)
+        got = ops.nhwc_to_nchw(out, 3).cpu().numpy()
+        for b, pl in enumerate(plans):
+            assert np.array_equal(got[b], P.render_pil(pl)), (var, b)
 
 
 @pytest.mark.gpu
