@@ -11,6 +11,7 @@
 // are built on the host with the same libm calls (denet_host_resample_coeffs), the passes are integer arithmetic.
 // All kernels are tiny and HBM/latency bound: one thread per output pixel, RGBX (4 bytes) pixels for aligned access.
 #include <math.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -347,4 +348,105 @@ extern "C" int denet_image_finish(const unsigned char* img_rgbx, float* out_nhwc
                        w, h, cp, fp, n_ops > 0 ? sums_ws : nullptr);
     DENET_CHECK_LAUNCH("image_finish");
     return DENET_OK;
+}
+
+// A whole batch in one call (the Python loader thread holds no interpreter lock meanwhile): copies the decoded images and
+// the coefficient tables of every resampling pass into the pinned staging buffer, issues ONE host-to-device copy and then
+// the kernels of every image's program, writing image b to out_dev + b * crop * crop * cp.
+//   ops: [n_ops][8] ints, per image the range op_off[b] .. op_off[b+1]:
+//        kind 0 crop    : sw, sh, px, py, x0, y0 ; the window size is (aux[0], aux[1]) = ops_wh
+//        kind 1 reduce  : in_w, in_h, fx, fy
+//        kind 2 pass    : horizontal, in_w, in_h, out_n, filter ; ops_in1: the upper end of the source box (in0 = 0)
+//   photo_ops / photo_alpha: [B][3] (photo_n[b] valid entries); noise: [B][3] doubles, used where has_noise[b];
+//   mean_std: 6 floats or NULL; the caller guarantees the previous batch's copy has finished reading `pinned_host`.
+extern "C" int denet_image_render_batch(int B, const unsigned char* const* src_host, const int* src_wh, const int* op_off,
+                                        const int* ops, const int* ops_wh, const double* ops_in1, const int* photo_n,
+                                        const int* photo_ops, const double* photo_alpha, const double* noise,
+                                        const unsigned char* has_noise, const float* mean_std, const unsigned char* mirror,
+                                        int crop, int cp, float* out_dev, unsigned char* pinned_host, size_t pinned_bytes,
+                                        unsigned char* staging_dev, unsigned char* scratch0, unsigned char* scratch1,
+                                        size_t scratch_bytes, unsigned long long* sums_dev, hipStream_t stream) {
+    DENET_CHECK_ARG(B > 0 && src_host && src_wh && op_off && ops && ops_wh && ops_in1 && photo_n && photo_ops && photo_alpha,
+                    "image_render_batch: null pointer");
+    DENET_CHECK_ARG(out_dev && pinned_host && staging_dev && scratch0 && scratch1 && sums_dev && mirror,
+                    "image_render_batch: null buffer");
+    auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const int n_ops = op_off[B];
+    struct Tab { size_t bounds, kk; int ksize; };
+    Tab* tabs = new Tab[n_ops > 0 ? n_ops : 1];
+    size_t* img_off = new size_t[B];
+    size_t off = 0;
+    int rc = DENET_OK;
+    for (int b = 0; b < B && rc == DENET_OK; ++b) {
+        const size_t bytes = (size_t)src_wh[2 * b] * src_wh[2 * b + 1] * 3;
+        if (off + bytes > pinned_bytes) { denet_set_error("image_render_batch: staging buffer too small"); rc = DENET_ERR_ARG; break; }
+        memcpy(pinned_host + off, src_host[b], bytes);
+        img_off[b] = off;
+        off = align16(off + bytes);
+        for (int o = op_off[b]; o < op_off[b + 1]; ++o) {
+            const int* q = ops + 8 * o;
+            if (q[0] != 2) continue;
+            const int in_size = q[1] ? q[2] : q[3], out_n = q[4];
+            const size_t bb = (size_t)2 * out_n * sizeof(int);
+            if (off + bb > pinned_bytes) { denet_set_error("image_render_batch: staging buffer too small"); rc = DENET_ERR_ARG; break; }
+            const long cap = (long)((pinned_bytes - off - bb) / sizeof(int));
+            const int ks = denet_host_resample_coeffs(in_size, 0.0, ops_in1[o], out_n, q[5], (int*)(pinned_host + off),
+                                                      (int*)(pinned_host + off + bb), cap);
+            if (ks <= 0) { rc = ks < 0 ? ks : DENET_ERR_ARG; break; }
+            tabs[o].bounds = off;
+            tabs[o].kk = off + bb;
+            tabs[o].ksize = ks;
+            off = align16(off + bb + (size_t)out_n * ks * sizeof(int));
+        }
+    }
+    if (rc == DENET_OK) {
+        hipError_t e = hipMemcpyAsync(staging_dev, pinned_host, off, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) { denet_set_error("image_render_batch: %s", hipGetErrorString(e)); rc = -(int)e; }
+    }
+    for (int b = 0; b < B && rc == DENET_OK; ++b) {
+        const unsigned char* cur = staging_dev + img_off[b];
+        int bpp = 3, cw = src_wh[2 * b], chh = src_wh[2 * b + 1], flip = 0;
+        auto to_rgbx = [&]() {      // a program that starts with a resampling step: unpack the decoded image first
+            unsigned char* dst = flip ? scratch1 : scratch0;
+            int r = denet_image_crop(cur, dst, cw, chh, 3, 0, 0, 0, 0, cw, chh, stream);
+            cur = dst; bpp = 4; flip ^= 1;
+            return r;
+        };
+        for (int o = op_off[b]; o < op_off[b + 1] && rc == DENET_OK; ++o) {
+            const int* q = ops + 8 * o;
+            if (q[0] != 0 && bpp == 3) rc = to_rgbx();
+            if (rc != DENET_OK) break;
+            unsigned char* dst = flip ? scratch1 : scratch0;
+            int ow = 0, oh = 0;
+            if (q[0] == 0) {
+                ow = ops_wh[2 * o]; oh = ops_wh[2 * o + 1];
+                if ((size_t)ow * oh * 4 > scratch_bytes) { denet_set_error("image_render_batch: scratch too small"); rc = DENET_ERR_ARG; break; }
+                rc = denet_image_crop(cur, dst, q[1], q[2], bpp, q[3], q[4], q[5], q[6], ow, oh, stream);
+            } else if (q[0] == 1) {
+                ow = (q[1] + q[3] - 1) / q[3]; oh = (q[2] + q[4] - 1) / q[4];
+                rc = denet_image_reduce(cur, dst, q[1], q[2], q[3], q[4], stream);
+            } else if (q[0] == 2) {
+                ow = q[1] ? q[4] : q[2]; oh = q[1] ? q[3] : q[4];
+                if ((size_t)ow * oh * 4 > scratch_bytes) { denet_set_error("image_render_batch: scratch too small"); rc = DENET_ERR_ARG; break; }
+                rc = denet_image_resample_pass(cur, dst, q[2], q[3], q[4], q[1], (const int*)(staging_dev + tabs[o].bounds),
+                                               (const int*)(staging_dev + tabs[o].kk), tabs[o].ksize, stream);
+            } else {
+                denet_set_error("image_render_batch: unknown op kind %d", q[0]);
+                rc = DENET_ERR_ARG;
+            }
+            cur = dst; bpp = 4; flip ^= 1; cw = ow; chh = oh;
+        }
+        if (rc == DENET_OK && bpp == 3) rc = to_rgbx();
+        if (rc == DENET_OK && (cw != crop || chh != crop)) {
+            denet_set_error("image_render_batch: image %d renders %dx%d, expected %dx%d", b, cw, chh, crop, crop);
+            rc = DENET_ERR_ARG;
+        }
+        if (rc == DENET_OK)
+            rc = denet_image_finish(cur, out_dev + (size_t)b * crop * crop * cp, crop, crop, cp, photo_n[b], photo_ops + 3 * b,
+                                    photo_alpha + 3 * b, (has_noise && has_noise[b]) ? noise + 3 * b : nullptr, mean_std,
+                                    mirror[b], sums_dev, stream);
+    }
+    delete[] tabs;
+    delete[] img_off;
+    return rc;
 }

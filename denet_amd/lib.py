@@ -55,6 +55,7 @@ SIGNATURES = {
     "denet_image_crop": (I, [P, P] + [I] * 9 + [P]),
     "denet_image_reduce": (I, [P, P, I, I, I, I, P]),
     "denet_image_resample_pass": (I, [P, P, I, I, I, I, P, P, I, P]),
+    "denet_image_render_batch": (I, [I] + [P] * 13 + [I, I, P, P, Z, P, P, P, Z, P, P]),
     "denet_image_finish": (I, [P, P, I, I, I, I, P, P, P, P, I, P, P]),
     "denet_border_fwd": (I, [P, P] + [I] * 8 + [P]),
     "denet_border_bwd": (I, [P, P] + [I] * 8 + [P]),

@@ -407,6 +407,18 @@ class ModelCNN:
             self.iteration += 1
         return total_cost
 
+    def train_epoch_device(self, loader, images, epoch, learning_rate, momentum=[0, 1, 0], decay=0.0):
+        """train_epoch over batches rendered on the GPU by a denet_amd.dataset.device_render.DeviceImageLoader: same
+        batches, metas and random-stream use as `train_epoch(dataset)` after `dataset.load_from_subset`"""
+        total_cost = 0
+        for data_x, data_m in loader.iterate(images, self.batch_size):
+            cost, _ = self.train_step(data_x, data_m, epoch, self.iteration, learning_rate, momentum, decay)
+            if math.isnan(cost):
+                raise Exception("ERROR: Cost is NaN")
+            total_cost += cost
+            self.iteration += 1
+        return total_cost
+
     def predict_output(self, dataset):
         """last-layer output for every sample of the loaded subset, padding of the last batch cropped
         (reference model_cnn.py:484-508)"""

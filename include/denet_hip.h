@@ -156,6 +156,13 @@ int denet_image_reduce(const unsigned char* in_rgbx, unsigned char* out_rgbx, in
                        hipStream_t stream);
 int denet_image_resample_pass(const unsigned char* in_rgbx, unsigned char* out_rgbx, int in_w, int in_h, int out_n,
                               int horizontal, const int* bounds_dev, const int* kk_dev, int ksize, hipStream_t stream);
+int denet_image_render_batch(int B, const unsigned char* const* src_host, const int* src_wh, const int* op_off, const int* ops,
+                             const int* ops_wh, const double* ops_in1, const int* photo_n, const int* photo_ops,
+                             const double* photo_alpha, const double* noise, const unsigned char* has_noise,
+                             const float* mean_std, const unsigned char* mirror, int crop, int cp, float* out_dev,
+                             unsigned char* pinned_host, size_t pinned_bytes, unsigned char* staging_dev,
+                             unsigned char* scratch0, unsigned char* scratch1, size_t scratch_bytes,
+                             unsigned long long* sums_dev, hipStream_t stream);
 int denet_image_finish(const unsigned char* img_rgbx, float* out_nhwc, int w, int h, int cp, int n_ops,
                        const int* ops_host, const double* alphas_host, const double* noise_host,
                        const float* mean_std_host, int mirror, unsigned long long* sums_ws, hipStream_t stream);

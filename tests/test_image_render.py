@@ -221,3 +221,56 @@ def test_device_loader_feeds_training_like_host_loader(hip, coco):
     random.seed(5)
     c_dev, _ = model.train_step(x_dev, metas, 0, 0, 0.01, [0.9], 1e-4)
     assert c_host == c_dev and np.isfinite(c_dev)
+
+
+@pytest.mark.gpu
+def test_device_epoch_equals_host_epoch(hip, coco):
+    """a whole epoch: host loader + DatasetAbstract.export + train_epoch against DeviceImageLoader.iterate +
+    train_epoch_device (next batch decoded / rendered on a side stream while the current one trains): identical
+    batches, random-stream use, costs and final parameters"""
+    import torch
+    from denet_amd.dataset.device_render import DeviceImageLoader
+    from denet_amd.model import zoo
+    fmt = {"crop": 128, "crop_mode": "denet", "check_center": True, "augment_photo": False}
+    images = [im for im in coco.images if len(im["bboxs"]) > 0]          # 10 images, batch 4 -> padded last batch
+    B = 4
+    model = zoo.denet34(B, "skip", 128, class_num=3, seed=1)
+    model.build_train_func("nesterov")
+    state = (model.P.clone(), model.M.clone(), model.S.clone())
+
+    class HostSet(mscoco.DatasetMSCOCO):
+        pass
+    random.seed(21)
+    host = HostSet()
+    host.output_size = 128
+    host.data = IL.ImageLoader(1, True, fmt).load(images)
+    c_host = model.train_epoch(host, 0, 0.01, [0.9], 1e-4)
+    after_host = random.random()
+    p_host = model.P.clone()
+
+    model.P.copy_(state[0]); model.M.copy_(state[1]); model.S.copy_(state[2])
+    model.iteration = 0
+    random.seed(21)
+    c_dev = model.train_epoch_device(DeviceImageLoader(2, True, fmt), images, 0, 0.01, [0.9], 1e-4)
+    assert random.random() == after_host
+    assert c_dev == c_host and np.isfinite(c_dev)
+    assert torch.equal(model.P, p_host)
+
+
+@pytest.mark.gpu
+def test_device_loader_process_decode(hip, coco):
+    """decode="process": workers write decoded images into shared memory; same batch as the thread mode"""
+    from denet_amd.dataset.device_render import DeviceImageLoader
+    fp = {"crop": 64, "crop_mode": "denet", "augment_photo": True}
+    images = coco.images[:6]
+    random.seed(3)
+    a = DeviceImageLoader(2, True, fp)
+    xa, ma = a.load_batch(images)
+    random.seed(3)
+    b = DeviceImageLoader(2, True, fp, decode="process")
+    try:
+        xb, mb = b.load_batch(images)
+        xb2, _ = b.load_batch(images[:3])          # second staging slot
+    finally:
+        b.close()
+    assert ma == mb and bool((xa == xb).all()) and tuple(xb2.shape) == (3, 64, 64, 4)
