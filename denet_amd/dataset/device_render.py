@@ -189,9 +189,10 @@ class DeviceImageLoader:
     bytes to numpy) or processes writing into a shared-memory block (decode="process": nothing but two integers per image
     crosses a pipe and the training thread keeps the interpreter to itself)."""
 
-    def __init__(self, thread_num, is_training, format_params={}, cp=4, decode="thread"):
+    def __init__(self, thread_num, is_training, format_params={}, cp=4, decode="thread", params=None):
         from .image_loader import ImageLoader
-        self.params = ImageLoader(1, is_training, format_params)       # parameter parsing and make_args only
+        # `params`: an existing ImageLoader (e.g. a dataset's, with its colour statistics) used for make_args only
+        self.params = params if params is not None else ImageLoader(1, is_training, format_params)
         self.renderer = DeviceRenderer(self.params.crop, cp)
         self.decode_mode = decode
         self.workers = max(1, int(thread_num))

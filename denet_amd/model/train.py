@@ -94,6 +94,9 @@ def build_parser():
     parser.add_argument("--thread-num", type=int, default=1, help="Worker processes for loading / augmenting data")
     parser.add_argument("--max-samples", type=int, default=None, help="Maximum samples to load from training set")
     parser.add_argument("--augment-mirror", default=False, action="store_true")
+    parser.add_argument("--device-render", default=False, action="store_true",
+                        help="render the augmentation (crop, resampling, colour jitter) on the GPU instead of in the loader "
+                             "processes: same batches, one host process per GPU keeps up with training")
     parser.add_argument("--border-mode", default="valid")
     parser.add_argument("--output-prefix", default="./model")
     parser.add_argument("--activation", default="relu")
@@ -144,11 +147,22 @@ def train(args, train_data, log=print, test_data=None):
     model.build_train_func(args.solver, args.cost_factors)
     learn_rate = args.learn_rate
     costs = []
+    device_loader = None
+    if getattr(args, "device_render", False) and hasattr(train_data, "images") and hasattr(train_data, "image_loader"):
+        from ..dataset.device_render import DeviceImageLoader
+        device_loader = DeviceImageLoader(max(1, getattr(args, "thread_num", 1)), True, cp=model.input.cp, decode="process",
+                                          params=train_data.image_loader)
     for epoch in range(args.epochs):
         train_data.shuffle()
         for subset in range(train_data.subset_num):
-            train_data.load_from_subset(subset)
-            cost = model.train_epoch(train_data, epoch, learn_rate, args.learn_momentum, args.learn_decay)
+            if device_loader is not None:
+                lo = subset * train_data.subset_size
+                hi = min((subset + 1) * train_data.subset_size, train_data.subset_total_size)
+                cost = model.train_epoch_device(device_loader, train_data.images[lo:hi], epoch, learn_rate,
+                                                args.learn_momentum, args.learn_decay)
+            else:
+                train_data.load_from_subset(subset)
+                cost = model.train_epoch(train_data, epoch, learn_rate, args.learn_momentum, args.learn_decay)
             costs.append(cost)
             log("epoch %i subset %i - cost: %.4f (lr %g)" % (epoch, subset, cost, learn_rate))
         if len(args.learn_anneal_epochs) == 0 or (epoch + 1) in args.learn_anneal_epochs:
@@ -159,6 +173,8 @@ def train(args, train_data, log=print, test_data=None):
             save_results(args.output_prefix + "_epoch%03i.test" % epoch, test_error, test_class_errors)
         if not args.disable_intermediate:
             model_cnn.save_to_file(model, args.output_prefix + "_epoch%03i.mdl.gz" % epoch)
+    if device_loader is not None:
+        device_loader.close()
     model_cnn.save_to_file(model, args.output_prefix + "_epoch%03i_final.mdl.gz" % (args.epochs - 1))
     return model, costs
 

@@ -129,3 +129,29 @@ def test_model_predict_classifier_modes(hip, tree, tmp_path):
     assert len(multi) == 60
     m1, m5 = predict.test_multicrop("multicrop", model, multi, log=lambda *a: None)
     assert 0.0 <= m1 <= 1.0 and m5 == 0.0
+
+
+def test_model_train_cli_device_render_equals_host_loader(hip, tree, tmp_path):
+    """`model-train --train <voc dir> --extension voc,... [--device-render]`: the two data paths give the same epoch costs
+    and the same checkpoint"""
+    from denet_amd.model import model_cnn, train as train_mod
+    desc = ("C.B[32,3,2] BN A nRSN.O[1,32,3] SKIPSRC[0] nRSN.O[1,64,3,2] PI[2] C[32,3] SKIP[0] BNA DNC[16,100] "
+            "DNS[3,4,0.01,0.1] C.B[64,1] BNA DND[0.5,1,1]").split()
+    outs = []
+    for mode in ([], ["--device-render"]):
+        prefix = str(tmp_path / ("m" + ("d" if mode else "h")))
+        args = train_mod.build_parser().parse_args(
+            ["--train", os.path.join(tree, "voc"), "--extension", "voc,2007-trainval,2012-trainval,crop=64,crop_mode=denet,check_center",
+             "--thread-num", "2", "--batch-size", "4", "--epochs", "2", "--seed", "7", "--solver", "nesterov",
+             "--learn-rate", "0.01", "--learn-momentum", "0.9", "--border-mode", "half", "--output-prefix", prefix,
+             "--disable-intermediate", "--model-desc"] + desc + mode)
+        random.seed(args.seed)
+        np.random.seed(args.seed)
+        data = train_mod.load_dataset(args.train, args.seed, args.extension, True, args.thread_num)
+        model, costs = train_mod.train(args, data, log=lambda *a: None)
+        if data.image_loader.procs is not None:
+            data.image_loader.procs.terminate()
+        outs.append((costs, model.P.clone()))
+    assert np.isfinite(outs[0][0]).all()
+    assert outs[0][0] == outs[1][0]
+    assert bool((outs[0][1] == outs[1][1]).all())
