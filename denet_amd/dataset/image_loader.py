@@ -120,7 +120,15 @@ class ImageLoader:
         self.rgb_eigen_vec = numpy.zeros((3, 3), dtype=numpy.float32)
         self.is_training = is_training
         self.thread_num = thread_num
-        self.procs = mp.Pool(self.thread_num) if self.thread_num > 1 else None
+        # spawned workers (the reference forks, image_loader.py:172): forking a process that has initialised the GPU
+        # runtime and carries its threads deadlocks sooner or later; the workers only import this light module
+        self.procs = mp.get_context("spawn").Pool(self.thread_num) if self.thread_num > 1 else None
+
+    def close(self):
+        if self.procs is not None:
+            self.procs.terminate()
+            self.procs.join()
+            self.procs = None
 
     def __str__(self):
         r = "thread_num: %i, is_training: %i, subtract_mean: %i, scale: %i, scale mode: %s, " % (

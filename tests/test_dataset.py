@@ -103,8 +103,7 @@ def test_loader_pool_and_inline_paths_agree(result):
         ds.load_from_subset(0)
         x, metas, n = ds.export(4)
         out.append((x, [(m["scale"], m["offset"], m["mirror"], m["bbox"]) for m in metas], n, random.random()))
-        if ds.image_loader.procs is not None:
-            ds.image_loader.procs.terminate()
+        ds.image_loader.close()
     assert out[0][1] == out[1][1] and out[0][2] == out[1][2] == 6 and out[0][3] == out[1][3]
     assert np.array_equal(out[0][0], out[1][0]) and out[0][0].shape == (8, 3, 40, 40)
 

@@ -149,8 +149,7 @@ def test_model_train_cli_device_render_equals_host_loader(hip, tree, tmp_path):
         np.random.seed(args.seed)
         data = train_mod.load_dataset(args.train, args.seed, args.extension, True, args.thread_num)
         model, costs = train_mod.train(args, data, log=lambda *a: None)
-        if data.image_loader.procs is not None:
-            data.image_loader.procs.terminate()
+        data.image_loader.close()
         outs.append((costs, model.P.clone()))
     assert np.isfinite(outs[0][0]).all()
     assert outs[0][0] == outs[1][0]
