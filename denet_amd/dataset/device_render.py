@@ -109,7 +109,8 @@ class DeviceRenderer:
         ops_all, wh_all, in1_all, op_off = [], [], [], [0]
         staging, scratch_px = 0, 1
         for p, a in zip(plans, images):
-            o, wh, in1, tab_ints, need = self._expand((a.shape[1], a.shape[0]), p["steps"])
+            cached = p.get("_device_ops")          # expanded at planning time (DeviceImageLoader.plan)
+            o, wh, in1, tab_ints, need = cached if cached is not None else self._expand((a.shape[1], a.shape[0]), p["steps"])
             ops_all += o
             wh_all += wh
             in1_all += in1
@@ -225,6 +226,8 @@ class DeviceImageLoader:
         plans = [planmod.plan_sample(a) for a in args_list]
         random.setstate(state)
         numpy.random.set_state(np_state)
+        for p in plans:       # the device program of each plan, so that the prefetch thread has no Python work left to do
+            p["_device_ops"] = self.renderer._expand(tuple(p["meta"]["image_size"]), p["steps"])
         return plans
 
     def _decode(self, plans):
