@@ -22,10 +22,16 @@
 // Compiled with -ffp-contract=off.
 #include "common.h"
 #include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
 
 namespace {
 
 constexpr int TIE_CAP = 4096;   // extra slots for candidates tying with the threshold key
+// tie slots actually used: the final sort keeps sample_count + ties <= 8192 candidates in LDS
+__host__ __device__ inline int tie_cap_for(int sample_count) { return sample_count <= 4096 ? TIE_CAP : 8192 - sample_count; }
 constexpr int NBLK_PAIR = 64;   // workgroups per image for the pair passes
 
 struct ImgState {
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(256) void pair_collect_kernel(PairCtx c, ImgState* 
             if (slot < (unsigned)sample_count) out[slot] = e;
         } else if (key == T) {
             const unsigned slot = atomicAdd(&state[b].ntie, 1u);
-            if (slot < (unsigned)TIE_CAP) out[sample_count + slot] = e;
+            if (slot < (unsigned)tie_cap_for(sample_count)) out[sample_count + slot] = e;
         }
     });
 }
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(1024) void pair_finalize_kernel(const ImgState* __r
     const int b = blockIdx.x;
     const ImgState st = state[b];
     const int nless = min((int)st.nless, sample_count);
-    const int ntie = min((int)st.ntie, TIE_CAP);
+    const int ntie = min((int)st.ntie, tie_cap_for(sample_count));
     const Cand* in = cand + (long)b * (sample_count + TIE_CAP);
     const int n = nless + ntie;
     for (int i = threadIdx.x; i < NP; i += 1024) {
@@ -437,7 +443,8 @@ extern "C" int denet_build_samples(const float* corner_pr, int* out_box, float* 
     DENET_CHECK_ARG(Cn == 4 || Cn == 5, "build_samples: Cn must be 4 or 5 (corner types + optional centre), got %d", Cn);
     DENET_CHECK_ARG(H > 0 && W > 0 && H <= 256 && W <= 256 && H * W <= 16384, "build_samples: map %dx%d unsupported", H, W);
     DENET_CHECK_ARG(max_corners > 0 && max_corners <= 1024, "build_samples: max_corners must be in 1..1024");
-    DENET_CHECK_ARG(sample_count > 0 && sample_count <= 4096, "build_samples: sample_count must be in 1..4096");
+    // the final per-image sort holds sample_count + tie slots (<= 8192 candidates, 96 KB) in LDS
+    DENET_CHECK_ARG(sample_count > 0 && sample_count <= 7936, "build_samples: sample_count must be in 1..7936");
     DENET_CHECK_ARG(local_max >= 0, "build_samples: negative local_max");
     const WsLayout l = ws_layout(B, Cn, H, W, max_corners, sample_count);
     DENET_CHECK_ARG(workspace_bytes >= l.total, "build_samples: workspace too small (%zu < %zu)", workspace_bytes, l.total);
@@ -479,7 +486,7 @@ extern "C" int denet_build_samples(const float* corner_pr, int* out_box, float* 
     hipLaunchKernelGGL(pair_pick_kernel<2>, pickg, dim3(256), 0, stream, state, hist, sample_count, B);
     hipLaunchKernelGGL(pair_collect_kernel, pg, dim3(256), 0, stream, c, state, cand, sample_count);
     int NP2 = 1;
-    while (NP2 < sample_count + TIE_CAP) NP2 <<= 1;
+    while (NP2 < sample_count + tie_cap_for(sample_count)) NP2 <<= 1;
     const size_t lds2 = (size_t)NP2 * sizeof(Cand);
     if (lds2 > lds2_set) {
         e = hipFuncSetAttribute((const void*)pair_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
@@ -515,5 +522,113 @@ extern "C" int denet_samples_finish_host(const int* box_host, const float* absd_
             }
         }
     }
+    return DENET_OK;
+}
+
+// apply_cluster of the RoI proposal (denet/layer/denet_sparse.cc:165-242; enabled when the DNS layer's nmsThreshold < 1
+// and an image has more than sample_num^2 candidates, :541-542). Host code like the reference's: the device hands over the
+// 10 * sample_num^2 best candidates in rank order (the clustering input, :171-175) and this routine groups them.
+//   A candidate joins every group that holds a member with IoU > threshold (fp32 IoU, bounding-box reject first); it is
+//   appended to the LAST such group in creation order and the other hit groups are merged into that one. If more than
+//   output_num groups remain, the largest are kept (stable by creation order). Each group contributes its
+//   1 + floor(size * ratio) best members, ratio = (output_num - groups) / (n - groups) in double; the result is ranked and
+//   cut to output_num (:547-549).
+// samples_host: [n][5] = pr, x0, y0, x1, y1 in rank order; out_host: [output_num][5]; out_count: rows written.
+namespace {
+struct CSample { float v[5]; };
+inline float cs_overlap(const float* a, const float* b) {
+    const float dx = fmaxf(0.0f, fminf(a[3], b[3]) - fmaxf(a[1], b[1]));
+    const float dy = fmaxf(0.0f, fminf(a[4], b[4]) - fmaxf(a[2], b[2]));
+    return dx * dy;
+}
+inline float cs_area(const float* a) { return (a[3] - a[1]) * (a[4] - a[2]); }
+struct CGroup {
+    float box[5];
+    std::vector<int> head;                    // members appended one by one
+    std::vector<std::vector<int>> merged;     // member lists of the groups merged into this one, in merge order
+    bool alive = true;
+    size_t size() const {
+        size_t n = head.size();
+        for (const auto& m : merged) n += m.size();
+        return n;
+    }
+};
+}  // namespace
+
+extern "C" int denet_host_cluster_samples(const float* samples_host, int n, float threshold, int output_num, float* out_host,
+                                          int* out_count) {
+    DENET_CHECK_ARG(samples_host && out_host && out_count, "cluster_samples: null pointer");
+    DENET_CHECK_ARG(n > output_num && output_num > 0, "cluster_samples: needs more candidates (%d) than outputs (%d)", n, output_num);
+    std::vector<CGroup> groups;          // creation order; dead entries stay in place
+    auto grow = [](float* box, const float* s) {
+        box[0] = fmaxf(s[0], box[0]);
+        box[1] = fminf(s[1], box[1]);
+        box[2] = fminf(s[2], box[2]);
+        box[3] = fmaxf(s[3], box[3]);
+        box[4] = fmaxf(s[4], box[4]);
+    };
+    std::vector<int> hit;
+    for (int i = 0; i < n; ++i) {
+        const float* s = samples_host + 5 * (size_t)i;
+        const float sa = cs_area(s);
+        hit.clear();
+        for (size_t g = 0; g < groups.size(); ++g) {
+            const CGroup& G = groups[g];
+            if (!G.alive || cs_overlap(s, G.box) == 0) continue;
+            bool found = false;
+            auto test = [&](const std::vector<int>& members) {
+                for (int m : members) {
+                    const float* t = samples_host + 5 * (size_t)m;
+                    const float ai = cs_overlap(s, t);
+                    const float au = sa + cs_area(t) - ai;
+                    if (ai / au > threshold) return true;
+                }
+                return false;
+            };
+            found = test(G.head);
+            for (size_t k = 0; !found && k < G.merged.size(); ++k) found = test(G.merged[k]);
+            if (found) hit.push_back((int)g);
+        }
+        if (hit.empty()) {
+            CGroup G;
+            memcpy(G.box, s, sizeof(G.box));
+            G.head.push_back(i);
+            groups.push_back(std::move(G));
+        } else {
+            CGroup& T = groups[hit.back()];
+            T.head.push_back(i);
+            grow(T.box, s);
+            for (size_t h = 0; h + 1 < hit.size(); ++h) {
+                CGroup& O = groups[hit[h]];
+                grow(T.box, O.box);
+                T.merged.push_back(std::move(O.head));
+                for (auto& m : O.merged) T.merged.push_back(std::move(m));
+                O.merged.clear();
+                O.alive = false;
+            }
+        }
+    }
+    std::vector<int> order;
+    for (size_t g = 0; g < groups.size(); ++g)
+        if (groups[g].alive) order.push_back((int)g);
+    if ((int)order.size() > output_num) {
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return groups[a].size() > groups[b].size(); });
+        order.resize(output_num);
+    }
+    const double ratio = (double)(output_num - (int)order.size()) / (double)(n - (int)order.size());
+    std::vector<int> picked, all;
+    auto better = [&](int a, int b) { return samples_host[5 * (size_t)a] > samples_host[5 * (size_t)b]; };
+    for (int g : order) {
+        const CGroup& G = groups[g];
+        all.assign(G.head.begin(), G.head.end());
+        for (const auto& m : G.merged) all.insert(all.end(), m.begin(), m.end());
+        const size_t take = 1 + (size_t)floor((double)all.size() * ratio);
+        std::stable_sort(all.begin(), all.end(), better);      // ties: member order (the reference's is unspecified)
+        picked.insert(picked.end(), all.begin(), all.begin() + take);
+    }
+    std::stable_sort(picked.begin(), picked.end(), better);
+    const int nout = std::min((int)picked.size(), output_num);
+    for (int i = 0; i < nout; ++i) memcpy(out_host + 5 * (size_t)i, samples_host + 5 * (size_t)picked[i], 5 * sizeof(float));
+    *out_count = nout;
     return DENET_OK;
 }

@@ -112,8 +112,13 @@ class DeNetSparseLayer(AbstractLayer):
 
         self.corner_layer = common.find_layers(layers, "denet-corner", True)
         assert self.corner_layer is not None, "denet-corner layer required before spare layer!"
-        if self.nms_threshold < 1.0:
-            raise NotImplementedError("RoI clustering (nms_threshold < 1, apply_cluster) is outside the hot path")
+        # nms_threshold < 1 turns on apply_cluster (denet_sparse.cc:541-542): the device proposal then returns the
+        # 10 * sn^2 best candidates (the clustering input, :171-175) instead of sn^2 and the grouping runs on the host
+        self.cluster = self.nms_threshold < 1.0
+        self.proposal_count = 10 * self.sample_num * self.sample_num if self.cluster else self.sample_num * self.sample_num
+        if self.cluster and self.proposal_count > 7936:
+            raise NotImplementedError("RoI clustering needs the %d best candidates per image; the device proposal ranks at "
+                                      "most 7936 (sample_num <= 28)" % self.proposal_count)
 
         self.sample_pr = []        # per image float64 [n]
         self.sample_boxes = []     # per image float64 [n,4]
@@ -153,7 +158,7 @@ class DeNetSparseLayer(AbstractLayer):
         import torch
         cl = self.corner_layer
         assert cl.corner_pr is not None, "run the model forward up to the corner layer first"
-        B, S = self.batch_size, self.sample_count
+        B, S = self.batch_size, self.proposal_count
         words = B * S * 5 + B
         if getattr(self, "_res_dev", None) is None:
             self._res_dev = torch.empty(words, dtype=torch.int32, device="cuda")
@@ -177,11 +182,14 @@ class DeNetSparseLayer(AbstractLayer):
         hbox = h[:B * S * 4].view(B, S, 4)
         habsd = h[B * S * 4:B * S * 5].view(torch.float32).view(B, S)
         raw = ops.samples_finish_host(hbox, habsd, hcount, cl.height, cl.width).numpy()
-        self._raw_samples = (raw, hcount.numpy())
+        hcount = hcount.numpy()
+        if self.cluster:
+            raw, hcount = ops.cluster_samples_host(raw, hcount, self.nms_threshold, self.sample_count)
+        self._raw_samples = (raw, hcount)
         if raw_only:
             return None, None
         samples = raw.astype(numpy.float64)
-        counts = hcount.tolist()
+        counts = [int(c) for c in hcount]
         prs = [samples[b, :counts[b], 0] for b in range(B)]
         boxes = [samples[b, :counts[b], 1:5] for b in range(B)]
         return prs, boxes

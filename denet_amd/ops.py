@@ -719,6 +719,28 @@ def samples_finish_host(box, absd, count, H, W):
     return out
 
 
+def cluster_samples_host(raw, counts, threshold, output_num):
+    """apply_cluster per image (denet_sparse.cc:541-542): raw [B, K, 5] ranked candidates, counts [B]; images with more than
+    output_num candidates are clustered. Returns (numpy [B, output_num, 5], numpy counts [B])"""
+    import ctypes
+    import numpy
+    raw = numpy.ascontiguousarray(raw, dtype=numpy.float32)
+    B = raw.shape[0]
+    out = numpy.zeros((B, output_num, 5), dtype=numpy.float32)
+    out_counts = numpy.zeros(B, dtype=numpy.int32)
+    n_out = ctypes.c_int(0)
+    for b in range(B):
+        n = int(counts[b])
+        if n > output_num:
+            check(_L().denet_host_cluster_samples(raw[b].ctypes.data, n, float(threshold), int(output_num), out[b].ctypes.data,
+                                                  ctypes.byref(n_out)), "cluster_samples")
+            out_counts[b] = n_out.value
+        else:
+            out[b, :n] = raw[b, :n]
+            out_counts[b] = n
+    return out, out_counts
+
+
 def detect_decode(logits, roi_bbox, class_num, jointfit, nreg, overlap_threshold, nfit=0):
     M, CP = logits.shape
     det_pr, fitness, bbox = empty(M, class_num + 1), empty(M, class_num + 1), empty(M, 4)

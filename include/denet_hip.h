@@ -268,11 +268,15 @@ int denet_soft_nms_host(const float* score_host, const float* box_host, int n, f
  *        out_count:[B].
  *      denet_samples_finish_host converts HOST copies of these into the reference's tuples
  *      (pr, x0/W, y0/H, (x1+1)/W, (y1+1)/H) with the reference's own host arithmetic (denet_sparse.cc:306-307);
- *      samples_host:[B,sample_count,5].  cluster_threshold < 1 (apply_cluster) is not provided.            */
+ *      samples_host:[B,sample_count,5].  cluster_threshold < 1: ask for sample_count = 10 * sample_num^2 (<= 7936) and
+ *      pass each image with more than sample_num^2 candidates through denet_host_cluster_samples (apply_cluster,
+ *      denet_sparse.cc:165-242, host code in the reference as well): out_host [output_num][5], out_count rows.   */
 size_t denet_build_samples_workspace_bytes(int B, int Cn, int H, int W, int max_corners, int sample_count);
 int denet_build_samples(const float* corner_pr, int* out_box, float* out_absd, int* out_count, void* workspace,
                         size_t workspace_bytes, int B, int Cn, int H, int W, float corner_threshold, int sample_count,
                         int max_corners, int local_max, hipStream_t stream);
+int denet_host_cluster_samples(const float* samples_host, int n, float threshold, int output_num, float* out_host,
+                               int* out_count);
 int denet_samples_finish_host(const int* box_host, const float* absd_host, const int* count_host, int B,
                               int sample_count, int H, int W, float* samples_host);
 

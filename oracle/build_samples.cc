@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <list>
 #include <unordered_map>
 #include <vector>
 
@@ -122,6 +123,88 @@ std::vector<Sample> search(const float* pr, int Cn, int H, int W, int b, const s
     return out;
 }
 
+// ---- apply_cluster, denet_sparse.cc:165-242 (with SampleType::overlap / overlap_iou :86-102 in fp32 and ClusterType
+// :105-163). Samples are visited in ranked order; a sample joins every cluster that holds a member with IoU > threshold
+// (cheap reject on the cluster's bounding box first): it is appended to the LAST such cluster in list order and the other
+// overlapping clusters are merged into that one. If more than output_num clusters remain the largest are kept (stable
+// list sort by member count). Every cluster then contributes its 1 + floor(size * ratio) best members,
+// ratio = (output_num - #clusters) / (#samples - #clusters) in double.
+float s_overlap(const Sample& a, const Sample& b) {
+    float dx = std::max(0.0f, std::min(a.x1, b.x1) - std::max(a.x0, b.x0));
+    float dy = std::max(0.0f, std::min(a.y1, b.y1) - std::max(a.y0, b.y0));
+    return dx * dy;
+}
+float s_area(const Sample& a) { return (a.x1 - a.x0) * (a.y1 - a.y0); }
+float s_iou(const Sample& a, const Sample& b) {
+    float ai = s_overlap(a, b);
+    float au = s_area(a) + s_area(b) - ai;
+    return ai / au;
+}
+struct Cluster {
+    Sample bbox;
+    std::vector<std::vector<Sample>> sv;      // sv[0] grows by add_sample; merged clusters append their vectors
+    size_t count() const {
+        size_t n = 0;
+        for (const auto& v : sv) n += v.size();
+        return n;
+    }
+    void bounds(const Sample& s) {
+        bbox.pr = std::max(s.pr, bbox.pr);
+        bbox.x0 = std::min(s.x0, bbox.x0);
+        bbox.y0 = std::min(s.y0, bbox.y0);
+        bbox.x1 = std::max(s.x1, bbox.x1);
+        bbox.y1 = std::max(s.y1, bbox.y1);
+    }
+    bool overlaps(const Sample& s, float thr) const {
+        if (s_overlap(s, bbox) == 0) return false;
+        for (const auto& v : sv)
+            for (const Sample& m : v)
+                if (s_iou(s, m) > thr) return true;
+        return false;
+    }
+};
+void apply_cluster(std::vector<Sample>& samples, float threshold, size_t input_num, size_t output_num) {
+    if (samples.size() > input_num) {
+        std::partial_sort(samples.begin(), samples.begin() + input_num, samples.end());
+        samples.resize(input_num);
+    }
+    std::list<Cluster> clusters;
+    for (const Sample& s : samples) {
+        std::vector<std::list<Cluster>::iterator> hit;
+        for (auto it = clusters.begin(); it != clusters.end(); ++it)
+            if (it->overlaps(s, threshold)) hit.push_back(it);
+        if (!hit.empty()) {
+            auto tgt = hit.back();
+            hit.pop_back();
+            tgt->sv[0].push_back(s);
+            tgt->bounds(s);
+            for (auto it : hit) {
+                tgt->bounds(it->bbox);
+                for (auto& v : it->sv) tgt->sv.push_back(std::move(v));
+                clusters.erase(it);
+            }
+        } else {
+            Cluster c;
+            c.bbox = s;
+            c.sv.push_back(std::vector<Sample>(1, s));
+            clusters.push_back(std::move(c));
+        }
+    }
+    if (clusters.size() > output_num) {
+        clusters.sort([](const Cluster& a, const Cluster& b) { return a.count() > b.count(); });
+        clusters.resize(output_num);
+    }
+    const double ratio = (double)(output_num - clusters.size()) / (double)(samples.size() - clusters.size());
+    samples.resize(0);
+    for (const Cluster& c : clusters) {
+        std::vector<Sample> all;
+        for (const auto& v : c.sv) all.insert(all.end(), v.begin(), v.end());
+        const size_t n = 1 + (size_t)std::floor(all.size() * ratio);
+        std::partial_sort(all.begin(), all.begin() + n, all.end());
+        samples.insert(samples.end(), all.begin(), all.begin() + n);
+    }
+}
+
 }  // namespace
 
 // corner_pr: [B,2,Cn,H,W] fp32 C-contiguous.  Outputs (caller allocated):
@@ -131,7 +214,6 @@ extern "C" int oracle_build_samples(const float* corner_pr, int B, int Cn, int H
                                     int sample_num, int max_corners, int local_max_r, float cluster_threshold,
                                     float* out_samples, int* out_box, float* out_absd, int* out_count) {
     const size_t sample_count = (size_t)sample_num * sample_num;
-    if (cluster_threshold < 1.0f) return -1;   // apply_cluster is not restated (no shipped recipe enables it)
     const float thr = std::log(corner_threshold);   // float overload, denet_sparse.cc:503
     for (int b = 0; b < B; ++b) {
         std::vector<std::vector<Corner>> cl(Cn);
@@ -151,6 +233,8 @@ extern "C" int oracle_build_samples(const float* corner_pr, int B, int Cn, int H
             }
         }
         std::vector<Sample> s = search(corner_pr, Cn, H, W, b, cl);
+        if (s.size() > sample_count && cluster_threshold < 1.0f)          // denet_sparse.cc:541-542
+            apply_cluster(s, cluster_threshold, 10 * sample_count, sample_count);
         std::partial_sort(s.begin(), s.begin() + std::min(s.size(), sample_count), s.end());
         if (s.size() > sample_count) s.resize(sample_count);
         out_count[b] = (int)s.size();

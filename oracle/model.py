@@ -505,7 +505,7 @@ def oracle_lib():
     return _lib
 
 
-def oracle_build_samples_raw(corner_pr, corner_threshold, sample_num, max_corners=1024, local_max=0):
+def oracle_build_samples_raw(corner_pr, corner_threshold, sample_num, max_corners=1024, local_max=0, cluster_threshold=1.0):
     pr = np.ascontiguousarray(corner_pr, dtype=F32)
     B, _, Cn, H, W = pr.shape
     S = sample_num * sample_num
@@ -517,16 +517,17 @@ def oracle_build_samples_raw(corner_pr, corner_threshold, sample_num, max_corner
     f.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                            ctypes.c_float] + [ctypes.c_void_p] * 4
     f.restype = ctypes.c_int
-    rc = f(pr.ctypes.data, B, Cn, H, W, float(corner_threshold), sample_num, max_corners, local_max, 1.0,
+    rc = f(pr.ctypes.data, B, Cn, H, W, float(corner_threshold), sample_num, max_corners, local_max, float(cluster_threshold),
            out.ctypes.data, box.ctypes.data, absd.ctypes.data, cnt.ctypes.data)
     if rc != 0:
         raise RuntimeError("oracle_build_samples failed")
     return out, box, absd, cnt
 
 
-def oracle_build_samples(corner_pr, corner_threshold, sample_num, max_corners=1024, local_max=0):
+def oracle_build_samples(corner_pr, corner_threshold, sample_num, max_corners=1024, local_max=0, cluster_threshold=1.0):
     """list[B] of list[(pr, (x0,y0,x1,y1))] like c_code.build_samples (denet/layer/denet_sparse.cc:587-592)"""
-    out, _, _, cnt = oracle_build_samples_raw(corner_pr, corner_threshold, sample_num, max_corners, local_max)
+    out, _, _, cnt = oracle_build_samples_raw(corner_pr, corner_threshold, sample_num, max_corners, local_max,
+                                              cluster_threshold)
     res = []
     for b in range(out.shape[0]):
         rows = out[b, :cnt[b]].tolist()

@@ -354,3 +354,45 @@ def test_data_parallel_gloo_world2(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=180)
         assert p.returncode == 0, out.decode()
+
+
+def _distinct_corner_map(seed, B, H, W, per_type, Cn=4):
+    """corner maps whose candidate scores are all distinct (no saturated log-probabilities): `per_type` firing cells
+    per corner type with P in (0.02, 0.6), background P in (1e-4, 2e-4)"""
+    rng = np.random.RandomState(seed)
+    P = rng.uniform(1e-4, 2e-4, (B, Cn, H, W))
+    for b in range(B):
+        for c in range(Cn):
+            idx = rng.choice(H * W, per_type, replace=False)
+            P[b, c].reshape(-1)[idx] = rng.uniform(0.02, 0.6, per_type)
+    return np.ascontiguousarray(np.stack([np.log(1 - P), np.log(P)], axis=1).astype(np.float32))
+
+
+@pytest.mark.parametrize("thr", [0.3, 0.5, 0.7])
+def test_native_roi_clustering_vs_oracle(thr):
+    """apply_cluster (denet_sparse.cc:165-242): the native host routine of the product on the oracle's ranked candidate
+    list against the oracle's own clustered proposal (sn = 6: 36 outputs from the 360 best of ~3000 candidates)"""
+    import ctypes
+    from oracle import model as OM
+    L = dlib.load()
+    sn, S = 6, 36
+    pr = _distinct_corner_map(3, 3, 32, 32, 70)
+    # the ranked candidate list = the unclustered proposal with a large sample_num (19^2 = 361 >= 10 * 36)
+    full, _, _, cnt = OM.oracle_build_samples_raw(pr, 0.01, 19, 1024, 0, 1.0)
+    ref, _, _, rcnt = OM.oracle_build_samples_raw(pr, 0.01, sn, 1024, 0, thr)
+    plain, _, _, _ = OM.oracle_build_samples_raw(pr, 0.01, sn, 1024, 0, 1.0)
+    changed = 0
+    for b in range(pr.shape[0]):
+        assert cnt[b] == 361
+        cand = np.ascontiguousarray(full[b, :10 * S])
+        assert len(np.unique(cand[:, 0])) == len(cand), "the test map must not produce score ties"
+        out = np.zeros((S, 5), np.float32)
+        n_out = ctypes.c_int(0)
+        rc = L.denet_host_cluster_samples(cand.ctypes.data_as(ctypes.c_void_p), 10 * S, thr, S,
+                                          out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n_out))
+        assert rc == 0 and n_out.value == rcnt[b]
+        assert np.array_equal(out[:n_out.value], ref[b, :rcnt[b]]), b
+        changed += int(not np.array_equal(ref[b, :rcnt[b]], plain[b, :rcnt[b]]))
+    assert changed > 0, "clustering never changed the selection: the test exercises nothing"
+    assert L.denet_host_cluster_samples(cand.ctypes.data_as(ctypes.c_void_p), 10, thr, S, out.ctypes.data_as(ctypes.c_void_p),
+                                        ctypes.byref(n_out)) == -1000

@@ -638,6 +638,58 @@ def test_denet_center_corner_variant_vs_oracle(hip):
     assert abs(cost - ocost) <= 1e-4 * abs(ocost), (cost, ocost)
 
 
+def test_roi_clustering_device_path_vs_oracle(hip):
+    """DNS nmsThreshold < 1 (apply_cluster, denet_sparse.cc:165-242, 541-542): (1) the device proposal asked for the
+    10 * sn^2 best candidates + the native host clustering against the C++ oracle on maps without score ties - exact;
+    (2) a DeNet-34 skip training step with `DNS[7,24,0.01,0.1,0,0.5]`: the layer's RoI lists equal the oracle's
+    clustered proposal on the product's own corner map, and the step stays in op-by-op parity"""
+    from tests.test_host import _distinct_corner_map
+    sn, S = 6, 36
+    pr = _distinct_corner_map(11, 4, 64, 64, 90)
+    d = torch.from_numpy(pr).cuda()
+    box, absd, cnt = ops.build_samples(d, 0.01, 10 * S, 1024, 0)
+    raw = ops.samples_finish_host(box.cpu(), absd.cpu(), cnt.cpu(), 64, 64).numpy()
+    assert int(cnt.min()) == 10 * S
+    for thr in (0.3, 0.6):
+        got, gcnt = ops.cluster_samples_host(raw, cnt.cpu().numpy(), thr, S)
+        ref, _, _, rcnt = OM.oracle_build_samples_raw(pr, 0.01, sn, 1024, 0, thr)
+        assert np.array_equal(gcnt, rcnt)
+        for b in range(pr.shape[0]):
+            assert np.array_equal(got[b, :gcnt[b]], ref[b, :rcnt[b]]), (thr, b)
+
+    B, IMG = 2, 128
+    desc = zoo.DENET34_SKIP_DESC.replace("DNS[7,24,0.01,0.1]", "DNS[7,24,0.01,0.1,0,0.5]")
+    model = zoo.denet34(B, "skip", IMG, class_num=80, seed=1, head_desc=desc)
+    dnc = [l for l in model.layers if l.type_name == "denet-corner"][0]
+    dns = [l for l in model.layers if l.type_name == "denet-sparse"][0]
+    assert dns.cluster and dns.proposal_count == 5760 and dns.export_json()["nmsThreshold"] == 0.5
+    rng = np.random.RandomState(5)
+    dconv = model.layers[-1].layers[0]
+    dconv.omega.set_value(rng.normal(0, 0.05, dconv.omega.value.shape))
+    _warm_corner_head(model, 2.5, 0.5)            # a busy detector: more than 576 candidates per image
+    x, metas = zoo.synthetic_batch(B, IMG, seed=3)
+    om = OM.OracleModel(model.export_json(), B)
+    model.build_train_func("nesterov")
+    random.seed(9)
+    cost, _ = model.train_step(x, metas, 0, 0, 0.05, [0.9], 1e-4)
+    roi_lists = dns.sample_bbox_list
+    cmap = dnc.corner_pr.cpu().numpy()
+    plain = OM.oracle_build_samples(cmap, dns.corner_threshold, dns.sample_num, 1024, 0)
+    lists = OM.oracle_build_samples(cmap, dns.corner_threshold, dns.sample_num, 1024, 0, 0.5)
+    assert all(len(l) == dns.sample_count for l in plain), "the detector must produce more candidates than RoIs"
+    assert lists != plain, "clustering changed nothing"
+    random.seed(9)
+    ref_lists = OL.edit_samples(lists, metas, dns.sample_count, dns.random_sample, dns.sample_gt)
+    assert [[p for p, _ in l] for l in ref_lists] == [[p for p, _ in l] for l in roi_lists]
+    for g, r in zip(roi_lists, ref_lists):          # boxes: equal wherever the score is unique
+        scores = [p for p, _ in r]
+        for (p, gb), (_, rb) in zip(g, r):
+            if scores.count(p) == 1:
+                assert gb == rb
+    ocost, _ = _forced_step_check(model, om, x, metas, 0, 0.05, 0.9, 1e-4, "nesterov", roi_lists)
+    assert abs(cost - ocost) <= 1e-4 * abs(ocost), (cost, ocost)
+
+
 def test_denet101_wide_train_step_vs_oracle(hip):
     """BASELINE config 5 at reduced size: ResNet-101 bottleneck backbone, three skip scales (one through a plain
     SKIPSRC), SPLIT points, 48x48 = 2304 RoIs per image, joint-fitness + bounded-IoU head (papers/dss/denet101.sh)"""
