@@ -62,20 +62,35 @@ def test_multicrop(mode, model, data, log=print):
     return error1, error5
 
 
-def test_detector(mode, model, data, output_fname, params, log=print):
+def test_detector(mode, model, data, output_fname, params, log=print, device_render=False, thread_num=1):
     detect_params = common.get_params_dict(params)
     detect_layer = model.layers[-1]
     class_labels_inv = {v: k for k, v in model.class_labels.items()} if model.class_labels else {}
     detections = []
+    loader = None
+    if device_render and hasattr(data, "images") and hasattr(data, "image_loader"):
+        # scale + centre crop rendered on the GPU straight into the batch (denet_amd/dataset/device_render.py)
+        from ..dataset.device_render import DeviceImageLoader
+        loader = DeviceImageLoader(max(1, thread_num), False, cp=model.input.cp if model.input is not None else 4,
+                                   decode="process", params=data.image_loader)
     for subset in range(data.subset_num):
-        data.load_from_subset(subset)
-        data_x, data_m, data_size = data.export(model.batch_size)
         subset_det = []
-        for n in range(data_x.shape[0] // model.batch_size):
-            dx = data_x[n * model.batch_size:(n + 1) * model.batch_size]
-            dm = data_m[n * model.batch_size:(n + 1) * model.batch_size]
-            subset_det += detect_layer.get_detections(model, dx, dm, detect_params)
+        if loader is not None:
+            lo = subset * data.subset_size
+            hi = min((subset + 1) * data.subset_size, data.subset_total_size)
+            data_size = hi - lo
+            for dx, dm in loader.iterate(data.images[lo:hi], model.batch_size):
+                subset_det += detect_layer.get_detections(model, dx, dm, detect_params)
+        else:
+            data.load_from_subset(subset)
+            data_x, data_m, data_size = data.export(model.batch_size)
+            for n in range(data_x.shape[0] // model.batch_size):
+                dx = data_x[n * model.batch_size:(n + 1) * model.batch_size]
+                dm = data_m[n * model.batch_size:(n + 1) * model.batch_size]
+                subset_det += detect_layer.get_detections(model, dx, dm, detect_params)
         detections += subset_det[:data_size]          # drop the padding of the last batch
+    if loader is not None:
+        loader.close()
     log("Found %i detections for %i samples" % (sum(len(d["detections"]) for d in detections), len(detections)))
 
     out_dir = os.path.dirname(output_fname)
@@ -114,6 +129,8 @@ def build_parser():
     parser.add_argument("--predict-mode", default="single", help="single, multicrop, detect[,voc|,mscoco|,imagenet]")
     parser.add_argument("--thread-num", default=1, type=int, help="Number of threads for dataset loading")
     parser.add_argument("--params", default="", type=str, help="Additional detection params")
+    parser.add_argument("--device-render", default=False, action="store_true",
+                        help="detect mode: scale / crop the images on the GPU instead of in the loader processes")
     return parser
 
 
@@ -127,7 +144,8 @@ def main(argv=None):
         assert "multicrop" in args.extension
         test_multicrop(args.predict_mode, model, data)
     elif "detect" in args.predict_mode:
-        test_detector(args.predict_mode, model, data, args.results, args.params)
+        test_detector(args.predict_mode, model, data, args.results, args.params, device_render=args.device_render,
+                      thread_num=args.thread_num)
     else:
         raise NotImplementedError("predict mode '%s' (segmentation is outside the detection hot path)" % args.predict_mode)
     return 0

@@ -89,6 +89,11 @@ def test_dataset_to_detections(hip, tree, tmp_path, fmt):
     results = str(tmp_path / "out" / "res")
     r = predict.test_detector("detect," + fmt, loaded, test, results,
                               "prThreshold=0.02,nmsThreshold=0.5,cornerThreshold=0.02", log=lambda *a: None)
+    # the same evaluation with the test views (scale + centre crop) rendered on the GPU: identical detections
+    r_dev = predict.test_detector("detect," + fmt, loaded, test, str(tmp_path / "out_dev" / "res"),
+                                  "prThreshold=0.02,nmsThreshold=0.5,cornerThreshold=0.02", log=lambda *a: None,
+                                  device_render=True, thread_num=2)
+    assert [d["detections"] for d in r_dev["detections"]] == [d["detections"] for d in r["detections"]]
     n_images = test.subset_total_size
     assert len(r["detections"]) == n_images
     raw = json.load(open(os.path.join(os.path.dirname(results), "detections.json")))
