@@ -11,7 +11,6 @@ import ctypes
 import numpy
 from PIL import Image
 
-from .. import lib
 from . import plan as planmod
 
 FILTER_ID = {int(Image.LANCZOS): 1, int(Image.BILINEAR): 2, int(Image.BICUBIC): 3}

@@ -18,7 +18,6 @@ import random
 import numpy
 from PIL import Image
 
-from .. import common
 from . import augment
 from .image_loader import _sample_meta
 

@@ -1,9 +1,6 @@
 """`BNA` layer — batch normalisation fused with ReLU. Mirrors denet/layer/batch_norm_relu.py
 (BatchNormReluOp :15-57: cuDNN BN followed by an in-place (x+|x|)/2; grad masks dy by xn > 0 then cuDNN BN-grad;
 BatchNormReluLayer :85-167). One normalise+ReLU kernel forward, one masked BN-gradient backward."""
-import numpy
-
-from . import Act, Param
 from .batch_norm import BatchNormLayer
 
 

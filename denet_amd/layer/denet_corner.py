@@ -2,8 +2,6 @@
 producing `corner_num` corner logits + `sample_feat` sampling features (:39), corner rows zero-initialised with
 bias +5 (:41-47), corner_pr = log_softmax([x,-x]) over a new axis (:50-53), host-side corner target rasteriser
 (get_target :81-123) and the corner NLL cost (:126-134). The layer passes its input through."""
-import math
-
 import numpy
 
 from . import AbstractLayer, InitialLayer

@@ -3,8 +3,6 @@ convolution -> class (+joint fitness) logits, box regressors (:60-107); IoU base
 (get_target :147-235); detection / box costs (get_errors :238-301, cost :304-313). Pass-through layer.
 The shipped recipes write `DND[0.5,1,1]`, i.e. a scalar overlap threshold that get_target then indexes as a
 pair (:172,:198) — a latent bug of the reference; scalar or [t_class, t_bbox] are both accepted here."""
-import math
-
 import numpy
 
 from . import AbstractLayer, InitialLayer

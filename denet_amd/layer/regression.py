@@ -4,7 +4,7 @@ import math
 
 import numpy
 
-from . import AbstractLayer, Act, get_train
+from . import AbstractLayer, Act
 from .convolution import ConvLayer
 from .. import ops
 

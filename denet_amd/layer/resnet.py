@@ -7,7 +7,6 @@ from .activation import ActivationLayer
 from .batch_norm import BatchNormLayer
 from .batch_norm_relu import BatchNormReluLayer
 from .convolution import ConvLayer
-from .. import ops
 
 
 class ResnetLayer(AbstractLayer):

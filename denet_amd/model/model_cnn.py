@@ -13,7 +13,6 @@ reached through the C-ABI (denet_amd/ops.py); torch provides device memory, stre
 import getpass
 import math
 import random
-import time
 
 import numpy
 

@@ -4,7 +4,6 @@
 `DeNetDetectLayer.get_detections` batch by batch (GPU forward + decode + NMS) and hands the per-image records to the
 dataset's writer: Pascal VOC result files + 11-point AP, MSCOCO results JSON, or the ImageNet localisation error."""
 import argparse
-import math
 import os
 import sys
 
