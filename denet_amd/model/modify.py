@@ -117,3 +117,108 @@ def layer_append(model, descs, activation="relu", border_mode="half", weight_ini
         model.build_layer(desc, model.layers, activation, border_mode, weight_init)
     model._packed = False
     return _reload(model)
+
+
+def merge_splits(model):
+    """--merge (modify.py:53-60): split points become plain pass-throughs (they already execute as such here)"""
+    j = model.export_json()
+    for l in j["layers"]:
+        if l["type"] == "split":
+            l["enabled"] = False
+        elif l["type"] == "skip-src":
+            l["split"] = False
+    return _reload(model, j)
+
+
+def set_activation(model, activation):
+    """modify.py:48-51: every activation / residual layer takes the activation named on the command line"""
+    j = model.export_json()
+    changed = False
+    for l in j["layers"]:
+        if l["type"] in ("activation", "resnet") and l.get("activation") != activation:
+            l["activation"] = activation
+            changed = True
+    return _reload(model, j) if changed else model
+
+
+def modify_layer(model, layer_name, assignments):
+    """--modify-layer TYPE key=value ...: set attributes of the FIRST layer of that type (modify.py:130-146); the value
+    takes the type of the attribute it replaces. The edit goes through the layer's JSON keys and a reload."""
+    for index, layer in enumerate(model.layers):
+        if layer.type_name != layer_name:
+            continue
+        before = layer.export_json()
+        for a in assignments:
+            name, text = a.split("=")
+            old = getattr(layer, name)
+            value = {"True": True, "False": False, "0": False, "1": True}[text] if type(old) is bool else type(old)(text)
+            setattr(layer, name, value)
+        after = layer.export_json()
+        if after == before:
+            raise Exception("--modify-layer: none of %s is part of the exported state of '%s'" % (assignments, layer_name))
+        j = model.export_json()
+        j["layers"][index - 1] = after
+        return _reload(model, j)
+    raise Exception("--modify-layer: no layer of type '%s'" % layer_name)
+
+
+def build_parser():
+    import argparse
+    parser = argparse.ArgumentParser(description="Modify a model file (same flags as the reference's model-modify)")
+    parser.add_argument("--seed", type=int, default=23455, help="Random Seed for weights")
+    parser.add_argument("--input", type=str, required=True)
+    parser.add_argument("--output", type=str, required=True)
+    parser.add_argument("--class-num", type=int, default=None)
+    parser.add_argument("--image-size", nargs="+", type=int, default=None)
+    parser.add_argument("--use-cudnn-pool", default=False, action="store_true",
+                        help="accepted for the recipes' sake: every pooling layer of this build already pools the cuDNN way")
+    parser.add_argument("--convert-bn-relu", default=False, action="store_true")
+    parser.add_argument("--merge", default=False, action="store_true", help="merge split layers")
+    parser.add_argument("--modify-bn", default=None, nargs="+", type=str, help="enabled momentum eps for batch norm")
+    parser.add_argument("--modify-layer", default=None, nargs="+", type=str, help="TYPE key=value ...")
+    parser.add_argument("--layer-insert", default=[], nargs="+", help="insert layer at position N:DESC")
+    parser.add_argument("--layer-remove", default=0, type=int, help="remove N layer from end")
+    parser.add_argument("--layer-append", default=[], nargs="+", type=str, help="append layers to end")
+    parser.add_argument("--border-mode", default="half")
+    parser.add_argument("--activation", default="relu")
+    parser.add_argument("--weight-init", nargs="+", default=["he-backward"])
+    return parser
+
+
+def main(argv=None):
+    """the edits of the reference's model-modify (modify.py:37-193)"""
+    import random
+    import numpy
+    args = build_parser().parse_args(argv)
+    random.seed(args.seed)
+    numpy.random.seed(args.seed)
+    model = model_cnn.load_from_file(args.input)
+    # the reference edits the loaded object and reloads ONCE (modify.py:153-159); here every edit reloads, so the ones
+    # that drop layers run before the ones that change the input geometry
+    if args.modify_bn is not None:
+        model = modify_bn(model, bool(args.modify_bn[0]), float(args.modify_bn[1]), float(args.modify_bn[2]))
+    if args.convert_bn_relu:
+        model = convert_bn_relu(model)
+    model = layer_remove(model, args.layer_remove)
+    if args.class_num is not None:
+        model = set_class_num(model, args.class_num)
+    if args.image_size is not None:
+        model = set_image_size(model, args.image_size[0], args.image_size[1])
+    model = set_activation(model, args.activation)
+    if args.merge:
+        model = merge_splits(model)
+    if args.modify_layer is not None:
+        model = modify_layer(model, args.modify_layer[0], args.modify_layer[1:])
+    if len(args.layer_insert) > 0:
+        model = layer_insert(model, args.layer_insert, args.activation, args.border_mode, args.weight_init)
+    if len(args.layer_append) > 0:
+        model = layer_append(model, args.layer_append, args.activation, args.border_mode, args.weight_init)
+    model_cnn.save_to_file(model, args.output)
+    for layer in model.layers:
+        print(layer)
+    return 0
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(main())

@@ -396,3 +396,44 @@ def test_native_roi_clustering_vs_oracle(thr):
     assert changed > 0, "clustering never changed the selection: the test exercises nothing"
     assert L.denet_host_cluster_samples(cand.ctypes.data_as(ctypes.c_void_p), 10, thr, S, out.ctypes.data_as(ctypes.c_void_p),
                                         ctypes.byref(n_out)) == -1000
+
+
+def test_model_modify_cli_replays_the_denet_recipe(tmp_path):
+    """the two model-modify commands of papers/dss/denet34.sh:87-88 (skip variant) through the CLI, on a small
+    ResNet-style classifier: same layer list, shapes and weights as the programmatic surgery"""
+    np.random.seed(4)
+    m = model_cnn.ModelCNN()
+    m.batch_size = 2
+    m.class_num = 10
+    m.build("C.B[32,7,2] BN A P[3,2,1] nRSN.O[2,32,3] nRSN.O[2,64,3,2] nRSN.O[2,128,3,2] P.A[2] R.TB", (3, 64, 64), "relu",
+            "half", ["he-backward"])
+    src, mid, dst = str(tmp_path / "cls.mdl.gz"), str(tmp_path / "skipsrc.mdl.gz"), str(tmp_path / "initial.mdl.gz")
+    model_cnn.save_to_file(m, src)
+    head = "PI[2] C[64,3] SKIP[1] BNA PI[2] C[32,3] SKIP[0] BNA DNC[16,100] DNS[3,4,0.01,0.1] C.B[64,1] BNA DND[0.5,1,1]"
+    assert modify.main(["--input", src, "--output", mid, "--modify-bn", "1", "0.9", "1e-5", "--convert-bn-relu",
+                        "--use-cudnn-pool", "--class-num", "20", "--image-size", "128", "128", "--layer-remove", "3",
+                        "--layer-insert", "6:SKIPSRC.X[0]", "7:SKIPSRC.X[1]"]) == 0
+    assert modify.main(["--input", mid, "--output", dst, "--layer-append"] + head.split()) == 0
+    got = model_cnn.load_from_file(dst, 2)
+    ref = modify.modify_bn(m, 1, 0.9, 1e-5)
+    ref = modify.convert_bn_relu(ref)
+    ref = modify.layer_remove(ref, 3)
+    ref = modify.set_class_num(ref, 20)
+    ref = modify.set_image_size(ref, 128, 128)
+    ref = modify.layer_insert(ref, ["6:SKIPSRC.X[0]", "7:SKIPSRC.X[1]"])
+    np.random.seed(23455)          # the CLI seeds numpy with --seed before it builds the new layers
+    random.seed(23455)
+    ref = modify.layer_append(ref, head)
+    assert [l.type_name for l in got.layers] == [l.type_name for l in ref.layers]
+    assert [l.output_shape for l in got.layers] == [l.output_shape for l in ref.layers]
+    assert got.class_num == 20 and tuple(got.data_shape) == (3, 128, 128)
+    assert got.layers[-1].type_name == "denet-detect" and got.layers[6].type_name == "skip-src" and got.layers[6].has_split
+    for a, b in zip(got.layers[:6], ref.layers[:6]):
+        for pa, pb in zip(a.params(), b.params()):
+            np.testing.assert_array_equal(pa.value, pb.value)
+    # --merge and --modify-layer
+    out2 = str(tmp_path / "merged.mdl.gz")
+    assert modify.main(["--input", dst, "--output", out2, "--merge", "--modify-layer", "denet-sparse", "corner_threshold=0.05"]) == 0
+    mm = model_cnn.load_from_file(out2, 2)
+    assert not any(getattr(l, "has_split", False) for l in mm.layers if l.type_name == "skip-src")
+    assert [l for l in mm.layers if l.type_name == "denet-sparse"][0].corner_threshold == 0.05
