@@ -437,3 +437,24 @@ def test_model_modify_cli_replays_the_denet_recipe(tmp_path):
     mm = model_cnn.load_from_file(out2, 2)
     assert not any(getattr(l, "has_split", False) for l in mm.layers if l.type_name == "skip-src")
     assert [l for l in mm.layers if l.type_name == "denet-sparse"][0].corner_threshold == 0.05
+
+
+def test_train_multi_sharding():
+    """model-train-multi: a global batch is world x batch consecutive samples; rank r takes the r-th slice; only whole
+    global batches are used so that every rank runs the same number of steps (the all-reduce would hang otherwise)"""
+    from denet_amd.model.train_multi import _Shard
+
+    class Data:
+        subset_size, subset_total_size = 23, 41
+        images = list(range(41))
+    world, B = 3, 4
+    shards = [_Shard(Data, r, world, B) for r in range(world)]
+    for subset, (lo, hi) in enumerate([(0, 23), (23, 41)]):
+        parts = [s.images_of_subset(subset) for s in shards]
+        n_glob = (hi - lo) // (world * B)
+        assert all(len(p) == n_glob * B for p in parts)
+        flat = sorted(sum(parts, []))
+        assert flat == list(range(lo, lo + n_glob * world * B))          # disjoint, in order, nothing skipped
+        for k in range(n_glob):
+            for r in range(world):
+                assert parts[r][k * B:(k + 1) * B] == list(range(lo + k * world * B + r * B, lo + k * world * B + (r + 1) * B))

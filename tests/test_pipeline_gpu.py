@@ -159,3 +159,24 @@ def test_model_train_cli_device_render_equals_host_loader(hip, tree, tmp_path):
     assert np.isfinite(outs[0][0]).all()
     assert outs[0][0] == outs[1][0]
     assert bool((outs[0][1] == outs[1][1]).all())
+
+
+def test_model_train_multi_launcher_single_rank(hip, tree, tmp_path):
+    """bin/model-train-multi under torch.distributed.run with one rank (the box has one GPU) and the collectives forced
+    on: RCCL init, broadcast, bucketed all-reduce behind the wgrad stream, sharding, device-rendered data, checkpoint"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prefix = str(tmp_path / "mm")
+    desc = ("C.B[32,3,2] BN A nRSN.O[1,32,3] SKIPSRC[0] nRSN.O[1,64,3,2] PI[2] C[32,3] SKIP[0] BNA DNC[16,100] "
+            "DNS[3,4,0.01,0.1] C.B[64,1] BNA DND[0.5,1,1]").split()
+    env = dict(os.environ, GPUS="1", DENET_FORCE_DP="1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [os.path.join(root, "bin", "model-train-multi"), "--train", os.path.join(tree, "voc"), "--extension",
+           "voc,2007-trainval,2012-trainval,crop=64,crop_mode=denet,check_center", "--thread-num", "2", "--batch-size", "2",
+           "--epochs", "2", "--seed", "7", "--learn-rate", "0.01", "--learn-momentum", "0.9", "--border-mode", "half",
+           "--output-prefix", prefix, "--disable-intermediate", "--device-render", "--model-desc"] + desc
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "cost (rank 0)" in r.stdout
+    from denet_amd.model import model_cnn
+    m = model_cnn.load_from_file(prefix + "_epoch001_final.mdl.gz", 2)
+    assert m.layers[-1].type_name == "denet-detect"
