@@ -336,14 +336,16 @@ extern "C" int denet_bn_fwd_train(const float* x, const float* res, float* y, co
 }
 
 extern "C" int denet_bn_fwd_test(const float* x, const float* res, float* y, const float* gamma, const float* beta,
-                                 const float* run_mean, const float* run_stdinv, void* workspace, long M, int C,
+                                 const float* run_mean, const float* run_stdinv, float* coef, int coef_ready, long M, int C,
                                  float eps, int relu, hipStream_t stream) {
-    DENET_CHECK_ARG(x && y && gamma && beta && run_mean && run_stdinv && workspace, "bn_fwd_test: null pointer");
+    // coef: 2*C floats owned by the caller (mean | inverse std of the inference transform). coef_ready != 0: they were
+    // written by an earlier call and the running statistics have not changed since (inference: one kernel per layer)
+    DENET_CHECK_ARG(x && y && gamma && beta && run_mean && run_stdinv && coef, "bn_fwd_test: null pointer");
     DENET_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "bn_fwd_test: bad shape M=%ld C=%d", M, C);
     BnMap m = bn_map(M, C);
-    float* coef = (float*)((double*)workspace + (size_t)m.gy * 2 * C);
-    hipLaunchKernelGGL(bn_test_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, run_mean, run_stdinv, C, eps,
-                       coef, coef + C);
+    if (!coef_ready)
+        hipLaunchKernelGGL(bn_test_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, run_mean, run_stdinv, C, eps,
+                           coef, coef + C);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, res, y, gamma, beta, coef, coef + C,
                        M, C, m.LC, relu);
     DENET_CHECK_LAUNCH("bn_fwd_test");

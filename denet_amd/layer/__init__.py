@@ -133,7 +133,9 @@ class Param:
         self.value = v
         if self.dev is not None:
             import torch
+            from .. import ops
             self.dev.copy_(torch.from_numpy(self.to_dev_layout()).reshape(self.dev.shape))
+            ops.bump_weights_version()
 
     def get_grad(self):
         """gradient in the reference layout (tests)"""

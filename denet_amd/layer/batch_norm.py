@@ -91,7 +91,7 @@ class BatchNormLayer(AbstractLayer):
             self._save = (sm, si, relu, out_act, res is not None)
         else:
             y = ops.bn_fwd_test(x, self.omega.dev, self.beta.dev, self.mean.dev, self.stdinv.dev, self.eps, relu=relu,
-                                res=res)
+                                res=res, cache=self.__dict__.setdefault("_infer_cache", {}))
         out_act.data = y
 
     def backward(self, ctx, want_dres=False):

@@ -43,7 +43,7 @@ SIGNATURES = {
     "denet_conv_wgrad": (I, [P, P, P, P, Z] + [I] * 12 + [P]),
     "denet_bn_workspace_bytes": (Z, [L, I]),
     "denet_bn_fwd_train": (I, [P] * 10 + [L, I, F, F, I, P]),
-    "denet_bn_fwd_test": (I, [P] * 8 + [L, I, F, I, P]),
+    "denet_bn_fwd_test": (I, [P] * 8 + [I, L, I, F, I, P]),
     "denet_bn_bwd": (I, [P] * 12 + [L, I, I, P]),
     "denet_maxpool_fwd": (I, [P, P, P] + [I] * 9 + [P]),
     "denet_maxpool_bwd": (I, [P, P, P] + [I] * 9 + [P]),

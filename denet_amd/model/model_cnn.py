@@ -262,6 +262,8 @@ class ModelCNN:
                     self.acts.append(a)
         self.cost_buf = torch.zeros(16, device="cuda")
         self._packed = True
+        from .. import ops
+        ops.bump_weights_version()
 
     def build_train_func(self, solver_mode="sgd", cost_factors=[], use_acc_mode=False, skip_build=False):
         if solver_mode not in SOLVER_MODES:
@@ -370,6 +372,7 @@ class ModelCNN:
             ops.solver_step(self.P[:self.n_trainable], self.M[:self.n_trainable], self.G[:self.n_trainable], n_decay,
                             float(learn_rate), float(momentum[0]), it, float(decay), SOLVER_MODES[self.solver_mode],
                             scale)
+        ops.bump_weights_version()       # parameters and BN running statistics moved: inference caches are stale
         if not fetch_cost:
             return None
         costs = self.cost_buf[:2 * len(self.cost_layers)].cpu().numpy().reshape(-1, 2)

@@ -45,6 +45,10 @@ class DataParallel:
         self.dist.broadcast(model.P, src=0)
         self.dist.broadcast(model.M, src=0)
         self.dist.broadcast(model.S, src=0)
+        import torch
+        if torch.cuda.is_available():
+            from .. import ops
+            ops.bump_weights_version()
 
     def make_buckets(self, layer_weight_range):
         """layer_weight_range: [(layer, lo, hi)] in layer order. Returns [(lo, hi, trigger_layer)]: contiguous

@@ -167,6 +167,12 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
         if cache is not None:
             cache["fwd_tile"] = tile
             u = _cached_u(cache, 0, tile)
+            if u is None and not cache.get("train"):
+                # inference: the filters do not change between calls - transform them once per weights version
+                ent = cache.get("u_test")
+                if ent is None or ent[0] != tile or ent[2] != WEIGHTS_VERSION:
+                    ent = cache["u_test"] = (tile, conv_wino_filter(w, tile, dgrad=False), WEIGHTS_VERSION)
+                u = ent[1]
             # the filter gradient of this layer uses the same transformed input when it runs with the same tile
             if cache.get("train") and _WINO.get((2, g)) == tile:
                 v_keep = cache.get("V")
@@ -427,12 +433,27 @@ def bn_fwd_train(x, gamma, beta, run_mean, run_stdinv, momentum=0.9, eps=1e-5, r
     return y, save_mean, save_invstd
 
 
-def bn_fwd_test(x, gamma, beta, run_mean, run_stdinv, eps=1e-5, relu=False, res=None, out=None):
+WEIGHTS_VERSION = 0       # bumped whenever parameters / running statistics change (solver step, set_value, packing)
+
+
+def bump_weights_version():
+    """invalidates what inference derives from the weights once and keeps: BN test coefficients, transformed filters"""
+    global WEIGHTS_VERSION
+    WEIGHTS_VERSION += 1
+
+
+def bn_fwd_test(x, gamma, beta, run_mean, run_stdinv, eps=1e-5, relu=False, res=None, out=None, cache=None):
+    """cache: a dict owned by the layer; its inference coefficients are computed once per weights version"""
     C = x.shape[-1]
     M = x.numel() // C
     y = out if out is not None else torch.empty_like(x)
+    ent = cache.get("test_coef") if cache is not None else None
+    ready = ent is not None and ent[1] == WEIGHTS_VERSION
+    coef = ent[0] if ent is not None else empty(2 * C)
     check(_L().denet_bn_fwd_test(ptr(x), ptr(res), ptr(y), ptr(gamma), ptr(beta), ptr(run_mean), ptr(run_stdinv),
-                                 ptr(_bn_ws(M, C)), M, C, eps, int(relu), stream_ptr()), "bn_fwd_test")
+                                 ptr(coef), int(ready), M, C, eps, int(relu), stream_ptr()), "bn_fwd_test")
+    if cache is not None and not ready:
+        cache["test_coef"] = (coef, WEIGHTS_VERSION)
     return y
 
 

@@ -120,7 +120,7 @@ int denet_bn_fwd_train(const float* x, const float* res, float* y, const float* 
                        float* run_mean, float* run_stdinv, float* save_mean, float* save_invstd, void* workspace,
                        long M, int C, float momentum, float eps, int relu, hipStream_t stream);
 int denet_bn_fwd_test(const float* x, const float* res, float* y, const float* gamma, const float* beta,
-                      const float* run_mean, const float* run_stdinv, void* workspace, long M, int C, float eps,
+                      const float* run_mean, const float* run_stdinv, float* coef, int coef_ready, long M, int C, float eps,
                       int relu, hipStream_t stream);
 /* relu mask of the backward: y > 0 if y is given; if y is NULL it is recomputed from x (needs beta) — the fused
  * residual blocks pass y, plain BNA layers pass NULL and save one pass over the activation                       */
