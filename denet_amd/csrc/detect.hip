@@ -9,6 +9,7 @@
 // Compiled with -ffp-contract=off: IoU comparisons against a threshold must not depend on FMA contraction.
 #include "common.h"
 #include <math.h>
+#include <string.h>
 #include <vector>
 
 namespace {
@@ -237,4 +238,58 @@ extern "C" int denet_soft_nms_host(const float* score, const float* box, int n, 
     }
     *out_n = k;
     return DENET_OK;
+}
+
+// The whole soft-NMS tail of a batch in one host call (denet_detect.cc:99-173 with use_soft_nms): for every image and
+// class, the RoIs with det_pr >= log(pr_threshold) go through denet_soft_nms_host (skipped when the threshold is outside
+// (0, 1), :129) and come out in selection order, classes ascending.
+//   det_pr / fitness: [B*S, C1] host copies; bbox: [B*S, 4]; counts[b]: valid RoIs of image b.
+//   out_score[k] = final log-domain score (the caller exponentiates), out_cls[k], out_row[k] = b*S + RoI index; out_count[b] detections of image b.
+//   capacity: entries available in the out_* arrays; returns the total number of detections, or a negative error code.
+extern "C" long denet_soft_nms_batch_host(const float* det_pr, const float* fitness, const float* bbox, const int* counts,
+                                          int B, int S, int class_num, float pr_threshold, float nms_threshold,
+                                          float* out_score, int* out_cls, int* out_row, int* out_count, long capacity) {
+    DENET_CHECK_ARG(det_pr && fitness && bbox && counts && out_score && out_cls && out_row && out_count,
+                    "soft_nms_batch_host: null pointer");
+    const int C1 = class_num + 1;
+    const float log_thr = logf(pr_threshold);
+    const bool do_nms = nms_threshold > 0.0f && nms_threshold < 1.0f;
+    std::vector<int> cand, order;
+    std::vector<float> sc, bx, fin;
+    long total = 0;
+    for (int b = 0; b < B; ++b) {
+        int nb = 0;
+        for (int cls = 0; cls < class_num; ++cls) {
+            cand.clear();
+            for (int i = 0; i < counts[b]; ++i)
+                if (det_pr[((size_t)b * S + i) * C1 + cls] >= log_thr) cand.push_back(b * S + i);
+            const int n = (int)cand.size();
+            if (n == 0) continue;
+            sc.resize(n);
+            bx.resize((size_t)n * 4);
+            for (int k = 0; k < n; ++k) {
+                sc[k] = fitness[(size_t)cand[k] * C1 + cls];
+                memcpy(&bx[(size_t)k * 4], bbox + (size_t)cand[k] * 4, 4 * sizeof(float));
+            }
+            order.resize(n);
+            fin.resize(n);
+            int kept = n;
+            if (do_nms) {
+                const int rc = denet_soft_nms_host(sc.data(), bx.data(), n, nms_threshold, order.data(), fin.data(), &kept);
+                if (rc != DENET_OK) return rc;
+            } else {
+                for (int k = 0; k < n; ++k) { order[k] = k; fin[k] = sc[k]; }
+            }
+            if (total + kept > capacity) { denet_set_error("soft_nms_batch_host: output capacity %ld exceeded", capacity); return DENET_ERR_ARG; }
+            for (int k = 0; k < kept; ++k) {
+                out_score[total] = fin[k];
+                out_cls[total] = cls;
+                out_row[total] = cand[order[k]];
+                ++total;
+            }
+            nb += kept;
+        }
+        out_count[b] = nb;
+    }
+    return total;
 }

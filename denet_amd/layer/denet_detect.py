@@ -314,28 +314,35 @@ class DeNetDetectLayer(AbstractLayer):
         if not use_soft_nms:
             keep = ops.detect_nms(det_pr, fitness, bbox, torch.from_numpy(counts).cuda(), B, S, self.class_num,
                                   pr_threshold, nms_threshold).cpu().numpy()
+            # one pass over the whole batch: the flat index walks (image, class, RoI), the reference's output order
+            flat = numpy.flatnonzero(keep.reshape(-1).view(numpy.bool_))
+            b_idx, rem = numpy.divmod(flat, self.class_num * S)
+            cls_idx, roi_idx = numpy.divmod(rem, S)
+            rows = b_idx * S + roi_idx
+            # tolist() turns the fp32 values into the same Python floats float() would, in one C loop
+            prs = numpy.exp(fit_h[rows, cls_idx]).tolist()
+            cls_l = cls_idx.tolist()
+            bx = box_h[rows]
+            boxes = list(zip(bx[:, 0].tolist(), bx[:, 1].tolist(), bx[:, 2].tolist(), bx[:, 3].tolist()))
+            ends = numpy.cumsum(numpy.bincount(b_idx, minlength=B)).tolist()
+            lo = 0
             for b in range(B):
-                cls_idx, roi_idx = numpy.nonzero(keep[b])          # class-major, RoI order inside a class
-                rows = b * S + roi_idx
-                prs = numpy.exp(fit_h[rows, cls_idx])
-                dets = [(float(p), int(c), tuple(float(v) for v in box_h[r])) for p, c, r in zip(prs, cls_idx, rows)]
-                results.append({"detections": dets, "meta": data_m[b] if data_m is not None else None})
+                hi = ends[b]
+                results.append({"detections": list(zip(prs[lo:hi], cls_l[lo:hi], boxes[lo:hi])),
+                                "meta": data_m[b] if data_m is not None else None})
+                lo = hi
         else:
-            det_h = det_pr.cpu().numpy()
-            log_thr = numpy.log(numpy.float32(pr_threshold))
+            det_h = numpy.ascontiguousarray(det_pr.cpu().numpy())
+            scores, cls_idx, rows, per = ops.soft_nms_batch_host(det_h, numpy.ascontiguousarray(fit_h), numpy.ascontiguousarray(box_h),
+                                                                 counts, B, S, self.class_num, pr_threshold, nms_threshold)
+            prs, cls_l = numpy.exp(scores).tolist(), cls_idx.tolist()
+            bx = box_h[rows]
+            boxes = list(zip(bx[:, 0].tolist(), bx[:, 1].tolist(), bx[:, 2].tolist(), bx[:, 3].tolist()))
+            lo = 0
             for b in range(B):
-                dets = []
-                rows = numpy.arange(b * S, b * S + counts[b])
-                for cls in range(self.class_num):
-                    cand = rows[det_h[rows, cls] >= log_thr]
-                    if len(cand) == 0:
-                        continue
-                    if 0.0 < nms_threshold < 1.0:
-                        order, score = ops.soft_nms_host(fit_h[cand, cls], box_h[cand], nms_threshold)
-                    else:
-                        order, score = numpy.arange(len(cand)), fit_h[cand, cls]
-                    for k, sc in zip(order, numpy.exp(score.astype(numpy.float32))):
-                        dets.append((float(sc), cls, tuple(float(v) for v in box_h[cand[k]])))
-                results.append({"detections": dets, "meta": data_m[b] if data_m is not None else None})
+                hi = lo + int(per[b])
+                results.append({"detections": list(zip(prs[lo:hi], cls_l[lo:hi], boxes[lo:hi])),
+                                "meta": data_m[b] if data_m is not None else None})
+                lo = hi
         self.detect_ms = timer.current_ms()
         return results

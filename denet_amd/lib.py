@@ -84,6 +84,7 @@ SIGNATURES = {
     "denet_detect_loss": (I, [P] * 9 + [I] * 6 + [F, F, F, I, P]),
     "denet_detect_decode": (I, [P] * 5 + [I] * 6 + [F, P]),
     "denet_detect_nms": (I, [P] * 5 + [I, I, I, F, F, P]),
+    "denet_soft_nms_batch_host": (L, [P, P, P, P, I, I, I, F, F, P, P, P, P, L]),
     "denet_soft_nms_host": (I, [P, P, I, F, P, P, P]),
     "denet_build_samples_workspace_bytes": (Z, [I] * 6),
     "denet_build_samples": (I, [P, P, P, P, P, Z] + [I] * 4 + [F, I, I, I, P]),

@@ -777,6 +777,23 @@ def detect_nms(det_pr, fitness, bbox, count, B, S, class_num, pr_threshold, nms_
     return keep
 
 
+def soft_nms_batch_host(det_h, fit_h, box_h, counts, B, S, class_num, pr_threshold, nms_threshold):
+    """the soft-NMS tail of a whole batch in one native call -> (log-domain scores fp32, classes, rows = b*S + RoI, per-image counts)"""
+    import numpy
+    cap = int(counts.sum()) * class_num + 1
+    score = numpy.empty(cap, dtype=numpy.float32)
+    cls = numpy.empty(cap, dtype=numpy.int32)
+    row = numpy.empty(cap, dtype=numpy.int32)
+    per = numpy.zeros(B, dtype=numpy.int32)
+    counts = numpy.ascontiguousarray(counts, dtype=numpy.int32)
+    n = _L().denet_soft_nms_batch_host(det_h.ctypes.data, fit_h.ctypes.data, box_h.ctypes.data, counts.ctypes.data, B, S,
+                                       class_num, float(pr_threshold), float(nms_threshold), score.ctypes.data,
+                                       cls.ctypes.data, row.ctypes.data, per.ctypes.data, cap)
+    if n < 0:
+        check(int(n), "soft_nms_batch_host")
+    return score[:n], cls[:n], row[:n], per
+
+
 def soft_nms_host(score, box, nms_threshold):
     """numpy in / numpy out: (order, final scores) of one class' candidates (Gaussian soft-NMS)"""
     import ctypes

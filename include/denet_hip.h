@@ -258,6 +258,9 @@ int denet_detect_nms(const float* det_pr, const float* fitness, const float* bbo
                      hipStream_t stream);
 int denet_soft_nms_host(const float* score_host, const float* box_host, int n, float nms_threshold,
                         int* out_order_host, float* out_score_host, int* out_n_host);
+long denet_soft_nms_batch_host(const float* det_pr, const float* fitness, const float* bbox, const int* counts, int B, int S,
+                               int class_num, float pr_threshold, float nms_threshold, float* out_score, int* out_cls,
+                               int* out_row, int* out_count, long capacity);
 
 /* ---- corner selection + RoI proposal  (denet/layer/denet_sparse.cc:489-557 run_build_samples, :321-471
  *      search_corners, :271-308 get_sample; Python-facing wrapper build_samples :559-668, which the reference
