@@ -6,9 +6,15 @@ per GPU under `torch.distributed.run`, gradients all-reduced over RCCL while the
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         -m denet_amd.model.train_multi --train DIR --extension mscoco,2014-train,crop=512,crop_mode=denet ... --device-render
 
-Same flags as model-train. Like the reference (train_multi.py:44-46) every rank shuffles the image list with the seed
-`seed + epoch`, so all ranks see the same order; a global batch is `world x batch_size` consecutive samples of which rank r
-takes the r-th slice. BN statistics stay per GPU; rank 0 writes the checkpoints."""
+Same flags as model-train plus `--batch-size-factor F`. Like the reference (train_multi.py:44-46) every rank shuffles the
+image list with the seed `seed + epoch`, so all ranks see the same order. One global iteration consumes `F x world` batches
+in the reference's order (train_multi.py:116-119: for f in range(F): for worker: next batch), i.e. rank r's f-th local step
+takes batch `f * world + r` of the iteration.
+  F = 1: gradients are all-reduced inside every step (equal to the reference's parameter averaging for sgd / nesterov);
+  F > 1: what the shipped recipes run (papers/dss/denet34.sh:43 `--batch-size-factor 2` without --use-acc-mode): every rank
+         takes F full local steps, then parameters, momentum and BN statistics are averaged over the ranks
+         (DataParallel.average_state) - the reference's scheme itself, over RCCL instead of host shared memory.
+Rank 0 writes the checkpoints."""
 import math
 import os
 import random
@@ -23,31 +29,36 @@ from . import train as train_mod
 class _Shard:
     """the rank's slices of a dataset's image list, with the loader / attributes the training loop needs"""
 
-    def __init__(self, data, rank, world, batch_size):
-        self.data, self.rank, self.world, self.batch_size = data, rank, world, batch_size
+    def __init__(self, data, rank, world, batch_size, factor=1):
+        self.data, self.rank, self.world, self.batch_size, self.factor = data, rank, world, batch_size, factor
 
     def images_of_subset(self, subset):
         d = self.data
         lo = subset * d.subset_size
         hi = min((subset + 1) * d.subset_size, d.subset_total_size)
         images = d.images[lo:hi]
-        g = self.world * self.batch_size
-        n_glob = math.floor(len(images) / g)          # whole global batches only: every rank runs the same step count
+        B = self.batch_size
+        per_it = self.world * self.factor             # batches of one global iteration
+        n_it = math.floor(len(images) / (per_it * B))  # whole iterations only: every rank runs the same step count
         mine = []
-        for k in range(n_glob):
-            mine += images[k * g + self.rank * self.batch_size:k * g + (self.rank + 1) * self.batch_size]
+        for it in range(n_it):
+            for f in range(self.factor):
+                k = it * per_it + f * self.world + self.rank
+                mine += images[k * B:(k + 1) * B]
         return mine
 
 
 def train(args, train_data, dp, log=print):
     model = model_cnn.initialize(args, train_data.get_data_shape(), train_data.class_labels, train_data.get_class_num())
     model.build_train_func(args.solver, args.cost_factors)
+    factor = max(1, int(getattr(args, "batch_size_factor", 1)))
     if dp is not None:
-        model.dist = dp
+        if factor == 1:
+            model.dist = dp                 # gradient all-reduce inside every step
         dp.broadcast_state(model)
     rank = dp.rank if dp is not None else 0
     world = dp.world_size if dp is not None else 1
-    shard = _Shard(train_data, rank, world, model.batch_size)
+    shard = _Shard(train_data, rank, world, model.batch_size, factor)
     loader = None
     if getattr(args, "device_render", False):
         from ..dataset.device_render import DeviceImageLoader
@@ -63,10 +74,20 @@ def train(args, train_data, dp, log=print):
             if len(images) == 0:
                 continue
             if loader is not None:
-                cost = model.train_epoch_device(loader, images, epoch, learn_rate, args.learn_momentum, args.learn_decay)
+                batches = loader.iterate(images, model.batch_size)
             else:
                 train_data.data = train_data.image_loader.load(images)
-                cost = model.train_epoch(train_data, epoch, learn_rate, args.learn_momentum, args.learn_decay)
+                dx, dm, n = train_data.export(model.batch_size)
+                batches = ((dx[i:i + model.batch_size], dm[i:i + model.batch_size]) for i in range(0, n, model.batch_size))
+            cost = 0.0
+            for step, (data_x, data_m) in enumerate(batches):
+                c, _ = model.train_step(data_x, data_m, epoch, model.iteration, learn_rate, args.learn_momentum, args.learn_decay)
+                if math.isnan(c):
+                    raise Exception("ERROR: Cost is NaN")
+                cost += c
+                model.iteration += 1
+                if factor > 1 and dp is not None and (step + 1) % factor == 0:
+                    dp.average_state(model)
             costs.append(cost)
             if rank == 0:
                 log("epoch %i subset %i - cost (rank 0): %.4f (lr %g, %i GPUs)" % (epoch, subset, cost, learn_rate, world))
@@ -83,7 +104,10 @@ def train(args, train_data, dp, log=print):
 
 def main(argv=None):
     import torch
-    args = train_mod.build_parser().parse_args(argv)
+    parser = train_mod.build_parser()
+    parser.add_argument("--batch-size-factor", type=int, default=1,
+                        help="local training steps per rank between two parameter averagings (1: gradient all-reduce every step)")
+    args = parser.parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dp = None

@@ -118,6 +118,22 @@ class DataParallel:
             from .. import ops
             ops.check(ops._L().denet_scale(t.data_ptr(), t.numel(), float(s), ops.stream_ptr()), "scale")
 
+    def average_state(self, model):
+        """the reference's own scheme (train_multi.py:96-145, shared.py:105-119): every rank has run its local training
+        steps; parameters, momentum and BN running statistics are replaced by their mean over the ranks"""
+        if self.world_size == 1 and not self.force_collectives:
+            return
+        d = self.dist
+        work = [d.all_reduce(t, op=d.ReduceOp.SUM, async_op=True) for t in (model.P, model.M, model.S)]
+        for w in work:
+            w.wait()
+        for t in (model.P, model.M, model.S):
+            self._scale(t, 1.0 / self.world_size)
+        import torch
+        if torch.cuda.is_available():
+            from .. import ops
+            ops.bump_weights_version()
+
     def barrier(self):
         self.dist.barrier()
 

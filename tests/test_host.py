@@ -337,6 +337,11 @@ for r in range(dp.world_size):
 assert torch.allclose(m.G, sum(others), atol=1e-6)
 assert torch.allclose(m.S, torch.full((32,), 0.5))
 assert dp.max_over_ranks(float(rank)) == 1.0
+# --batch-size-factor > 1: local steps, then parameters / momentum / BN statistics averaged (train_multi.py:96-145)
+m.P = torch.full((8,), 1.0 + rank); m.M = torch.full((8,), 10.0 * rank); m.S = torch.full((32,), 3.0 - rank)
+dp.average_state(m)
+assert torch.allclose(m.P, torch.full((8,), 1.5)) and torch.allclose(m.M, torch.full((8,), 5.0))
+assert torch.allclose(m.S, torch.full((32,), 2.5))
 print("rank", rank, "ok")
 '''
 
@@ -458,3 +463,11 @@ def test_train_multi_sharding():
         for k in range(n_glob):
             for r in range(world):
                 assert parts[r][k * B:(k + 1) * B] == list(range(lo + k * world * B + r * B, lo + k * world * B + (r + 1) * B))
+    # --batch-size-factor 2 (train_multi.py:116-119): an iteration = F x world batches, rank r's f-th local step takes
+    # batch f * world + r
+    world, B, F = 2, 3, 2
+    Data.subset_size, Data.subset_total_size, Data.images = 40, 40, list(range(40))
+    parts = [_Shard(Data, r, world, B, F).images_of_subset(0) for r in range(world)]
+    assert parts[0][:6] == [0, 1, 2, 6, 7, 8] and parts[1][:6] == [3, 4, 5, 9, 10, 11]
+    assert len(parts[0]) == len(parts[1]) == (40 // (world * F * B)) * F * B
+    assert sorted(parts[0] + parts[1]) == list(range(36))

@@ -177,6 +177,11 @@ def test_model_train_multi_launcher_single_rank(hip, tree, tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "cost (rank 0)" in r.stdout
+    # the recipes' mode: --batch-size-factor 2 = two local steps, then parameter averaging
+    r2 = subprocess.run(cmd[:1] + ["--batch-size-factor", "2"] + cmd[1:], env=dict(env, MASTER_PORT="29534"),
+                        capture_output=True, text=True, timeout=240)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-3000:]
+    assert "cost (rank 0)" in r2.stdout
     from denet_amd.model import model_cnn
     m = model_cnn.load_from_file(prefix + "_epoch001_final.mdl.gz", 2)
     assert m.layers[-1].type_name == "denet-detect"
