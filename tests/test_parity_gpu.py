@@ -497,7 +497,8 @@ def test_direct_and_measured_paths_agree(hip):
         ops._WINO.clear()
         ops._WINO.update(saved[1])
     assert not any(res[0][3].values()), "the heuristic run must not use Winograd passes"
-    assert any(res[1][3].values()), "the measured run chose no Winograd pass at all: the test compares nothing"
+    if ops.WINOGRAD:           # DENET_WINOGRAD=0 leaves only the measured direct configurations to compare
+        assert any(res[1][3].values()), "the measured run chose no Winograd pass at all: the test compares nothing"
     # one step only: the RoI proposal of a second step is a discontinuous function of the corner map (threshold
     # crossings), so rounding-level differences in the parameters legitimately change its RoI set
     assert abs(res[0][0] - res[1][0]) <= 1e-4 * abs(res[0][0])
