@@ -355,6 +355,31 @@ def test_denet34_edge_case_ground_truth_vs_oracle(hip):
         assert abs(cost - ocost) <= 1e-4 * abs(ocost), (cost, ocost)
 
 
+def test_denet34_odd_geometry_vs_oracle(hip):
+    """batch 3 at 160x160: feature maps of 40 / 20 / 10 / 5 cells - the 5x5 and 10x10 maps are not multiples of the
+    Winograd tile (direct kernels there), M is not a multiple of the GEMM tile anywhere; op-by-op against the oracle"""
+    B, IMG = 3, 160
+    model = zoo.denet34(B, "skip", IMG, class_num=80, seed=1)
+    rng = np.random.RandomState(5)
+    dconv = model.layers[40].layers[0]
+    dconv.omega.set_value(rng.normal(0, 0.05, dconv.omega.value.shape))
+    _warm_corner_head(model, 4.0, 0.3)
+    x, metas = zoo.synthetic_batch(B, IMG, seed=6)
+    om = OM.OracleModel(model.export_json(), B)
+    model.build_train_func("nesterov")
+    for it in range(2):
+        random.seed(40 + it)
+        cost, _ = model.train_step(x, metas, 0, it, 0.05, [0.9], 1e-4)
+        dns, cl = model.layers[31], model.layers[30]
+        roi_lists = dns.sample_bbox_list
+        lists = OM.oracle_build_samples(cl.corner_pr.cpu().numpy(), dns.corner_threshold, dns.sample_num, 1024, 0)
+        random.seed(40 + it)
+        ref_lists = OL.edit_samples(lists, metas, dns.sample_count, dns.random_sample, dns.sample_gt)
+        assert [[p for p, _ in l] for l in ref_lists] == [[p for p, _ in l] for l in roi_lists]
+        ocost, _ = _forced_step_check(model, om, x, metas, it, 0.05, 0.9, 1e-4, "nesterov", roi_lists)
+        assert abs(cost - ocost) <= 1e-4 * abs(ocost), (cost, ocost)
+
+
 def test_cifar3_train_step_vs_oracle(hip):
     """BASELINE config 1 (README.md:52 three-layer CNN): unfused BN / A / P / P.A / R path"""
     B = 8
