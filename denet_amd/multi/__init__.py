@@ -53,18 +53,23 @@ class DataParallel:
     def make_buckets(self, layer_weight_range):
         """layer_weight_range: [(layer, lo, hi)] in layer order. Returns [(lo, hi, trigger_layer)]: contiguous
         slices of the weight region, built from the LAST layer backwards; a bucket is complete once the backward
-        sweep has finished `trigger_layer` (its lowest-index layer)."""
+        sweep has finished `trigger_layer` (its lowest-index layer). DeNet-34 skip at the default 32 MB: 40 / 34 / 33 / 24 MB
+        (head, up path + stage 4, stage 4-3, stage 3) and a 6 MB remainder (stages 1-2, stem) for the exposed tail."""
         buckets = []
         cur_hi = None
         cur_lo = None
         trigger = None
         min_elems = max(1, self.bucket_bytes // 4)
+        tail_elems = max(1, min_elems // 4)
         for layer, lo, hi in reversed(layer_weight_range):
             if cur_hi is None:
                 cur_hi = hi
             cur_lo = lo
             trigger = layer
-            if cur_hi - cur_lo >= min_elems:
+            # close the bucket when it is full - or when what is left below it (the first layers of the network, whose
+            # gradients arrive at the very end of the backward sweep) is small: the last collective, which nothing
+            # overlaps, then carries only that remainder instead of a whole bucket
+            if cur_hi - cur_lo >= min_elems or (0 < cur_lo <= tail_elems and cur_hi - cur_lo >= tail_elems):
                 buckets.append((cur_lo, cur_hi, trigger))
                 cur_hi = None
         if cur_hi is not None:
