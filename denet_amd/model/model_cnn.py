@@ -314,9 +314,6 @@ class ModelCNN:
             a.grad = None
         self._upload_input(data_x)
         ctx = StepContext(self)
-        if train and data_m is not None:
-            for layer in self.layers[1:]:
-                layer.begin_step(data_m)
         for i, layer in enumerate(self.layers[1:]):
             if train and data_m is not None:
                 layer.prepare_target(ctx, self, data_x, data_m)
@@ -330,6 +327,11 @@ class ModelCNN:
                     convs = self._conv_layers = [l for l in walk_layers(self.layers) if l.type_name == "conv" and
                                                  getattr(l, "enabled", True)]
                 ops.wino_prefetch_filters([(l._cache(), l._w()) for l in convs])
+            if train and data_m is not None and i == 0:
+                # host work that needs no device result (corner targets, ...): done while the first layer runs, so the
+                # device is not left idle in front of it
+                for other in self.layers[2:]:
+                    other.begin_step(data_m)
         return ctx
 
     def backward(self, ctx):
@@ -343,6 +345,17 @@ class ModelCNN:
                 g = layer.dconv if layer.type_name == "denet-corner" else (
                     layer.conv.output.grad if hasattr(layer, "conv") else layer.input.grad)
                 ops._L().denet_scale(g.data_ptr(), g.numel(), float(self.cost_factors[i]), ops.stream_ptr())
+        # the costs are final here (the loss kernels are queued): copy them to the host on a side stream now, so that
+        # train_step can return them without waiting for the backward sweep and the solver - the host then prepares the
+        # next step while the device finishes this one
+        if getattr(self, "_cost_host", None) is None:
+            self._cost_host = torch.empty(16, dtype=torch.float32).pin_memory()
+            self._cost_stream = torch.cuda.Stream()
+        self._cost_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._cost_stream):
+            self._cost_host.copy_(self.cost_buf, non_blocking=True)
+            self._cost_ready = torch.cuda.Event()
+            self._cost_ready.record(self._cost_stream)
         dist = self.dist
         if dist is not None:
             dist.begin_step(self)
@@ -375,7 +388,8 @@ class ModelCNN:
         ops.bump_weights_version()       # parameters and BN running statistics moved: inference caches are stale
         if not fetch_cost:
             return None
-        costs = self.cost_buf[:2 * len(self.cost_layers)].cpu().numpy().reshape(-1, 2)
+        self._cost_ready.synchronize()
+        costs = self._cost_host[:2 * len(self.cost_layers)].numpy().reshape(-1, 2).copy()
         layer_costs = []
         for i, layer in enumerate(self.cost_layers):
             c = float(costs[i, 0]) + (float(costs[i, 1]) if layer.type_name == "denet-detect" else 0.0)
