@@ -100,11 +100,27 @@ class DeNetCornerLayer(AbstractLayer):
     def conv(self):
         return self.layers[-1]
 
+    def begin_step(self, metas):
+        """the corner targets depend on the ground truth only: rasterised and uploaded (copy stream) while the first
+        layers run, instead of in front of this layer where the device would wait for the host"""
+        target = self.get_target(None, None, metas)
+        self.set_target(None, target[0], target[1])
+        self._target_metas = metas
+
+    def prepare_target(self, ctx, model, data_x, metas):
+        if getattr(self, "_target_metas", None) is metas:
+            self._target_metas = None         # prepared by begin_step of this very step
+            return
+        super().prepare_target(ctx, model, data_x, metas)
+
     def set_target(self, ctx, yt_index, yt_value):
         import torch
         v = numpy.ascontiguousarray(yt_value, dtype=numpy.float32)
         if getattr(self, "_pinned", None) is None or self._pinned.numel() != v.size:
             self._pinned = torch.empty(v.size, dtype=torch.float32).pin_memory()
+        ev = getattr(self, "_target_ev", None)
+        if ev is not None:
+            ev.synchronize()                   # the previous upload has finished reading the pinned buffer
         self._pinned.copy_(torch.from_numpy(v))
         self._target, self._target_ev = ops.upload_async(self._pinned)
 
