@@ -165,6 +165,8 @@ def modify_layer(model, layer_name, assignments):
 def build_parser():
     import argparse
     parser = argparse.ArgumentParser(description="Modify a model file (same flags as the reference's model-modify)")
+    from ..common import logging
+    logging.add_arguments(parser)
     parser.add_argument("--seed", type=int, default=23455, help="Random Seed for weights")
     parser.add_argument("--input", type=str, required=True)
     parser.add_argument("--output", type=str, required=True)

@@ -14,6 +14,13 @@ from .. import dataset
 from . import model_cnn
 
 
+def _log(log):
+    if log is not None:
+        return log
+    from ..common import logging
+    return logging.info
+
+
 def _top_errors(y, yy, yt):
     y, yy, yt = numpy.array(y, numpy.int64), numpy.array(yy, numpy.int64), numpy.array(yt, numpy.int64)
     error1 = float(numpy.sum(yt != y) / yt.shape[0])
@@ -26,8 +33,9 @@ def _top5(pr_i):
     return numpy.argpartition(-pr_i, k - 1)[:k] if k < pr_i.shape[0] else numpy.arange(pr_i.shape[0])
 
 
-def test_single(mode, model, data, log=print):
+def test_single(mode, model, data, log=None):
     """top-1 / top-5 error of a classifier, one centre crop per image"""
+    log = _log(log)
     y, yy, yt = [], [], []
     for subset in range(data.subset_num):
         data.load_from_subset(subset)
@@ -43,8 +51,9 @@ def test_single(mode, model, data, log=print):
     return error1, error5
 
 
-def test_multicrop(mode, model, data, log=print):
+def test_multicrop(mode, model, data, log=None):
     """10-crop testing: the probabilities of the ten views of an image are summed"""
+    log = _log(log)
     y, yy, yt = [], [], []
     for subset in range(data.subset_num):
         data.load_from_subset(subset)
@@ -61,7 +70,8 @@ def test_multicrop(mode, model, data, log=print):
     return error1, error5
 
 
-def test_detector(mode, model, data, output_fname, params, log=print, device_render=False, thread_num=1):
+def test_detector(mode, model, data, output_fname, params, log=None, device_render=False, thread_num=1):
+    log = _log(log)
     detect_params = common.get_params_dict(params)
     detect_layer = model.layers[-1]
     class_labels_inv = {v: k for k, v in model.class_labels.items()} if model.class_labels else {}
@@ -120,6 +130,8 @@ def test_detector(mode, model, data, output_fname, params, log=print, device_ren
 
 def build_parser():
     parser = argparse.ArgumentParser(description="Predict labels / detections using a trained model")
+    from ..common import logging
+    logging.add_arguments(parser)
     parser.add_argument("--model", required=True, help="the model file")
     parser.add_argument("--input", required=True, help="The folder with data")
     parser.add_argument("--results", default="./results", type=str, help="Results folder / filename")
@@ -135,6 +147,8 @@ def build_parser():
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    from ..common import logging
+    logging.init(args)
     model = model_cnn.load_from_file(args.model, args.batch_size)
     data = dataset.load(args.input, args.extension, class_labels=model.class_labels, thread_num=args.thread_num)
     if "single" in args.predict_mode:

@@ -84,6 +84,8 @@ def load_dataset(spec, seed, extension="ppm", is_training=True, thread_num=1, cl
 
 def build_parser():
     parser = argparse.ArgumentParser(description="Train a convolutional network (MI355X hot path of lachlants/denet)")
+    from ..common import logging
+    logging.add_arguments(parser)
     parser.add_argument("--model", required=False, default=None, help="Model (.mdl.gz) to continue training.")
     parser.add_argument("--cost-factors", default=[], nargs="+", help="Multiplicative factors for model costs")
     parser.add_argument("--train", default="synthetic",
@@ -141,8 +143,14 @@ def save_results(fname, error, class_errors):
             print("Class %i=%.2f%% (%i samples)" % (d[0], d[1], d[2] * d[1] / 100), file=f)
 
 
-def train(args, train_data, log=print, test_data=None):
+def _default_log():
+    from ..common import logging
+    return logging.info
+
+
+def train(args, train_data, log=None, test_data=None):
     """the epoch loop of train.py:117-151 (shuffle, train_epoch, learning-rate annealing, checkpoint per epoch)"""
+    log = _default_log() if log is None else log
     model = model_cnn.initialize(args, train_data.get_data_shape(), train_data.class_labels, train_data.get_class_num())
     model.build_train_func(args.solver, args.cost_factors)
     learn_rate = args.learn_rate
@@ -181,6 +189,8 @@ def train(args, train_data, log=print, test_data=None):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    from ..common import logging
+    logging.init(args)
     random.seed(args.seed)
     numpy.random.seed(args.seed)
     train_data = load_dataset(args.train, args.seed, args.extension, True, args.thread_num)

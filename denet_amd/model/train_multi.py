@@ -48,7 +48,10 @@ class _Shard:
         return mine
 
 
-def train(args, train_data, dp, log=print):
+def train(args, train_data, dp, log=None):
+    if log is None:
+        from ..common import logging
+        log = logging.info
     model = model_cnn.initialize(args, train_data.get_data_shape(), train_data.class_labels, train_data.get_class_num())
     model.build_train_func(args.solver, args.cost_factors)
     factor = max(1, int(getattr(args, "batch_size_factor", 1)))
@@ -108,6 +111,8 @@ def main(argv=None):
     parser.add_argument("--batch-size-factor", type=int, default=1,
                         help="local training steps per rank between two parameter averagings (1: gradient all-reduce every step)")
     args = parser.parse_args(argv)
+    from ..common import logging
+    logging.init(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dp = None
