@@ -311,6 +311,25 @@ __global__ void bn_test_coef_kernel(const float* __restrict__ run_mean, const fl
 
 }  // namespace
 
+// inference: batch norm folded into the filters of the convolution in front of it. With the test-mode transform
+// y = gamma * (x - mean) * inv + beta, inv = 1 / sqrt((1/stdinv)^2 + eps) (bn_test_coef_kernel: the reference's double
+// epsilon), conv(x, w) + b followed by BN equals conv(x, w * s[k]) + (beta - (mean - b) * s), s = gamma * inv.
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ w, const float* __restrict__ conv_bias,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ run_mean, const float* __restrict__ run_stdinv,
+                                                      float eps, float* __restrict__ w_out, float* __restrict__ b_out, int K,
+                                                      long per_k) {
+    const int k = blockIdx.x;
+    const float sd = 1.0f / run_stdinv[k];
+    const float inv = 1.0f / sqrtf(sd * sd + eps);
+    const float s = gamma[k] * inv;
+    for (long i = threadIdx.x; i < per_k; i += blockDim.x) w_out[(long)k * per_k + i] = w[(long)k * per_k + i] * s;
+    if (threadIdx.x == 0) {
+        const float b = conv_bias ? conv_bias[k] : 0.f;
+        b_out[k] = beta[k] - (run_mean[k] - b) * s;
+    }
+}
+
 extern "C" size_t denet_bn_workspace_bytes(long M, int C) {
     if (C <= 0 || C % 4) return 0;
     BnMap m = bn_map(M, C);
@@ -369,5 +388,17 @@ extern "C" int denet_bn_bwd(const float* x, const float* y, const float* dy, con
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, gamma, beta, save_mean,
                        save_invstd, coef, dx, dres, M, C, m.LC, relu);
     DENET_CHECK_LAUNCH("bn_bwd");
+    return DENET_OK;
+}
+
+// w: [K][per_k] filters (KRSC, per_k = R*S*C), conv_bias: [K] or NULL -> w_out, b_out of the folded convolution
+extern "C" int denet_bn_fold(const float* w, const float* conv_bias, const float* gamma, const float* beta,
+                             const float* run_mean, const float* run_stdinv, float eps, float* w_out, float* b_out, int K,
+                             long per_k, hipStream_t stream) {
+    DENET_CHECK_ARG(w && gamma && beta && run_mean && run_stdinv && w_out && b_out, "bn_fold: null pointer");
+    DENET_CHECK_ARG(K > 0 && per_k > 0, "bn_fold: bad shape");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(K), dim3(256), 0, stream, w, conv_bias, gamma, beta, run_mean, run_stdinv, eps,
+                       w_out, b_out, K, per_k);
+    DENET_CHECK_LAUNCH("bn_fold");
     return DENET_OK;
 }

@@ -35,6 +35,7 @@ struct IgemmParams {
     float* out;         // fwd: y        dgrad: dx       wgrad: dw or split workspace
     const float* bias;  // fwd only, [K] or null
     const float* add;   // fwd/dgrad: tensor of the output's shape added in the epilogue, or null
+    int relu;           // fwd: max(., 0) after bias and add (inference with batch norm folded into the filters)
     int N, H, W, C;     // x geometry (C = physical channels)
     int OH, OW, K;      // y geometry (K = physical channels)
     int R, S, S_real;   // filter taps (S may be padded; taps s >= S_real carry zero weight)
@@ -626,6 +627,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
                     }
                     float v = acc[i][j][r] + bv;
                     if (MODE != MODE_WGRAD && p.add) v += p.add[idx];
+                    if (MODE == MODE_FWD && p.relu) v = fmaxf(v, 0.f);
                     out[idx] = v;
                 }
             }
@@ -933,6 +935,9 @@ extern "C" int denet_conv_profile_read(int i, float* ms, int* mode, int* bm, int
 extern "C" int denet_conv_fwd(const float* x, const float* w, const float* bias, const float* add, float* y, int N,
                               int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH,
                               int OW, hipStream_t stream);
+extern "C" int denet_conv_fwd_act(const float* x, const float* w, const float* bias, const float* add, float* y, int relu,
+                                  int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH,
+                                  int OW, hipStream_t stream);
 extern "C" int denet_conv_dgrad(const float* dy, const float* w, const float* add, float* dx, int N, int H, int W,
                                 int C, int K, int R, int S, int S_real, int stride, int pad, int OH, int OW,
                                 hipStream_t stream);
@@ -1162,11 +1167,18 @@ extern "C" int denet_conv_last_config(int* mode, int* bm, int* bn, int* nbuf, in
 extern "C" int denet_conv_fwd(const float* x, const float* w, const float* bias, const float* add, float* y, int N,
                               int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH,
                               int OW, hipStream_t stream) {
+    return denet_conv_fwd_act(x, w, bias, add, y, 0, N, H, W, C, K, R, S, S_real, stride, pad, OH, OW, stream);
+}
+
+// forward convolution with an activation in the epilogue: y = act(conv(x, w) + bias + add), relu != 0: max(., 0)
+extern "C" int denet_conv_fwd_act(const float* x, const float* w, const float* bias, const float* add, float* y, int relu,
+                                  int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH,
+                                  int OW, hipStream_t stream) {
     int rc = check_geom(N, H, W, C, K, R, S, S_real, stride, pad, OH, OW);
     if (rc) return rc;
     DENET_CHECK_ARG(x && w && y, "conv_fwd: null pointer");
     IgemmParams p = {};
-    p.act = x; p.wgt = w; p.out = y; p.bias = bias; p.add = add;
+    p.act = x; p.wgt = w; p.out = y; p.bias = bias; p.add = add; p.relu = relu ? 1 : 0;
     p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K;
     p.R = R; p.S = S; p.S_real = S_real; p.stride = stride; p.sshift = ilog2_exact(stride); p.pad = pad;
     p.act_bytes = (unsigned)((size_t)N * H * W * C * 4); p.wgt_bytes = (unsigned)((size_t)K * R * S * C * 4);

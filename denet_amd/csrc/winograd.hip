@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
 template <int MO>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias,
                                                           const float* __restrict__ add, float* __restrict__ y, int N,
-                                                          int H, int W, int K, int TH, int TW, long T) {
+                                                          int H, int W, int K, int TH, int TW, long T, int relu) {
     using WT = Wino<MO>;
     constexpr int TS = WT::TS;
     const int k4n = K / 4;
@@ -185,6 +185,12 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
             const long o = (((long)n * H + MO * ty + i) * W + MO * tx + j) * K + k4 * 4;
             acc += b;
             if (add) acc += ld4(add + o);
+            if (relu) {
+                acc[0] = fmaxf(acc[0], 0.f);
+                acc[1] = fmaxf(acc[1], 0.f);
+                acc[2] = fmaxf(acc[2], 0.f);
+                acc[3] = fmaxf(acc[3], 0.f);
+            }
             *(f32x4*)(y + o) = acc;
         }
 }
@@ -307,7 +313,7 @@ int wino_filter(int mo, bool dgrad, const float* w, float* U, int K, int C, hipS
 // input is written (NULL: inside the workspace) - the filter gradient of the same layer can reuse it
 int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u_cached, float* v_keep, const float* bias,
              const float* add, float* out, float* ws, size_t ws_bytes, int N, int H, int W, int Cin, int Cout,
-             hipStream_t stream) {
+             hipStream_t stream, int relu = 0) {
     // in: [N,H,W,Cin]   out: [N,H,W,Cout]   w: KRSC with (K,C) = dgrad ? (Cin,Cout) : (Cout,Cin)
     DENET_CHECK_ARG(in && w && out && ws, "conv_wino: null pointer");
     WinoDims d;
@@ -329,7 +335,7 @@ int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u
     DENET_CHECK_LAUNCH("conv_wino transforms");
     rc = denet_gemm_batched_nt(V, U, Mx, d.NX, (int)d.T, Cout, Cin, d.T * Cin, kc, d.T * Cout, stream);
     if (rc) return rc;
-    WINO_LAUNCH(mo, wino_output_kernel, d.T * (Cout / 4), Mx, bias, add, out, N, H, W, Cout, d.TH, d.TW, d.T);
+    WINO_LAUNCH(mo, wino_output_kernel, d.T * (Cout / 4), Mx, bias, add, out, N, H, W, Cout, d.TH, d.TW, d.T, relu);
     DENET_CHECK_LAUNCH("conv_wino output");
     return DENET_OK;
 }
@@ -393,6 +399,15 @@ extern "C" int denet_conv_wino_fwd(const float* x, const float* w, const float* 
                                    const float* add, float* y, float* workspace, size_t workspace_bytes, int tile, int N,
                                    int H, int W, int C, int K, hipStream_t stream) {
     return wino_run(tile, false, x, w, u_cached, v_keep, bias, add, y, workspace, workspace_bytes, N, H, W, C, K, stream);
+}
+
+// the same with max(., 0) after bias and add (see denet_conv_fwd_act)
+extern "C" int denet_conv_wino_fwd_act(const float* x, const float* w, const float* u_cached, float* v_keep,
+                                       const float* bias, const float* add, float* y, int relu, float* workspace,
+                                       size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
+                                       hipStream_t stream) {
+    return wino_run(tile, false, x, w, u_cached, v_keep, bias, add, y, workspace, workspace_bytes, N, H, W, C, K, stream,
+                    relu ? 1 : 0);
 }
 
 // transformed filters of a layer, prepared ahead of its passes (e.g. for all layers on a side stream right after the

@@ -157,6 +157,22 @@ class ConvLayer(AbstractLayer):
                                         stride=self.stride[0], pad=self.pad, s_real=self.filter_shape[3],
                                         logical=self._logical(), cache=cache)
 
+    def forward_folded(self, ctx, bn, add=None, relu=False, out_act=None):
+        """inference only: this convolution with the batch-norm layer behind it folded into its filters (recomputed
+        when the weights change), residual `add` and ReLU in the epilogue; writes the batch norm's output"""
+        cache = self._cache()
+        cache["train"] = False
+        ent = cache.get("fold")
+        if ent is None or ent[0] != ops.WEIGHTS_VERSION or ent[1] is not bn:
+            w_f, b_f = ops.bn_fold(self._w(), self.beta.dev if self.use_bias else None, bn.omega.dev, bn.beta.dev,
+                                   bn.mean.dev, bn.stdinv.dev, bn.eps)
+            ent = cache["fold"] = (ops.WEIGHTS_VERSION, bn, w_f, b_f)
+        y = ops.conv_fwd(self.input.data, ent[2], bias=ent[3], add=add, stride=self.stride[0], pad=self.pad,
+                         s_real=self.filter_shape[3], logical=self._logical(), cache=cache, relu=relu)
+        self.output.data = y
+        (out_act if out_act is not None else bn.output).data = y
+        return y
+
     def backward(self, ctx):
         dy = self.output.grad
         x = self.input.data

@@ -122,7 +122,42 @@ class ResnetLayer(AbstractLayer):
     def _shortcut(self):
         return self.layers[self.n_main:]
 
+    def _fold_plan(self):
+        """inference: [(conv, bn, relu)] of the main path and of the shortcut when every batch norm sits directly behind
+        a convolution (the `original` blocks with fused BN-ReLU), else None"""
+        if "pre-activation" in self.version or not self.bn_json_param.get("enabled", True):
+            return None
+        main, sc = self._main(), self._shortcut()
+
+        def pairs(ls):
+            out, i = [], 0
+            while i < len(ls):
+                if ls[i].type_name != "conv" or i + 1 >= len(ls) or ls[i + 1].type_name not in ("batchnorm", "batchnorm-relu") \
+                        or not ls[i].enabled or not ls[i + 1].enabled:
+                    return None
+                out.append((ls[i], ls[i + 1], ls[i + 1].type_name == "batchnorm-relu"))
+                i += 2
+            return out
+        pm, ps = pairs(main), pairs(sc)
+        if pm is None or ps is None or pm[-1][2]:
+            return None
+        return pm, ps
+
     def forward(self, ctx):
+        from . import get_train
+        from .. import ops
+        plan = None if get_train() or not ops.INFER_FOLD else self.__dict__.setdefault("_plan", self._fold_plan())
+        if plan:
+            pm, ps = plan
+            for conv, bn, relu in pm[:-1]:
+                conv.forward_folded(ctx, bn, relu=relu)
+            for conv, bn, relu in ps:
+                conv.forward_folded(ctx, bn, relu=relu)
+            res = ps[-1][1].output.data if ps else self.input.data
+            relu = self.activation in ("relu", "relu-safe")
+            assert relu or self.activation == "none", self.activation
+            pm[-1][0].forward_folded(ctx, pm[-1][1], add=res, relu=relu, out_act=self.output)
+            return
         main, sc = self._main(), self._shortcut()
         for l in main[:-1]:
             l.forward(ctx)

@@ -314,7 +314,19 @@ class ModelCNN:
             a.grad = None
         self._upload_input(data_x)
         ctx = StepContext(self)
+        from .. import ops
+        fold = (not train) and ops.INFER_FOLD
+        skip_next = False
         for i, layer in enumerate(self.layers[1:]):
+            if skip_next:          # a batch norm folded into the convolution in front of it (inference)
+                skip_next = False
+                continue
+            if fold and layer.type_name == "conv" and layer.enabled and i + 2 < len(self.layers):
+                nxt = self.layers[i + 2]
+                if nxt.type_name in ("batchnorm", "batchnorm-relu") and nxt.enabled and nxt.input is layer.output:
+                    layer.forward_folded(ctx, nxt, relu=nxt.type_name == "batchnorm-relu")
+                    skip_next = True
+                    continue
             if train and data_m is not None:
                 layer.prepare_target(ctx, self, data_x, data_m)
             layer.forward(ctx)

@@ -148,18 +148,18 @@ def _tune_first(mode, g, a, b, bias, add, out, ws):
     return True
 
 
-def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, logical=None, cache=None):
+def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, logical=None, cache=None, relu=False):
     g = conv_geom(x.shape, w.shape, stride, pad, s_real)
     N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
     y = out if out is not None else empty(N, OH, OW, K)
     _tune_first(0, g, x, w, bias, add, y, None)
 
     def direct():
-        check(_L().denet_conv_fwd(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), *g, stream_ptr()), "conv_fwd")
+        check(_L().denet_conv_fwd_act(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), int(relu), *g, stream_ptr()), "conv_fwd")
 
     # the implementation is fixed on the first call; the timed candidates scribble over `y`, so the call always ends
     # with a launch of the chosen one (run-to-run determinism)
-    tile = _wino_tile(0, g, direct, lambda t: conv_wino_fwd(x, w, bias, add, out=y, tile=t))
+    tile = _wino_tile(0, g, direct, lambda t: conv_wino_fwd(x, w, bias, add, out=y, tile=t, relu=relu))
     if tile:
         if PROFILE is not None:
             PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])     # the FLOPs its batched GEMM really executes
@@ -170,8 +170,8 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
             if u is None and not cache.get("train"):
                 # inference: the filters do not change between calls - transform them once per weights version
                 ent = cache.get("u_test")
-                if ent is None or ent[0] != tile or ent[2] != WEIGHTS_VERSION:
-                    ent = cache["u_test"] = (tile, conv_wino_filter(w, tile, dgrad=False), WEIGHTS_VERSION)
+                if ent is None or ent[0] != tile or ent[2] != WEIGHTS_VERSION or ent[3] != w.data_ptr():
+                    ent = cache["u_test"] = (tile, conv_wino_filter(w, tile, dgrad=False), WEIGHTS_VERSION, w.data_ptr())
                 u = ent[1]
             # the filter gradient of this layer uses the same transformed input when it runs with the same tile
             if cache.get("train") and _WINO.get((2, g)) == tile:
@@ -180,7 +180,7 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
                 if v_keep is None or v_keep.numel() != nv:
                     v_keep = cache["V"] = torch.empty(nv, dtype=torch.float32, device="cuda")
                 cache["V_tile"] = tile
-        return conv_wino_fwd(x, w, bias, add, out=y, tile=tile, u=u, v_keep=v_keep)
+        return conv_wino_fwd(x, w, bias, add, out=y, tile=tile, u=u, v_keep=v_keep, relu=relu)
     if cache is not None:
         cache["fwd_tile"] = 0
     if PROFILE is not None:
@@ -327,13 +327,13 @@ def _wino_ws(tile, N, H, W, C, K):
     return WS.get("wino_side" if _ON_WGRAD_STREAM else "wino", _L().denet_conv_wino_workspace_bytes(tile, N, H, W, C, K))
 
 
-def conv_wino_fwd(x, w, bias=None, add=None, out=None, tile=2, u=None, v_keep=None):
+def conv_wino_fwd(x, w, bias=None, add=None, out=None, tile=2, u=None, v_keep=None, relu=False):
     N, H, W, C = x.shape
     K = w.shape[0]
     y = out if out is not None else empty(N, H, W, K)
     ws = _wino_ws(tile, N, H, W, C, K)
-    check(_L().denet_conv_wino_fwd(ptr(x), ptr(w), ptr(u), ptr(v_keep), ptr(bias), ptr(add), ptr(y), ptr(ws), ws.numel(),
-                                   tile, N, H, W, C, K, stream_ptr()), "conv_wino_fwd")
+    check(_L().denet_conv_wino_fwd_act(ptr(x), ptr(w), ptr(u), ptr(v_keep), ptr(bias), ptr(add), ptr(y), int(relu), ptr(ws),
+                                       ws.numel(), tile, N, H, W, C, K, stream_ptr()), "conv_wino_fwd")
     return y
 
 
@@ -440,6 +440,18 @@ def bump_weights_version():
     """invalidates what inference derives from the weights once and keeps: BN test coefficients, transformed filters"""
     global WEIGHTS_VERSION
     WEIGHTS_VERSION += 1
+
+
+INFER_FOLD = os.environ.get("DENET_INFER_FOLD", "1") != "0"      # inference: batch norm folded into the convolution in front
+
+
+def bn_fold(w, conv_bias, gamma, beta, run_mean, run_stdinv, eps):
+    """filters / bias of the convolution that equals conv(x, w) + conv_bias followed by test-mode batch norm"""
+    K = w.shape[0]
+    w_f, b_f = torch.empty_like(w), empty(K)
+    check(_L().denet_bn_fold(ptr(w), ptr(conv_bias), ptr(gamma), ptr(beta), ptr(run_mean), ptr(run_stdinv), float(eps),
+                             ptr(w_f), ptr(b_f), K, w.numel() // K, stream_ptr()), "bn_fold")
+    return w_f, b_f
 
 
 def bn_fwd_test(x, gamma, beta, run_mean, run_stdinv, eps=1e-5, relu=False, res=None, out=None, cache=None):

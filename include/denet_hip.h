@@ -65,6 +65,12 @@ int denet_host_detect_targets(const double* gt_host, const int* gt_off_host, con
  *      output) is summed in the epilogue: residual / skip accumulation without an extra pass.          */
 int denet_conv_fwd(const float* x, const float* w, const float* bias, const float* add, float* y, int N, int H, int W,
                    int C, int K, int R, int S, int S_real, int stride, int pad, int OH, int OW, hipStream_t stream);
+/* the same with an activation in the epilogue: y = act(conv(x, w) + bias + add), relu != 0: max(., 0). Used at
+ * inference, where a batch-norm layer behind the convolution is folded into its filters (denet_bn_fold) and the ReLU /
+ * residual add of batch_norm_relu.py:34-48, resnet.py:109-113 ride in the convolution's epilogue. */
+int denet_conv_fwd_act(const float* x, const float* w, const float* bias, const float* add, float* y, int relu, int N, int H,
+                       int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH, int OW,
+                       hipStream_t stream);
 int denet_conv_dgrad(const float* dy, const float* w, const float* add, float* dx, int N, int H, int W, int C, int K,
                      int R, int S, int S_real, int stride, int pad, int OH, int OW, hipStream_t stream);
 size_t denet_conv_wgrad_workspace_bytes(int N, int C, int K, int R, int S, int OH, int OW);
@@ -85,6 +91,9 @@ int denet_conv_wino_filter(const float* w, float* u, int tile, int dgrad, int C,
 int denet_conv_wino_fwd(const float* x, const float* w, const float* u_cached, float* v_keep, const float* bias,
                         const float* add, float* y, float* workspace, size_t workspace_bytes, int tile, int N, int H, int W,
                         int C, int K, hipStream_t stream);
+int denet_conv_wino_fwd_act(const float* x, const float* w, const float* u_cached, float* v_keep, const float* bias,
+                            const float* add, float* y, int relu, float* workspace, size_t workspace_bytes, int tile, int N,
+                            int H, int W, int C, int K, hipStream_t stream);
 int denet_conv_wino_dgrad(const float* dy, const float* w, const float* u_cached, const float* add, float* dx,
                           float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
                           hipStream_t stream);
@@ -122,6 +131,10 @@ int denet_bn_fwd_train(const float* x, const float* res, float* y, const float* 
 int denet_bn_fwd_test(const float* x, const float* res, float* y, const float* gamma, const float* beta,
                       const float* run_mean, const float* run_stdinv, float* coef, int coef_ready, long M, int C, float eps,
                       int relu, hipStream_t stream);
+/* inference: conv(x, w) + b followed by test-mode batch norm == conv(x, w_out) + b_out (batch_norm.py:50-52 incl. its
+ * double epsilon). w: [K][per_k] KRSC filters, conv_bias: [K] or NULL. */
+int denet_bn_fold(const float* w, const float* conv_bias, const float* gamma, const float* beta, const float* run_mean,
+                  const float* run_stdinv, float eps, float* w_out, float* b_out, int K, long per_k, hipStream_t stream);
 /* relu mask of the backward: y > 0 if y is given; if y is NULL it is recomputed from x (needs beta) — the fused
  * residual blocks pass y, plain BNA layers pass NULL and save one pass over the activation                       */
 int denet_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,

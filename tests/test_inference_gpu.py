@@ -191,3 +191,47 @@ def test_denet34_get_detections_vs_oracle(hip, soft):
             assert cls == int(r[1]) and np.array_equal(np.array(box, np.float32), r[2:])
             assert abs(pr - r[0]) <= 2e-6 * r[0]
     assert total > 0, "no detections: the test exercises nothing"
+
+
+def test_inference_bn_folding_matches_unfolded(hip):
+    """inference folds every batch norm that sits directly behind a convolution into that convolution's filters
+    (denet_bn_fold) and moves ReLU / residual add into its epilogue (denet_conv_fwd_act): same activations as the
+    layer-by-layer test-mode pass to rounding, for top-level pairs and inside the residual blocks"""
+    from denet_amd import ops
+    from tests.test_parity_gpu import _warm_corner_head
+    B, IMG = 2, 128
+    model = zoo.denet34(B, "skip", IMG, class_num=20, seed=1)
+    rng = np.random.RandomState(5)
+    _warm_corner_head(model, 4.0, 0.3)
+    # non-trivial running statistics and affine parameters so that the fold has something to get wrong
+    for l in model_cnn_walk(model):
+        if l.type_name in ("batchnorm", "batchnorm-relu"):
+            C = l.mean.value.shape[0]
+            l.mean.set_value(rng.normal(0, 0.2, C).astype(np.float32))
+            l.stdinv.set_value(rng.uniform(0.7, 1.4, C).astype(np.float32))
+            l.omega.set_value(rng.uniform(0.5, 1.5, C).astype(np.float32))
+            l.beta.set_value(rng.normal(0, 0.2, C).astype(np.float32))
+    x, _ = zoo.synthetic_batch(B, IMG, seed=2)
+    outs = []
+    saved = ops.INFER_FOLD
+    try:
+        for fold in (False, True):
+            ops.INFER_FOLD = fold
+            for l in model_cnn_walk(model):
+                l.__dict__.pop("_plan", None)
+            model.forward(x, None, train=False)
+            dnc = [l for l in model.layers if l.type_name == "denet-corner"][0]
+            res = [l for l in model.layers if l.type_name == "resnet"]
+            outs.append([ops.nhwc_to_nchw(a.output.data, a.output_shape[1]).cpu().numpy() for a in (res[0], res[7], res[-1])] +
+                        [dnc.corner_pr.cpu().numpy(), ops.nhwc_to_nchw(model.layers[2].output.data, 64).cpu().numpy()])
+    finally:
+        ops.INFER_FOLD = saved
+    for a, b in zip(*outs):
+        scale = float(np.abs(a).max())
+        assert float(np.abs(a - b).max()) <= 2e-5 * scale + 1e-6, (float(np.abs(a - b).max()), scale)
+    assert float(np.abs(outs[0][0]).max()) > 0
+
+
+def model_cnn_walk(model):
+    from denet_amd.model.model_cnn import walk_layers
+    return walk_layers(model.layers)
