@@ -10,9 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # no test of this suite runs longer than a minute: a hang (worker pool, device) must fail, not eat the GPU box's time
+    # no test of this suite runs longer than a minute or two (a fresh box may page the image in for another minute or two): a hang (worker pool, device) must fail, not eat the GPU box's time
     if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
-        config.option.timeout = 300
+        config.option.timeout = 900
 
 
 @pytest.fixture(scope="session")
