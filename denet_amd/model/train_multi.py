@@ -8,8 +8,10 @@ per GPU under `torch.distributed.run`, gradients all-reduced over RCCL while the
 
 Same flags as model-train plus `--batch-size-factor F`. Like the reference (train_multi.py:44-46) every rank shuffles the
 image list with the seed `seed + epoch`, so all ranks see the same order. One global iteration consumes `F x world` batches
-in the reference's order (train_multi.py:116-119: for f in range(F): for worker: next batch), i.e. rank r's f-th local step
-takes batch `f * world + r` of the iteration.
+in the reference's order (train_multi.py:113-119: `for worker: for _ in range(F): index += 1`), i.e. worker r takes the F
+CONSECUTIVE batches `r * F ... r * F + F - 1` of the iteration. Like the reference's export(batch_size = world x B x F)
+(train_multi.py:53-55, dataset/__init__.py:349-354) the last partial iteration of a subset is padded with samples drawn by
+`random.randint(0, len - 1)` - every rank draws all of them, so the random streams stay in step.
   F = 1: gradients are all-reduced inside every step (equal to the reference's parameter averaging for sgd / nesterov);
   F > 1: what the shipped recipes run (papers/dss/denet34.sh:43 `--batch-size-factor 2` without --use-acc-mode): every rank
          takes F full local steps, then parameters, momentum and BN statistics are averaged over the ranks
@@ -36,14 +38,19 @@ class _Shard:
         d = self.data
         lo = subset * d.subset_size
         hi = min((subset + 1) * d.subset_size, d.subset_total_size)
-        images = d.images[lo:hi]
+        images = list(d.images[lo:hi])
         B = self.batch_size
         per_it = self.world * self.factor             # batches of one global iteration
-        n_it = math.floor(len(images) / (per_it * B))  # whole iterations only: every rank runs the same step count
+        n = len(images)
+        if n == 0:
+            return []
+        n_it = math.ceil(n / (per_it * B))
+        # export() pads to a multiple of world x B x F with random samples of the subset (dataset/__init__.py:350-354)
+        images += [images[random.randint(0, n - 1)] for _ in range(n_it * per_it * B - n)]
         mine = []
         for it in range(n_it):
             for f in range(self.factor):
-                k = it * per_it + f * self.world + self.rank
+                k = it * per_it + self.rank * self.factor + f
                 mine += images[k * B:(k + 1) * B]
         return mine
 

@@ -42,13 +42,19 @@ class DataParallel:
     def broadcast_state(self, model):
         """identical initial state on every rank (reference: model_write of the shared state to every worker,
         train_multi.py:102, shared.py:90-92)"""
-        self.dist.broadcast(model.P, src=0)
-        self.dist.broadcast(model.M, src=0)
-        self.dist.broadcast(model.S, src=0)
+        for t in self._state(model):
+            self.dist.broadcast(t, src=0)
         import torch
         if torch.cuda.is_available():
             from .. import ops
             ops.bump_weights_version()
+
+    @staticmethod
+    def _state(model):
+        """every update target the reference averages (shared.py:105-119 walks model.updates: parameters, momentum, the
+        adam second moments once they exist, BN running statistics)"""
+        v = getattr(model, "V", None)
+        return [model.P, model.M, model.S] + ([v] if v is not None else [])
 
     def make_buckets(self, layer_weight_range):
         """layer_weight_range: [(layer, lo, hi)] in layer order. Returns [(lo, hi, trigger_layer)]: contiguous
@@ -129,10 +135,11 @@ class DataParallel:
         if self.world_size == 1 and not self.force_collectives:
             return
         d = self.dist
-        work = [d.all_reduce(t, op=d.ReduceOp.SUM, async_op=True) for t in (model.P, model.M, model.S)]
+        state = self._state(model)
+        work = [d.all_reduce(t, op=d.ReduceOp.SUM, async_op=True) for t in state]
         for w in work:
             w.wait()
-        for t in (model.P, model.M, model.S):
+        for t in state:
             self._scale(t, 1.0 / self.world_size)
         import torch
         if torch.cuda.is_available():

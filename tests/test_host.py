@@ -445,8 +445,10 @@ def test_model_modify_cli_replays_the_denet_recipe(tmp_path):
 
 
 def test_train_multi_sharding():
-    """model-train-multi: a global batch is world x batch consecutive samples; rank r takes the r-th slice; only whole
-    global batches are used so that every rank runs the same number of steps (the all-reduce would hang otherwise)"""
+    """model-train-multi: a global iteration is world x F batches of consecutive samples; worker r takes the F consecutive
+    batches r*F .. r*F+F-1 (train_multi.py:113-119); the last partial iteration is padded with random.randint draws like
+    export(batch_size = world x B x F) (train_multi.py:53-55, dataset/__init__.py:349-354), identically on every rank"""
+    import random
     from denet_amd.model.train_multi import _Shard
 
     class Data:
@@ -455,19 +457,30 @@ def test_train_multi_sharding():
     world, B = 3, 4
     shards = [_Shard(Data, r, world, B) for r in range(world)]
     for subset, (lo, hi) in enumerate([(0, 23), (23, 41)]):
-        parts = [s.images_of_subset(subset) for s in shards]
-        n_glob = (hi - lo) // (world * B)
+        parts = []
+        for s in shards:
+            random.seed(5)
+            parts.append(s.images_of_subset(subset))
+        n = hi - lo
+        n_glob = -(-n // (world * B))
         assert all(len(p) == n_glob * B for p in parts)
-        flat = sorted(sum(parts, []))
-        assert flat == list(range(lo, lo + n_glob * world * B))          # disjoint, in order, nothing skipped
+        # the reference's export: first n samples in order, then randint pads
+        random.seed(5)
+        full = list(range(lo, hi)) + [lo + random.randint(0, n - 1) for _ in range(n_glob * world * B - n)]
         for k in range(n_glob):
             for r in range(world):
-                assert parts[r][k * B:(k + 1) * B] == list(range(lo + k * world * B + r * B, lo + k * world * B + (r + 1) * B))
-    # --batch-size-factor 2 (train_multi.py:116-119): an iteration = F x world batches, rank r's f-th local step takes
-    # batch f * world + r
+                assert parts[r][k * B:(k + 1) * B] == full[(k * world + r) * B:(k * world + r + 1) * B]
+    # --batch-size-factor 2: an iteration = world x F batches, worker r takes batches r*F, r*F+1 of it
     world, B, F = 2, 3, 2
     Data.subset_size, Data.subset_total_size, Data.images = 40, 40, list(range(40))
-    parts = [_Shard(Data, r, world, B, F).images_of_subset(0) for r in range(world)]
-    assert parts[0][:6] == [0, 1, 2, 6, 7, 8] and parts[1][:6] == [3, 4, 5, 9, 10, 11]
-    assert len(parts[0]) == len(parts[1]) == (40 // (world * F * B)) * F * B
-    assert sorted(parts[0] + parts[1]) == list(range(36))
+    parts = []
+    for r in range(world):
+        random.seed(9)
+        parts.append(_Shard(Data, r, world, B, F).images_of_subset(0))
+    assert parts[0][:6] == [0, 1, 2, 3, 4, 5] and parts[1][:6] == [6, 7, 8, 9, 10, 11]
+    assert parts[0][6:12] == [12, 13, 14, 15, 16, 17] and parts[1][6:12] == [18, 19, 20, 21, 22, 23]
+    assert len(parts[0]) == len(parts[1]) == -(-40 // (world * F * B)) * F * B
+    random.seed(9)
+    pads = [random.randint(0, 39) for _ in range(48 - 40)]
+    assert (parts[0] + parts[1])[:0] == [] and sorted(parts[0][:18] + parts[1][:18]) == list(range(36))
+    assert parts[0][18:] == [36, 37, 38, 39] + pads[:2] and parts[1][18:] == pads[2:]
