@@ -9,6 +9,8 @@ The fixtures hold inputs and the reference's outputs for the host helpers that s
   ndarray_unpack   denet/common/__init__.py:125-133   (flat target vectors, model_cnn.py:560, denet_detect.py:247)
   overlap / overlap_rel / overlap_iou   :91-110       (RoI coverage, denet_sparse.py:176)
   numpy_to_json / json_to_gz            denet/common/json_util.py:8-37  (the .mdl.gz parameter codec)
+  multi.shared.ModelUpdate.set_mean_*   denet/multi/shared.py:105-119   (the parameter averaging of model-train-multi,
+                                        train_multi.py:131-137; the build's DataParallel.average_state must give the same mean)
 Only data is written: no reference source text."""
 import json
 import os
@@ -86,6 +88,30 @@ x, metas, n = ds.export(4)
 fix["dataset"] = {"samples": [a.reshape(-1).tolist() for a in samples], "seed": 42, "batch": 4, "size": n,
                   "ids": [m["id"] for m in metas], "x_shape": list(x.shape), "x_sum": float(x.astype(numpy.float64).sum()),
                   "next_random": random.random()}
+
+# the reference's multi-GPU exchange: every worker's update targets are summed into a zeroed ModelUpdate in worker order and
+# multiplied by 1/N (shared.py:105-119: fill 0, add_array per worker, mul_value(1.0 / N))
+import tempfile  # noqa: E402
+import denet.multi.shared as SH  # noqa: E402
+dims = [(3, 5), (17,), (2, 2, 3)]
+with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as tf:
+    json.dump({"input": [2, 3, 8, 8], "output": [2, 10], "dims": [{"shape": list(d)} for d in dims]}, tf)
+fix["multi_mean"] = []
+for workers in (2, 3):
+    ups = []
+    for wk in range(workers):
+        u = SH.ModelUpdate(tf.name)
+        for a, d in zip(u.updates, dims):
+            a.get_array()[...] = (rng.randn(*d) * 10 ** rng.uniform(-3, 3)).astype(numpy.float32)
+        ups.append(u)
+    mean = SH.ModelUpdate(tf.name)
+    mean.set_mean_init()
+    for u in ups:
+        mean.set_mean_update(u)
+    mean.set_mean_finish()
+    fix["multi_mean"].append({"workers": [[a.get_array().reshape(-1).tolist() for a in u.updates] for u in ups],
+                              "mean": [a.get_array().reshape(-1).tolist() for a in mean.updates]})
+os.unlink(tf.name)
 
 with open(os.path.join(HERE, "common_fixtures.json"), "w") as f:
     json.dump(fix, f)

@@ -342,13 +342,21 @@ m.P = torch.full((8,), 1.0 + rank); m.M = torch.full((8,), 10.0 * rank); m.S = t
 dp.average_state(m)
 assert torch.allclose(m.P, torch.full((8,), 1.5)) and torch.allclose(m.M, torch.full((8,), 5.0))
 assert torch.allclose(m.S, torch.full((32,), 2.5))
+# the same averaging against the REFERENCE's own (denet.multi.shared.ModelUpdate.set_mean_*, fixture generated by importing
+# it: tests/golden/make_common_fixtures.py): two workers, bit-identical mean
+import json
+fx = json.load(open(os.path.join(%r, "tests", "golden", "common_fixtures.json")))["multi_mean"][0]
+flat = lambda parts: torch.tensor([v for p in parts for v in p], dtype=torch.float32)
+m.P = flat(fx["workers"][rank]); m.M = m.P.clone(); m.S = m.P.clone()
+dp.average_state(m)
+assert torch.equal(m.P, flat(fx["mean"])), (m.P - flat(fx["mean"])).abs().max()
 print("rank", rank, "ok")
 '''
 
 
 def test_data_parallel_gloo_world2(tmp_path):
     script = tmp_path / "dp_worker.py"
-    script.write_text(DP_WORKER % ROOT)
+    script.write_text(DP_WORKER % (ROOT, ROOT))
     port = 29500 + (os.getpid() % 1000)
     procs = []
     for r in range(2):

@@ -41,6 +41,180 @@ def test_build_samples_known_answers():
             assert sorted(tuple(g[1]) for g in got) == sorted(tuple(b) for b in case["expect_boxes"]), case["name"]
 
 
+def _random_corner_map(rng, B, Cn, H, W, mu, quantise=0):
+    """log-probability maps [B,2,Cn,H,W] from random logits; quantise > 0 rounds the logits to that many levels so that
+    exactly equal scores (tie groups) occur"""
+    z = rng.normal(mu, 2.0, (B, Cn, H, W))
+    if quantise:
+        z = np.round(z * quantise) / quantise
+    p = 1.0 / (1.0 + np.exp(-z))
+    return np.ascontiguousarray(np.stack([np.log1p(-p), np.log(p)], axis=1).astype(np.float32))
+
+
+def _assert_same_ranking(cpp_rows, cpp_boxes, naive_full, count, tag):
+    """cpp: the C++ oracle's output rows (pr, box fp32) + integer boxes; naive_full: the naive implementation's ranked list
+    WITHOUT the final cut. Scores must agree bit for bit position by position; boxes are compared per tie group (the
+    reference's std::partial_sort leaves the order inside a group, and the members of a group cut by the top-K limit,
+    unspecified)."""
+    from oracle import build_samples_naive as NV
+    want = naive_full[:count]
+    assert len(cpp_rows) == len(want), (tag, len(cpp_rows), len(want))
+    for i, (row, w) in enumerate(zip(cpp_rows, want)):
+        assert np.float32(row[0]) == w[0], (tag, i, row[0], w[0])
+    full_groups = NV.tie_groups(naive_full)
+    pos = 0
+    for score, members in full_groups:
+        if pos >= len(cpp_rows):
+            break
+        n = min(len(members), len(cpp_rows) - pos)
+        got = {tuple(int(v) for v in cpp_boxes[pos + k]) for k in range(n)}
+        assert len(got) == n, (tag, "duplicate boxes inside a tie group")
+        if n == len(members):
+            assert got == members, (tag, pos, score)
+        else:
+            assert got <= members, (tag, pos, score)        # the group straddles the cut: any n members
+        for k in range(n):
+            x0, y0, x1, y1 = (int(v) for v in cpp_boxes[pos + k])
+            b = cpp_rows[pos + k][1:5]
+            H, W = _assert_same_ranking.hw
+            assert tuple(np.float32(v) for v in b) == (np.float32(x0 / W), np.float32(y0 / H), np.float32((x1 + 1) / W),
+                                                      np.float32((y1 + 1) / H)), (tag, pos + k)
+        pos += n
+
+
+def test_build_samples_cpp_vs_independent_naive_implementation():
+    """oracle/build_samples.cc (the checker of the GPU RoI proposal) against oracle/build_samples_naive.py, a
+    second implementation written separately from denet_sparse.cc:271-557 (dict de-dup, sorted + explicit tie groups):
+    several hundred random maps - sparse, dense, > max_corners per type (truncation re-orders the corner lists,
+    :526-530), local_max 0..2 (:474-487), C = 5 (:374-466), quantised maps with exact score ties."""
+    from oracle import build_samples_naive as NV
+    rng = np.random.RandomState(20260928)
+    n_cases = 0
+    for case in range(260):
+        Cn = 5 if case % 5 == 4 else 4
+        H = int(rng.randint(6, 21))
+        W = int(rng.randint(6, 21))
+        B = 1 + case % 2
+        mu = [-3.5, -2.5, -1.5, -0.5][case % 4]
+        quant = 2 if case % 7 == 3 else 0
+        local_max = case % 3
+        max_corners = [1024, 1024, 12, 5][(case // 3) % 4]
+        sample_num = [24, 6, 3][(case // 2) % 3]
+        thr = [0.01, 0.05, 0.3][(case // 5) % 3]
+        pr = _random_corner_map(rng, B, Cn, H, W, mu, quant)
+        if quant and max_corners < 1024:
+            max_corners = 1024          # ties at the corner truncation cut leave the kept SET unspecified in the reference
+        out, box, absd, cnt = OM.oracle_build_samples_raw(pr, thr, sample_num, max_corners, local_max, 1.0)
+        _assert_same_ranking.hw = (H, W)
+        for b in range(B):
+            corners = [NV.find_corners(pr, b, ci, NV._logf(np.float32(thr)), max_corners, local_max) for ci in range(Cn)]
+            full = NV.rank(NV.search_corners(pr, b, corners))
+            _assert_same_ranking(out[b, :cnt[b]], box[b, :cnt[b]], full, sample_num * sample_num,
+                                 (case, b, Cn, H, W, mu, quant, local_max, max_corners, sample_num, thr))
+            n_cases += 1
+    assert n_cases >= 380
+
+
+def test_build_samples_clustering_cpp_vs_naive():
+    """apply_cluster (denet_sparse.cc:165-242) of the C++ oracle against the naive implementation: continuous random maps
+    (no score ties, so the result is fully specified): identical sample sequences"""
+    from oracle import build_samples_naive as NV
+    rng = np.random.RandomState(77)
+    ran = 0
+    for case in range(40):
+        H = W = int(rng.randint(10, 19))
+        sample_num = [3, 4, 5][case % 3]
+        cthr = [0.3, 0.5, 0.7, 0.9][case % 4]
+        pr = _random_corner_map(rng, 1, 4, H, W, -1.5)
+        out, box, absd, cnt = OM.oracle_build_samples_raw(pr, 0.05, sample_num, 1024, 0, cthr)
+        want = NV.build_samples(pr, 0.05, sample_num, 1024, 0, cthr)[0]
+        plain = NV.build_samples(pr, 0.05, sample_num, 1024, 0, 1.0)[0]
+        scores = [float(w[0]) for w in want]
+        if len(set(scores)) != len(scores):
+            continue
+        ran += want != plain
+        assert cnt[0] == len(want), (case, cnt[0], len(want))
+        for i, w in enumerate(want):
+            assert np.float32(out[0, i, 0]) == w[0], (case, i)
+            assert tuple(int(v) for v in box[0, i]) == w[1], (case, i)
+    assert ran >= 20         # clustering really changed the selection in most cases
+
+
+def test_build_samples_hand_derived_known_answers():
+    """Known answers derived BY HAND from denet_sparse.cc (no implementation involved in the expectation): both the C++
+    oracle and the naive implementation must reproduce them."""
+    from oracle import build_samples_naive as NV
+    lo, hi = 1e-4, 0.9
+
+    def run(corners, H=8, W=8, Cn=4, thr=0.01, sample_num=24, max_corners=1024, local_max=0):
+        case = {"H": H, "W": W, "Cn": Cn, "default_p": lo, "corners": corners}
+        pr = _corner_map(case)
+        out, box, absd, cnt = OM.oracle_build_samples_raw(pr, thr, sample_num, max_corners, local_max, 1.0)
+        cpp = [tuple(int(v) for v in box[0, i]) for i in range(cnt[0])]
+        nv = [s[1] for s in NV.build_samples(pr, thr, sample_num, max_corners, local_max, 1.0)[0]]
+        return cpp, nv, pr
+
+    def c(t, x, y, p=hi):
+        return {"type": t, "x": x, "y": y, "p": p}
+
+    # (1) duplicate through both generators: TL(1,1) x BR(5,6) (:333-352) and TR(x=5,y=1) x BL(x=1,y=6) (:358-373) describe
+    # the same box (1,1,5,6); the 64-bit key (:311-318) is already in the map when the second loop reaches it (:367) ->
+    # exactly one sample
+    cpp, nv, _ = run([c(0, 1, 1), c(3, 5, 6), c(1, 5, 1), c(2, 1, 6)])
+    assert cpp == nv == [(1, 1, 5, 6)]
+
+    # (2) degenerate pairs are skipped (:343 `x1 <= x0 || y1 <= y0`): BR in the same column / the same row / above-left
+    cpp, nv, _ = run([c(0, 3, 3), c(3, 3, 6), c(3, 6, 3), c(3, 1, 1)])
+    assert cpp == nv == []
+
+    # (3) ranking (:78, :547): score = 1/(1+exp|pr_f - pr_t|), pr_f - pr_t = sum over the 4 cells of log(1-p) - log(p).
+    # The TR / BL cells of these boxes carry the default p = 1e-4 (+9.21 each), the TL cell p = .9 (-2.197); a BR cell at
+    # p = .9 adds -2.197 (total 14.03), at p = .5 adds 0 (total 16.22). Smaller |.| = larger score: the box through the
+    # p = .9 BR corner (6,6) ranks first although it is generated second (BR inner loop in raster order: (4,4) before (6,6))
+    cpp, nv, pr = run([c(0, 1, 1), c(3, 4, 4, 0.5), c(3, 6, 6, hi)])
+    assert cpp == nv == [(1, 1, 6, 6), (1, 1, 4, 4)]
+
+    # (4) generation order on exact ties (:333-352: TL outer in raster order y-major, BR inner): four boxes whose corner
+    # cells all carry p = hi and whose other two cells (TR, BL planes) carry the default -> four identical scores. The
+    # naive implementation keeps generation order on ties (stable sort): TL(1,1)xBR(5,5), TL(1,1)xBR(6,6), TL(2,2)xBR(5,5),
+    # TL(2,2)xBR(6,6); the C++ oracle may permute them (std::partial_sort) but must return the same set
+    cpp, nv, _ = run([c(0, 1, 1), c(0, 2, 2), c(3, 5, 5), c(3, 6, 6)])
+    assert nv == [(1, 1, 5, 5), (1, 1, 6, 6), (2, 2, 5, 5), (2, 2, 6, 6)]
+    assert sorted(cpp) == sorted(nv)
+
+    # (5) corner truncation (:526-530): three TL candidates, max_corners = 2 -> the two with the highest log-probability
+    # survive ((1,1) p=.9 and (3,1) p=.8; (2,1) p=.5 is dropped), so only two boxes are produced
+    cpp, nv, _ = run([c(0, 1, 1, 0.9), c(0, 2, 1, 0.5), c(0, 3, 1, 0.8), c(3, 6, 6, 0.9)], max_corners=2)
+    assert sorted(cpp) == sorted(nv) == [(1, 1, 6, 6), (3, 1, 6, 6)]
+
+    # (6) top-K cut (:547-549): sample_num = 1 keeps the single best box of case (3)
+    cpp, nv, _ = run([c(0, 1, 1), c(3, 4, 4, 0.5), c(3, 6, 6, hi)], sample_num=1)
+    assert cpp == nv == [(1, 1, 6, 6)]
+
+    # (7) local maximum window (:474-487) is [y-l, y+l) x [x-l, x+l) after clipping the upper bound to size-1: with l = 1 a
+    # stronger neighbour at (x-1, y-1) suppresses the corner, a stronger neighbour at (x+1, y+1) does not
+    cpp, nv, _ = run([c(0, 2, 2, 0.5), c(0, 1, 1, 0.9), c(3, 6, 6)], local_max=1)
+    assert sorted(cpp) == sorted(nv) == [(1, 1, 6, 6)]                      # (2,2) suppressed by (1,1)
+    cpp, nv, _ = run([c(0, 2, 2, 0.5), c(0, 3, 3, 0.9), c(3, 6, 6)], local_max=1)
+    assert sorted(cpp) == sorted(nv) == [(2, 2, 6, 6), (3, 3, 6, 6)]        # (3,3) is outside (2,2)'s half-open window
+
+    # (8) threshold is strict on the log-probability (:510 `log_pr > threshold`, threshold = logf(corner_threshold) :503): a
+    # corner whose fp32 log-probability equals logf(thr) exactly is NOT a corner
+    thr = 0.25
+    case = {"H": 8, "W": 8, "Cn": 4, "default_p": lo, "corners": [c(0, 1, 1, 0.9), c(3, 6, 6, 0.9), c(3, 5, 5, 0.9)]}
+    pr = _corner_map(case)
+    pr[0, 1, 3, 5, 5] = NV._logf(np.float32(thr))
+    out, box, absd, cnt = OM.oracle_build_samples_raw(pr, thr, 24, 1024, 0, 1.0)
+    nv = [s[1] for s in NV.build_samples(pr, thr, 24, 1024, 0, 1.0)[0]]
+    assert [tuple(int(v) for v in box[0, i]) for i in range(cnt[0])] == nv == [(1, 1, 6, 6)]
+
+    # (9) the score of case (1), from the formula alone (fp32 running sums in the order TL,TR,BL,BR :276-294; expf; double
+    # division :306): SURVEY 8c recorded 3.6007157e-07 from the compiled reference for P = 0.9 / 0.8 at the two corners
+    pr = _corner_map({"H": 8, "W": 8, "Cn": 4, "default_p": 1e-4, "corners": [c(0, 1, 1, 0.9), c(3, 5, 6, 0.8)]})
+    got = NV.build_samples(pr, 0.01, 24)[0]
+    assert len(got) == 1 and got[0][0] == np.float32(3.6007157e-07) and got[0][2] == (0.125, 0.125, 0.75, 0.875)
+
+
 def test_bn_known_answer():
     """the reference's own BN test block (denet/layer/batch_norm.py:131-154)"""
     np.random.seed(1002)
