@@ -143,52 +143,103 @@ __global__ __launch_bounds__(256) void sparse_fwd_kernel(const float* __restrict
         o[k] = (k == ntap * F) ? bh : (k == ntap * F + 1) ? bw : 0.f;
 }
 
-// per (image, run): the tap slots [run*32768, (run+1)*32768) of the image are sorted by (cell << 15 | slot - base)
-// ascending in LDS (bitonic, 32768 slots = 128 KiB). Runs partition the slots by range, so walking run 0, run 1, ...
-// visits the entries of a cell in ascending slot order - the same order one full sort would give.
-__global__ __launch_bounds__(1024) void sparse_sort_kernel(const int* __restrict__ taps, unsigned* __restrict__ sorted,
-                                                           int n_total) {
-    extern __shared__ __attribute__((aligned(16))) unsigned skey[];
-    constexpr int NS = 32768;
-    const int b = blockIdx.x;
-    const int base = blockIdx.y * NS;
-    const int n = min(NS, n_total - base);
-    taps += (long)b * n_total + base;
-    sorted += (long)b * n_total + base;
-    for (int i = threadIdx.x; i < NS; i += 1024)
-        skey[i] = (i < n) ? (((unsigned)taps[i] << 15) | (unsigned)i) : 0xFFFFFFFFu;
+// ---- gather gradient, step 1: the tap list of every image grouped by feature-map cell (counting sort) --------------
+// The reference scatters with atomicAdd (denet_sparse_op.py:171-212); here the (roi, tap) slots that sampled a cell are
+// listed per cell in ASCENDING SLOT ORDER and summed in that order: deterministic, no floating-point atomics.
+// A slot is s = roi * ntap + tap (n = rois_per_image * ntap per image); slots are cut into chunks of SORT_CHUNK; one
+// wave owns one chunk (B x nchunk waves fill the chip - the per-image LDS bitonic sort this replaces ran on B workgroups):
+//   sparse_count    chunk histogram over the cells (LDS integer atomics)         -> table[b][chunk][cell]
+//   sparse_offsets  per image: cell totals, exclusive scan -> cell_start[b][0..HW]; table becomes the first output
+//                   position of (chunk, cell)
+//   sparse_scatter  the wave walks its chunk in slot order, 64 slots at a time; the lanes holding the same cell are
+//                   found with one ballot per key bit (no match-any instruction on gfx950), a lane's rank among them is
+//                   a popcount below its lane id, the lowest lane advances the cell's LDS cursor: stable by construction
+constexpr int SORT_CHUNK = 2048;
+
+__global__ __launch_bounds__(64) void sparse_count_kernel(const int* __restrict__ taps, int* __restrict__ table, int n,
+                                                          int HW, int nchunk) {
+    extern __shared__ int s_hist[];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    for (int c = threadIdx.x; c < HW; c += 64) s_hist[c] = 0;
     __syncthreads();
-    for (int k = 2; k <= NS; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < NS / 2; t += 1024) {
-                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int hi = lo | j;
-                const bool up = ((lo & k) == 0);
-                const unsigned a = skey[lo], c = skey[hi];
-                if ((a > c) == up) {
-                    skey[lo] = c;
-                    skey[hi] = a;
-                }
-            }
-            __syncthreads();
+    const int lo = chunk * SORT_CHUNK, hi = min(n, lo + SORT_CHUNK);
+    const int* t = taps + (long)b * n;
+    for (int i = lo + threadIdx.x; i < hi; i += 64) atomicAdd(&s_hist[t[i]], 1);
+    __syncthreads();
+    int* row = table + ((long)b * nchunk + chunk) * HW;
+    for (int c = threadIdx.x; c < HW; c += 64) row[c] = s_hist[c];
+}
+
+// one workgroup per image; thread t owns the cells [t*per, (t+1)*per)
+__global__ __launch_bounds__(1024) void sparse_offsets_kernel(int* __restrict__ table, int* __restrict__ cell_start, int HW,
+                                                             int nchunk) {
+    __shared__ int s_part[1024];
+    const int b = blockIdx.x;
+    int* tb = table + (long)b * nchunk * HW;
+    const int per = (HW + 1023) / 1024;
+    const int c0 = threadIdx.x * per, c1 = min(HW, c0 + per);
+    int tot = 0;
+    for (int c = c0; c < c1; ++c)
+        for (int k = 0; k < nchunk; ++k) tot += tb[(long)k * HW + c];
+    s_part[threadIdx.x] = tot;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // inclusive scan of the per-thread totals
+        const int v = (threadIdx.x >= off) ? s_part[threadIdx.x - off] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int pos = s_part[threadIdx.x] - tot;
+    int* cs = cell_start + (long)b * (HW + 1);
+    for (int c = c0; c < c1; ++c) {
+        cs[c] = pos;
+        for (int k = 0; k < nchunk; ++k) {
+            const int cnt = tb[(long)k * HW + c];
+            tb[(long)k * HW + c] = pos;
+            pos += cnt;
         }
     }
-    for (int i = threadIdx.x; i < n; i += 1024) sorted[i] = skey[i];
+    if (threadIdx.x == 1023) cs[HW] = s_part[1023];
 }
 
-__device__ __forceinline__ int lower_bound_u32(const unsigned* a, int n, unsigned v) {
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (a[mid] < v) lo = mid + 1; else hi = mid;
+__global__ __launch_bounds__(64) void sparse_scatter_kernel(const int* __restrict__ taps, const int* __restrict__ table,
+                                                            int* __restrict__ order, int n, int HW, int nchunk,
+                                                            int key_bits) {
+    extern __shared__ int s_cur[];
+    const int b = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x;
+    const int* row = table + ((long)b * nchunk + chunk) * HW;
+    for (int c = lane; c < HW; c += 64) s_cur[c] = row[c];
+    __syncthreads();
+    const int lo = chunk * SORT_CHUNK, hi = min(n, lo + SORT_CHUNK);
+    const int* t = taps + (long)b * n;
+    int* o = order + (long)b * n;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int base = lo; base < hi; base += 64) {
+        const int i = base + lane;
+        const bool live = i < hi;
+        const int cell = live ? t[i] : 0;
+        unsigned long long same = __ballot(live);
+        for (int bit = 0; bit < key_bits; ++bit) {
+            const unsigned long long set = __ballot((cell >> bit) & 1);
+            same &= ((cell >> bit) & 1) ? set : ~set;
+        }
+        if (!live) same = 0;
+        const int rank = __popcll(same & below);
+        int start = 0;
+        if (live && rank == 0) {                        // lowest lane of its group: distinct cells, no conflict
+            start = s_cur[cell];
+            s_cur[cell] = start + __popcll(same);
+        }
+        const int leader = live ? (__ffsll((long long)same) - 1) : lane;
+        start = __shfl(start, leader, 64);
+        if (live) o[start + rank] = i;
     }
-    return lo;
 }
 
-// one wave per feature-map cell: sums the dy rows of every (roi, tap) that sampled this cell, in the
-// fixed order of the sorted list (deterministic replacement for the reference's atomicAdd scatter)
-__global__ __launch_bounds__(256) void sparse_bwd_kernel(const float* __restrict__ dy,
-                                                         const unsigned* __restrict__ sorted,
+// gather gradient, step 2: one wave per feature-map cell sums the dy rows of every (roi, tap) that sampled this cell, in
+// ascending slot order (deterministic replacement for the reference's atomicAdd scatter)
+__global__ __launch_bounds__(256) void sparse_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ order,
+                                                         const int* __restrict__ cell_start,
                                                          float* __restrict__ dfmap, int HW, int CP, int coff, int F,
                                                          int rois_per_image, int ntap, int KP, int zero_from,
                                                          long ncell_total) {
@@ -202,21 +253,16 @@ __global__ __launch_bounds__(256) void sparse_bwd_kernel(const float* __restrict
     const int epi = 64 / F4;  // entries per iteration
     const int e = lane / F4, f4 = lane - e * F4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    // a lane keeps ONE accumulator over all runs: the sum of a cell is the same left-to-right chain as for one run
-    for (int base = 0, k = 0; base < n; base += 32768) {
-        const unsigned* sl = sorted + (long)b * n + base;
-        const int nr = min(32768, n - base);
-        const int start = lower_bound_u32(sl, nr, (unsigned)cell << 15);
-        const int end = lower_bound_u32(sl, nr, (unsigned)(cell + 1) << 15);
-        if (e < epi) {
-            // entry j of the cell (counted over all runs) belongs to lane group j % epi
-            for (int i = start + ((e - k % epi + epi) % epi); i < end; i += epi) {
-                const unsigned slot = (sl[i] & 0x7FFFu) + (unsigned)base;
-                const int roi = slot / ntap, tap = slot - roi * ntap;
-                acc += *(const f32x4*)(dy + ((long)b * rois_per_image + roi) * KP + (long)tap * F + f4 * 4);
-            }
+    const int* cs = cell_start + (long)b * (HW + 1);
+    const int start = cs[cell], end = cs[cell + 1];
+    const int* ord = order + (long)b * n;
+    if (e < epi) {
+        // entry j of the cell belongs to lane group j % epi: a fixed left-to-right chain per group
+        for (int i = start + e; i < end; i += epi) {
+            const int slot = ord[i];
+            const int roi = slot / ntap, tap = slot - roi * ntap;
+            acc += *(const f32x4*)(dy + ((long)b * rois_per_image + roi) * KP + (long)tap * F + f4 * 4);
         }
-        k += end - start;
     }
     f32x4 tot = acc;
     for (int k = 1; k < epi; ++k) {
@@ -424,45 +470,88 @@ extern "C" int denet_sparse_fwd(const float* fmap, const float* bbox, float* out
     return DENET_OK;
 }
 
-// sorts the tap list of every image into runs (see sparse_sort_kernel); depends only on `taps`, so the host may queue
-// it on a side stream right after the forward gather, off the critical path of the backward sweep
-extern "C" int denet_sparse_sort(const int* taps, unsigned* sorted_ws, int B, int H, int W, int rois_per_image, int gs,
-                                 hipStream_t stream) {
-    DENET_CHECK_ARG(taps && sorted_ws && B > 0 && rois_per_image > 0 && gs > 0, "sparse_sort: bad arguments");
-    DENET_CHECK_ARG(H * W <= (1 << 17) - 1, "sparse_sort: feature map too large for 17-bit cell keys");
-    const int n = rois_per_image * gs * gs;
+// Workspace of denet_sparse_sort / denet_sparse_bwd: order [B][n] | cell_start [B][HW+1] | table [B][nchunk][HW] (int32)
+namespace {
+struct SortLayout {
+    int n, HW, nchunk, key_bits;
+    size_t off_start, off_table, total;   // in ints
+};
+int sort_layout(int B, int H, int W, int rois_per_image, int gs, SortLayout* L) {
+    DENET_CHECK_ARG(B > 0 && H > 0 && W > 0 && rois_per_image > 0 && gs > 0, "sparse_sort: bad arguments");
+    DENET_CHECK_ARG((long)H * W <= 32768, "sparse_sort: feature map of %d x %d cells exceeds the 32768-cell LDS cursor", H, W);
+    L->n = rois_per_image * gs * gs;
+    L->HW = H * W;
+    L->nchunk = (L->n + SORT_CHUNK - 1) / SORT_CHUNK;
+    L->key_bits = 1;
+    while ((1 << L->key_bits) < L->HW) L->key_bits++;
+    L->off_start = (size_t)B * L->n;
+    L->off_table = L->off_start + (size_t)B * (L->HW + 1);
+    L->total = L->off_table + (size_t)B * L->nchunk * L->HW;
+    return DENET_OK;
+}
+}  // namespace
+
+extern "C" size_t denet_sparse_sort_workspace_bytes(int B, int H, int W, int rois_per_image, int gs) {
+    SortLayout L;
+    if (sort_layout(B, H, W, rois_per_image, gs, &L)) return 0;
+    return L.total * sizeof(int);
+}
+
+// groups the tap list of every image by cell (see sparse_count_kernel); depends only on `taps`, so the host may queue it
+// on a side stream right after the forward gather, off the critical path of the backward sweep
+extern "C" int denet_sparse_sort(const int* taps, void* sort_ws, size_t sort_ws_bytes, int B, int H, int W,
+                                 int rois_per_image, int gs, hipStream_t stream) {
+    DENET_CHECK_ARG(taps && sort_ws, "sparse_sort: null pointer");
+    SortLayout L;
+    int rc = sort_layout(B, H, W, rois_per_image, gs, &L);
+    if (rc) return rc;
+    DENET_CHECK_ARG(sort_ws_bytes >= L.total * sizeof(int), "sparse_sort: workspace too small (%zu < %zu)", sort_ws_bytes,
+                    L.total * sizeof(int));
+    int* order = (int*)sort_ws;
+    int* cell_start = order + L.off_start;
+    int* table = order + L.off_table;
+    const size_t lds = (size_t)L.HW * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)sparse_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)sparse_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            32768 * 4);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)sparse_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
         if (e != hipSuccess) {
             denet_set_error("sparse_sort: hipFuncSetAttribute: %s", hipGetErrorString(e));
             return -(int)e;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(sparse_sort_kernel, dim3(B, (n + 32767) / 32768), dim3(1024), 32768 * 4, stream, taps, sorted_ws, n);
+    hipLaunchKernelGGL(sparse_count_kernel, dim3(L.nchunk, B), dim3(64), lds, stream, taps, table, L.n, L.HW, L.nchunk);
+    hipLaunchKernelGGL(sparse_offsets_kernel, dim3(B), dim3(1024), 0, stream, table, cell_start, L.HW, L.nchunk);
+    hipLaunchKernelGGL(sparse_scatter_kernel, dim3(L.nchunk, B), dim3(64), lds, stream, taps, table, order, L.n, L.HW,
+                       L.nchunk, L.key_bits);
     DENET_CHECK_LAUNCH("sparse_sort");
     return DENET_OK;
 }
 
-// taps == NULL: `sorted_ws` already holds the runs written by denet_sparse_sort for the same tap list
-extern "C" int denet_sparse_bwd(const float* dy, const int* taps, unsigned* sorted_ws, float* dfmap, int B, int H,
-                                int W, int CP, int coff, int F, int rois_per_image, int gs, int KP, int zero_from,
+// taps == NULL: `sort_ws` already holds the lists written by denet_sparse_sort for the same tap list
+extern "C" int denet_sparse_bwd(const float* dy, const int* taps, void* sort_ws, size_t sort_ws_bytes, float* dfmap, int B,
+                                int H, int W, int CP, int coff, int F, int rois_per_image, int gs, int KP, int zero_from,
                                 hipStream_t stream) {
-    DENET_CHECK_ARG(dy && sorted_ws && dfmap, "sparse_bwd: null pointer");
+    DENET_CHECK_ARG(dy && sort_ws && dfmap, "sparse_bwd: null pointer");
     const int ntap = gs * gs;
-    DENET_CHECK_ARG(H * W <= (1 << 17) - 1, "sparse_bwd: feature map too large for 17-bit cell keys");
     DENET_CHECK_ARG(F % 4 == 0 && F / 4 <= 64 && CP % 4 == 0 && KP % 4 == 0,
                     "sparse_bwd: F/CP/KP must be multiples of 4 and F <= 256");
     DENET_CHECK_ARG(zero_from >= coff + F && zero_from <= CP, "sparse_bwd: zero_from out of range");
+    SortLayout L;
+    int rc = sort_layout(B, H, W, rois_per_image, gs, &L);
+    if (rc) return rc;
+    DENET_CHECK_ARG(sort_ws_bytes >= L.total * sizeof(int), "sparse_bwd: workspace too small");
     if (taps) {
-        int rc = denet_sparse_sort(taps, sorted_ws, B, H, W, rois_per_image, gs, stream);
+        rc = denet_sparse_sort(taps, sort_ws, sort_ws_bytes, B, H, W, rois_per_image, gs, stream);
         if (rc) return rc;
     }
+    const int* order = (const int*)sort_ws;
     const long ncell = (long)B * H * W;
-    hipLaunchKernelGGL(sparse_bwd_kernel, dim3((unsigned)((ncell + 3) / 4)), dim3(256), 0, stream, dy, sorted_ws, dfmap,
-                       H * W, CP, coff, F, rois_per_image, ntap, KP, zero_from, ncell);
+    hipLaunchKernelGGL(sparse_bwd_kernel, dim3((unsigned)((ncell + 3) / 4)), dim3(256), 0, stream, dy, order,
+                       order + L.off_start, dfmap, H * W, CP, coff, F, rois_per_image, ntap, KP, zero_from, ncell);
     DENET_CHECK_LAUNCH("sparse_bwd");
     return DENET_OK;
 }

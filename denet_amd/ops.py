@@ -697,10 +697,10 @@ def sparse_sort_async(taps, B, H, W, rois_per_image, gs):
     global _SORT_STREAM
     if _SORT_STREAM is None:
         _SORT_STREAM = torch.cuda.Stream()
-    ws = WS.get("sparse_sort", B * rois_per_image * gs * gs * 4)
+    ws = WS.get("sparse_sort", _L().denet_sparse_sort_workspace_bytes(B, H, W, rois_per_image, gs))
     _SORT_STREAM.wait_stream(torch.cuda.current_stream())          # taps are written by sparse_fwd on this stream
     with torch.cuda.stream(_SORT_STREAM):
-        check(_L().denet_sparse_sort(ptr(taps), ptr(ws), B, H, W, rois_per_image, gs, stream_ptr()), "sparse_sort")
+        check(_L().denet_sparse_sort(ptr(taps), ptr(ws), ws.numel(), B, H, W, rois_per_image, gs, stream_ptr()), "sparse_sort")
         ev = torch.cuda.Event()
         ev.record(_SORT_STREAM)
     return ev
@@ -709,10 +709,10 @@ def sparse_sort_async(taps, B, H, W, rois_per_image, gs):
 def sparse_bwd(dy, taps, dfmap, coff, F, rois_per_image, gs, zero_from, presorted=None):
     B, H, W, CP = dfmap.shape
     kp = dy.shape[-1]
-    ws = WS.get("sparse_sort", B * rois_per_image * gs * gs * 4)
+    ws = WS.get("sparse_sort", _L().denet_sparse_sort_workspace_bytes(B, H, W, rois_per_image, gs))
     if presorted is not None:
         torch.cuda.current_stream().wait_event(presorted)
-    check(_L().denet_sparse_bwd(ptr(dy), None if presorted is not None else ptr(taps), ptr(ws), ptr(dfmap), B, H, W, CP,
+    check(_L().denet_sparse_bwd(ptr(dy), None if presorted is not None else ptr(taps), ptr(ws), ws.numel(), ptr(dfmap), B, H, W, CP,
                                 coff, F, rois_per_image, gs, kp, zero_from, stream_ptr()), "sparse_bwd")
     return dfmap
 

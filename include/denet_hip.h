@@ -239,15 +239,19 @@ int denet_corner_loss(const float* corner_pr, const float* target, float* dconv,
  *      fmap:[B,H,W,CP] channels [coff,coff+F) are sampled; bbox:[B*rois,4] normalised x0,y0,x1,y1;
  *      out:[B*rois,KP] = gs*gs*F features, box height, box width, zero padding; taps:[B*rois,gs*gs] receives
  *      the sampled cell index ys*W+xs (bit-exact parity surface).  The gradient is a deterministic segmented
- *      sum (LDS bitonic sort of the taps per image) instead of the reference's atomicAdd scatter.         */
+ *      sum (the taps of every image grouped by cell with a stable counting sort, summed in ascending
+ *      (roi, tap) order) instead of the reference's atomicAdd scatter.                                     */
 int denet_sparse_fwd(const float* fmap, const float* bbox, float* out, int* taps, int B, int H, int W, int CP,
                      int coff, int F, int rois_per_image, int gs, int KP, int tap_rule, hipStream_t stream);
-/* denet_sparse_sort: the per-image sort of the tap list alone (it depends only on `taps`; a caller may queue it on a
- * side stream during the forward pass); denet_sparse_bwd with taps == NULL then consumes the sorted runs.         */
-int denet_sparse_sort(const int* taps, unsigned* sorted_ws, int B, int H, int W, int rois_per_image, int gs,
-                      hipStream_t stream);
-int denet_sparse_bwd(const float* dy, const int* taps, unsigned* sorted_ws, float* dfmap, int B, int H, int W, int CP,
-                     int coff, int F, int rois_per_image, int gs, int KP, int zero_from, hipStream_t stream);
+/* denet_sparse_sort: the grouping of the tap list by cell alone (it depends only on `taps`; a caller may queue it on a
+ * side stream during the forward pass); denet_sparse_bwd with taps == NULL then consumes the lists. sort_ws holds
+ * denet_sparse_sort_workspace_bytes(...) bytes; H*W <= 32768 cells.                                               */
+size_t denet_sparse_sort_workspace_bytes(int B, int H, int W, int rois_per_image, int gs);
+int denet_sparse_sort(const int* taps, void* sort_ws, size_t sort_ws_bytes, int B, int H, int W, int rois_per_image,
+                      int gs, hipStream_t stream);
+int denet_sparse_bwd(const float* dy, const int* taps, void* sort_ws, size_t sort_ws_bytes, float* dfmap, int B, int H,
+                     int W, int CP, int coff, int F, int rois_per_image, int gs, int KP, int zero_from,
+                     hipStream_t stream);
 
 /* ---- detection cost  (denet/layer/denet_detect.py:238-313 get_errors/cost; theano_util.py:27-34)
  *      logits:[M,CP] (ncls class logits, nreg box regressors, nfit independent-fitness logits); det_target:[M,ncls];

@@ -414,6 +414,36 @@ def test_sparse_fwd_bwd(hip, rule):
     assert torch.equal(dfmap2[..., coff:], dfmap[..., coff:])
 
 
+@pytest.mark.parametrize("case", [(32, 64, 64, 576, 7), (3, 20, 36, 100, 5), (2, 128, 128, 2304, 7), (1, 9, 7, 3000, 2)])
+def test_sparse_tap_counting_sort(hip, case):
+    """the grouping of the (roi, tap) slots by cell that the gather gradient sums over (replaces the reference's atomicAdd
+    scatter, denet_sparse_op.py:171-212): per image it must be exactly the STABLE sort of the tap list by cell - every
+    cell's slots in ascending order - including cells hit thousands of times and lists that span many 2048-slot chunks"""
+    import ctypes
+    from denet_amd import ops
+    B, H, W, rois, gs = case
+    rng = np.random.RandomState(B * 7 + rois)
+    n = rois * gs * gs
+    taps = rng.randint(0, H * W, (B, n)).astype(np.int32)
+    taps[0, : n // 2] = rng.randint(0, 3, n // 2)              # three cells collect half of image 0's slots
+    taps[-1, n // 3:] = H * W - 1                               # the last cell collects two thirds of the last image's
+    L = ops._L()
+    nbytes = L.denet_sparse_sort_workspace_bytes(B, H, W, rois, gs)
+    ws = torch.zeros(nbytes // 4, dtype=torch.int32, device="cuda")
+    td = torch.from_numpy(taps).cuda()
+    ops.check(L.denet_sparse_sort(ops.ptr(td), ops.ptr(ws), nbytes, B, H, W, rois, gs, ops.stream_ptr()), "sparse_sort")
+    got = ws.cpu().numpy()
+    order = got[:B * n].reshape(B, n)
+    start = got[B * n:B * n + B * (H * W + 1)].reshape(B, H * W + 1)
+    for b in range(B):
+        assert np.array_equal(order[b], np.argsort(taps[b], kind="stable")), b
+        cnt = np.bincount(taps[b], minlength=H * W)
+        assert np.array_equal(start[b], np.concatenate([[0], np.cumsum(cnt)])), b
+    # too small a workspace / too large a map are argument errors, not memory corruption
+    assert L.denet_sparse_sort(ops.ptr(td), ops.ptr(ws), nbytes - 4, B, H, W, rois, gs, ops.stream_ptr()) == -1000
+    assert L.denet_sparse_sort_workspace_bytes(1, 256, 256, 4, 2) == 0
+
+
 @pytest.mark.parametrize("bounded", [False, True])
 def test_detect_loss(hip, bounded):
     from denet_amd import ops

@@ -497,11 +497,42 @@ def test_resnet_variants_vs_oracle(hip, convert):
     assert all(("bnrelu" in v) == (convert and "original" in v) or "pre-activation" in v for v in versions)
 
 
+def test_resnet34_224_config2_vs_oracle(hip):
+    """BASELINE config 2 (ResNet-34 backbone, 224x224, examples/resnet34-imagenet.sh:7) at B=2 against the numpy oracle:
+    free-running activations and cost, then the op-by-op teacher-forced step (gradients, running statistics, update)"""
+    _generic_step_check(zoo.RESNET34_DESC, (3, 224, 224), 2, steps=1, class_num=1000, seed=5)
+
+
+def test_resnet34_224_config2_full_size_properties(hip):
+    """config 2 at its workload (B=64, 224x224, 1000 classes): two training steps are finite, bit-reproducible run to run
+    (same measured launch configurations inside one process), the cost moves; the per-layer numerics at these shapes are covered by tests/test_conv_fullsize_gpu.py (r34_*)"""
+    B = 64
+    rng = np.random.RandomState(3)
+    x = torch.from_numpy(rng.uniform(0, 1, (B, 3, 224, 224)).astype(np.float32)).cuda()
+    metas = [{"image_class": int(rng.randint(0, 1000)), "bbox": [], "class": []} for _ in range(B)]
+    results = []
+    for run in range(2):
+        model = zoo.resnet34(B, 224, seed=1)
+        model.build_train_func("nesterov")
+        c0 = model.train_step(x, metas, 0, 0, 0.1, [0.9], 1e-4)
+        c1 = model.train_step(x, metas, 0, 1, 0.1, [0.9], 1e-4)
+        results.append((c0, c1, model.P.clone()))
+        assert np.isfinite(c0[0]) and np.isfinite(c1[0])
+    assert results[0][0] == results[1][0] and results[0][1] == results[1][1]
+    assert torch.equal(results[0][2], results[1][2])
+    assert results[0][0][0] != results[0][1][0] and results[0][0][0] > 0
+
+
 def test_direct_and_measured_paths_agree(hip):
     """the same training step with the heuristic direct kernels (DENET_AUTOTUNE=0 behaviour) and with the measured
-    configurations / Winograd passes: costs and parameters agree to rounding (1e-4), both are checked against the oracle
-    by the other tests"""
+    configurations / Winograd passes: the costs agree to rounding, and - layer by layer, on the tensors of the real step -
+    every convolution pass of the measured implementation agrees with the direct kernel within the per-layer bound that
+    tests/test_conv_fullsize_gpu.py establishes against fp64 at the benchmark geometries (direct 4e-6, F(4x4) 2.5e-5
+    measured; 1e-4 asserted). The whole-network parameter update is NOT compared element-wise: it is a discontinuous
+    function of 1e-6-level forward differences (ReLU mask flips move a BN beta gradient by 0.5 % at M = 1152, see
+    _forced_step_check), which says nothing about a kernel."""
     from denet_amd import ops
+    from denet_amd.model import model_cnn
     B, IMG = 2, 128
     x, metas = zoo.synthetic_batch(B, IMG, seed=2)
     res = []
@@ -513,24 +544,44 @@ def test_direct_and_measured_paths_agree(hip):
             model = zoo.denet34(B, "skip", IMG, class_num=80, seed=1)
             _warm_corner_head(model, 4.0, 0.3)
             model.build_train_func("nesterov")
-            p_before = model.P.clone()
             random.seed(3)
             c0, _ = model.train_step(x, metas, 0, 0, 0.002, [0.9], 1e-4)
-            res.append((c0, None, (model.P - p_before).double(), dict(ops._WINO)))
+            torch.cuda.synchronize()
+            res.append((c0, dict(ops._WINO)))
+        assert not any(res[0][1].values()), "the heuristic run must not use Winograd passes"
+        if ops.WINOGRAD:           # DENET_WINOGRAD=0 leaves only the measured direct configurations to compare
+            assert any(res[1][1].values()), "the measured run chose no Winograd pass at all: the test compares nothing"
+        assert abs(res[0][0] - res[1][0]) <= 1e-4 * abs(res[0][0])
+        # per layer, on the step's own tensors (the model of the measured run is still alive): x, dy, w of every convolution
+        convs = [l for l in model_cnn.walk_layers(model.layers) if l.type_name == "conv" and l.output.grad is not None]
+        assert len(convs) >= 40
+        worst = {}
+        for l in convs:
+            xin, dy, w = l.input.data, l.output.grad, l._w()
+            st, pad, sr = l.stride[0], l.pad, l.filter_shape[3]
+            out = {}
+            for tuned in (True, False):
+                ops.AUTOTUNE = tuned
+                if not tuned:
+                    ops._WINO.clear()
+                y = ops.conv_fwd(xin, w, stride=st, pad=pad, s_real=sr)
+                dw = ops.conv_wgrad(xin, dy, tuple(w.shape), stride=st, pad=pad, s_real=sr)
+                dx = ops.conv_dgrad(dy, w, tuple(xin.shape), stride=st, pad=pad, s_real=sr) if xin.shape[-1] >= 32 else None
+                out[tuned] = (y, dw, dx)
+            ops._WINO.clear()
+            ops._WINO.update(res[1][1])
+            for name, a, d in zip(("fwd", "wgrad", "dgrad"), out[True], out[False]):
+                if a is None:
+                    continue
+                err = float((a - d).abs().max()) / (float(d.abs().max()) + 1e-30)
+                worst[name] = max(worst.get(name, 0.0), err)
+                assert err <= 1e-4, "layer %d %s: measured vs direct implementation differ by %.2e (max-norm)" % (
+                    l.layer_index, name, err)
+        print("worst per-layer measured-vs-direct difference:", worst)
     finally:
         ops.AUTOTUNE = saved[0]
         ops._WINO.clear()
         ops._WINO.update(saved[1])
-    assert not any(res[0][3].values()), "the heuristic run must not use Winograd passes"
-    if ops.WINOGRAD:           # DENET_WINOGRAD=0 leaves only the measured direct configurations to compare
-        assert any(res[1][3].values()), "the measured run chose no Winograd pass at all: the test compares nothing"
-    # one step only: the RoI proposal of a second step is a discontinuous function of the corner map (threshold
-    # crossings), so rounding-level differences in the parameters legitimately change its RoI set
-    assert abs(res[0][0] - res[1][0]) <= 1e-4 * abs(res[0][0])
-    # whole-network gradients are ill-conditioned element-wise (ReLU mask flips under 1e-6 forward differences, see
-    # _forced_step_check); the parameter update as a vector must agree
-    du = float((res[1][2] - res[0][2]).norm() / res[0][2].norm())
-    assert du <= 5e-2, "relative L2 difference of the parameter update %.3e" % du     # measured: 2.5e-2 (mask flips)
 
 
 def test_adam_solver_vs_oracle(hip):
