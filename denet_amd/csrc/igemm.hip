@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb & 1][i][t], bv[kb & 1][j][t], acc[i][j],
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[kb & 1][j][t], av[kb & 1][i][t], acc[i][j],
                                                                          0, 0, 0);
         }
     };
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
                         for (int i = 0; i < TM; ++i)
 #pragma unroll
                             for (int j = 0; j < TN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb & 1][i][t], bv[kb & 1][j][t],
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[kb & 1][j][t], av[kb & 1][i][t],
                                                                                  acc[i][j], 0, 0, 0);
                     constexpr int NM = 4 * TM * TN;
                     constexpr int NR = rd ? (A_KIN ? TM : 4 * TM) + (B_KIN ? TN : 4 * TN) : 0;
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb & 1][i][t], bv[kb & 1][j][t], acc[i][j],
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[kb & 1][j][t], av[kb & 1][i][t], acc[i][j],
                                                                              0, 0, 0);
                 // issue order of this block
                 constexpr int NM = 4 * TM * TN;
@@ -603,33 +603,38 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
     }
 
     // ---------------- epilogue ----------------
+    // The MFMAs were issued with the B fragment as the row operand and the A fragment as the column operand, so the
+    // accumulators hold the TRANSPOSED 32x32 blocks: lane (li, lh) owns output row m = .. + li and, per register group g,
+    // the four consecutive columns n = .. + 8g + 4lh + {0..3}: one 16-byte store per group instead of four scalar ones
+    // (the scalar form is store-issue bound: a quarter of the run time of the short-reduction component GEMMs).
     float* out = p.out;
     if (MODE == MODE_WGRAD) out += (long)split_id * p.split_stride;
     if (MODE == MODE_FWD || MODE == MODE_WGRAD) out += by * p.batch_out;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        const int m = m0 + (wm * TM + i) * 32 + li;
+        if (m >= p.M) continue;
+        long row = (long)m * p.NC;
+        if (MODE == MODE_DGRAD && p.stride > 1) {
+            const uint32_t ni = p.div_row_hw.div(m);
+            const uint32_t rem = m - ni * (p.Hc * p.Wc);
+            const uint32_t ya = p.div_row_w.div(rem);
+            const uint32_t xa = rem - ya * p.Wc;
+            row = (((long)ni * p.H + (ya * p.stride + dg_py)) * p.W + (xa * p.stride + dg_px)) * p.NC;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 32 + li;
-            if (n >= p.NC) continue;
-            const float bv = (MODE == MODE_FWD && p.bias) ? p.bias[n] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < p.M) {
-                    long idx = (long)m * p.NC + n;
-                    if (MODE == MODE_DGRAD && p.stride > 1) {
-                        const uint32_t ni = p.div_row_hw.div(m);
-                        const uint32_t rem = m - ni * (p.Hc * p.Wc);
-                        const uint32_t ya = p.div_row_w.div(rem);
-                        const uint32_t xa = rem - ya * p.Wc;
-                        idx = (((long)ni * p.H + (ya * p.stride + dg_py)) * p.W + (xa * p.stride + dg_px)) * p.NC + n;
-                    }
-                    float v = acc[i][j][r] + bv;
-                    if (MODE != MODE_WGRAD && p.add) v += p.add[idx];
-                    if (MODE == MODE_FWD && p.relu) v = fmaxf(v, 0.f);
-                    out[idx] = v;
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + (wn * TN + j) * 32 + 8 * g + 4 * lh;
+                if (n >= p.NC) continue;                 // NC is a multiple of 4: the group is all inside or all outside
+                f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                if (MODE == MODE_FWD && p.bias) v += *(const f32x4*)(p.bias + n);
+                if (MODE != MODE_WGRAD && p.add) v += *(const f32x4*)(p.add + row + n);
+                if (MODE == MODE_FWD && p.relu) {
+                    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
                 }
+                *(f32x4*)(out + row + n) = v;
             }
         }
     }
