@@ -29,7 +29,9 @@ class Workspace:
         nbytes = int(nbytes)
         buf = self.bufs.get(name)
         if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device="cuda")
+            # zero-filled: the stream-K component GEMMs keep hand-off flags at the start of the Winograd workspace, which
+            # must never hold a stale value that equals a launch epoch
+            buf = torch.zeros(max(nbytes, 1), dtype=torch.uint8, device="cuda")
             self.bufs[name] = buf
         return buf
 

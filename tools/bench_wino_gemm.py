@@ -12,7 +12,9 @@ def timeit(fn, iters=20):
     return s.elapsed_time(e) / iters
 B = 32
 torch.manual_seed(0)
+ONLY = os.environ.get("SHAPE")
 for name, HW, C, K in [("l1", 128, 64, 64), ("l2", 64, 128, 128), ("l3", 32, 256, 256), ("l4", 16, 512, 512), ("up1", 32, 512, 256), ("up2", 64, 256, 128)]:
+    if ONLY and name != ONLY: continue
     x = torch.randn(B, HW, HW, C, device="cuda"); w = torch.randn(K, 3, 3, C, device="cuda") * 0.05
     dy = torch.randn(B, HW, HW, K, device="cuda")
     u = ops.conv_wino_filter(w, 4, dgrad=False); ud = ops.conv_wino_filter(w, 4, dgrad=True)
