@@ -354,6 +354,23 @@ extern "C" int denet_bn_fwd_train(const float* x, const float* res, float* y, co
     return DENET_OK;
 }
 
+// batch norm whose per-channel sums were already produced by the convolution in front of it (denet_conv_fwd_stats /
+// denet_conv_wino_fwd_stats): partial [rows][2][C] doubles (sum | sum of squares over disjoint row sets covering all M rows)
+extern "C" int denet_bn_fwd_train_pre(const float* x, const float* res, float* y, const float* gamma, const float* beta,
+                                      float* run_mean, float* run_stdinv, float* save_mean, float* save_invstd,
+                                      const double* partial, int rows, long M, int C, float momentum, float eps, int relu,
+                                      hipStream_t stream) {
+    DENET_CHECK_ARG(x && y && gamma && beta && save_mean && save_invstd && partial && rows > 0, "bn_fwd_train_pre: bad arguments");
+    DENET_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "bn_fwd_train_pre: bad shape M=%ld C=%d", M, C);
+    BnMap m = bn_map(M, C);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, rows, M, C, eps,
+                       momentum, save_mean, save_invstd, run_mean, run_stdinv);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, res, y, gamma, beta, save_mean,
+                       save_invstd, M, C, m.LC, relu);
+    DENET_CHECK_LAUNCH("bn_fwd_train_pre");
+    return DENET_OK;
+}
+
 extern "C" int denet_bn_fwd_test(const float* x, const float* res, float* y, const float* gamma, const float* beta,
                                  const float* run_mean, const float* run_stdinv, float* coef, int coef_ready, long M, int C,
                                  float eps, int relu, hipStream_t stream) {

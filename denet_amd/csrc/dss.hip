@@ -149,8 +149,8 @@ __global__ __launch_bounds__(256) void sparse_fwd_kernel(const float* __restrict
 // A slot is s = roi * ntap + tap (n = rois_per_image * ntap per image); slots are cut into chunks of SORT_CHUNK; one
 // wave owns one chunk (B x nchunk waves fill the chip - the per-image LDS bitonic sort this replaces ran on B workgroups):
 //   sparse_count    chunk histogram over the cells (LDS integer atomics)         -> table[b][chunk][cell]
-//   sparse_offsets  per image: cell totals, exclusive scan -> cell_start[b][0..HW]; table becomes the first output
-//                   position of (chunk, cell)
+//   sparse_offsets  per (image, 256-cell slab): cell totals, exclusive scan -> cell_start[b][0..HW]; table becomes the
+//                   first output position of (chunk, cell)
 //   sparse_scatter  the wave walks its chunk in slot order, 64 slots at a time; the lanes holding the same cell are
 //                   found with one ballot per key bit (no match-any instruction on gfx950), a lane's rank among them is
 //                   a popcount below its lane id, the lowest lane advances the cell's LDS cursor: stable by construction
@@ -170,36 +170,52 @@ __global__ __launch_bounds__(64) void sparse_count_kernel(const int* __restrict_
     for (int c = threadIdx.x; c < HW; c += 64) row[c] = s_hist[c];
 }
 
-// one workgroup per image; thread t owns the cells [t*per, (t+1)*per)
-__global__ __launch_bounds__(1024) void sparse_offsets_kernel(int* __restrict__ table, int* __restrict__ cell_start, int HW,
-                                                             int nchunk) {
-    __shared__ int s_part[1024];
-    const int b = blockIdx.x;
-    int* tb = table + (long)b * nchunk * HW;
-    const int per = (HW + 1023) / 1024;
-    const int c0 = threadIdx.x * per, c1 = min(HW, c0 + per);
+// workgroup (slab, image): the 256 cells [256 slab, 256 slab + 256) of one image. base = number of slots in the cells in
+// front of the slab (recomputed from the table by every workgroup: coalesced, a few thousand loads), then a block scan of
+// the slab's own cell totals; table_pos[chunk][cell] = first output position of (chunk, cell)
+__global__ __launch_bounds__(256) void sparse_offsets_kernel(const int* __restrict__ table, int* __restrict__ table_pos,
+                                                            int* __restrict__ cell_start, int HW, int nchunk, int n) {
+    __shared__ int s_red[256];
+    const int b = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x;
+    const int* tb = table + (long)b * nchunk * HW;
+    int* tp = table_pos + (long)b * nchunk * HW;       // a second table: other workgroups still read the counts
+    int before = 0;
+    for (int k = 0; k < nchunk; ++k) {
+        const int* row = tb + (long)k * HW;
+        for (int c = tid; c < slab * 256; c += 256) before += row[c];
+    }
+    const int c = slab * 256 + tid;
     int tot = 0;
-    for (int c = c0; c < c1; ++c)
+    if (c < HW)
         for (int k = 0; k < nchunk; ++k) tot += tb[(long)k * HW + c];
-    s_part[threadIdx.x] = tot;
+    // block sum of `before`, inclusive block scan of `tot`
+    s_red[tid] = before;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {          // inclusive scan of the per-thread totals
-        const int v = (threadIdx.x >= off) ? s_part[threadIdx.x - off] : 0;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) s_red[tid] += s_red[tid + st];
         __syncthreads();
     }
-    int pos = s_part[threadIdx.x] - tot;
+    const int base = s_red[0];
+    __syncthreads();
+    s_red[tid] = tot;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = (tid >= off) ? s_red[tid - off] : 0;
+        __syncthreads();
+        s_red[tid] += v;
+        __syncthreads();
+    }
+    int pos = base + s_red[tid] - tot;
     int* cs = cell_start + (long)b * (HW + 1);
-    for (int c = c0; c < c1; ++c) {
+    if (c < HW) {
         cs[c] = pos;
         for (int k = 0; k < nchunk; ++k) {
             const int cnt = tb[(long)k * HW + c];
-            tb[(long)k * HW + c] = pos;
+            tp[(long)k * HW + c] = pos;
             pos += cnt;
         }
     }
-    if (threadIdx.x == 1023) cs[HW] = s_part[1023];
+    if (slab == gridDim.x - 1 && tid == 0) cs[HW] = n;
 }
 
 __global__ __launch_bounds__(64) void sparse_scatter_kernel(const int* __restrict__ taps, const int* __restrict__ table,
@@ -207,17 +223,25 @@ __global__ __launch_bounds__(64) void sparse_scatter_kernel(const int* __restric
                                                             int key_bits) {
     extern __shared__ int s_cur[];
     const int b = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x;
+    const int lo = chunk * SORT_CHUNK, hi = min(n, lo + SORT_CHUNK);
+    const int* t = taps + (long)b * n;
+    // the whole chunk's cells first: SORT_CHUNK / 64 independent loads in flight per lane (the walk below is serial)
+    int cells[SORT_CHUNK / 64];
+#pragma unroll
+    for (int r = 0; r < SORT_CHUNK / 64; ++r) {
+        const int i = lo + r * 64 + lane;
+        cells[r] = (i < hi) ? t[i] : 0;
+    }
     const int* row = table + ((long)b * nchunk + chunk) * HW;
     for (int c = lane; c < HW; c += 64) s_cur[c] = row[c];
     __syncthreads();
-    const int lo = chunk * SORT_CHUNK, hi = min(n, lo + SORT_CHUNK);
-    const int* t = taps + (long)b * n;
     int* o = order + (long)b * n;
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int base = lo; base < hi; base += 64) {
-        const int i = base + lane;
+#pragma unroll
+    for (int r = 0; r < SORT_CHUNK / 64; ++r) {
+        const int i = lo + r * 64 + lane;
         const bool live = i < hi;
-        const int cell = live ? t[i] : 0;
+        const int cell = cells[r];
         unsigned long long same = __ballot(live);
         for (int bit = 0; bit < key_bits; ++bit) {
             const unsigned long long set = __ballot((cell >> bit) & 1);
@@ -470,7 +494,8 @@ extern "C" int denet_sparse_fwd(const float* fmap, const float* bbox, float* out
     return DENET_OK;
 }
 
-// Workspace of denet_sparse_sort / denet_sparse_bwd: order [B][n] | cell_start [B][HW+1] | table [B][nchunk][HW] (int32)
+// Workspace of denet_sparse_sort / denet_sparse_bwd: order [B][n] | cell_start [B][HW+1] | counts [B][nchunk][HW] |
+// positions [B][nchunk][HW] (int32)
 namespace {
 struct SortLayout {
     int n, HW, nchunk, key_bits;
@@ -486,7 +511,7 @@ int sort_layout(int B, int H, int W, int rois_per_image, int gs, SortLayout* L) 
     while ((1 << L->key_bits) < L->HW) L->key_bits++;
     L->off_start = (size_t)B * L->n;
     L->off_table = L->off_start + (size_t)B * (L->HW + 1);
-    L->total = L->off_table + (size_t)B * L->nchunk * L->HW;
+    L->total = L->off_table + (size_t)2 * B * L->nchunk * L->HW;      // counts | positions
     return DENET_OK;
 }
 }  // namespace
@@ -524,8 +549,10 @@ extern "C" int denet_sparse_sort(const int* taps, void* sort_ws, size_t sort_ws_
         attr_set = true;
     }
     hipLaunchKernelGGL(sparse_count_kernel, dim3(L.nchunk, B), dim3(64), lds, stream, taps, table, L.n, L.HW, L.nchunk);
-    hipLaunchKernelGGL(sparse_offsets_kernel, dim3(B), dim3(1024), 0, stream, table, cell_start, L.HW, L.nchunk);
-    hipLaunchKernelGGL(sparse_scatter_kernel, dim3(L.nchunk, B), dim3(64), lds, stream, taps, table, order, L.n, L.HW,
+    int* table_pos = table + (size_t)B * L.nchunk * L.HW;
+    hipLaunchKernelGGL(sparse_offsets_kernel, dim3((L.HW + 255) / 256, B), dim3(256), 0, stream, table, table_pos, cell_start,
+                       L.HW, L.nchunk, L.n);
+    hipLaunchKernelGGL(sparse_scatter_kernel, dim3(L.nchunk, B), dim3(64), lds, stream, taps, table_pos, order, L.n, L.HW,
                        L.nchunk, L.key_bits);
     DENET_CHECK_LAUNCH("sparse_sort");
     return DENET_OK;

@@ -36,6 +36,8 @@ struct IgemmParams {
     const float* bias;  // fwd only, [K] or null
     const float* add;   // fwd/dgrad: tensor of the output's shape added in the epilogue, or null
     int relu;           // fwd: max(., 0) after bias and add (inference with batch norm folded into the filters)
+    double* stats;      // fwd, optional: per M tile the column sums [tiles_m][2][NC] (sum, sum of squares) of the stored values:
+                        // the batch-norm statistics of the layer behind this convolution (batch_norm.py:50-53), no extra pass
     int N, H, W, C;     // x geometry (C = physical channels)
     int OH, OW, K;      // y geometry (K = physical channels)
     int R, S, S_real;   // filter taps (S may be padded; taps s >= S_real carry zero weight)
@@ -610,6 +612,67 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
     float* out = p.out;
     if (MODE == MODE_WGRAD) out += (long)split_id * p.split_stride;
     if (MODE == MODE_FWD || MODE == MODE_WGRAD) out += by * p.batch_out;
+    if (MODE == MODE_FWD && p.stats) {
+        // ---- store + batch-norm column sums. Lane (li, lh) holds row m and, per (j, g), 4 consecutive columns: the sums
+        // over the rows of the tile are a reduction over li (shuffles inside each 32-lane half), then over the two waves
+        // stacked along M (LDS), written as doubles: partial[tile_m][0][n] = sum, [1][n] = sum of squares.
+        __syncthreads();                       // the operand buffers are reused below: every wave is out of the main loop
+        float* red = smem;                     // [WM][2][BN]
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = (wn * TN + j) * 32 + 8 * g + 4 * lh;      // column inside the tile
+                const int n = n0 + nl;
+                f32x4 sv = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+                if (n < p.NC) {
+                    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias) bias4 = *(const f32x4*)(p.bias + n);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int m = m0 + (wm * TM + i) * 32 + li;
+                        if (m < p.M) {
+                            const long row = (long)m * p.NC;
+                            f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                            v += bias4;
+                            if (p.add) v += *(const f32x4*)(p.add + row + n);
+                            if (p.relu) {
+                                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                            }
+                            *(f32x4*)(p.out + row + n) = v;
+                            sv += v;
+                            sq += v * v;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        sv[c] += __shfl_xor(sv[c], off, 64);
+                        sq[c] += __shfl_xor(sq[c], off, 64);
+                    }
+                }
+                if (li == 0) {
+                    *(f32x4*)(red + (wm * 2 + 0) * BN + nl) = sv;
+                    *(f32x4*)(red + (wm * 2 + 1) * BN + nl) = sq;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.NC) {
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                a += (double)red[(w * 2 + 0) * BN + tid];
+                b += (double)red[(w * 2 + 1) * BN + tid];
+            }
+            double* ps = p.stats + (long)tile_m * 2 * p.NC;
+            ps[n0 + tid] = a;
+            ps[p.NC + n0 + tid] = b;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + (wm * TM + i) * 32 + li;
@@ -1210,15 +1273,38 @@ extern "C" int denet_conv_fwd(const float* x, const float* w, const float* bias,
     return denet_conv_fwd_act(x, w, bias, add, y, 0, N, H, W, C, K, R, S, S_real, stride, pad, OH, OW, stream);
 }
 
+static int conv_fwd_impl(const float* x, const float* w, const float* bias, const float* add, float* y, int relu,
+                         double* stats, int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad,
+                         int OH, int OW, hipStream_t stream);
+
 // forward convolution with an activation in the epilogue: y = act(conv(x, w) + bias + add), relu != 0: max(., 0)
 extern "C" int denet_conv_fwd_act(const float* x, const float* w, const float* bias, const float* add, float* y, int relu,
                                   int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH,
                                   int OW, hipStream_t stream) {
+    return conv_fwd_impl(x, w, bias, add, y, relu, nullptr, N, H, W, C, K, R, S, S_real, stride, pad, OH, OW, stream);
+}
+
+// the same, and the epilogue also emits the per-channel sums of y for the batch norm that follows (batch_norm.py:50-53;
+// batch_norm_relu.py:34-54): stats_partial [ceil(N*OH*OW / 128)][2][K] doubles (sum | sum of squares per row tile);
+// *stats_rows receives the row count. Feed both to denet_bn_fwd_train_pre: the normalisation then needs no statistics pass.
+extern "C" int denet_conv_fwd_stats(const float* x, const float* w, const float* bias, const float* add, float* y,
+                                    double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int C,
+                                    int K, int R, int S, int S_real, int stride, int pad, int OH, int OW, hipStream_t stream) {
+    DENET_CHECK_ARG(stats_partial && stats_rows, "conv_fwd_stats: null pointer");
+    const long rows = ((long)N * OH * OW + 127) / 128;
+    DENET_CHECK_ARG(stats_bytes >= (size_t)rows * 2 * K * sizeof(double), "conv_fwd_stats: statistics buffer too small");
+    *stats_rows = (int)rows;
+    return conv_fwd_impl(x, w, bias, add, y, 0, stats_partial, N, H, W, C, K, R, S, S_real, stride, pad, OH, OW, stream);
+}
+
+static int conv_fwd_impl(const float* x, const float* w, const float* bias, const float* add, float* y, int relu,
+                         double* stats, int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad,
+                         int OH, int OW, hipStream_t stream) {
     int rc = check_geom(N, H, W, C, K, R, S, S_real, stride, pad, OH, OW);
     if (rc) return rc;
     DENET_CHECK_ARG(x && w && y, "conv_fwd: null pointer");
     IgemmParams p = {};
-    p.act = x; p.wgt = w; p.out = y; p.bias = bias; p.add = add; p.relu = relu ? 1 : 0;
+    p.act = x; p.wgt = w; p.out = y; p.bias = bias; p.add = add; p.relu = relu ? 1 : 0; p.stats = stats;
     p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K;
     p.R = R; p.S = S; p.S_real = S_real; p.stride = stride; p.sshift = ilog2_exact(stride); p.pad = pad;
     p.act_bytes = (unsigned)((size_t)N * H * W * C * 4); p.wgt_bytes = (unsigned)((size_t)K * R * S * C * 4);

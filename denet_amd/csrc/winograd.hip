@@ -146,54 +146,127 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
         }
 }
 
-// y tile = A^T M A (+ bias) (+ add): one thread per (tile, 4 output channels)
+// Data-gradient filters U'[xi][c][k] from the rotated taps of w[k][r][s][c]: the (k, c) -> (c, k) transposition goes through
+// LDS so that global reads (16 consecutive c) and writes (16 consecutive k) both move 64-byte segments (the one-thread-per-
+// (k, c) form of wino_filter_kernel<MO, true> wrote 4-byte words K floats apart: 4x the time of the forward transform).
+// Block = 16 k x 16 c.
+template <int MO>
+__global__ __launch_bounds__(256) void wino_filter_dgrad_kernel(const float* __restrict__ w, float* __restrict__ U, int K,
+                                                                int C) {
+    using WT = Wino<MO>;
+    constexpr int TS = WT::TS;
+    __shared__ float tile[TS * TS][16][17];
+    const int kl = threadIdx.x >> 4, cl = threadIdx.x & 15;
+    const int k0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
+    {
+        const int k = k0 + kl, c = c0 + cl;
+        float g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) g[r][q] = w[(((long)k * 3 + (2 - r)) * 3 + (2 - q)) * C + c];
+        float a[TS][3];
+#pragma unroll
+        for (int i = 0; i < TS; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                float acc = 0.f;
+                WINO_DOT(acc, 3, WT::G[i][l_], g[l_][q]);
+                a[i][q] = acc;
+            }
+#pragma unroll
+        for (int i = 0; i < TS; ++i)
+#pragma unroll
+            for (int j = 0; j < TS; ++j) {
+                float acc = 0.f;
+                WINO_DOT(acc, 3, WT::G[j][l_], a[i][l_]);
+                tile[TS * i + j][cl][kl] = acc;
+            }
+    }
+    __syncthreads();
+    const long KC = (long)K * C;
+    const int co = threadIdx.x >> 4, ko = threadIdx.x & 15;      // consecutive threads -> consecutive k
+#pragma unroll
+    for (int xi = 0; xi < TS * TS; ++xi) U[(long)xi * KC + (long)(c0 + co) * K + k0 + ko] = tile[xi][co][ko];
+}
+
+// y tile = A^T M A (+ bias) (+ add): one thread per (tile, 4 output channels). stats != NULL (needs 256 % (K/4) == 0): the
+// block also writes the per-channel sums of what it stored, stats[blockIdx.x][2][K] doubles (sum | sum of squares): the
+// batch-norm statistics of the layer behind this convolution without a pass of their own
 template <int MO>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias,
                                                           const float* __restrict__ add, float* __restrict__ y, int N,
-                                                          int H, int W, int K, int TH, int TW, long T, int relu) {
+                                                          int H, int W, int K, int TH, int TW, long T, int relu,
+                                                          double* __restrict__ stats) {
     using WT = Wino<MO>;
     constexpr int TS = WT::TS;
+    __shared__ f32x4 red[2][256];
     const int k4n = K / 4;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= T * k4n) return;
-    const int k4 = (int)(idx % k4n);
-    const long t = idx / k4n;
-    const int tx = (int)(t % TW);
-    const int ty = (int)((t / TW) % TH);
-    const int n = (int)(t / ((long)TW * TH));
+    const bool valid = idx < T * k4n;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f32x4 s[MO][TS];        // A^T m, column by column
+    f32x4 ssum = z, ssq = z;
+    if (valid) {
+        const int k4 = (int)(idx % k4n);
+        const long t = idx / k4n;
+        const int tx = (int)(t % TW);
+        const int ty = (int)((t / TW) % TH);
+        const int n = (int)(t / ((long)TW * TH));
+        f32x4 s[MO][TS];        // A^T m, column by column
 #pragma unroll
-    for (int j = 0; j < TS; ++j) {
-        f32x4 m[TS];
+        for (int j = 0; j < TS; ++j) {
+            f32x4 m[TS];
 #pragma unroll
-        for (int i = 0; i < TS; ++i) m[i] = ld4(Mx + ((long)(TS * i + j) * T + t) * K + k4 * 4);
+            for (int i = 0; i < TS; ++i) m[i] = ld4(Mx + ((long)(TS * i + j) * T + t) * K + k4 * 4);
 #pragma unroll
-        for (int i = 0; i < MO; ++i) {
-            f32x4 acc = z;
-            WINO_DOT(acc, TS, WT::AT[i][l_], m[l_]);
-            s[i][j] = acc;
+            for (int i = 0; i < MO; ++i) {
+                f32x4 acc = z;
+                WINO_DOT(acc, TS, WT::AT[i][l_], m[l_]);
+                s[i][j] = acc;
+            }
+        }
+        f32x4 b = z;
+        if (bias) b = ld4(bias + k4 * 4);
+#pragma unroll
+        for (int i = 0; i < MO; ++i)
+#pragma unroll
+            for (int j = 0; j < MO; ++j) {
+                f32x4 acc = z;
+                WINO_DOT(acc, TS, WT::AT[j][l_], s[i][l_]);
+                const long o = (((long)n * H + MO * ty + i) * W + MO * tx + j) * K + k4 * 4;
+                acc += b;
+                if (add) acc += ld4(add + o);
+                if (relu) {
+                    acc[0] = fmaxf(acc[0], 0.f);
+                    acc[1] = fmaxf(acc[1], 0.f);
+                    acc[2] = fmaxf(acc[2], 0.f);
+                    acc[3] = fmaxf(acc[3], 0.f);
+                }
+                *(f32x4*)(y + o) = acc;
+                ssum += acc;
+                ssq += acc * acc;
+            }
+    }
+    if (!stats) return;
+    // threads tid, tid + k4n, tid + 2 k4n, ... hold the same channels of different tiles
+    red[0][threadIdx.x] = ssum;
+    red[1][threadIdx.x] = ssq;
+    __syncthreads();
+    for (int st = 128; st >= k4n; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + st];
+            red[1][threadIdx.x] += red[1][threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < k4n) {
+        double* ps = stats + (long)blockIdx.x * 2 * K + threadIdx.x * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            ps[c] = (double)red[0][threadIdx.x][c];
+            ps[K + c] = (double)red[1][threadIdx.x][c];
         }
     }
-    f32x4 b = z;
-    if (bias) b = ld4(bias + k4 * 4);
-#pragma unroll
-    for (int i = 0; i < MO; ++i)
-#pragma unroll
-        for (int j = 0; j < MO; ++j) {
-            f32x4 acc = z;
-            WINO_DOT(acc, TS, WT::AT[j][l_], s[i][l_]);
-            const long o = (((long)n * H + MO * ty + i) * W + MO * tx + j) * K + k4 * 4;
-            acc += b;
-            if (add) acc += ld4(add + o);
-            if (relu) {
-                acc[0] = fmaxf(acc[0], 0.f);
-                acc[1] = fmaxf(acc[1], 0.f);
-                acc[2] = fmaxf(acc[2], 0.f);
-                acc[3] = fmaxf(acc[3], 0.f);
-            }
-            *(f32x4*)(y + o) = acc;
-        }
 }
 
 // filter gradient, step 1: dM[xi][t][k] = (A dy_tile A^T)[xi], the adjoint of the output transform
@@ -299,7 +372,10 @@ int wino_dims(int mo, int N, int H, int W, int C, int K, WinoDims* d) {
 int wino_filter(int mo, bool dgrad, const float* w, float* U, int K, int C, hipStream_t stream) {
     // w: [K,3,3,C]; forward: U[xi][K][C]; data gradient: U'[xi][C][K]
     const unsigned fb = (unsigned)(((long)K * C + 255) / 256);
-    if (dgrad) {
+    if (dgrad && K % 16 == 0 && C % 16 == 0) {
+        if (mo == 2) hipLaunchKernelGGL(wino_filter_dgrad_kernel<2>, dim3(C / 16, K / 16), dim3(256), 0, stream, w, U, K, C);
+        else hipLaunchKernelGGL(wino_filter_dgrad_kernel<4>, dim3(C / 16, K / 16), dim3(256), 0, stream, w, U, K, C);
+    } else if (dgrad) {
         if (mo == 2) hipLaunchKernelGGL((wino_filter_kernel<2, true>), dim3(fb), dim3(256), 0, stream, w, U, K, C);
         else hipLaunchKernelGGL((wino_filter_kernel<4, true>), dim3(fb), dim3(256), 0, stream, w, U, K, C);
     } else {
@@ -314,7 +390,7 @@ int wino_filter(int mo, bool dgrad, const float* w, float* U, int K, int C, hipS
 // input is written (NULL: inside the workspace) - the filter gradient of the same layer can reuse it
 int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u_cached, float* v_keep, const float* bias,
              const float* add, float* out, float* ws, size_t ws_bytes, int N, int H, int W, int Cin, int Cout,
-             hipStream_t stream, int relu = 0) {
+             hipStream_t stream, int relu = 0, double* stats = nullptr) {
     // in: [N,H,W,Cin]   out: [N,H,W,Cout]   w: KRSC with (K,C) = dgrad ? (Cin,Cout) : (Cout,Cin)
     DENET_CHECK_ARG(in && w && out && ws, "conv_wino: null pointer");
     WinoDims d;
@@ -339,7 +415,7 @@ int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u
     DENET_CHECK_LAUNCH("conv_wino transforms");
     rc = denet_gemm_batched_nt(V, U, Mx, d.NX, (int)d.T, Cout, Cin, d.T * Cin, kc, d.T * Cout, bws, bws_bytes, stream);
     if (rc) return rc;
-    WINO_LAUNCH(mo, wino_output_kernel, d.T * (Cout / 4), Mx, bias, add, out, N, H, W, Cout, d.TH, d.TW, d.T, relu);
+    WINO_LAUNCH(mo, wino_output_kernel, d.T * (Cout / 4), Mx, bias, add, out, N, H, W, Cout, d.TH, d.TW, d.T, relu, stats);
     DENET_CHECK_LAUNCH("conv_wino output");
     return DENET_OK;
 }
@@ -415,6 +491,23 @@ extern "C" int denet_conv_wino_fwd_act(const float* x, const float* w, const flo
                                        hipStream_t stream) {
     return wino_run(tile, false, x, w, u_cached, v_keep, bias, add, y, workspace, workspace_bytes, N, H, W, C, K, stream,
                     relu ? 1 : 0);
+}
+
+// denet_conv_wino_fwd whose output transform also emits the batch-norm column sums (see denet_conv_fwd_stats):
+// stats_partial [rows][2][K] doubles, rows = N*(H/tile)*(W/tile)*(K/4) / 256 written to *stats_rows; *stats_rows = 0 (and no
+// sums) when 256 is not a multiple of K/4 - the caller then lets the batch norm compute its own statistics
+extern "C" int denet_conv_wino_fwd_stats(const float* x, const float* w, const float* u_cached, float* v_keep,
+                                         const float* bias, const float* add, float* y, double* stats_partial,
+                                         size_t stats_bytes, int* stats_rows, float* workspace, size_t workspace_bytes,
+                                         int tile, int N, int H, int W, int C, int K, hipStream_t stream) {
+    DENET_CHECK_ARG(stats_partial && stats_rows && (tile == 2 || tile == 4), "conv_wino_fwd_stats: bad arguments");
+    const int k4n = K / 4;
+    const long threads = (long)N * (H / tile) * (W / tile) * k4n;
+    const long rows = (threads + 255) / 256;
+    const bool ok = k4n > 0 && k4n <= 256 && 256 % k4n == 0 && stats_bytes >= (size_t)rows * 2 * K * sizeof(double);
+    *stats_rows = ok ? (int)rows : 0;
+    return wino_run(tile, false, x, w, u_cached, v_keep, bias, add, y, workspace, workspace_bytes, N, H, W, C, K, stream, 0,
+                    ok ? stats_partial : nullptr);
 }
 
 // transformed filters of a layer, prepared ahead of its passes (e.g. for all layers on a side stream right after the

@@ -32,6 +32,7 @@ class BatchNormLayer(AbstractLayer):
             self.mean = Param(numpy.zeros((c,)), "bn mean")
             self.stdinv = Param(numpy.ones((c,)), "bn std inv")
             self.output = Act(self.output_shape, self.input.cp, "bn%i" % self.layer_index)
+            self.input.want_stats = True      # a convolution writing this tensor also emits its per-channel sums
         else:
             self.output = self.input
         self._save = None
@@ -86,8 +87,11 @@ class BatchNormLayer(AbstractLayer):
         out_act = self.output if out_act is None else out_act
         x = self.input.data
         if get_train():
+            # per-channel sums already written by the convolution that produced x (ConvLayer.forward), valid for this tensor only
+            pre = getattr(self.input, "stats", None)
+            self.input.stats = None
             y, sm, si = ops.bn_fwd_train(x, self.omega.dev, self.beta.dev, self.mean.dev, self.stdinv.dev,
-                                         self.momentum, self.eps, relu=relu, res=res)
+                                         self.momentum, self.eps, relu=relu, res=res, pre=pre)
             self._save = (sm, si, relu, out_act, res is not None)
         else:
             y = ops.bn_fwd_test(x, self.omega.dev, self.beta.dev, self.mean.dev, self.stdinv.dev, self.eps, relu=relu,

@@ -153,9 +153,12 @@ class ConvLayer(AbstractLayer):
         x = self.input.data
         cache = self._cache()
         cache["train"] = bool(get_train()) and self.enabled and self.omega.grad is not None
+        # a batch norm directly behind this layer (it flags its input Act) gets its statistics from this pass's epilogue
+        want_stats = bool(get_train()) and getattr(self.output, "want_stats", False)
         self.output.data = ops.conv_fwd(x, self._w(), bias=self.beta.dev if self.use_bias else None, add=add,
                                         stride=self.stride[0], pad=self.pad, s_real=self.filter_shape[3],
-                                        logical=self._logical(), cache=cache)
+                                        logical=self._logical(), cache=cache, bn_stats=want_stats)
+        self.output.stats = cache.pop("bn_stats", None) if want_stats else None
 
     def forward_folded(self, ctx, bn, add=None, relu=False, out_act=None):
         """inference only: this convolution with the batch-norm layer behind it folded into its filters (recomputed

@@ -27,6 +27,7 @@ SIGNATURES = {
     "denet_host_detect_targets": (I, [P, P, P, P, I, I, I, I, I, I, ctypes.c_double, ctypes.c_double, P, P, P, P]),
     "denet_conv_fwd": (I, [P, P, P, P, P] + [I] * 12 + [P]),
     "denet_conv_fwd_act": (I, [P, P, P, P, P] + [I] * 13 + [P]),
+    "denet_conv_fwd_stats": (I, [P, P, P, P, P, P, Z, P] + [I] * 12 + [P]),
     "denet_conv_dgrad": (I, [P, P, P, P] + [I] * 12 + [P]),
     "denet_conv_wgrad_workspace_bytes": (Z, [I] * 7),
     "denet_conv_wino_workspace_bytes": (Z, [I] * 6),
@@ -35,6 +36,7 @@ SIGNATURES = {
     "denet_conv_wino_filter": (I, [P, P, I, I, I, I, P]),
     "denet_conv_wino_fwd": (I, [P] * 8 + [Z] + [I] * 6 + [P]),
     "denet_conv_wino_fwd_act": (I, [P] * 7 + [I, P, Z] + [I] * 6 + [P]),
+    "denet_conv_wino_fwd_stats": (I, [P] * 8 + [Z, P, P, Z] + [I] * 6 + [P]),
     "denet_conv_wino_dgrad": (I, [P] * 6 + [Z] + [I] * 6 + [P]),
     "denet_conv_tune": (I, [I, P, P, P, P, P, P, Z] + [I] * 12 + [P]),
     "denet_conv_tuned": (I, [I] * 11 + [P, P, P]),
@@ -45,6 +47,7 @@ SIGNATURES = {
     "denet_conv_wgrad": (I, [P, P, P, P, Z] + [I] * 12 + [P]),
     "denet_bn_workspace_bytes": (Z, [L, I]),
     "denet_bn_fwd_train": (I, [P] * 10 + [L, I, F, F, I, P]),
+    "denet_bn_fwd_train_pre": (I, [P] * 10 + [I, L, I, F, F, I, P]),
     "denet_bn_fold": (I, [P] * 6 + [F, P, P, I, L, P]),
     "denet_bn_fwd_test": (I, [P] * 8 + [I, L, I, F, I, P]),
     "denet_bn_bwd": (I, [P] * 12 + [L, I, I, P]),

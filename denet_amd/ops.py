@@ -150,13 +150,30 @@ def _tune_first(mode, g, a, b, bias, add, out, ws):
     return True
 
 
-def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, logical=None, cache=None, relu=False):
+def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, logical=None, cache=None, relu=False,
+             bn_stats=False):
+    """bn_stats (training, the layer behind is a batch norm): the epilogue of the pass also writes the per-channel sums of y;
+    cache["bn_stats"] = (partial sums tensor, rows) for bn_fwd_train(pre=...), or None when the chosen kernel cannot"""
     g = conv_geom(x.shape, w.shape, stride, pad, s_real)
     N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
     y = out if out is not None else empty(N, OH, OW, K)
     _tune_first(0, g, x, w, bias, add, y, None)
+    st = None
+    if bn_stats and cache is not None and not relu:
+        rows = max((N * OH * OW + 127) // 128, (N * (OH // 2 + 1) * (OW // 2 + 1) * (K // 4) + 255) // 256)
+        st = cache.get("bn_stats_buf")
+        if st is None or st.numel() < rows * 2 * K:
+            st = cache["bn_stats_buf"] = torch.empty(rows * 2 * K, dtype=torch.float64, device="cuda")
+        cache["bn_stats"] = None
 
-    def direct():
+    def direct(final=False):
+        if final and st is not None:
+            import ctypes
+            rows = ctypes.c_int(0)
+            check(_L().denet_conv_fwd_stats(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), ptr(st), st.numel() * 8,
+                                            ctypes.byref(rows), *g, stream_ptr()), "conv_fwd_stats")
+            cache["bn_stats"] = (st, rows.value)
+            return
         check(_L().denet_conv_fwd_act(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), int(relu), *g, stream_ptr()), "conv_fwd")
 
     # the implementation is fixed on the first call; the timed candidates scribble over `y`, so the call always ends
@@ -182,12 +199,12 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
                 if v_keep is None or v_keep.numel() != nv:
                     v_keep = cache["V"] = torch.empty(nv, dtype=torch.float32, device="cuda")
                 cache["V_tile"] = tile
-        return conv_wino_fwd(x, w, bias, add, out=y, tile=tile, u=u, v_keep=v_keep, relu=relu)
+        return conv_wino_fwd(x, w, bias, add, out=y, tile=tile, u=u, v_keep=v_keep, relu=relu, stats=(st, cache) if st is not None else None)
     if cache is not None:
         cache["fwd_tile"] = 0
     if PROFILE is not None:
         PROFILE.add(_conv_flops(g, logical))
-    direct()
+    direct(final=True)
     return y
 
 
@@ -329,11 +346,21 @@ def _wino_ws(tile, N, H, W, C, K):
     return WS.get("wino_side" if _ON_WGRAD_STREAM else "wino", _L().denet_conv_wino_workspace_bytes(tile, N, H, W, C, K))
 
 
-def conv_wino_fwd(x, w, bias=None, add=None, out=None, tile=2, u=None, v_keep=None, relu=False):
+def conv_wino_fwd(x, w, bias=None, add=None, out=None, tile=2, u=None, v_keep=None, relu=False, stats=None):
+    """stats = (float64 buffer, cache dict): the output transform also writes the batch-norm column sums (conv_fwd bn_stats)"""
     N, H, W, C = x.shape
     K = w.shape[0]
     y = out if out is not None else empty(N, H, W, K)
     ws = _wino_ws(tile, N, H, W, C, K)
+    if stats is not None and not relu:
+        import ctypes
+        st, cache = stats
+        rows = ctypes.c_int(0)
+        check(_L().denet_conv_wino_fwd_stats(ptr(x), ptr(w), ptr(u), ptr(v_keep), ptr(bias), ptr(add), ptr(y), ptr(st),
+                                             st.numel() * 8, ctypes.byref(rows), ptr(ws), ws.numel(), tile, N, H, W, C, K,
+                                             stream_ptr()), "conv_wino_fwd_stats")
+        cache["bn_stats"] = (st, rows.value) if rows.value > 0 else None
+        return y
     check(_L().denet_conv_wino_fwd_act(ptr(x), ptr(w), ptr(u), ptr(v_keep), ptr(bias), ptr(add), ptr(y), int(relu), ptr(ws),
                                        ws.numel(), tile, N, H, W, C, K, stream_ptr()), "conv_wino_fwd")
     return y
@@ -424,11 +451,18 @@ def _bn_ws(M, C):
     return WS.get("bn", _L().denet_bn_workspace_bytes(M, C))
 
 
-def bn_fwd_train(x, gamma, beta, run_mean, run_stdinv, momentum=0.9, eps=1e-5, relu=False, res=None, out=None):
+def bn_fwd_train(x, gamma, beta, run_mean, run_stdinv, momentum=0.9, eps=1e-5, relu=False, res=None, out=None, pre=None):
+    """pre = (partial sums float64 [rows][2][C], rows) written by the convolution that produced x (conv_fwd bn_stats): the
+    statistics pass over x is skipped"""
     C = x.shape[-1]
     M = x.numel() // C
     y = out if out is not None else torch.empty_like(x)
     save_mean, save_invstd = empty(C), empty(C)
+    if pre is not None:
+        check(_L().denet_bn_fwd_train_pre(ptr(x), ptr(res), ptr(y), ptr(gamma), ptr(beta), ptr(run_mean), ptr(run_stdinv),
+                                          ptr(save_mean), ptr(save_invstd), ptr(pre[0]), int(pre[1]), M, C, momentum, eps,
+                                          int(relu), stream_ptr()), "bn_fwd_train_pre")
+        return y, save_mean, save_invstd
     check(_L().denet_bn_fwd_train(ptr(x), ptr(res), ptr(y), ptr(gamma), ptr(beta), ptr(run_mean), ptr(run_stdinv),
                                   ptr(save_mean), ptr(save_invstd), ptr(_bn_ws(M, C)), M, C, momentum, eps,
                                   int(relu), stream_ptr()), "bn_fwd_train")

@@ -71,6 +71,12 @@ int denet_conv_fwd(const float* x, const float* w, const float* bias, const floa
 int denet_conv_fwd_act(const float* x, const float* w, const float* bias, const float* add, float* y, int relu, int N, int H,
                        int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH, int OW,
                        hipStream_t stream);
+/* the same (no activation), and the epilogue also writes the per-channel sums of y for the batch norm that follows
+ * (denet/layer/batch_norm.py:50-53, batch_norm_relu.py:34-54): stats_partial [ceil(N*OH*OW/128)][2][K] doubles (sum |
+ * sum of squares per row tile), *stats_rows = number of rows. denet_bn_fwd_train_pre consumes them.               */
+int denet_conv_fwd_stats(const float* x, const float* w, const float* bias, const float* add, float* y,
+                         double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int C, int K,
+                         int R, int S, int S_real, int stride, int pad, int OH, int OW, hipStream_t stream);
 int denet_conv_dgrad(const float* dy, const float* w, const float* add, float* dx, int N, int H, int W, int C, int K,
                      int R, int S, int S_real, int stride, int pad, int OH, int OW, hipStream_t stream);
 size_t denet_conv_wgrad_workspace_bytes(int N, int C, int K, int R, int S, int OH, int OW);
@@ -94,6 +100,12 @@ int denet_conv_wino_fwd(const float* x, const float* w, const float* u_cached, f
 int denet_conv_wino_fwd_act(const float* x, const float* w, const float* u_cached, float* v_keep, const float* bias,
                             const float* add, float* y, int relu, float* workspace, size_t workspace_bytes, int tile, int N,
                             int H, int W, int C, int K, hipStream_t stream);
+/* denet_conv_wino_fwd with the batch-norm column sums written by the output transform: stats_partial [rows][2][K] doubles,
+ * *stats_rows = rows, or 0 (no sums written) when 256 is not a multiple of K/4                                    */
+int denet_conv_wino_fwd_stats(const float* x, const float* w, const float* u_cached, float* v_keep, const float* bias,
+                              const float* add, float* y, double* stats_partial, size_t stats_bytes, int* stats_rows,
+                              float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
+                              hipStream_t stream);
 int denet_conv_wino_dgrad(const float* dy, const float* w, const float* u_cached, const float* add, float* dx,
                           float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
                           hipStream_t stream);
@@ -128,6 +140,10 @@ size_t denet_bn_workspace_bytes(long M, int C);
 int denet_bn_fwd_train(const float* x, const float* res, float* y, const float* gamma, const float* beta,
                        float* run_mean, float* run_stdinv, float* save_mean, float* save_invstd, void* workspace,
                        long M, int C, float momentum, float eps, int relu, hipStream_t stream);
+/* batch norm (training) whose statistics pass is replaced by the sums a convolution epilogue wrote: partial [rows][2][C] */
+int denet_bn_fwd_train_pre(const float* x, const float* res, float* y, const float* gamma, const float* beta,
+                           float* run_mean, float* run_stdinv, float* save_mean, float* save_invstd, const double* partial,
+                           int rows, long M, int C, float momentum, float eps, int relu, hipStream_t stream);
 int denet_bn_fwd_test(const float* x, const float* res, float* y, const float* gamma, const float* beta,
                       const float* run_mean, const float* run_stdinv, float* coef, int coef_ready, long M, int C, float eps,
                       int relu, hipStream_t stream);

@@ -70,6 +70,55 @@ def test_conv_fwd_dgrad_wgrad(hip, case):
     _close(dx2, dx + addx)
 
 
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1), (3, 20, 12, 32, 160, 1, 1, 0), (2, 16, 16, 64, 128, 3, 2, 1),
+                                  (1, 12, 12, 128, 128, 3, 1, 1), (2, 24, 24, 64, 96, 3, 1, 1)])
+def test_conv_epilogue_batch_norm_sums(hip, case):
+    """the convolution's epilogue (direct kernel and Winograd output transform) also writes the per-channel sum / sum of squares
+    of its output - the statistics of the batch norm behind it (denet/layer/batch_norm.py:50-53) - and bn_fwd_train(pre=...)
+    normalises with them: same result as the stand-alone statistics pass"""
+    from denet_amd import ops
+    N, H, W, C, K, R, stride, pad = case
+    g = torch.Generator(device="cpu").manual_seed(sum(case))
+    x = torch.randn(N, H, W, C, generator=g).cuda()
+    w = (torch.randn(K, R, R, C, generator=g) * 0.1).cuda()
+    bias = torch.randn(K, generator=g).cuda()
+    OH = (H + 2 * pad - R) // stride + 1
+    addt = torch.randn(N, OH, OH if H == W else (W + 2 * pad - R) // stride + 1, K, generator=g).cuda()
+    gamma, beta = torch.rand(K, generator=g).cuda() + 0.5, torch.randn(K, generator=g).cuda()
+    saved = (ops.AUTOTUNE, dict(ops._WINO), set(ops._TUNED))
+    try:
+        for force_wino in (0, 2, 4):
+            geom = ops.conv_geom(x.shape, w.shape, stride, pad, None)
+            if force_wino and not ops.conv_wino_ok(geom, force_wino):
+                continue
+            ops._WINO.clear()
+            ops._WINO[(0, geom)] = force_wino
+            cache = {"train": True}
+            y = ops.conv_fwd(x, w, bias=bias, add=addt, stride=stride, pad=pad, cache=cache, bn_stats=True)
+            st = cache.get("bn_stats")
+            if force_wino and K // 4 not in (8, 16, 32, 64, 128, 256):
+                assert st is None                     # 256 % (K/4) != 0: the batch norm computes its own statistics
+                continue
+            assert st is not None
+            buf, rows = st
+            part = buf[:rows * 2 * K].view(rows, 2, K).sum(0)
+            yd = y.double().reshape(-1, K)
+            torch.testing.assert_close(part[0], yd.sum(0), rtol=1e-5, atol=1e-4)
+            torch.testing.assert_close(part[1], (yd * yd).sum(0), rtol=1e-5, atol=1e-4)
+            rm, rs = torch.zeros(K).cuda(), torch.ones(K).cuda()
+            rm2, rs2 = rm.clone(), rs.clone()
+            a, sm, si = ops.bn_fwd_train(y, gamma, beta, rm, rs, relu=True, pre=st)
+            b, sm2, si2 = ops.bn_fwd_train(y, gamma, beta, rm2, rs2, relu=True)
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+            torch.testing.assert_close(sm, sm2, rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(si, si2, rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(rs, rs2, rtol=1e-5, atol=1e-6)
+    finally:
+        ops.AUTOTUNE = saved[0]
+        ops._WINO.clear()
+        ops._WINO.update(saved[1])
+
+
 def test_conv_stem_small_c(hip):
     """7x7/2 stem: C=3 padded to 4, S padded 7->8 (zero tap); wgrad must leave the padded tap at 0."""
     from denet_amd import ops
