@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-warm", action="store_true", help="skip the warm-corner-regime leg (rank 0, N=1)")
     ap.add_argument("--regime", default="cold", choices=["cold", "warm"],
                     help="cold = weights as initialised (corner bias +5: no detector RoIs, SURVEY §8d); warm = corner "
                          "head re-biased so that ~1%% of the cells fire")
@@ -93,14 +94,7 @@ def main():
     # identical initial weights on every rank (seed), per-rank data shard (seed + rank)
     model = zoo.denet34(BATCH_PER_GPU, "skip", 512, class_num=80, seed=1)
     if args.regime == "warm":
-        rng = numpy.random.RandomState(3)
-        conv = model.layers[30].layers[-1]
-        w = conv.omega.get_value().copy()
-        w[:4] = rng.normal(0, 0.3, w[:4].shape)
-        conv.omega.set_value(w)
-        b = conv.beta.get_value().copy()
-        b[:4] = 7.5
-        conv.beta.set_value(b)
+        zoo.warm_corner_head(model)
     model.build_train_func("nesterov")
     if dp is not None:
         model.dist = dp
@@ -153,8 +147,10 @@ def main():
                    "global_batch": BATCH_PER_GPU * world, "batch_per_gpu": BATCH_PER_GPU, "classes": 80,
                    "rois_per_image": 576, "parallelism": "dp%d" % world, "solver": "nesterov",
                    "conv_algorithms": "fp32 throughout; per layer and pass the faster of the direct implicit GEMM and "
-                                      "Winograd F(2x2,3x3)/F(4x4,3x3) is measured on the first step (DENET_WINOGRAD=0: "
-                                      "direct kernels only)",
+                                      "Winograd F(2x2,3x3)/F(4x4,3x3), as measured once by tools/tune.py and stored in "
+                                      "denet_amd/tuned/gfx950.json (every process runs the same kernels; geometries not "
+                                      "in the file are measured on the first step; DENET_WINOGRAD=0: direct kernels only)",
+                   "input": "fp32 NCHW batch resident in HBM before the timed region",
                    "final_cost": round(float(cost), 5)},
         # rate in FLOPs of the reference's direct algorithm (164.3 GFLOP per image and step); layers that run Winograd
         # execute fewer, so this is an effective rate - the MFMA utilisation of the kernels is in `roofline`
@@ -183,6 +179,46 @@ def main():
                                              "ms_per_step": round(v["ms"] / nprof, 3),
                                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
                                          for k, v in sorted(agg.items())}}
+
+    if rank == 0 and world == 1 and not args.no_warm and args.regime == "cold":
+        # the headline regime has no detector RoIs (cold corner head); the same step with a firing corner head
+        # exercises the RoI proposal for real (pair enumeration of a few hundred corners per type, top-576 selection)
+        del model
+        torch.cuda.empty_cache()
+        mw = zoo.warm_corner_head(zoo.denet34(BATCH_PER_GPU, "skip", 512, class_num=80, seed=1))
+        mw.build_train_func("nesterov")
+        random.seed(1)
+        wit = 0
+        for _ in range(max(args.warmup, 2)):
+            mw.train_step(xd, metas, 0, wit, lr, mom, decay)
+            wit += 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rois = []
+        for _ in range(args.steps):
+            wcost, _ = mw.train_step(xd, metas, 0, wit, lr, mom, decay)
+            wit += 1
+            dns = [l for l in mw.layers if l.type_name == "denet-sparse"][0]
+            raw = getattr(dns, "_raw_samples", None)
+            rois.append(float(raw[1].mean()) if raw is not None else 0.0)
+        torch.cuda.synchronize()
+        wdt = time.perf_counter() - t0
+        # the RoI proposal alone (corner_select + pair_* kernels) on the last corner map, event-timed on its stream
+        dnc = [l for l in mw.layers if l.type_name == "denet-corner"][0]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ops.build_samples(dnc.corner_pr, dns.corner_threshold, dns.proposal_count, 1024, dns.local_max)
+        e0.record()
+        for _ in range(10):
+            ops.build_samples(dnc.corner_pr, dns.corner_threshold, dns.proposal_count, 1024, dns.local_max)
+        e1.record()
+        torch.cuda.synchronize()
+        out["warm_regime"] = {"value": round(BATCH_PER_GPU * args.steps / wdt, 2), "unit": "images/sec",
+                              "ms_per_step": round(1e3 * wdt / args.steps, 3),
+                              "detector_rois_per_image": round(sum(rois) / len(rois), 1),
+                              "roi_proposal_kernels_ms": round(e0.elapsed_time(e1) / 10, 4),
+                              "final_cost": round(float(wcost), 5),
+                              "note": "same step, DNC corner head re-biased (zoo.warm_corner_head) so that ~1 % of the cells "
+                                      "fire; the proposal replaces the reference's host pair search (denet_sparse.cc:337-373)"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import model as OM

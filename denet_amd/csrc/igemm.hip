@@ -1258,6 +1258,40 @@ extern "C" int denet_conv_tuned(int mode, int N, int H, int W, int C, int K, int
     return DENET_OK;
 }
 
+// ---- persistence of the measured launch configurations (reproducible runs: the same geometry always runs the same kernels)
+// a record is 14 ints: the 11 key fields (mode, N, H, W, C, K, R, S, S_real, stride, pad; modes 3 / 4 = batched component
+// GEMM / batched filter-gradient product of the Winograd passes, see tune_key call sites) + tile, nbuf, rounds
+extern "C" int denet_tune_export(int* records, int capacity) {
+    int n = 0;
+    for (const auto& kv : g_tuned) {
+        if (records && n < capacity) {
+            int* r = records + (size_t)n * 14;
+            for (int i = 0; i < 11; ++i) r[i] = kv.first.v[i];
+            r[11] = kv.second.tile; r[12] = kv.second.nbuf; r[13] = kv.second.rounds;
+        }
+        ++n;
+    }
+    return n;
+}
+
+extern "C" int denet_tune_import(const int* records, int count) {
+    DENET_CHECK_ARG(records || count == 0, "tune_import: null records");
+    for (int n = 0; n < count; ++n) {
+        const int* r = records + (size_t)n * 14;
+        TuneKey k;
+        for (int i = 0; i < 11; ++i) k.v[i] = r[i];
+        DENET_CHECK_ARG(r[0] >= 0 && r[0] <= 4 && r[11] >= 0 && r[11] <= 1 && r[12] >= 1 && r[12] <= 12 && r[13] >= 0 && r[13] <= 6,
+                        "tune_import: record %d is not a launch configuration", n);
+        g_tuned[k] = TuneVal{r[11], r[12], r[13]};
+    }
+    return DENET_OK;
+}
+
+extern "C" int denet_tune_clear(void) {
+    g_tuned.clear();
+    return DENET_OK;
+}
+
 extern "C" int denet_conv_last_config(int* mode, int* bm, int* bn, int* nbuf, int* grid_y) {
     if (mode) *mode = g_last_cfg[0];
     if (bm) *bm = g_last_cfg[1];

@@ -95,6 +95,23 @@ def cifar3(batch_size=32, class_num=10, seed=1):
     return m
 
 
+def warm_corner_head(model, bias=7.5, std=0.3, seed=3):
+    """SURVEY.md section 8(d) "warm" corner regime: the DNC corner rows (zero weights / bias +5 as initialised,
+    denet_corner.py:41-47, i.e. P(corner) = 4.5e-5 < threshold: no detector RoIs) get random weights and a bias such that
+    roughly 1 % of the cells of every corner type fire - the RoI proposal (denet_sparse.cc:337-373, the reference's dominant
+    host cost) then has a few hundred corners per type and image to pair"""
+    rng = numpy.random.RandomState(seed)
+    dnc = [l for l in model.layers if l.type_name == "denet-corner"][0]
+    conv = dnc.layers[-1]
+    w = conv.omega.get_value().copy()
+    w[:dnc.corner_num] = rng.normal(0, std, w[:dnc.corner_num].shape)
+    conv.omega.set_value(w)
+    b = conv.beta.get_value().copy()
+    b[:dnc.corner_num] = bias
+    conv.beta.set_value(b)
+    return model
+
+
 def synthetic_batch(batch_size, image=512, class_num=80, seed=1, image_class=False):
     """x ~ U(0,1) (B,3,H,W) float32 NCHW (the value range after /255,
     denet/dataset/__init__.py:359); per image n ~ clip(Poisson(7),1,30) boxes, centre ~ U(0.1,0.9)^2,

@@ -140,8 +140,68 @@ AUTOTUNE = os.environ.get("DENET_AUTOTUNE", "1") != "0"
 _TUNED = set()
 
 
+# ---- persisted launch configurations ------------------------------------------------------------------------------------
+# denet_amd/tuned/gfx950.json (written by tools/tune.py on an MI355X, committed) holds, per geometry, the measured kernel
+# configuration of every pass and the direct / Winograd decision. It is loaded with the library: the geometries it covers are
+# never measured again, so two processes run the SAME kernels (bench.py, the rocprofv3 profiles and the PMC passes
+# describe one launch population). DENET_TUNE_CACHE=<path> selects another file, DENET_TUNE_CACHE=0 ignores it.
+TUNE_CACHE = os.environ.get("DENET_TUNE_CACHE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gfx950.json"))
+_TUNE_LOADED = False
+
+
+def _geom_of_record(r):
+    mode, N, H, W, C, K, R, S, s_real, stride, pad = r[:11]
+    OH = (H + 2 * pad - R) // stride + 1
+    OW = (W + 2 * pad - s_real) // stride + 1
+    return mode, (N, H, W, C, K, R, S, s_real, stride, pad, OH, OW)
+
+
+def load_tuned(path=None):
+    """imports a configuration file; returns the number of kernel records"""
+    import ctypes
+    import json
+    path = path or TUNE_CACHE
+    with open(path) as f:
+        d = json.load(f)
+    rec = d.get("kernels", [])
+    if rec:
+        flat = (ctypes.c_int * (14 * len(rec)))(*[v for r in rec for v in r])
+        check(_L().denet_tune_import(flat, len(rec)), "tune_import")
+    for r in rec:
+        if r[0] <= 2:
+            _TUNED.add(_geom_of_record(r))
+    for mode, g, tile in d.get("winograd", []):
+        if int(tile) <= WINOGRAD:            # DENET_WINOGRAD=0|2 restricts the tiles: excluded entries are decided afresh
+            _WINO[(int(mode), tuple(int(v) for v in g))] = int(tile)
+    return len(rec)
+
+
+def save_tuned(path, meta=None):
+    import ctypes
+    import json
+    n = _L().denet_tune_export(None, 0)
+    buf = (ctypes.c_int * (14 * max(n, 1)))()
+    _L().denet_tune_export(buf, n)
+    rec = sorted([list(buf[i * 14:(i + 1) * 14]) for i in range(n)])
+    wino = sorted([[m, list(g), t] for (m, g), t in _WINO.items()])
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "w") as f:
+        json.dump({"meta": meta or {}, "kernels": rec, "winograd": wino}, f, separators=(",", ":"))
+    return n
+
+
+def _load_tuned_once():
+    global _TUNE_LOADED
+    if _TUNE_LOADED:
+        return
+    _TUNE_LOADED = True
+    if AUTOTUNE and TUNE_CACHE not in ("0", "") and os.path.exists(TUNE_CACHE):
+        load_tuned(TUNE_CACHE)
+
+
 def _tune_first(mode, g, a, b, bias, add, out, ws):
     """True if this call was served by the tuner (which leaves the pass's result in `out`)"""
+    _load_tuned_once()
     if not AUTOTUNE or PROFILE is not None or (mode, g) in _TUNED:
         return False
     _TUNED.add((mode, g))

@@ -121,6 +121,11 @@ int denet_conv_tune(int mode, const float* a, const float* b, const float* bias,
                     int stride, int pad, int OH, int OW, hipStream_t stream);
 int denet_conv_tuned(int mode, int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad,
                      int* tile, int* nbuf, int* rounds);
+/* persistence of the measured configurations: records of 14 ints (11 key fields + tile, nbuf, rounds). export returns the
+ * number of entries (writes at most `capacity`); import adds / replaces entries; geometries present are not measured again */
+int denet_tune_export(int* records, int capacity);
+int denet_tune_import(const int* records, int count);
+int denet_tune_clear(void);
 int denet_conv_last_config(int* mode, int* bm, int* bn, int* nbuf, int* grid_y);
 /* live timing of the igemm kernel alone (bench.py roofline leg): denet_conv_profile(1) starts recording one HIP event
  * pair per convolution launch on the launch stream, (0) stops and frees; _read returns the duration of launch i and the
