@@ -45,7 +45,6 @@ struct BgemmParams {
     unsigned* flags;        // [G] epoch of the slab's last publication
     unsigned* err;          // set to 1 if a wait timed out
     unsigned epoch;
-    int dbg;                // experiments: 1 = nt stores of C, 2 = no stores of C, 4 = no fix-up traffic
 };
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -250,13 +249,7 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const BgemmParams p) {
                     const int nn = n0 + (wn * TN + j) * 32 + 8 * q + 4 * lh;
                     if (nn >= p.N) continue;
                     const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                    if (p.dbg & 2) {
-                        if (v[0] == 123.456f) *(f32x4*)(out + row + nn) = v;
-                    } else if (p.dbg & 1) {
-                        __builtin_nontemporal_store(v, (f32x4*)(out + row + nn));
-                    } else {
-                        *(f32x4*)(out + row + nn) = v;
-                    }
+                    *(f32x4*)(out + row + nn) = v;
                 }
         }
     };
@@ -269,9 +262,9 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(const BgemmParams p) {
             return;
         }
         if (tile_done && in_first_tile && first_is_tail) {
-            if (!(p.dbg & 4)) publish_partial();
+            publish_partial();
         } else {
-            if (!tile_done && !(p.dbg & 4)) add_partial();       // range ends inside the tile: we hold the head part
+            if (!tile_done) add_partial();       // range ends inside the tile: we hold the head part
             store_tile();
         }
         in_first_tile = false;
@@ -428,10 +421,6 @@ int denet_bgemm(const float* a, const float* b, float* c, int batch, int M, int 
     p.flags = (unsigned*)workspace;
     p.err = p.flags + 4095;
     p.partial = (float*)((char*)workspace + 16384);
-    {
-        const char* e = getenv("DENET_BGEMM_DBG");
-        p.dbg = e ? atoi(e) : 0;
-    }
     p.epoch = ++g_epoch;
     if (p.epoch == 0) p.epoch = ++g_epoch;
     if (tile == 0 && N >= 128) {
