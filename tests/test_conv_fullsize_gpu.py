@@ -121,6 +121,18 @@ def test_conv_passes_at_benchmark_geometry(hip, geom):
                 ent["dgrad"] = _metrics(dx, dx_ref)
             if S != s_real:
                 assert float(dw[:, :, s_real:, :].abs().max()) == 0.0
+            # the same forward pass with the batch-norm column sums written by its epilogue (what ConvLayer.forward runs in
+            # training): identical output, sums against fp64
+            cache = {"train": True}
+            y2 = ops.conv_fwd(x, w, stride=stride, pad=pad, s_real=s_real, cache=cache, bn_stats=True)
+            st = cache.get("bn_stats")
+            assert torch.equal(y2, y)
+            if st is not None:
+                part = st[0][:st[1] * 2 * K].view(st[1], 2, K).sum(0)
+                yd = y_ref.reshape(-1, K)
+                ent["bn_sums"] = (float((part[0] - yd.sum(0)).abs().max() / (yd.abs().sum(0).max() + 1e-30)),
+                                  float((part[1] - (yd * yd).sum(0)).abs().max() / (yd * yd).sum(0).max()))
+                assert ent["bn_sums"][0] <= 1e-5 and ent["bn_sums"][1] <= 1e-5, (name, label, ent["bn_sums"])
             res[label] = ent
     finally:
         ops.AUTOTUNE = saved[0]
