@@ -304,6 +304,17 @@ class ModelCNN:
         assert tuple(x.shape) == self.get_input_shape(), (tuple(x.shape), self.get_input_shape())
         self.input.data = ops.nchw_to_nhwc(x.contiguous(), self.input.cp)
 
+    def _consumers(self, act):
+        """number of layers (nested ones included) that read `act` as their input or as a skip tap"""
+        counts = self.__dict__.get("_consumer_counts")
+        if counts is None:
+            counts = self.__dict__["_consumer_counts"] = {}
+            for l in walk_layers(self.layers):
+                for a in {id(getattr(l, k)): getattr(l, k) for k in ("input", "x", "y", "skip") if getattr(l, k, None) is not None}.values():
+                    if a is not getattr(l, "output", None) or l.type_name == "skip-src":
+                        counts[id(a)] = counts.get(id(a), 0) + 1
+        return counts.get(id(act), 0)
+
     def forward(self, data_x, data_m=None, train=True):
         """runs the layers in order; in training mode get_target of layer i is called right before its forward
         (so DNS sees the corner map of this very pass and DND sees the edited RoI list)"""
@@ -323,7 +334,10 @@ class ModelCNN:
                 continue
             if fold and layer.type_name == "conv" and layer.enabled and i + 2 < len(self.layers):
                 nxt = self.layers[i + 2]
-                if nxt.type_name in ("batchnorm", "batchnorm-relu") and nxt.enabled and nxt.input is layer.output:
+                if nxt.type_name in ("batchnorm", "batchnorm-relu") and nxt.enabled and nxt.input is layer.output \
+                        and self._consumers(layer.output) == 1:
+                    # folded only when the batch norm is the ONLY reader of the convolution's output: the folded pass
+                    # writes normalised values into it, any other consumer (skip source, split, detection tail) needs the raw ones
                     layer.forward_folded(ctx, nxt, relu=nxt.type_name == "batchnorm-relu")
                     skip_next = True
                     continue

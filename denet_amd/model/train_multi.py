@@ -16,7 +16,12 @@ CONSECUTIVE batches `r * F ... r * F + F - 1` of the iteration. Like the referen
   F > 1: what the shipped recipes run (papers/dss/denet34.sh:43 `--batch-size-factor 2` without --use-acc-mode): every rank
          takes F full local steps, then parameters, momentum and BN statistics are averaged over the ranks
          (DataParallel.average_state) - the reference's scheme itself, over RCCL instead of host shared memory.
-Rank 0 writes the checkpoints."""
+Rank 0 writes the checkpoints with the reference's names: `<prefix>_epochNNN_final.mdl.gz` after every epoch
+(train_multi.py:166) - the reference's timed `_epochNNN_subsetMMM` files are written with `--save-subsets` after every subset.
+`--epoch-start E` skips the first E epochs (the learning rate is annealed for them, train_multi.py:406-410; the shuffle seed is
+seed + epoch, so the data order of the remaining epochs is unchanged); `--restart` finds the newest `<prefix>_epoch*.mdl.gz`
+like load_restart_args (train_multi.py:242-268) and continues behind it. The momentum buffer is not part of a .mdl.gz (as in
+the reference): a restarted run begins with zero momentum."""
 import math
 import os
 import random
@@ -76,7 +81,11 @@ def train(args, train_data, dp, log=None):
                                    params=train_data.image_loader)
     learn_rate = args.learn_rate
     costs = []
-    for epoch in range(args.epochs):
+    epoch_start = int(getattr(args, "epoch_start", 0))
+    for epoch in range(0, epoch_start):                 # train_multi.py:406-410
+        if len(args.learn_anneal_epochs) == 0 or (epoch + 1) in args.learn_anneal_epochs:
+            learn_rate *= args.learn_anneal
+    for epoch in range(epoch_start, args.epochs):
         random.seed(args.seed + epoch)                 # same order on every rank (train_multi.py:44-46)
         train_data.shuffle()
         for subset in range(train_data.subset_num):
@@ -101,15 +110,28 @@ def train(args, train_data, dp, log=None):
             costs.append(cost)
             if rank == 0:
                 log("epoch %i subset %i - cost (rank 0): %.4f (lr %g, %i GPUs)" % (epoch, subset, cost, learn_rate, world))
+                if getattr(args, "save_subsets", False) and not args.disable_intermediate:
+                    model_cnn.save_to_file(model, args.output_prefix + "_epoch%03i_subset%03i.mdl.gz" % (epoch, subset + 1))
         if len(args.learn_anneal_epochs) == 0 or (epoch + 1) in args.learn_anneal_epochs:
             learn_rate *= args.learn_anneal
-        if rank == 0 and not args.disable_intermediate:
-            model_cnn.save_to_file(model, args.output_prefix + "_epoch%03i.mdl.gz" % epoch)
+        if rank == 0 and (not args.disable_intermediate or epoch == args.epochs - 1):
+            model_cnn.save_to_file(model, args.output_prefix + "_epoch%03i_final.mdl.gz" % epoch)     # train_multi.py:166
     if loader is not None:
         loader.close()
-    if rank == 0:
-        model_cnn.save_to_file(model, args.output_prefix + "_epoch%03i_final.mdl.gz" % (args.epochs - 1))
     return model, costs
+
+
+def find_restart(output_prefix):
+    """(model file, epoch_start) of the newest checkpoint of a run (load_restart_args, train_multi.py:242-268): a `_final`
+    file continues with the next epoch, a `_subsetMMM` file repeats its epoch"""
+    import glob
+    files = sorted(glob.glob(output_prefix + "_epoch*.mdl.gz"))
+    if not files:
+        raise Exception("Could not find any intermediate models to continue training from!")
+    v = os.path.basename(files[-1])
+    v = v[:v.find(".")].split("_")
+    epoch = int(v[-2][5:]) + 1 if v[-1] == "final" else int(v[-2][5:])
+    return files[-1], epoch
 
 
 def main(argv=None):
@@ -117,7 +139,12 @@ def main(argv=None):
     parser = train_mod.build_parser()
     parser.add_argument("--batch-size-factor", type=int, default=1,
                         help="local training steps per rank between two parameter averagings (1: gradient all-reduce every step)")
+    parser.add_argument("--epoch-start", type=int, default=0, help="Epoch to start from")
+    parser.add_argument("--restart", default=False, action="store_true", help="Restart training of model")
+    parser.add_argument("--save-subsets", default=False, action="store_true", help="checkpoint after every subset")
     args = parser.parse_args(argv)
+    if args.restart:
+        args.model, args.epoch_start = find_restart(args.output_prefix)
     from ..common import logging
     logging.init(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))

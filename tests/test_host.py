@@ -452,6 +452,21 @@ def test_model_modify_cli_replays_the_denet_recipe(tmp_path):
     assert [l for l in mm.layers if l.type_name == "denet-sparse"][0].corner_threshold == 0.05
 
 
+def test_train_multi_restart_lookup(tmp_path):
+    """--restart: newest checkpoint of the run and the epoch to continue with (load_restart_args, train_multi.py:242-268)"""
+    from denet_amd.model.train_multi import find_restart
+    prefix = str(tmp_path / "run")
+    with pytest.raises(Exception):
+        find_restart(prefix)
+    for name in ("_epoch000_final", "_epoch001_subset003", "_epoch001_final", "_epoch002_subset001"):
+        open(prefix + name + ".mdl.gz", "w").close()
+    assert find_restart(prefix) == (prefix + "_epoch002_subset001.mdl.gz", 2)
+    os.remove(prefix + "_epoch002_subset001.mdl.gz")
+    assert find_restart(prefix) == (prefix + "_epoch001_subset003.mdl.gz", 1)      # sorted(): "subset" > "final", as in the reference
+    os.remove(prefix + "_epoch001_subset003.mdl.gz")
+    assert find_restart(prefix) == (prefix + "_epoch001_final.mdl.gz", 2)
+
+
 def test_train_multi_sharding():
     """model-train-multi: a global iteration is world x F batches of consecutive samples; worker r takes the F consecutive
     batches r*F .. r*F+F-1 (train_multi.py:113-119); the last partial iteration is padded with random.randint draws like

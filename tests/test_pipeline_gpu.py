@@ -185,3 +185,11 @@ def test_model_train_multi_launcher_single_rank(hip, tree, tmp_path):
     from denet_amd.model import model_cnn
     m = model_cnn.load_from_file(prefix + "_epoch001_final.mdl.gz", 2)
     assert m.layers[-1].type_name == "denet-detect"
+    # --restart (train_multi.py:242-268): continues behind the newest checkpoint of the run: epoch 2 only
+    i = cmd.index("--epochs")
+    cmd3 = cmd[:i + 1] + ["3"] + cmd[i + 2:] + []
+    cmd3 = cmd3[:1] + ["--restart"] + cmd3[1:]
+    r3 = subprocess.run(cmd3, env=dict(env, MASTER_PORT="29535"), capture_output=True, text=True, timeout=240)
+    assert r3.returncode == 0, r3.stdout[-2000:] + r3.stderr[-3000:]
+    assert "epoch 2 subset" in r3.stdout and "epoch 1 subset" not in r3.stdout and "epoch 0 subset" not in r3.stdout
+    assert os.path.exists(prefix + "_epoch002_final.mdl.gz")
