@@ -278,3 +278,28 @@ extern "C" int denet_host_detect_targets(const double* gt, const int* gt_off, co
     }
     return DENET_OK;
 }
+
+// ---- stream placement probe -------------------------------------------------------------------------------------------
+// One wavefront that does nothing for `cycles` shader clocks. Two of them on two streams finish in ~1x the time when the
+// streams sit on different hardware queues and in ~2x when the runtime multiplexed both onto one queue (HIP gives a process
+// GPU_MAX_HW_QUEUES = 4 queues; torch's stream pool and RCCL create dozens of streams). The host picks, for the
+// filter-gradient chain, a stream that really runs beside the compute stream (ops.init_streams).
+namespace {
+__global__ void spin_kernel(long long cycles, int* sink) {
+    const long long t0 = wall_clock64();
+    long long t = t0;
+    while (t - t0 < cycles) {
+        __builtin_amdgcn_s_sleep(32);
+        t = wall_clock64();
+    }
+    if (sink && t == 0) *sink = 1;
+}
+}  // namespace
+
+// wall_clock64 ticks at 100 MHz on gfx950: `microseconds` x 100 ticks
+extern "C" int denet_spin(int microseconds, hipStream_t stream) {
+    DENET_CHECK_ARG(microseconds > 0 && microseconds <= 100000, "spin: duration out of range");
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, stream, (long long)microseconds * 100, (int*)nullptr);
+    DENET_CHECK_LAUNCH("spin");
+    return DENET_OK;
+}

@@ -27,6 +27,7 @@ SIGNATURES = {
     "denet_host_detect_targets": (I, [P, P, P, P, I, I, I, I, I, I, ctypes.c_double, ctypes.c_double, P, P, P, P]),
     "denet_conv_fwd": (I, [P, P, P, P, P] + [I] * 12 + [P]),
     "denet_conv_fwd_act": (I, [P, P, P, P, P] + [I] * 13 + [P]),
+    "denet_spin": (I, [I, P]),
     "denet_tune_export": (I, [P, I]),
     "denet_tune_import": (I, [P, I]),
     "denet_tune_clear": (I, []),

@@ -271,6 +271,10 @@ class ModelCNN:
         if use_acc_mode:
             raise NotImplementedError("--use-acc-mode is outside the hot path")
         self.solver_mode = solver_mode
+        import torch
+        if torch.cuda.is_available():
+            from .. import ops
+            ops.init_streams()
         self.cost_layers = []
         self.cost_layer_names = []
         for layer in self.layers:

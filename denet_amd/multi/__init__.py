@@ -30,6 +30,13 @@ class DataParallel:
             if backend == "nccl":
                 torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
             dist.init_process_group(backend=backend)
+            if backend == "nccl":
+                # RCCL and the process group have taken their hardware queues: place the side streams now
+                import torch.distributed as _d
+                t = torch.zeros(1, device="cuda")
+                _d.all_reduce(t)
+                from .. import ops
+                ops.init_streams(force=True)
         self.backend = dist.get_backend()
         self.world_size = dist.get_world_size()
         self.rank = dist.get_rank()

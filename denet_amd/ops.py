@@ -76,6 +76,43 @@ PROFILE = None
 _COPY_STREAM = None
 
 
+def _runs_beside(stream, main, us=300):
+    """True if a kernel on `stream` really overlaps one on `main` (they sit on different hardware queues)"""
+    L = _L()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(main)
+    check(L.denet_spin(us, main.cuda_stream), "spin")
+    stream.wait_event(e0)
+    check(L.denet_spin(us, stream.cuda_stream), "spin")
+    e2 = torch.cuda.Event()
+    e2.record(stream)
+    main.wait_event(e2)
+    e1.record(main)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 < 1.5 * us
+
+
+def init_streams(force=False):
+    """Creates the side streams. The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES (4) hardware
+    queues, and torch's stream pool + RCCL create dozens: if the filter-gradient stream lands on the compute stream's queue
+    the two backward chains serialise silently (measured under torch.distributed: 831 instead of 884 img/s). So the candidates
+    are PROBED (two idle kernels, _runs_beside) and a stream that really runs beside the current one is taken. Call it after
+    torch.distributed is initialised (DataParallel does) and when a model is prepared for training."""
+    global _COPY_STREAM, _SIDE_FILTER, _WGRAD_STREAM, _SORT_STREAM
+    main = torch.cuda.current_stream()
+    if _WGRAD_STREAM is None or force:
+        cands = [torch.cuda.Stream() for _ in range(12)]
+        good = [s for s in cands if _runs_beside(s, main)]
+        _WGRAD_STREAM = good[0] if good else cands[0]
+        # filter transforms / tap sort: beside the compute stream too, and preferably not on the filter-gradient queue
+        rest = [s for s in good[1:] if _runs_beside(s, _WGRAD_STREAM)] or good[1:] or cands[1:]
+        _SIDE_FILTER = rest[0]
+        _SORT_STREAM = rest[1] if len(rest) > 1 else rest[0]
+    if _COPY_STREAM is None:
+        _COPY_STREAM = torch.cuda.Stream()
+
+
 def upload_async(pinned):
     """H2D copy of a pinned host tensor on a dedicated copy stream: a target array issued on the compute stream
     would sit between two kernels and stall them for the PCIe time (4-8 MB = 0.1-0.3 ms per step). Returns

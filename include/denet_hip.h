@@ -123,6 +123,9 @@ int denet_conv_tuned(int mode, int N, int H, int W, int C, int K, int R, int S, 
                      int* tile, int* nbuf, int* rounds);
 /* persistence of the measured configurations: records of 14 ints (11 key fields + tile, nbuf, rounds). export returns the
  * number of entries (writes at most `capacity`); import adds / replaces entries; geometries present are not measured again */
+/* a single wavefront that idles for `microseconds` on `stream`: lets a host find out whether two streams run concurrently
+ * (different hardware queues) or were multiplexed onto one queue by the runtime                                      */
+int denet_spin(int microseconds, hipStream_t stream);
 int denet_tune_export(int* records, int capacity);
 int denet_tune_import(const int* records, int count);
 int denet_tune_clear(void);

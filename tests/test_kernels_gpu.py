@@ -527,6 +527,26 @@ def test_stream_k_batched_gemm(hip, shape):
             assert err < 5e-6, (tile, wg, err)
 
 
+def test_side_streams_run_beside_the_compute_stream(hip):
+    """ops.init_streams: the filter-gradient / side streams are picked by probing (two idle kernels) so that they sit on a
+    hardware queue of their own - the HIP runtime multiplexes all streams of a process onto 4 queues, and a filter-gradient
+    stream that shares the compute stream's queue serialises the two backward chains silently"""
+    import time
+    from denet_amd import ops
+    ops.init_streams(force=True)
+    main = torch.cuda.current_stream()
+    assert ops._runs_beside(ops._WGRAD_STREAM, main)
+    assert ops._runs_beside(ops._SIDE_FILTER, main) and ops._runs_beside(ops._SORT_STREAM, main)
+    assert not ops._runs_beside(main, main)                       # same stream: strictly serial
+    # the probe kernel idles for about the time asked for
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ops.check(hip.denet_spin(20000, main.cuda_stream), "spin")
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert 0.015 < dt < 0.08, dt
+
+
 @pytest.mark.parametrize("bounded", [False, True])
 def test_detect_loss(hip, bounded):
     from denet_amd import ops
