@@ -380,7 +380,7 @@ class ModelCNN:
         # next step while the device finishes this one
         if getattr(self, "_cost_host", None) is None:
             self._cost_host = torch.empty(16, dtype=torch.float32).pin_memory()
-            self._cost_stream = torch.cuda.Stream()
+            self._cost_stream = ops.side_stream(3)
         self._cost_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._cost_stream):
             self._cost_host.copy_(self.cost_buf, non_blocking=True)

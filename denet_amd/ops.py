@@ -76,6 +76,15 @@ PROFILE = None
 _COPY_STREAM = None
 
 
+SIDE_STREAMS = []          # probed streams that run beside the compute stream (init_streams)
+
+
+def side_stream(i=0):
+    """a stream that really runs beside the compute stream (for small asynchronous copies)"""
+    init_streams()
+    return SIDE_STREAMS[i % len(SIDE_STREAMS)] if SIDE_STREAMS else torch.cuda.Stream()
+
+
 def _runs_beside(stream, main, us=300):
     """True if a kernel on `stream` really overlaps one on `main` (they sit on different hardware queues)"""
     L = _L()
@@ -109,8 +118,10 @@ def init_streams(force=False):
         rest = [s for s in good[1:] if _runs_beside(s, _WGRAD_STREAM)] or good[1:] or cands[1:]
         _SIDE_FILTER = rest[0]
         _SORT_STREAM = rest[1] if len(rest) > 1 else rest[0]
-    if _COPY_STREAM is None:
-        _COPY_STREAM = torch.cuda.Stream()
+        # uploads of targets / the early copy of the costs: off the compute stream's queue as well (behind it they would wait
+        # for whatever kernels are queued there)
+        _COPY_STREAM = rest[2 % len(rest)]
+        SIDE_STREAMS[:] = rest
 
 
 def upload_async(pinned):
@@ -119,7 +130,7 @@ def upload_async(pinned):
     (device tensor, event); the consumer calls wait_upload(event) right before the first kernel that reads it."""
     global _COPY_STREAM
     if _COPY_STREAM is None:
-        _COPY_STREAM = torch.cuda.Stream()
+        init_streams()
     with torch.cuda.stream(_COPY_STREAM):
         dev = pinned.cuda(non_blocking=True)
         ev = torch.cuda.Event()
