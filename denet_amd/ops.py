@@ -389,7 +389,7 @@ def wino_prefetch_filters(caches_and_weights):
     if not todo:
         return
     if _SIDE_FILTER is None:
-        _SIDE_FILTER = torch.cuda.Stream()
+        init_streams()
     _SIDE_FILTER.wait_stream(torch.cuda.current_stream())        # the solver update of the weights
     with torch.cuda.stream(_SIDE_FILTER):
         for c, w in todo:
@@ -429,7 +429,7 @@ class wgrad_stream:
         if not self.active:
             return self
         if _WGRAD_STREAM is None:
-            _WGRAD_STREAM = torch.cuda.Stream()
+            init_streams()
         _WGRAD_STREAM.wait_stream(torch.cuda.current_stream())
         self.ctx = torch.cuda.stream(_WGRAD_STREAM)
         self.ctx.__enter__()
@@ -840,7 +840,7 @@ def sparse_sort_async(taps, B, H, W, rois_per_image, gs):
     taps); returns the event sparse_bwd(presorted=...) waits for"""
     global _SORT_STREAM
     if _SORT_STREAM is None:
-        _SORT_STREAM = torch.cuda.Stream()
+        init_streams()
     ws = WS.get("sparse_sort", _L().denet_sparse_sort_workspace_bytes(B, H, W, rois_per_image, gs))
     _SORT_STREAM.wait_stream(torch.cuda.current_stream())          # taps are written by sparse_fwd on this stream
     with torch.cuda.stream(_SORT_STREAM):
