@@ -272,7 +272,8 @@ class DeviceImageLoader:
         n = len(plans)
         size = batch_size * math.ceil(n / batch_size)
         index = list(range(n)) + [random.randint(0, n - 1) for _ in range(size - n)]
-        side = torch.cuda.Stream()
+        from .. import ops
+        side = ops.side_stream(1)        # a stream that really runs beside the compute stream (ops.init_streams)
         bufs = [torch.empty(batch_size, self.renderer.crop, self.renderer.crop, self.renderer.cp, device="cuda") for _ in range(2)]
 
         def job(k):
