@@ -268,8 +268,11 @@ class ModelCNN:
     def build_train_func(self, solver_mode="sgd", cost_factors=[], use_acc_mode=False, skip_build=False):
         if solver_mode not in SOLVER_MODES:
             raise NotImplementedError("unknown solver '%s' (sgd, torch, nesterov, adam)" % solver_mode)
-        if use_acc_mode:
-            raise NotImplementedError("--use-acc-mode is outside the hot path")
+        if use_acc_mode and solver_mode == "adam":
+            raise NotImplementedError("--use-acc-mode averages would-be updates; that equals one update with the mean "
+                                      "gradient only for the linear solvers (sgd, torch, nesterov)")
+        self.use_acc_mode = bool(use_acc_mode)
+        self._acc = None
         self.solver_mode = solver_mode
         import torch
         if torch.cuda.is_available():
@@ -397,13 +400,49 @@ class ModelCNN:
         if dist is not None:
             dist.finish_step(self)
 
+    # ---- --use-acc-mode (model_cnn.py:374-392): train_begin zeroes accumulators, every train_step ADDS the values the
+    # update targets would take (parameters, momentum, BN running statistics - all computed from the state at train_begin)
+    # instead of applying them, train_end installs their mean. For the linear solvers that is one update with the mean
+    # gradient and the mean of the would-be running statistics, which is how it is computed here: gradients and would-be
+    # statistics are accumulated, the solver runs once in train_end.
+    def train_begin(self):
+        import torch
+        assert self.use_acc_mode, "build_train_func(use_acc_mode=True) first"
+        if not self._packed:
+            self.pack_device()
+        self._acc = {"G": torch.zeros_like(self.G), "S": torch.zeros_like(self.S), "S0": self.S.clone(), "n": 0, "args": None}
+
+    def train_end(self):
+        from .. import ops
+        acc = self._acc
+        assert acc is not None and acc["n"] > 0, "train_end without accumulated steps"
+        it, learn_rate, momentum, decay = acc["args"]
+        n_decay = self.n_trainable if self.bias_decay else self.n_weights
+        scale = 1.0 / acc["n"]
+        ops.solver_step(self.P[:self.n_trainable], self.M[:self.n_trainable], acc["G"][:self.n_trainable], n_decay,
+                        float(learn_rate), float(momentum[0]), it, float(decay), SOLVER_MODES[self.solver_mode], scale)
+        self.S.copy_(acc["S"])
+        ops.check(ops._L().denet_scale(self.S.data_ptr(), self.S.numel(), scale, ops.stream_ptr()), "scale")
+        ops.bump_weights_version()
+        self._acc = None
+
     def _device_step(self, epoch, it, learn_rate, momentum, decay, data_x, data_m, fetch_cost=True):
         from .. import ops
+        acc = self._acc if getattr(self, "use_acc_mode", False) else None
+        if getattr(self, "use_acc_mode", False) and acc is None:
+            raise Exception("--use-acc-mode: call train_begin() before train_step()")
+        if acc is not None:
+            self.S.copy_(acc["S0"])            # every sub-step starts from the statistics at train_begin
         ctx = self.forward(data_x, data_m, train=True)
         self.backward(ctx)
         scale = 1.0 / self.dist.world_size if self.dist is not None else 1.0
         n_decay = self.n_trainable if self.bias_decay else self.n_weights
-        if self.solver_mode == "adam":
+        if acc is not None:
+            ops.add(acc["G"], self.G, out=acc["G"])
+            ops.add(acc["S"], self.S, out=acc["S"])
+            acc["n"] += 1
+            acc["args"] = (it, learn_rate, momentum, decay)
+        elif self.solver_mode == "adam":
             import torch
             assert len(momentum) >= 2, "adam takes momentum = (beta1, beta2)"
             if getattr(self, "V", None) is None:

@@ -14,7 +14,8 @@ CONSECUTIVE batches `r * F ... r * F + F - 1` of the iteration. Like the referen
 `random.randint(0, len - 1)` - every rank draws all of them, so the random streams stay in step.
   F = 1: gradients are all-reduced inside every step (equal to the reference's parameter averaging for sgd / nesterov);
   F > 1: what the shipped recipes run (papers/dss/denet34.sh:43 `--batch-size-factor 2` without --use-acc-mode): every rank
-         takes F full local steps, then parameters, momentum and BN statistics are averaged over the ranks
+         takes F full local steps (with `--use-acc-mode`: F accumulated steps from the same parameters, one averaged update,
+         model_cnn.py:374-392 / worker.py:60-116), then parameters, momentum and BN statistics are averaged over the ranks
          (DataParallel.average_state) - the reference's scheme itself, over RCCL instead of host shared memory.
 Rank 0 writes the checkpoints with the reference's names: `<prefix>_epochNNN_final.mdl.gz` after every epoch
 (train_multi.py:166) - the reference's timed `_epochNNN_subsetMMM` files are written with `--save-subsets` after every subset.
@@ -65,8 +66,9 @@ def train(args, train_data, dp, log=None):
         from ..common import logging
         log = logging.info
     model = model_cnn.initialize(args, train_data.get_data_shape(), train_data.class_labels, train_data.get_class_num())
-    model.build_train_func(args.solver, args.cost_factors)
     factor = max(1, int(getattr(args, "batch_size_factor", 1)))
+    use_acc_mode = factor > 1 and bool(getattr(args, "use_acc_mode", False))          # worker.py:60
+    model.build_train_func(args.solver, args.cost_factors, use_acc_mode=use_acc_mode)
     if dp is not None:
         if factor == 1:
             model.dist = dp                 # gradient all-reduce inside every step
@@ -100,11 +102,15 @@ def train(args, train_data, dp, log=None):
                 batches = ((dx[i:i + model.batch_size], dm[i:i + model.batch_size]) for i in range(0, n, model.batch_size))
             cost = 0.0
             for step, (data_x, data_m) in enumerate(batches):
+                if use_acc_mode and step % factor == 0:
+                    model.train_begin()                                  # worker.py:95-97
                 c, _ = model.train_step(data_x, data_m, epoch, model.iteration, learn_rate, args.learn_momentum, args.learn_decay)
                 if math.isnan(c):
                     raise Exception("ERROR: Cost is NaN")
                 cost += c
                 model.iteration += 1
+                if use_acc_mode and (step + 1) % factor == 0:
+                    model.train_end()                                    # worker.py:114-116
                 if factor > 1 and dp is not None and (step + 1) % factor == 0:
                     dp.average_state(model)
             costs.append(cost)
@@ -139,6 +145,9 @@ def main(argv=None):
     parser = train_mod.build_parser()
     parser.add_argument("--batch-size-factor", type=int, default=1,
                         help="local training steps per rank between two parameter averagings (1: gradient all-reduce every step)")
+    parser.add_argument("--use-acc-mode", default=False, action="store_true",
+                        help="Use model accumulation over multiple batches (with --batch-size-factor F > 1: the F local steps "
+                             "of an iteration all start from the same parameters and their updates are averaged)")
     parser.add_argument("--epoch-start", type=int, default=0, help="Epoch to start from")
     parser.add_argument("--restart", default=False, action="store_true", help="Restart training of model")
     parser.add_argument("--save-subsets", default=False, action="store_true", help="checkpoint after every subset")

@@ -584,6 +584,56 @@ def test_direct_and_measured_paths_agree(hip):
         ops._WINO.update(saved[1])
 
 
+def test_acc_mode_accumulates_and_averages(hip):
+    """--use-acc-mode (model_cnn.py:374-392): train_begin / F x train_step / train_end = ONE update with the mean gradient and
+    the mean of the would-be batch-norm running statistics, every sub-step starting from the same parameters"""
+    from denet_amd.model import model_cnn
+    B, IMG = 2, 128
+    xa, ma = zoo.synthetic_batch(B, IMG, seed=21)
+    xb, mb = zoo.synthetic_batch(B, IMG, seed=22)
+
+    def fresh(acc):
+        m = zoo.warm_corner_head(zoo.denet34(B, "skip", IMG, class_num=80, seed=1), 4.0, 0.3)
+        m.build_train_func("nesterov", use_acc_mode=acc)
+        return m
+    # (1) two identical sub-steps == one ordinary step on that batch (sum of two equal gradients x 1/2 is exact)
+    m1, m2 = fresh(True), fresh(False)
+    with pytest.raises(Exception):
+        m1.train_step(xa, ma, 0, 0, 0.02, [0.9], 1e-4)           # train_begin is mandatory
+    m1.train_begin()
+    for _ in range(2):
+        random.seed(5)
+        m1.train_step(xa, ma, 0, 0, 0.02, [0.9], 1e-4)
+    p_mid = m1.P.clone()
+    m1.train_end()
+    random.seed(5)
+    m2.train_step(xa, ma, 0, 0, 0.02, [0.9], 1e-4)
+    torch.cuda.synchronize()
+    assert torch.equal(p_mid, fresh(False).P)                      # nothing is applied before train_end
+    for k in ("P", "M", "S"):
+        assert torch.equal(getattr(m1, k), getattr(m2, k)), k
+    # (2) two different batches == solver applied to the mean of the two gradients, statistics averaged
+    m3, ga, gb = fresh(True), fresh(False), fresh(False)
+    m3.train_begin()
+    random.seed(6); m3.train_step(xa, ma, 0, 0, 0.02, [0.9], 1e-4)
+    random.seed(7); m3.train_step(xb, mb, 0, 0, 0.02, [0.9], 1e-4)
+    m3.train_end()
+    grads, stats = [], []
+    for m, (x, me, seed) in ((ga, (xa, ma, 6)), (gb, (xb, mb, 7))):
+        random.seed(seed)
+        ctx = m.forward(x, me, train=True)
+        m.backward(ctx)
+        torch.cuda.synchronize()
+        grads.append(m.G.clone()); stats.append(m.S.clone())
+    ref = fresh(False)
+    g = grads[0] + grads[1]
+    ops.solver_step(ref.P[:ref.n_trainable], ref.M[:ref.n_trainable], g[:ref.n_trainable], ref.n_weights, 0.02, 0.9, 0, 1e-4,
+                    model_cnn.SOLVER_MODES["nesterov"], 0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(m3.P, ref.P) and torch.equal(m3.M, ref.M)
+    torch.testing.assert_close(m3.S, (stats[0] + stats[1]) * 0.5, rtol=1e-6, atol=1e-7)
+
+
 def test_adam_solver_vs_oracle(hip):
     """adam updates (denet/model/model_cnn.py:296-305): first / second moments, bias correction, L2 on weights only"""
     _generic_step_check("C.B[32,3] BN A nRSN.O[2,32,3] P.A[16] R", (3, 16, 16), 4, solver="adam", steps=3)
