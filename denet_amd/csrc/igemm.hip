@@ -904,7 +904,10 @@ int wgrad_dispatch(IgemmParams& p, int K, float* dw, float* workspace, size_t wo
     int rc = DENET_OK;
     const bool big_m = (K >= 128);
     const int bm = big_m ? 128 : 64;
-    p.tiles_m = ceil_div(K, bm); p.tiles_n = ceil_div(p.NC, 128);
+    // 64 x 64 tiles when the product has at most 64 columns (the batched filter-gradient products of the 64-channel Winograd
+    // layers: dU[64][64]): with 128-wide tiles half of the waves would own nothing but padding
+    const bool narrow = !big_m && p.NC <= 64;
+    p.tiles_m = ceil_div(K, bm); p.tiles_n = ceil_div(p.NC, narrow ? 64 : 128);
     const long wsize = (long)K * p.NC * batch;     // all batch members of one split slice
     p.split_stride = wsize;
     // Split-K selection. Every candidate (rounds r of a full chip, LDS buffering) fixes the number of slices so
@@ -958,6 +961,8 @@ int wgrad_dispatch(IgemmParams& p, int K, float* dw, float* workspace, size_t wo
     splits = ceil_div(p.ksteps, p.steps_per_split);
     if (big_m)
         rc = LAUNCH_NBUF(MODE_WGRAD, 128, 128, wg_nbuf, p, splits, stream);
+    else if (narrow)
+        rc = LAUNCH_NBUF(MODE_WGRAD, 64, 64, wg_nbuf, p, splits, stream);
     else
         rc = LAUNCH_NBUF(MODE_WGRAD, 64, 128, wg_nbuf, p, splits, stream);
     if (rc) return rc;
