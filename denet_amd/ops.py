@@ -124,8 +124,12 @@ def init_streams(force=False):
     global _COPY_STREAM, _SIDE_FILTER, _WGRAD_STREAM, _SORT_STREAM
     main = torch.cuda.current_stream()
     if _WGRAD_STREAM is None or force:
-        cands = [torch.cuda.Stream() for _ in range(12)]
-        good = [s for s in cands if _runs_beside(s, main)]
+        cands, good = [], []
+        while len(good) < 4 and len(cands) < 32:          # torch hands out pool streams round-robin: a few tries reach every queue
+            st = torch.cuda.Stream()
+            cands.append(st)
+            if _runs_beside(st, main):
+                good.append(st)
         _WGRAD_STREAM = good[0] if good else cands[0]
         # filter transforms / tap sort: beside the compute stream too, and preferably not on the filter-gradient queue
         rest = [s for s in good[1:] if _runs_beside(s, _WGRAD_STREAM)] or good[1:] or cands[1:]
