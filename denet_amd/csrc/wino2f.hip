@@ -43,6 +43,11 @@ constexpr int UH_SLOTS = 8 * 4 * 64;                        // one half of a fil
 constexpr int RED_BYTES = 4 * 2 * 64 * 4;                   // batch-norm sums of the 4 tile-row waves
 constexpr int LDS_BYTES = P_BYTES + 2 * UH_SLOTS * 16 + RED_BYTES;      // 161 792 of 163 840
 constexpr int OOB = (int)0xF0000000u;
+#ifdef W2F_TRACE
+constexpr int LDS_ALLOC = LDS_BYTES + 1024;
+#else
+constexpr int LDS_ALLOC = LDS_BYTES;
+#endif
 
 // s_waitcnt vmcnt(vm) lgkmcnt(0) [gfx9 encoding: vmcnt = bits 15:14 | 3:0, expcnt 6:4, lgkmcnt 11:8] + s_barrier. The raw
 // barrier leaves the newest `vm` vector-memory operations of the wave in flight (LDS-DMA pieces that are not needed yet,
@@ -52,6 +57,17 @@ constexpr int OOB = (int)0xF0000000u;
         __builtin_amdgcn_s_waitcnt(((vm) & 15) | ((((vm) >> 4) & 3) << 14) | (7 << 4));          \
         __builtin_amdgcn_s_barrier();                                                            \
     }
+
+#ifdef W2F_TRACE
+__device__ unsigned g_w2f_trace[8 * 32];
+#define W2_MARK(idx)                                                      \
+    if (trace_on) {                                                       \
+        const unsigned t_ = (unsigned)__builtin_readcyclecounter();       \
+        if (lane == 0) trc[wave * 32 + (idx)] = t_;                       \
+    }
+#else
+#define W2_MARK(idx)
+#endif
 
 struct W2Item {
     int n, oy0, ox0, co0, block;
@@ -76,6 +92,11 @@ __global__ __launch_bounds__(512, 2) void wino2f_kernel(const W2Params p) {
     f32x4* UA = (f32x4*)(smem + P_BYTES);
     f32x4* UB = UA + UH_SLOTS;
     float* red = (float*)(smem + P_BYTES + 2 * UH_SLOTS * 16);
+#ifdef W2F_TRACE
+    unsigned* trc = (unsigned*)(smem + LDS_BYTES);
+    int iter = 0;
+    bool trace_on = false;
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: addresses derived from it stay scalar
     const int t = lane & 15, q = lane >> 4;          // tile inside the wave's 16, channel quad inside a group of 16
@@ -95,12 +116,15 @@ __global__ __launch_bounds__(512, 2) void wino2f_kernel(const W2Params p) {
     // input patch: plane (channel quad) c of the 18 x 18 pixels = 6 pieces of 64 slots; the 24 pieces of channel group g
     // are spread over the waves: wave w moves plane 4g + w/2, pieces 3 (w & 1) + j, j = 0..2. A lane's slot -> (row, column)
     // does not depend on the item; image borders and the padding slots come back as zeros from the buffer bounds check.
+    // Piece 5 of a plane starts at slot 296 = 360 - 64 (it rewrites 24 slots of piece 4 with the same values): every piece is
+    // a full wave instruction, no lane mask, no branch.
     int pc[3];                                       // row | column << 8; column 255: not a pixel
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int sl = 64 * (3 * (wave & 1) + j) + lane;
+        const int k = 3 * (wave & 1) + j;
+        const int sl = (k == 5 ? P_USED - 64 : 64 * k) + lane;
         const int row = sl / P_ROW, r = sl - row * P_ROW, par = r / P_PAR, col = r - par * P_PAR;
-        pc[j] = row | ((col < 9 && sl < P_USED ? 2 * col + par : 255) << 8);
+        pc[j] = row | ((col < 9 ? 2 * col + par : 255) << 8);
     }
     auto patch_piece = [&](int g, int j, const W2Item& it) {
         const int plane = 4 * g + (wave >> 1);
@@ -108,106 +132,150 @@ __global__ __launch_bounds__(512, 2) void wino2f_kernel(const W2Params p) {
         const int iy = it.oy0 - 1 + (pc[j] & 255), ix = it.ox0 - 1 + (pc[j] >> 8);
         const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && (pc[j] >> 8) != 255;
         const int off = (((it.n * p.H + iy) * p.W + ix) * CI + plane * 4) * 4;
-        if (j < 2 || 64 * k + lane < P_USED)          // the last piece of a plane is 40 slots
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(P + plane * P_PLANE + 64 * k), 16, ok ? off : OOB, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(P + plane * P_PLANE + (k == 5 ? P_USED - 64 : 64 * k)), 16,
+                                                 ok ? off : OOB, 0, 0, 0);
+    };
+
+    // t = B^T d, row i of the lane's tile for its 4 channels of group g: a combination of two patch rows
+    //   row 0 = d0 - d2, row 1 = d1 + d2, row 2 = d2 - d1, row 3 = d1 - d3
+    auto load_tt = [&](f32x4 (&tt)[4], int g, int i) {
+        const int ra = i == 0 ? 0 : 1, rb = i == 3 ? 3 : 2;
+        const f32x4* Pp = P + (4 * g + q) * P_PLANE + (2 * ty) * P_ROW + tx;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const f32x4* c = Pp + (bb & 1) * P_PAR + (bb >> 1);
+            const f32x4 ea = c[ra * P_ROW], eb = c[rb * P_ROW];
+            tt[bb] = i == 0 ? ea - eb : i == 1 ? ea + eb : i == 2 ? eb - ea : ea - eb;
+        }
     };
 
     int item = blockIdx.x;
     if (item >= p.items) return;
+#ifdef W2F_TRACE
+    trace_on = blockIdx.x == 0;
+    W2_MARK(26);
+#endif
     W2Item cur = w2_item(p, item);
+    // prologue: channel groups 0..2 of the first patch (group 3 comes with the first half, like every later one) and the
+    // first filter half
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int j = 0; j < 3; ++j) patch_piece(g, j, cur);
 #pragma unroll
     for (int k = 0; k < 4; ++k) u_piece(UA, 0, 0, cur.co0, k);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) u_piece(UB, 1, 0, cur.co0, k);
     W2_BARRIER(0);
+
+    // Software pipeline over the halves h = (item, group g, A | B); half h multiplies components 8 (h & 1) .. + 7 of group g
+    // out of buffer UA (A) / UB (B) in 8 steps of 8 products:
+    //   steps 0-1  the 4 DMA pieces of the NEXT half's filters go into the other buffer
+    //   steps 2-4  (A halves) 3 pieces refill the patch planes of the previous channel group for the next item
+    //   step  5    the filter operands of steps 6-7 are read into registers: no wave reads this buffer after the barrier
+    //   step  6    wait for the own pieces, ONE barrier: the other buffer is complete, this one may be refilled next half
+    //   steps 6-7  the first row of t = B^T d and the first filter operands of the next half are read: it starts without
+    //              an LDS round trip (its second row is read during its first steps)
+    f32x4 tt[4], uc0, uc1;                           // first row + operands: carried from half to half (across the epilogue)
+    load_tt(tt, 0, 0);
+    uc0 = UA[q * 64 + ucol];
+    uc1 = UA[q * 64 + ucol + 16];
 
     while (true) {
         const int next = item + gridDim.x;
         const bool has_next = next < p.items;
         const W2Item nxt = w2_item(p, has_next ? next : item);
+#ifdef W2F_TRACE
+        trace_on = blockIdx.x == 0 && iter == 2;
+        ++iter;
+#endif
+        W2_MARK(0);
 
-        f32x4 acc[16][2];
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[16][2];                            // started by the first product of channel group 0 (C operand 0)
 
-        // components xi = 4 i + j, i = i0, i0 + 1, out of the filter half Uh. t = B^T d for these two rows comes from three
-        // patch rows (two transformed rows at a time halve the registers held through the products); `issue(s)` is called
-        // in step s = 0..7 and puts the DMA pieces for the other buffers between the products (a piece costs 60 - 180 issue
-        // cycles: back to back after a barrier both waves of a SIMD would leave the matrix pipe idle for all of them).
-        auto half = [&](const f32x4* Uh, int g, auto I0, auto issue) {
-            constexpr int i0 = decltype(I0)::value;
-            f32x4 tt[2][4];
-            {
-                const f32x4* Pp = P + (4 * g + q) * P_PLANE + (2 * ty + (i0 ? 1 : 0)) * P_ROW + tx;
-#pragma unroll
-                for (int bb = 0; bb < 4; ++bb) {
-                    const f32x4* c = Pp + (bb & 1) * P_PAR + (bb >> 1);
-                    const f32x4 e0 = c[0], e1 = c[P_ROW], e2 = c[2 * P_ROW];
-                    if (i0 == 0) {                   // rows 0, 1 of B^T d from d0, d1, d2
-                        tt[0][bb] = e0 - e2;
-                        tt[1][bb] = e1 + e2;
-                    } else {                         // rows 2, 3 from d1, d2, d3
-                        tt[0][bb] = e1 - e0;
-                        tt[1][bb] = e0 - e2;
-                    }
-                }
-            }
-            const f32x4* up = Uh + q * 64 + ucol;
+        auto half = [&](auto G, auto HB) {
+            constexpr int g = decltype(G)::value;
+            constexpr int hb = decltype(HB)::value;              // 0: half A, 1: half B
+            constexpr int i0 = 2 * hb;
+            const f32x4* up = (hb ? UB : UA) + q * 64 + ucol;
+            f32x4* const other = hb ? UA : UB;
+            // what the next half is. The pipeline has no branches: past the last item the pieces and reads repeat this item's
+            // (`nxt` = `cur`), into buffers that nobody reads again.
+            constexpr int ng = hb ? (g + 1) & 3 : g;
+            const int nco0 = (hb && g == 3) ? nxt.co0 : cur.co0;
+            f32x4 U0[8], U1[8], t2[4], tn[4], un0, un1;  // filter operands per step: read one step ahead
+            U0[0] = uc0;
+            U1[0] = uc1;
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
                 const int i = i0 + ii;
+                const f32x4 (&tr)[4] = ii ? t2 : tt;
                 f32x4 V[4];
-                V[0] = tt[ii][0] - tt[ii][2];
-                V[1] = tt[ii][1] + tt[ii][2];
-                V[2] = tt[ii][2] - tt[ii][1];
-                V[3] = tt[ii][1] - tt[ii][3];
+                V[0] = tr[0] - tr[2];
+                V[1] = tr[1] + tr[2];
+                V[2] = tr[2] - tr[1];
+                V[3] = tr[1] - tr[3];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int xi8 = ii * 4 + j;
-                    const f32x4 u0 = up[xi8 * 256], u1 = up[xi8 * 256 + 16];
-                    issue(xi8);
+                    const int st = ii * 4 + j;
+#ifdef W2F_PRIO
+                    // the two waves of a SIMD (nh = 0, 1) take turns at the higher issue priority, step by step: the older one
+                    // would otherwise run ahead and leave the other to finish the half alone
+                    if ((st + nh) & 1) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+#endif
+                    if (st < 5) {
+                        U0[st + 1] = up[(st + 1) * 256];
+                        U1[st + 1] = up[(st + 1) * 256 + 16];
+                    } else if (st == 5) {            // the last reads of this buffer, before the barrier of step 6
+                        U0[6] = up[6 * 256];
+                        U1[6] = up[6 * 256 + 16];
+                        U0[7] = up[7 * 256];
+                        U1[7] = up[7 * 256 + 16];
+                    }
+                    if (st == 1) load_tt(t2, g, i0 + 1);         // the second row of this half, used from step 4 on
+                    const f32x4 u0 = U0[st], u1 = U1[st];
+                    if (st < 2) {
+                        u_piece(other, hb ^ 1, ng, nco0, 2 * st);
+                        u_piece(other, hb ^ 1, ng, nco0, 2 * st + 1);
+                    } else if (st < 5 && !hb) {
+                        // patch refill in A halves: group g - 1 for the next item; g = 0: group 3 for THIS item (its planes
+                        // were last read in the previous item's half B of group 3)
+                        patch_piece((g + 3) & 3, st - 2, g == 0 ? cur : nxt);
+                    }
+                    if (st == 6) {
+                        W2_MARK(1 + (2 * g + hb) * 3);
+                        if (!hb) W2_BARRIER(3)       // the 3 patch pieces, issued after the filter pieces, may still fly
+                        else W2_BARRIER(0)
+                        W2_MARK(2 + (2 * g + hb) * 3);
+                        load_tt(tn, ng, hb ? 0 : 2); // the first row of the next half
+                        un0 = other[q * 64 + ucol];
+                        un1 = other[q * 64 + ucol + 16];
+                    }
                     // the two accumulators alternate: a dependent v_mfma_f32_16x16x4_f32 issues after 40 cycles, an
                     // independent one after 32
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        acc[4 * i + j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u0[c], V[j][c], acc[4 * i + j][0], 0, 0, 0);
-                        acc[4 * i + j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u1[c], V[j][c], acc[4 * i + j][1], 0, 0, 0);
+                        const bool start = g == 0 && c == 0;
+                        acc[4 * i + j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u0[c], V[j][c], start ? zero : acc[4 * i + j][0], 0, 0, 0);
+                        acc[4 * i + j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u1[c], V[j][c], start ? zero : acc[4 * i + j][1], 0, 0, 0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);           // the steps stay in this order
                 }
             }
+            W2_MARK(3 + (2 * g + hb) * 3);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) tt[b] = tn[b];
+            uc0 = un0;
+            uc1 = un1;
         };
-
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            // half A; meanwhile the B half of this group lands (g = 0: it came with the previous item / the prologue) and
-            // the patch planes of the previous channel group, which no wave reads again, are refilled for the next item
-            half(UA, g, std::integral_constant<int, 0>{}, [&](int s) {
-                if (g == 0) return;
-                if (s < 4) u_piece(UB, 1, g, cur.co0, s);
-                else if (s < 7 && has_next) patch_piece(g - 1, s - 4, nxt);
-            });
-            if (g > 0 && has_next) W2_BARRIER(3)     // every wave is done with A; B has landed; the patch pieces may fly
-            else W2_BARRIER(0)
-            // half B; meanwhile the A half of the next group (or of the next item) lands
-            half(UB, g, std::integral_constant<int, 2>{}, [&](int s) {
-                if (s >= 4) return;
-                if (g < 3) u_piece(UA, 0, g + 1, cur.co0, s);
-                else if (has_next) u_piece(UA, 0, 0, nxt.co0, s);
-            });
-            W2_BARRIER(0);
-        }
-        if (has_next) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) u_piece(UB, 1, 0, nxt.co0, k);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) patch_piece(3, j, nxt);
-        }
+        half(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        half(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        half(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        half(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        half(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+        half(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+        half(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
+        half(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
 
         // ---- epilogue: Y = A^T M A per (tile, 4 output channels), + bias, + add; 16-byte stores -------------------------
         const long pix = ((long)cur.n * p.H + cur.oy0 + 2 * ty) * p.W + cur.ox0 + 2 * tx;
@@ -271,16 +339,25 @@ __global__ __launch_bounds__(512, 2) void wino2f_kernel(const W2Params p) {
                 ps[p.Co + cur.co0 + tid] = bq;
             }
         }
+        W2_MARK(25);
         if (!has_next) break;
         item = next;
         cur = nxt;
-        // the next item's patch and first filter group have landed: they were issued before this item's result stores (16
-        // per lane; wave 0 adds the 2 statistics stores), and vector memory operations complete in order
-        W2_BARRIER(16);
     }
+    __builtin_amdgcn_s_waitcnt(0);                   // no LDS-DMA piece may land after the workgroup has released its LDS
+#ifdef W2F_TRACE
+    trace_on = blockIdx.x == 0;
+    W2_MARK(27);
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < 256) g_w2f_trace[tid] = trc[tid];
+#endif
 }
 
 }  // namespace
+
+#ifdef W2F_TRACE
+extern "C" int denet_w2f_trace(unsigned* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w2f_trace), sizeof(unsigned) * 256); }
+#endif
 
 // geometry this kernel covers
 extern "C" int denet_conv_wino2f_ok(int N, int H, int W, int Ci, int Co) {
@@ -311,7 +388,7 @@ extern "C" int denet_conv_wino2f(const float* x, const float* u, const float* bi
     }
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)wino2f_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)wino2f_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
         if (e != hipSuccess) {
             denet_set_error("conv_wino2f: hipFuncSetAttribute(%d B LDS): %s", LDS_BYTES, hipGetErrorString(e));
             return -(int)e;
@@ -330,7 +407,7 @@ extern "C" int denet_conv_wino2f(const float* x, const float* u, const float* bi
         cus = prop.multiProcessorCount;
     }
     const int grid = p.items < cus ? p.items : cus;
-    hipLaunchKernelGGL(wino2f_kernel, dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(wino2f_kernel, dim3((unsigned)grid), dim3(512), LDS_ALLOC, stream, p);
     DENET_CHECK_LAUNCH("conv_wino2f");
     return DENET_OK;
 }
