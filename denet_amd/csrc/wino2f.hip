@@ -32,6 +32,7 @@ struct W2Params {
     int by, bx;          // 16x16 output blocks per image
     int nco;             // Co / 64
     int items;           // N * by * bx * nco work items: (block, 64 output channels)
+    int relu;            // y = max(y, 0) (the inference fold of a ReLU layer)
     unsigned x_bytes;
 };
 
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(512, 2) void wino2f_kernel(const W2Params p) {
                 f32x4 yv = (ij & 1) ? (s[i][1] - s[i][2] - s[i][3]) : (s[i][0] + s[i][1] + s[i][2]);
                 yv += bias4;
                 if (p.add) yv += addv[ij];
+                if (p.relu) yv = __builtin_elementwise_max(yv, f32x4{0.f, 0.f, 0.f, 0.f});
                 *(f32x4*)(p.y + (pix + i * p.W + (ij & 1)) * p.Co + ch) = yv;
                 ssum[nb] += yv;
                 ssq[nb] += yv * yv;
@@ -368,7 +370,7 @@ extern "C" int denet_conv_wino2f_ok(int N, int H, int W, int Ci, int Co) {
 // y = conv3x3(x) stride 1 pad 1 (+ bias) (+ add) from the F(2x2) transformed filters u = [16][Co][64]
 // (denet_conv_wino_filter with tile 2: dgrad = 0 for the forward pass, 1 for the data gradient, where x = dy, Co = C).
 // stats_partial (optional): [N*(H/16)*(W/16)][2][Co] doubles, the batch-norm column sums of y (see denet_conv_fwd_stats).
-extern "C" int denet_conv_wino2f(const float* x, const float* u, const float* bias, const float* add, float* y,
+extern "C" int denet_conv_wino2f(const float* x, const float* u, const float* bias, const float* add, float* y, int relu,
                                  double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int Ci,
                                  int Co, hipStream_t stream) {
     DENET_CHECK_ARG(x && u && y, "conv_wino2f: null pointer");
@@ -378,6 +380,7 @@ extern "C" int denet_conv_wino2f(const float* x, const float* u, const float* bi
     p.N = N; p.H = H; p.W = W; p.Co = Co;
     p.by = H / 16; p.bx = W / 16;
     p.nco = Co / 64;
+    p.relu = relu;
     p.x_bytes = (unsigned)((size_t)N * H * W * 64 * 4);
     const long blocks = (long)N * p.by * p.bx;
     p.items = (int)(blocks * p.nco);

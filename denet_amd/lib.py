@@ -43,7 +43,7 @@ SIGNATURES = {
     "denet_conv_wino_fwd_stats": (I, [P] * 8 + [Z, P, P, Z] + [I] * 6 + [P]),
     "denet_conv_wino_dgrad": (I, [P] * 6 + [Z] + [I] * 6 + [P]),
     "denet_conv_wino2f_ok": (I, [I] * 5),
-    "denet_conv_wino2f": (I, [P] * 6 + [Z, P] + [I] * 5 + [P]),
+    "denet_conv_wino2f": (I, [P] * 5 + [I, P, Z, P] + [I] * 5 + [P]),
     "denet_conv_tune": (I, [I, P, P, P, P, P, P, Z] + [I] * 12 + [P]),
     "denet_conv_tuned": (I, [I] * 11 + [P, P, P]),
     "denet_conv_last_config": (I, [P] * 5),

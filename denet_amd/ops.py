@@ -236,8 +236,8 @@ def load_tuned(path=None):
         if r[0] <= 2:
             _TUNED.add(_geom_of_record(r))
     for mode, g, tile in d.get("winograd", []):
-        if int(tile) <= WINOGRAD:            # DENET_WINOGRAD=0|2 restricts the tiles: excluded entries are decided afresh
-            _WINO[(int(mode), tuple(int(v) for v in g))] = int(tile)
+        if _tile_allowed(int(mode), int(tile)):  # DENET_WINOGRAD / DENET_WINO2F restrict the algorithms: excluded entries
+            _WINO[(int(mode), tuple(int(v) for v in g))] = int(tile)         # are decided afresh
     return len(rec)
 
 
@@ -315,7 +315,7 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
                 # inference: the filters do not change between calls - transform them once per weights version
                 ent = cache.get("u_test")
                 if ent is None or ent[0] != tile or ent[2] != WEIGHTS_VERSION or ent[3] != w.data_ptr():
-                    ent = cache["u_test"] = (tile, conv_wino_filter(w, tile, dgrad=False), WEIGHTS_VERSION, w.data_ptr())
+                    ent = cache["u_test"] = (tile, conv_wino_filter(w, _filter_tile(tile), dgrad=False), WEIGHTS_VERSION, w.data_ptr())
                 u = ent[1]
             # the filter gradient of this layer uses the same transformed input when it runs with the same tile
             if cache.get("train") and _WINO.get((2, g)) == tile:
@@ -338,7 +338,31 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
 # DENET_WINOGRAD=2 allows only F(2x2,3x3).
 WINOGRAD = int(os.environ.get("DENET_WINOGRAD", "4"))
 _WINO = {}
-_WINO_GAIN = {2: 2.25, 4: 4.0}      # direct multiplications / Winograd multiplications
+# A third alternative for the 64-input-channel layers: FUSED2, F(2x2,3x3) with the transforms and the products in one kernel
+# (csrc/wino2f.hip). DENET_WINO2F: bit 0 allows it for the forward pass, bit 1 for the data gradient.
+FUSED2 = 22
+WINO2F = int(os.environ.get("DENET_WINO2F", "3"))
+_WINO_GAIN = {2: 2.25, 4: 4.0, FUSED2: 2.25}      # direct multiplications / Winograd multiplications
+
+
+def _tile_allowed(mode, tile):
+    if tile == FUSED2:
+        return WINOGRAD >= 2 and mode in (0, 1) and bool((WINO2F >> mode) & 1)
+    return tile <= WINOGRAD
+
+
+def _filter_tile(tile):
+    """the Winograd tile whose transformed filters the algorithm consumes"""
+    return 2 if tile == FUSED2 else tile
+
+
+def conv_wino2f_ok(mode, g):
+    """geometry the fused F(2x2,3x3) kernel covers for the forward pass (mode 0) / the data gradient (mode 1)"""
+    N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
+    if not (R == 3 and S == 3 and s_real == 3 and stride == 1 and pad == 1):
+        return False
+    ci, co = (C, K) if mode == 0 else (K, C)
+    return bool(_L().denet_conv_wino2f_ok(N, H, W, ci, co))
 
 
 def _time_ms(fn, reps=3):
@@ -369,6 +393,8 @@ def _wino_tile(mode, g, direct, wino):
     use = _WINO.get(key)
     if use is None:
         tiles = [t for t in (2, 4) if t <= WINOGRAD and conv_wino_ok(g, t)] if AUTOTUNE else []
+        if AUTOTUNE and mode in (0, 1) and _tile_allowed(mode, FUSED2) and conv_wino2f_ok(mode, g):
+            tiles.append(FUSED2)
         if not tiles:
             use = 0
         elif PROFILE is not None:
@@ -378,9 +404,10 @@ def _wino_tile(mode, g, direct, wino):
             sws = WS.get("wgrad", WGRAD_WS_BYTES)
             best, use = 0.97 * _time_ms(direct), 0
             for t in tiles:
-                ws = WS.get("wino", _L().denet_conv_wino_workspace_bytes(t, N, H, W, C, K))
-                check(_L().denet_conv_wino_tune(ptr(ws), ws.numel(), ptr(sws), sws.numel(), t, N, H, W, C, K, stream_ptr()),
-                      "conv_wino_tune")
+                if t != FUSED2:                  # the batched products of the un-fused passes have configurations of their own
+                    ws = WS.get("wino", _L().denet_conv_wino_workspace_bytes(t, N, H, W, C, K))
+                    check(_L().denet_conv_wino_tune(ptr(ws), ws.numel(), ptr(sws), sws.numel(), t, N, H, W, C, K, stream_ptr()),
+                          "conv_wino_tune")
                 ms = _time_ms(lambda: wino(t))
                 if ms < best:
                     best, use = ms, t
@@ -415,10 +442,11 @@ def wino_prefetch_filters(caches_and_weights):
                 if not tile:
                     continue
                 ent = c.get(("u", dgrad))
+                ft = _filter_tile(tile)
                 if ent is None or ent[0] != tile:
                     K, _, _, C = w.shape
-                    ent = c[("u", dgrad)] = [tile, torch.empty((tile + 2) * (tile + 2) * K * C, dtype=torch.float32, device="cuda"), False]
-                conv_wino_filter(w, tile, dgrad, out=ent[1])
+                    ent = c[("u", dgrad)] = [tile, torch.empty((ft + 2) * (ft + 2) * K * C, dtype=torch.float32, device="cuda"), False]
+                conv_wino_filter(w, ft, dgrad, out=ent[1])
                 ent[2] = True
         ev = torch.cuda.Event()
         ev.record(_SIDE_FILTER)
@@ -476,6 +504,17 @@ def conv_wino_fwd(x, w, bias=None, add=None, out=None, tile=2, u=None, v_keep=No
     N, H, W, C = x.shape
     K = w.shape[0]
     y = out if out is not None else empty(N, H, W, K)
+    if tile == FUSED2:
+        import ctypes
+        if u is None:
+            u = conv_wino_filter(w, 2, dgrad=False)
+        st, cache = stats if stats is not None and not relu else (None, None)
+        rows = ctypes.c_int(0)
+        check(_L().denet_conv_wino2f(ptr(x), ptr(u), ptr(bias), ptr(add), ptr(y), int(relu), ptr(st), st.numel() * 8 if st is not None
+                                     else 0, ctypes.byref(rows), N, H, W, C, K, stream_ptr()), "conv_wino2f")
+        if st is not None:
+            cache["bn_stats"] = (st, rows.value)
+        return y
     ws = _wino_ws(tile, N, H, W, C, K)
     if stats is not None and not relu:
         import ctypes
@@ -495,6 +534,14 @@ def conv_wino_dgrad(dy, w, add=None, out=None, tile=2, u=None):
     N, H, W, K = dy.shape
     C = w.shape[3]
     dx = out if out is not None else empty(N, H, W, C)
+    if tile == FUSED2:
+        import ctypes
+        if u is None:
+            u = conv_wino_filter(w, 2, dgrad=True)
+        rows = ctypes.c_int(0)
+        check(_L().denet_conv_wino2f(ptr(dy), ptr(u), None, ptr(add), ptr(dx), 0, None, 0, ctypes.byref(rows), N, H, W, K, C,
+                                     stream_ptr()), "conv_wino2f")
+        return dx
     ws = _wino_ws(tile, N, H, W, C, K)
     check(_L().denet_conv_wino_dgrad(ptr(dy), ptr(w), ptr(u), ptr(add), ptr(dx), ptr(ws), ws.numel(), tile, N, H, W, C, K,
                                      stream_ptr()), "conv_wino_dgrad")

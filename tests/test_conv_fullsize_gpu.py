@@ -5,7 +5,7 @@ are compared with an fp64 reference of the same sums, max-norm and element-wise.
 
 Reference op: denet/layer/convolution.py:80-83 (forward) and tensor.grad of it, model_cnn.py:318 (data / filter gradient);
 north_star budget: 1e-3 relative for fp32 activations. Measured (MI355X, round 2): direct kernels <= 4.1e-6 max-norm
-(up1 forward, 4608-term sums), F(2x2) <= 8e-7, F(4x4) <= 2.1e-5 max-norm / 2.5e-5 p99.9 (l4 / up1); asserted with a margin:
+(up1 forward, 4608-term sums), F(2x2) <= 8e-7 (fused kernel of the 64-channel layers: 4e-7), F(4x4) <= 2.1e-5 max-norm / 2.5e-5 p99.9 (l4 / up1); asserted with a margin:
 1e-5 / 2e-5 / 8e-5. The per-layer numbers of a run are written to gpurun_out/conv_fullsize_parity.json.
 
 Metrics (both against the fp64 result `r`, s = max|r|):
@@ -152,7 +152,7 @@ def test_conv_passes_at_benchmark_geometry(hip, geom):
             wino = ent["algo"][p]
             # direct kernels: fp32 FMA chains of <= 524 288 terms; Winograd F(4x4): transform constants up to 8 amplify the
             # rounding of the 36-point products (Lavin & Gray report ~1e-5 for F(4x4) in fp32)
-            bound = {0: 1e-5, 2: 2e-5, 4: 8e-5}[wino]
+            bound = {0: 1e-5, 2: 2e-5, 4: 8e-5, 22: 1e-5}[wino]     # 22: ops.FUSED2, F(2x2) in one kernel
             assert mx <= bound, "%s %s %s (winograd tile %d): max-norm error %.2e > %.0e" % (name, label, p, wino, mx, bound)
             assert p999 <= 3 * bound, "%s %s %s: p99.9 element-wise error %.2e" % (name, label, p, p999)
             assert mx <= 1e-3 and p999 <= 1e-3                      # the north-star budget itself

@@ -119,6 +119,57 @@ def test_conv_epilogue_batch_norm_sums(hip, case):
         ops._WINO.update(saved[1])
 
 
+@pytest.mark.parametrize("case", [(1, 16, 16, 64), (2, 32, 48, 64), (1, 16, 32, 128), (5, 128, 128, 64), (3, 128, 64, 128)])
+def test_fused_winograd_f2_kernel(hip, case):
+    """csrc/wino2f.hip through ops (algorithm ops.FUSED2) against an fp64 convolution: forward with bias / add / ReLU / the
+    batch-norm sums, and the data gradient with the accumulated add. (5,128,128,64) = 320 work items on 256 persistent
+    workgroups (uneven loop), (3,128,64,128) = two output-channel chunks per block. F(2x2) in fp32: <= 1e-6 max-norm."""
+    import torch.nn.functional as Fn
+    from denet_amd import ops
+    N, H, W, Co = case
+    gen = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, H, W, 64, generator=gen).cuda()
+    w = (torch.randn(Co, 3, 3, 64, generator=gen) * (2.0 / 576) ** 0.5).cuda()
+    bias = torch.randn(Co, generator=gen).cuda()
+    addt = torch.randn(N, H, W, Co, generator=gen).cuda()
+    g = ops.conv_geom(x.shape, w.shape, 1, 1, None)
+    assert ops.conv_wino2f_ok(0, g) and ops.conv_wino2f_ok(1, g) == (Co == 64)
+    saved = (ops.AUTOTUNE, dict(ops._WINO), set(ops._TUNED))
+    try:
+        ops._WINO.clear()
+        ops._WINO[(0, g)] = ops.FUSED2
+        ops._WINO[(1, g)] = ops.FUSED2 if Co == 64 else 0
+        xd, wd = x.double().permute(0, 3, 1, 2).contiguous().requires_grad_(True), w.double().permute(0, 3, 1, 2)
+        ref = Fn.conv2d(xd, wd, None, padding=1)
+        r = ref.detach().permute(0, 2, 3, 1)
+        s = float(r.abs().max())
+        y = ops.conv_fwd(x, w, stride=1, pad=1)
+        assert float((y.double() - r).abs().max()) / s <= 1e-6
+        cache = {"train": True}
+        y2 = ops.conv_fwd(x, w, bias=bias, add=addt, stride=1, pad=1, cache=cache, bn_stats=True)
+        assert cache["fwd_tile"] == ops.FUSED2
+        r2 = r + bias.double() + addt.double()
+        assert float((y2.double() - r2).abs().max()) / float(r2.abs().max()) <= 1e-6
+        buf, rows = cache["bn_stats"]
+        assert rows == N * (H // 16) * (W // 16)
+        part = buf[:rows * 2 * Co].view(rows, 2, Co).sum(0)
+        rr = r2.reshape(-1, Co)
+        assert float((part[0] - rr.sum(0)).abs().max() / rr.abs().sum(0).max()) <= 1e-6
+        assert float((part[1] - (rr * rr).sum(0)).abs().max() / (rr * rr).sum(0).max()) <= 1e-6
+        y3 = ops.conv_fwd(x, w, bias=bias, stride=1, pad=1, relu=True)
+        assert float((y3.double() - (r + bias.double()).clamp_min(0)).abs().max()) / s <= 1e-6
+        if Co == 64:
+            dy = torch.randn(N, H, W, 64, generator=gen).cuda()
+            acc0 = torch.randn(N, H, W, 64, generator=gen).cuda()
+            rdx = torch.autograd.grad(ref, xd, dy.double().permute(0, 3, 1, 2))[0].permute(0, 2, 3, 1) + acc0.double()
+            dx = ops.conv_dgrad(dy, w, tuple(x.shape), add=acc0, stride=1, pad=1)
+            assert float((dx.double() - rdx).abs().max()) / float(rdx.abs().max()) <= 1e-6
+    finally:
+        ops.AUTOTUNE = saved[0]
+        ops._WINO.clear()
+        ops._WINO.update(saved[1])
+
+
 def test_conv_stem_small_c(hip):
     """7x7/2 stem: C=3 padded to 4, S padded 7->8 (zero tap); wgrad must leave the padded tap at 0."""
     from denet_amd import ops

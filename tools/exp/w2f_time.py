@@ -10,5 +10,5 @@ y = torch.empty(N, H, W, 64, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
 import ctypes
 rows = ctypes.c_int(0)
-f = lambda: L.denet_conv_wino2f(x.data_ptr(), u.data_ptr(), None, None, y.data_ptr(), None, 0, ctypes.byref(rows), N, H, W, 64, 64, s)
+f = lambda: L.denet_conv_wino2f(x.data_ptr(), u.data_ptr(), None, None, y.data_ptr(), 0, None, 0, ctypes.byref(rows), N, H, W, 64, 64, s)
 print("DBG", os.environ.get("DENET_W2F_DBG"), "%.1f us" % timeit(f, 50))

@@ -21,7 +21,7 @@ def run(x, u, Co, bias=None, add=None, stats=False):
     rows = ctypes.c_int(0)
     st = torch.zeros(N * (H // 16) * (W // 16) * 2 * Co, dtype=torch.float64, device="cuda") if stats else None
     rc = L.denet_conv_wino2f(x.data_ptr(), u.data_ptr(), bias.data_ptr() if bias is not None else None,
-                             add.data_ptr() if add is not None else None, y.data_ptr(), st.data_ptr() if stats else None,
+                             add.data_ptr() if add is not None else None, y.data_ptr(), 0, st.data_ptr() if stats else None,
                              st.numel() * 8 if stats else 0, ctypes.byref(rows), N, H, W, Ci, Co,
                              torch.cuda.current_stream().cuda_stream)
     assert rc == 0, lib.last_error()
