@@ -73,15 +73,15 @@ __device__ unsigned g_w2f_trace[8 * 32];
 struct W2Item {
     int n, oy0, ox0, co0, block;
 };
-__device__ __forceinline__ W2Item w2_item(const W2Params& p, int item) {
+__device__ __forceinline__ W2Item w2_item(int bx, int by, int nco, int item) {
     W2Item it;
-    it.co0 = (item % p.nco) * 64;
-    it.block = item / p.nco;
+    it.co0 = (item % nco) * 64;
+    it.block = item / nco;
     int b = it.block;
-    it.ox0 = (b % p.bx) * 16;
-    b /= p.bx;
-    it.oy0 = (b % p.by) * 16;
-    it.n = b / p.by;
+    it.ox0 = (b % bx) * 16;
+    b /= bx;
+    it.oy0 = (b % by) * 16;
+    it.n = b / by;
     return it;
 }
 
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void wino2f_kernel(const W2Params p) {
     trace_on = blockIdx.x == 0;
     W2_MARK(26);
 #endif
-    W2Item cur = w2_item(p, item);
+    W2Item cur = w2_item(p.bx, p.by, p.nco, item);
     // prologue: channel groups 0..2 of the first patch (group 3 comes with the first half, like every later one) and the
     // first filter half
 #pragma unroll
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void wino2f_kernel(const W2Params p) {
     while (true) {
         const int next = item + gridDim.x;
         const bool has_next = next < p.items;
-        const W2Item nxt = w2_item(p, has_next ? next : item);
+        const W2Item nxt = w2_item(p.bx, p.by, p.nco, has_next ? next : item);
 #ifdef W2F_TRACE
         trace_on = blockIdx.x == 0 && iter == 2;
         ++iter;
@@ -355,6 +355,267 @@ __global__ __launch_bounds__(512, 2) void wino2f_kernel(const W2Params p) {
 #endif
 }
 
+
+// ================================================================================================================
+// Filter gradient of the same layers (64 -> 64 channels), fused: dw = G^T dU G with dU[xi][k][c] = sum over all 2x2 tiles of
+// (A dy A^T)[xi][k] * (B^T d B)[xi][c]  (the adjoint of the forward pass; winograd.hip computes it as wino_input + wino_dout
+// + a batched product). Here the two transforms feed the matrix cores straight from LDS:
+//   * persistent workgroups; a work item = a 16x16-pixel block of one image: its 18x18x64 input patch and its 16x16x64 block
+//     of dy live in LDS as channel-quad planes (the layout of the forward kernel, plane stride = 1 mod 16 slots so that
+//     16 lanes reading the same pixel of 16 planes fall into 16 bank groups);
+//   * the contraction runs over TILES: one v_mfma_f32_16x16x4_f32 consumes 4 tiles (lane = (channel quad, tile)); with a
+//     float4 of 4 consecutive channels per lane on both sides, the 16 pairs (j, j') of components give the full 64 x 64
+//     (k = 4 m + j, c = 4 n + j') product of one Winograd component: 16 accumulators per component;
+//   * a wave owns 2 of the 16 components (row I = wave / 2, columns J0, J0 + 1 with J0 = 2 (wave & 1)) for ALL tiles: 128
+//     accumulator registers that live through the whole kernel; it needs 2 patch rows x 3 columns and the 2x2 dy values per
+//     tile and a handful of additions - no transformed tensor ever exists in memory;
+//   * the LDS is refilled for the next item while this one is multiplied, in two halves: rows that no wave reads again
+//     (three barriers per item);
+//   * at the end every workgroup stores its 16 x 64 x 64 partial sums; w2g_reduce_kernel adds them in a fixed order and
+//     applies G^T . G.
+constexpr int GP_PLANE = 369, GD_PLANE = 257;                // slots per patch plane (360 used) / dy plane (256 used)
+constexpr int GP_BYTES = 16 * GP_PLANE * 16;
+constexpr int GD_BYTES = 16 * GD_PLANE * 16;
+constexpr int G_LDS_BYTES = GP_BYTES + GD_BYTES;             // 160 256
+
+struct W2GParams {
+    const float* x;      // [N,H,W,64]
+    const float* dy;     // [N,H,W,64]
+    float* part;         // [grid][16][64][64] partial dU
+    int N, H, W;
+    int by, bx;
+    int items;
+    unsigned x_bytes;
+};
+
+template <int I, int J0>
+__device__ __forceinline__ void w2g_run(const W2GParams& p, char* smem) {
+    f32x4* P = (f32x4*)smem;
+    f32x4* D = (f32x4*)(smem + GP_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int idx = lane & 15, kk = lane >> 4;       // channel quad (of c for the patch, of k for dy); tile inside a step
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, p.x_bytes, 0x00020000);
+
+    // ---- LDS-DMA pieces: 64 consecutive slots of one plane per wave instruction -----------------------------------------
+    // patch: plane c = 6 pieces (the last one overlaps the fifth: slots 296..359); wave w moves planes 2w, 2w+1
+    // dy:    plane k = 4 pieces of 4 pixel rows;                                   wave w moves planes 2w, 2w+1
+    // piece numbers 0..11 = patch (plane 2w + n / 6, piece n % 6), 12..19 = dy (plane 2w + (n - 12) / 4, piece (n - 12) % 4)
+    // per-lane constants of the pieces (kept small: the compiler would otherwise keep 20 hoisted address sets in registers)
+    int pcl[3];                                      // patch pieces 2j, 2j+1: row | column << 8 (column 255: padding slot)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        pcl[j] = 0;
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int k = 2 * j + hlf;
+            const int sl = (k == 5 ? P_USED - 64 : 64 * k) + lane;
+            const int row = sl / P_ROW, r = sl - row * P_ROW, par = r / P_PAR, col = r - par * P_PAR;
+            pcl[j] |= (row | ((col < 9 ? 2 * col + par : 255) << 8)) << (16 * hlf);
+        }
+    }
+    const int dyl = ((lane >> 4) * p.W + 2 * (lane & 7) + ((lane >> 3) & 1)) * CI * 4;   // dy pieces: lane part of the offset
+    auto piece = [&](int n, const W2Item& it) {
+        if (n < 12) {
+            const int plane = 2 * wave + n / 6, k = n % 6;
+            const int e = (pcl[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
+            const int iy = it.oy0 - 1 + (e & 255), ix = it.ox0 - 1 + (e >> 8);
+            const bool ok = (e >> 8) != 255 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const int off = (((it.n * p.H + iy) * p.W + ix) * CI + plane * 4) * 4;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(P + plane * GP_PLANE + (k == 5 ? P_USED - 64 : 64 * k)), 16,
+                                                     ok ? off : OOB, 0, 0, 0);
+        } else {
+            const int m = n - 12;
+            const int plane = 2 * wave + m / 4, k = m % 4;
+            const int base = (((it.n * p.H + it.oy0 + 4 * k) * p.W + it.ox0) * CI + plane * 4) * 4;      // wave-uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(D + plane * GD_PLANE + 64 * k), 16, dyl, base, 0, 0);
+        }
+    };
+    // Which pieces a tile row needs: patch piece k holds slots 64 k .. (rows 3.2 k ..), dy piece k rows 4 k .. 4 k + 3. The first
+    // half of an item (tile rows 0..2, steps 0..5) reads patch rows 0..7 (pieces 0, 1, 2) and dy rows 0..5 (pieces 0, 1); they
+    // are refilled for the next item once tile row 4 is done (patch rows <= 9 free: slots < 200 -> pieces 0, 1, 2; dy rows < 8).
+    // The rest (patch pieces 3, 4, 5; dy pieces 2, 3) is refilled when the item is done and is in flight during the next
+    // item's first half.
+    auto in_first_half = [](int n) { return n < 12 ? (n % 6) < 3 : ((n - 12) % 4) < 2; };
+
+    f32x4 acc[2][4][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[a][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int item = blockIdx.x;
+    if (item < p.items) {
+        W2Item cur = w2_item(p.bx, p.by, 1, item);
+#pragma unroll
+        for (int n = 0; n < 20; ++n) piece(n, cur);
+        W2_BARRIER(0);
+
+        // the two patch rows / three patch columns / dy rows this wave's components need
+        constexpr int RA = I == 0 ? 0 : I == 2 ? 2 : 1, RB = I == 0 ? 2 : I == 1 ? 2 : I == 2 ? 1 : 3;
+        constexpr float SG = I == 1 ? 1.f : -1.f;                  // t[I] = d[RA] + SG d[RB]
+        constexpr int C0 = J0 == 0 ? 0 : 1;                        // columns C0, C0 + 1, C0 + 2 of t
+        const f32x4* Pl = P + idx * GP_PLANE + kk;
+        const f32x4* Dl = D + idx * GD_PLANE + kk;
+
+        // operands of one step: the lane's tile = (tile row s / 2, tile column 4 (s & 1) + kk)
+        auto load = [&](int s, f32x4 (&d)[2][3], f32x4 (&g)[2][2]) {
+            const int ty = s >> 1, txb = 4 * (s & 1);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int bb = C0 + b;
+                d[0][b] = Pl[(2 * ty + RA) * P_ROW + (bb & 1) * P_PAR + (bb >> 1) + txb];
+                d[1][b] = Pl[(2 * ty + RB) * P_ROW + (bb & 1) * P_PAR + (bb >> 1) + txb];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    if ((I != 0 || a == 0) && (I != 3 || a == 1)) g[a][b] = Dl[(2 * ty + a) * 16 + b * 8 + txb];
+        };
+
+        f32x4 d[2][3], g[2][2];
+        load(0, d, g);
+        while (true) {
+            const int next = item + gridDim.x;
+            const bool has_next = next < p.items;
+            const W2Item nxt = w2_item(p.bx, p.by, 1, has_next ? next : item);
+#pragma unroll 1
+            for (int s = 0; s < 16; ++s) {
+                // this step's operands from the values read one step ago
+                f32x4 V[2], M[2];
+                {
+                    f32x4 t[3];
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) t[b] = d[0][b] + SG * d[1][b];
+                    if (J0 == 0) {
+                        V[0] = t[0] - t[2];          // (B^T d B)[I][0]
+                        V[1] = t[1] + t[2];          //            [I][1]
+                    } else {
+                        V[0] = t[1] - t[0];          //            [I][2]   (t = columns 1, 2, 3)
+                        V[1] = t[0] - t[2];          //            [I][3]
+                    }
+                    f32x4 r[2];                      // (A dy)[I][b]
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        r[b] = I == 0 ? g[0][b] : I == 1 ? g[0][b] + g[1][b] : I == 2 ? g[0][b] - g[1][b] : -g[1][b];
+                    if (J0 == 0) {
+                        M[0] = r[0];                 // (A dy A^T)[I][0]
+                        M[1] = r[0] + r[1];          //            [I][1]
+                    } else {
+                        M[0] = r[0] - r[1];          //            [I][2]
+                        M[1] = -r[1];                //            [I][3]
+                    }
+                }
+                // X (step 15): every wave has consumed its last values of this item, and the first-half refill (steps 10..14)
+                // has landed: the next item's first tile can be read, its second half refilled.
+                // Y (step 5): the second-half refill (steps 0..3) has landed before tile row 3 is read.
+                if (s == 15 || s == 5) W2_BARRIER(0);
+                // the next step's values, read one step ahead (past the last step: the next item's first tile)
+                load((s + 1) & 15, d, g);
+                // refills, two or three pieces per step: the second half of THIS item's LDS image during its steps 0..3 (the
+                // first item came complete), the first half of the NEXT item's during steps 10..14
+                if (s < 4 && item != (int)blockIdx.x) {
+                    int ord = 0;
+#pragma unroll
+                    for (int n = 0; n < 20; ++n)
+                        if (!in_first_half(n)) {
+                            if ((ord < 6 ? ord / 3 : 2 + (ord - 6) / 2) == s) piece(n, cur);
+                            ++ord;
+                        }
+                }
+                if (has_next && s >= 10 && s < 15) {
+                    int ord = 0;
+#pragma unroll
+                    for (int n = 0; n < 20; ++n)
+                        if (in_first_half(n)) {
+                            if (ord / 2 == s - 10) piece(n, nxt);
+                            ++ord;
+                        }
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            acc[a][j][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(M[a][j], V[a][k], acc[a][j][k], 0, 0, 0);
+                if (s == 9) W2_BARRIER(0);           // Z: tile rows 0..4 are done everywhere: the first half may be refilled
+            }
+            if (!has_next) break;
+            item = next;
+            cur = nxt;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    // partial sums: component xi = 4 I + J0 + a; lane (n = idx, q = kk) holds k = 16 q + 4 r + j, c = 4 n + j'
+    float* out = p.part + (long)blockIdx.x * 16 * 4096;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * kk + 4 * r + j;
+                const f32x4 v = {acc[a][j][0][r], acc[a][j][1][r], acc[a][j][2][r], acc[a][j][3][r]};
+                *(f32x4*)(out + (4 * I + J0 + a) * 4096 + k * 64 + 4 * idx) = v;
+            }
+}
+
+__global__ __launch_bounds__(512, 2) void wino2f_wgrad_kernel(const W2GParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
+        case 0: w2g_run<0, 0>(p, smem); break;
+        case 1: w2g_run<0, 2>(p, smem); break;
+        case 2: w2g_run<1, 0>(p, smem); break;
+        case 3: w2g_run<1, 2>(p, smem); break;
+        case 4: w2g_run<2, 0>(p, smem); break;
+        case 5: w2g_run<2, 2>(p, smem); break;
+        case 6: w2g_run<3, 0>(p, smem); break;
+        default: w2g_run<3, 2>(p, smem); break;
+    }
+}
+
+// dU[xi][k][c] = sum over the workgroups' partial sums, in workgroup order (deterministic); block = (xi, k), 64 c x 4 slices
+__global__ __launch_bounds__(256) void w2g_reduce_kernel(const float* __restrict__ part, int parts, float* __restrict__ dU) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long o = (long)blockIdx.x * 64 + c;            // (xi * 64 + k) * 64 + c
+    const int per = (parts + 3) / 4;
+    float a = 0.f;
+    for (int w = sl * per; w < parts && w < (sl + 1) * per; ++w) a += part[(long)w * 16 * 4096 + o];
+    red[sl][c] = a;
+    __syncthreads();
+    if (sl == 0) dU[o] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+}
+
+// dw[k][r][s][c] = (G^T dU G)[r][s]: the adjoint of the filter transform (G of F(2x2,3x3))
+__global__ __launch_bounds__(256) void w2g_dfilter_kernel(const float* __restrict__ dU, float* __restrict__ dw) {
+    const int t = blockIdx.x * 256 + threadIdx.x;        // k * 64 + c
+    const int c = t & 63, k = t >> 6;
+    float u[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[i][j] = dU[(4 * i + j) * 4096 + t];
+    float r[3][4];                                       // G^T u: rows (u0 + (u1 + u2) / 2, (u1 - u2) / 2, (u1 + u2) / 2 + u3)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r[0][j] = u[0][j] + 0.5f * u[1][j] + 0.5f * u[2][j];
+        r[1][j] = 0.5f * u[1][j] - 0.5f * u[2][j];
+        r[2][j] = 0.5f * u[1][j] + 0.5f * u[2][j] + u[3][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        dw[((k * 3 + i) * 3 + 0) * 64 + c] = r[i][0] + 0.5f * r[i][1] + 0.5f * r[i][2];
+        dw[((k * 3 + i) * 3 + 1) * 64 + c] = 0.5f * r[i][1] - 0.5f * r[i][2];
+        dw[((k * 3 + i) * 3 + 2) * 64 + c] = 0.5f * r[i][1] + 0.5f * r[i][2] + r[i][3];
+    }
+}
+
 }  // namespace
 
 #ifdef W2F_TRACE
@@ -412,5 +673,60 @@ extern "C" int denet_conv_wino2f(const float* x, const float* u, const float* bi
     const int grid = p.items < cus ? p.items : cus;
     hipLaunchKernelGGL(wino2f_kernel, dim3((unsigned)grid), dim3(512), LDS_ALLOC, stream, p);
     DENET_CHECK_LAUNCH("conv_wino2f");
+    return DENET_OK;
+}
+
+// geometry the fused filter-gradient kernel covers
+extern "C" int denet_conv_wino2f_wgrad_ok(int N, int H, int W, int C, int K) {
+    return (C == 64 && K == 64 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0 && N > 0 &&
+            (long)N * H * W * 64 * 4 < 0xF0000000L) ? 1 : 0;
+}
+
+static int w2g_grid(int N, int H, int W) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        cus = prop.multiProcessorCount;
+    }
+    const long items = (long)N * (H / 16) * (W / 16);
+    return (int)(items < cus ? items : cus);
+}
+
+extern "C" size_t denet_conv_wino2f_wgrad_workspace_bytes(int N, int H, int W) {
+    const int grid = w2g_grid(N, H, W);
+    return grid < 0 ? 0 : ((size_t)grid + 1) * 16 * 4096 * sizeof(float);
+}
+
+// dw[64][3][3][64] = the filter gradient of a 3x3 stride-1 pad-1 convolution x [N,H,W,64] -> y [N,H,W,64] for dy
+// (denet/model/model_cnn.py:318, tensor.grad of convolution.py:80-83), F(2x2,3x3) with the transforms and the products fused
+extern "C" int denet_conv_wino2f_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int N,
+                                       int H, int W, int C, int K, hipStream_t stream) {
+    DENET_CHECK_ARG(x && dy && dw && workspace, "conv_wino2f_wgrad: null pointer");
+    DENET_CHECK_ARG(denet_conv_wino2f_wgrad_ok(N, H, W, C, K), "conv_wino2f_wgrad: needs C = K = 64, H, W multiples of 16");
+    const int grid = w2g_grid(N, H, W);
+    DENET_CHECK_ARG(grid > 0, "conv_wino2f_wgrad: cannot query the device");
+    DENET_CHECK_ARG(workspace_bytes >= denet_conv_wino2f_wgrad_workspace_bytes(N, H, W), "conv_wino2f_wgrad: workspace too small");
+    W2GParams p = {};
+    p.x = x; p.dy = dy; p.part = (float*)workspace;
+    p.N = N; p.H = H; p.W = W;
+    p.by = H / 16; p.bx = W / 16;
+    p.items = N * p.by * p.bx;
+    p.x_bytes = (unsigned)((size_t)N * H * W * 64 * 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)wino2f_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES);
+        if (e != hipSuccess) {
+            denet_set_error("conv_wino2f_wgrad: hipFuncSetAttribute(%d B LDS): %s", G_LDS_BYTES, hipGetErrorString(e));
+            return -(int)e;
+        }
+        attr_set = true;
+    }
+    float* dU = p.part + (size_t)grid * 16 * 4096;
+    hipLaunchKernelGGL(wino2f_wgrad_kernel, dim3(grid), dim3(512), G_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(w2g_reduce_kernel, dim3(16 * 64), dim3(256), 0, stream, p.part, grid, dU);
+    hipLaunchKernelGGL(w2g_dfilter_kernel, dim3(16), dim3(256), 0, stream, dU, dw);
+    DENET_CHECK_LAUNCH("conv_wino2f_wgrad");
     return DENET_OK;
 }

@@ -44,6 +44,9 @@ SIGNATURES = {
     "denet_conv_wino_dgrad": (I, [P] * 6 + [Z] + [I] * 6 + [P]),
     "denet_conv_wino2f_ok": (I, [I] * 5),
     "denet_conv_wino2f": (I, [P] * 5 + [I, P, Z, P] + [I] * 5 + [P]),
+    "denet_conv_wino2f_wgrad_ok": (I, [I] * 5),
+    "denet_conv_wino2f_wgrad_workspace_bytes": (Z, [I] * 3),
+    "denet_conv_wino2f_wgrad": (I, [P] * 4 + [Z] + [I] * 5 + [P]),
     "denet_conv_tune": (I, [I, P, P, P, P, P, P, Z] + [I] * 12 + [P]),
     "denet_conv_tuned": (I, [I] * 11 + [P, P, P]),
     "denet_conv_last_config": (I, [P] * 5),

@@ -339,15 +339,16 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
 WINOGRAD = int(os.environ.get("DENET_WINOGRAD", "4"))
 _WINO = {}
 # A third alternative for the 64-input-channel layers: FUSED2, F(2x2,3x3) with the transforms and the products in one kernel
-# (csrc/wino2f.hip). DENET_WINO2F: bit 0 allows it for the forward pass, bit 1 for the data gradient.
+# (csrc/wino2f.hip). DENET_WINO2F: bit 0 allows it for the forward pass, bit 1 for the data gradient, bit 2 for the filter
+# gradient (64 -> 64 channels only).
 FUSED2 = 22
-WINO2F = int(os.environ.get("DENET_WINO2F", "3"))
+WINO2F = int(os.environ.get("DENET_WINO2F", "7"))
 _WINO_GAIN = {2: 2.25, 4: 4.0, FUSED2: 2.25}      # direct multiplications / Winograd multiplications
 
 
 def _tile_allowed(mode, tile):
     if tile == FUSED2:
-        return WINOGRAD >= 2 and mode in (0, 1) and bool((WINO2F >> mode) & 1)
+        return WINOGRAD >= 2 and mode in (0, 1, 2) and bool((WINO2F >> mode) & 1)
     return tile <= WINOGRAD
 
 
@@ -357,10 +358,13 @@ def _filter_tile(tile):
 
 
 def conv_wino2f_ok(mode, g):
-    """geometry the fused F(2x2,3x3) kernel covers for the forward pass (mode 0) / the data gradient (mode 1)"""
+    """geometry the fused F(2x2,3x3) kernels cover for the forward pass (mode 0) / the data gradient (1) / the filter
+    gradient (2)"""
     N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
     if not (R == 3 and S == 3 and s_real == 3 and stride == 1 and pad == 1):
         return False
+    if mode == 2:
+        return bool(_L().denet_conv_wino2f_wgrad_ok(N, H, W, C, K))
     ci, co = (C, K) if mode == 0 else (K, C)
     return bool(_L().denet_conv_wino2f_ok(N, H, W, ci, co))
 
@@ -393,7 +397,7 @@ def _wino_tile(mode, g, direct, wino):
     use = _WINO.get(key)
     if use is None:
         tiles = [t for t in (2, 4) if t <= WINOGRAD and conv_wino_ok(g, t)] if AUTOTUNE else []
-        if AUTOTUNE and mode in (0, 1) and _tile_allowed(mode, FUSED2) and conv_wino2f_ok(mode, g):
+        if AUTOTUNE and _tile_allowed(mode, FUSED2) and conv_wino2f_ok(mode, g):
             tiles.append(FUSED2)
         if not tiles:
             use = 0
@@ -552,6 +556,11 @@ def conv_wino_wgrad(x, dy, out=None, tile=2, v=None):
     N, H, W, C = x.shape
     K = dy.shape[3]
     dw = out if out is not None else empty(K, 3, 3, C)
+    if tile == FUSED2:
+        ws = WS.get("wino2f_side" if _ON_WGRAD_STREAM else "wino2f", _L().denet_conv_wino2f_wgrad_workspace_bytes(N, H, W))
+        check(_L().denet_conv_wino2f_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel(), N, H, W, C, K, stream_ptr()),
+              "conv_wino2f_wgrad")
+        return dw
     ws = _wino_ws(tile, N, H, W, C, K)
     sws = WS.get("wgrad", WGRAD_WS_BYTES)
     check(_L().denet_conv_wino_wgrad(ptr(x), ptr(dy), ptr(v), ptr(dw), ptr(ws), ws.numel(), ptr(sws), sws.numel(), tile, N, H,

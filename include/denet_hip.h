@@ -114,6 +114,12 @@ int denet_conv_wino2f_ok(int N, int H, int W, int Ci, int Co);
 int denet_conv_wino2f(const float* x, const float* u, const float* bias, const float* add, float* y, int relu,
                       double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int Ci, int Co,
                       hipStream_t stream);
+/* The filter gradient of the same layers (C = K = 64), fused the same way: dw [64][3][3][64] from x and dy [N,H,W,64]
+ * (model_cnn.py:318). workspace: denet_conv_wino2f_wgrad_workspace_bytes (per-workgroup partial sums, added in a fixed order). */
+int denet_conv_wino2f_wgrad_ok(int N, int H, int W, int C, int K);
+size_t denet_conv_wino2f_wgrad_workspace_bytes(int N, int H, int W);
+int denet_conv_wino2f_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int H,
+                            int W, int C, int K, hipStream_t stream);
 int denet_conv_wino_dgrad(const float* dy, const float* w, const float* u_cached, const float* add, float* dx,
                           float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
                           hipStream_t stream);

@@ -164,6 +164,18 @@ def test_fused_winograd_f2_kernel(hip, case):
             rdx = torch.autograd.grad(ref, xd, dy.double().permute(0, 3, 1, 2))[0].permute(0, 2, 3, 1) + acc0.double()
             dx = ops.conv_dgrad(dy, w, tuple(x.shape), add=acc0, stride=1, pad=1)
             assert float((dx.double() - rdx).abs().max()) / float(rdx.abs().max()) <= 1e-6
+            # the filter gradient, fused the same way (64 -> 64 only): sums over all N * H * W / 4 tiles
+            assert ops.conv_wino2f_ok(2, g)
+            ops._WINO[(2, g)] = ops.FUSED2
+            wd2 = w.double().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+            rdw = torch.autograd.grad(Fn.conv2d(xd.detach(), wd2, None, padding=1), wd2, dy.double().permute(0, 3, 1, 2))[0]
+            rdw = rdw.permute(0, 2, 3, 1)
+            dw = ops.conv_wgrad(x, dy, tuple(w.shape), stride=1, pad=1)
+            assert float((dw.double() - rdw).abs().max()) / float(rdw.abs().max()) <= 2e-6
+            dw2 = ops.conv_wgrad(x, dy, tuple(w.shape), stride=1, pad=1)
+            assert torch.equal(dw, dw2)                                   # partial sums are added in a fixed order
+        else:
+            assert not ops.conv_wino2f_ok(2, g)
     finally:
         ops.AUTOTUNE = saved[0]
         ops._WINO.clear()
