@@ -378,6 +378,8 @@ constexpr int GP_BYTES = 16 * GP_PLANE * 16;
 constexpr int GD_BYTES = 16 * GD_PLANE * 16;
 constexpr int G_LDS_BYTES = GP_BYTES + GD_BYTES;             // 160 256
 
+__host__ __device__ constexpr int gp_start(int k) { return k < 3 ? 64 * k : k == 3 ? 136 : k == 4 ? 200 : k == 5 ? 264 : 296; }
+
 struct W2GParams {
     const float* x;      // [N,H,W,64]
     const float* dy;     // [N,H,W,64]
@@ -403,41 +405,41 @@ __device__ __forceinline__ void w2g_run(const W2GParams& p, char* smem) {
     // dy:    plane k = 4 pieces of 4 pixel rows;                                   wave w moves planes 2w, 2w+1
     // piece numbers 0..11 = patch (plane 2w + n / 6, piece n % 6), 12..19 = dy (plane 2w + (n - 12) / 4, piece (n - 12) % 4)
     // per-lane constants of the pieces (kept small: the compiler would otherwise keep 20 hoisted address sets in registers)
-    int pcl[3];                                      // patch pieces 2j, 2j+1: row | column << 8 (column 255: padding slot)
+    int pcl[4];                                      // patch pieces 2j, 2j+1: row | column << 8 (column 255: padding slot)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < 4; ++j) {
         pcl[j] = 0;
 #pragma unroll
         for (int hlf = 0; hlf < 2; ++hlf) {
             const int k = 2 * j + hlf;
-            const int sl = (k == 5 ? P_USED - 64 : 64 * k) + lane;
+            const int sl = gp_start(k < 7 ? k : 6) + lane;
             const int row = sl / P_ROW, r = sl - row * P_ROW, par = r / P_PAR, col = r - par * P_PAR;
             pcl[j] |= (row | ((col < 9 ? 2 * col + par : 255) << 8)) << (16 * hlf);
         }
     }
     const int dyl = ((lane >> 4) * p.W + 2 * (lane & 7) + ((lane >> 3) & 1)) * CI * 4;   // dy pieces: lane part of the offset
+    // piece numbers 0..13 = patch (plane 2w + n / 7, piece n % 7), 14..21 = dy (plane 2w + (n - 14) / 4, piece (n - 14) % 4).
+    // The 7 patch pieces of a plane start at slots 0, 64, 128, 136 (rows 0..9 = slots 0..199: the FIRST HALF) and 200, 264, 296
+    // (rows 10..17: the second half); pieces 3 and 6 overlap their predecessors with the same values.
     auto piece = [&](int n, const W2Item& it) {
-        if (n < 12) {
-            const int plane = 2 * wave + n / 6, k = n % 6;
+        if (n < 14) {
+            const int plane = 2 * wave + n / 7, k = n % 7;
             const int e = (pcl[k >> 1] >> (16 * (k & 1))) & 0xFFFF;
             const int iy = it.oy0 - 1 + (e & 255), ix = it.ox0 - 1 + (e >> 8);
             const bool ok = (e >> 8) != 255 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             const int off = (((it.n * p.H + iy) * p.W + ix) * CI + plane * 4) * 4;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(P + plane * GP_PLANE + (k == 5 ? P_USED - 64 : 64 * k)), 16,
-                                                     ok ? off : OOB, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(P + plane * GP_PLANE + gp_start(k)), 16, ok ? off : OOB, 0, 0, 0);
         } else {
-            const int m = n - 12;
+            const int m = n - 14;
             const int plane = 2 * wave + m / 4, k = m % 4;
             const int base = (((it.n * p.H + it.oy0 + 4 * k) * p.W + it.ox0) * CI + plane * 4) * 4;      // wave-uniform
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(D + plane * GD_PLANE + 64 * k), 16, dyl, base, 0, 0);
         }
     };
-    // Which pieces a tile row needs: patch piece k holds slots 64 k .. (rows 3.2 k ..), dy piece k rows 4 k .. 4 k + 3. The first
-    // half of an item (tile rows 0..2, steps 0..5) reads patch rows 0..7 (pieces 0, 1, 2) and dy rows 0..5 (pieces 0, 1); they
-    // are refilled for the next item once tile row 4 is done (patch rows <= 9 free: slots < 200 -> pieces 0, 1, 2; dy rows < 8).
-    // The rest (patch pieces 3, 4, 5; dy pieces 2, 3) is refilled when the item is done and is in flight during the next
-    // item's first half.
-    auto in_first_half = [](int n) { return n < 12 ? (n % 6) < 3 : ((n - 12) % 4) < 2; };
+    // The first half of the LDS image (patch rows 0..9, dy rows 0..7) serves tile rows 0..3 and the top of tile row 4; it is
+    // refilled for the next item once tile row 4 is done (barrier Z), the rest when the item is done (barrier X) - in flight
+    // during the next item's tile rows 0..3 (barrier Y before tile row 4 is read).
+    auto in_first_half = [](int n) { return n < 14 ? (n % 7) < 4 : ((n - 14) % 4) < 2; };
 
     f32x4 acc[2][4][4];
 #pragma unroll
@@ -451,7 +453,7 @@ __device__ __forceinline__ void w2g_run(const W2GParams& p, char* smem) {
     if (item < p.items) {
         W2Item cur = w2_item(p.bx, p.by, 1, item);
 #pragma unroll
-        for (int n = 0; n < 20; ++n) piece(n, cur);
+        for (int n = 0; n < 22; ++n) piece(n, cur);
         W2_BARRIER(0);
 
         // the two patch rows / three patch columns / dy rows this wave's components need
@@ -510,29 +512,29 @@ __device__ __forceinline__ void w2g_run(const W2GParams& p, char* smem) {
                         M[1] = -r[1];                //            [I][3]
                     }
                 }
-                // X (step 15): every wave has consumed its last values of this item, and the first-half refill (steps 10..14)
+                // X (step 15): every wave has consumed its last values of this item, and the first-half refill (steps 10..12)
                 // has landed: the next item's first tile can be read, its second half refilled.
-                // Y (step 5): the second-half refill (steps 0..3) has landed before tile row 3 is read.
-                if (s == 15 || s == 5) W2_BARRIER(0);
+                // Y (step 7): the second-half refill (steps 0..3) has landed before tile row 4 is read.
+                if (s == 15 || s == 7) W2_BARRIER(0);
                 // the next step's values, read one step ahead (past the last step: the next item's first tile)
                 load((s + 1) & 15, d, g);
-                // refills, two or three pieces per step: the second half of THIS item's LDS image during its steps 0..3 (the
-                // first item came complete), the first half of the NEXT item's during steps 10..14
+                // refills, a few pieces per step: the second half of THIS item's LDS image during its steps 0..3 (the first item
+                // came complete), the first half of the NEXT item's during steps 10..12
                 if (s < 4 && item != (int)blockIdx.x) {
                     int ord = 0;
 #pragma unroll
-                    for (int n = 0; n < 20; ++n)
-                        if (!in_first_half(n)) {
+                    for (int n = 0; n < 22; ++n)
+                        if (!in_first_half(n)) {                         // 10 per wave: 3, 3, 2, 2
                             if ((ord < 6 ? ord / 3 : 2 + (ord - 6) / 2) == s) piece(n, cur);
                             ++ord;
                         }
                 }
-                if (has_next && s >= 10 && s < 15) {
+                if (has_next && s >= 10 && s < 13) {
                     int ord = 0;
 #pragma unroll
-                    for (int n = 0; n < 20; ++n)
-                        if (in_first_half(n)) {
-                            if (ord / 2 == s - 10) piece(n, nxt);
+                    for (int n = 0; n < 22; ++n)
+                        if (in_first_half(n)) {                          // 12 per wave: 4, 4, 4
+                            if (ord / 4 == s - 10) piece(n, nxt);
                             ++ord;
                         }
                 }
