@@ -4,15 +4,10 @@
 // Nothing but x (or dy) is read and y (or dx) written - the un-fused passes move the 4x (F2) / 2.25x (F4) expanded V and M
 // tensors through HBM, which is what bounds them at 64 channels (winograd.hip: 0.33 ms per pass; the direct kernel 0.34).
 //
-// Workgroup = 8 waves, one 16x16-pixel output block (8x8 tiles of 2x2) x 64 output channels, all 64 input channels:
-//   * the 18x18-pixel input patch lives in LDS for the whole workgroup (channel-quad planes, even / odd columns apart: the
-//     16-byte reads of the 16 tiles of a wave fall into 16 different bank groups);
-//   * the transformed filters U[xi][co][ci] stream through LDS in 16-channel groups, as two halves (components 0-7, 8-15)
-//     filled by LDS-DMA (global_load_lds: no staging registers) while the other half is being multiplied;
-//   * v_mfma_f32_16x16x4_f32 with the filter as the row operand: a lane ends up with ALL 16 components of its tile for 4
-//     consecutive output channels, so the output transform A^T M A is register-local and the result is stored 16 bytes
-//     at a time; a wave = 16 tiles x 32 output channels x 16 components = 128 accumulator registers;
-//   * the epilogue adds bias / the accumulated gradient and can emit the batch-norm column sums (batch_norm.py:50-53).
+// Three kernels below share the LDS image of the input (18x18-pixel patch of a 16x16-pixel block as channel-quad planes, even
+// and odd columns apart, filled by LDS-DMA with the image border zeroed by the buffer bounds check) and the persistent-
+// workgroup scheme (one workgroup per CU, work items strided over the grid, the next item's patch streaming in while this one
+// is multiplied): wino2f_ws_kernel (forward / data gradient) and wino2f_wgrad_kernel (filter gradient) + its two reducers.
 // Exact fp32 FMA chains; the association differs from the direct kernel (F(2x2): ~1e-6 relative).
 #include "common.h"
 
@@ -38,17 +33,8 @@ struct W2Params {
 
 constexpr int CI = 64;
 constexpr int P_ROW = 20, P_PAR = 10, P_PLANE = 368;        // 16-byte slots: row / parity / plane strides of the patch
-constexpr int P_USED = 18 * P_ROW;                          // slots of a plane that hold pixels (or in-row padding)
 constexpr int P_BYTES = 16 * P_PLANE * 16;                  // 16 channel-quad planes
-constexpr int UH_SLOTS = 8 * 4 * 64;                        // one half of a filter group: [8 xi][4 q][64 co] float4
-constexpr int RED_BYTES = 4 * 2 * 64 * 4;                   // batch-norm sums of the 4 tile-row waves
-constexpr int LDS_BYTES = P_BYTES + 2 * UH_SLOTS * 16 + RED_BYTES;      // 161 792 of 163 840
 constexpr int OOB = (int)0xF0000000u;
-#ifdef W2F_TRACE
-constexpr int LDS_ALLOC = LDS_BYTES + 1024;
-#else
-constexpr int LDS_ALLOC = LDS_BYTES;
-#endif
 
 // s_waitcnt vmcnt(vm) lgkmcnt(0) [gfx9 encoding: vmcnt = bits 15:14 | 3:0, expcnt 6:4, lgkmcnt 11:8] + s_barrier. The raw
 // barrier leaves the newest `vm` vector-memory operations of the wave in flight (LDS-DMA pieces that are not needed yet,
@@ -58,17 +44,6 @@ constexpr int LDS_ALLOC = LDS_BYTES;
         __builtin_amdgcn_s_waitcnt(((vm) & 15) | ((((vm) >> 4) & 3) << 14) | (7 << 4));          \
         __builtin_amdgcn_s_barrier();                                                            \
     }
-
-#ifdef W2F_TRACE
-__device__ unsigned g_w2f_trace[8 * 32];
-#define W2_MARK(idx)                                                      \
-    if (trace_on) {                                                       \
-        const unsigned t_ = (unsigned)__builtin_readcyclecounter();       \
-        if (lane == 0) trc[wave * 32 + (idx)] = t_;                       \
-    }
-#else
-#define W2_MARK(idx)
-#endif
 
 struct W2Item {
     int n, oy0, ox0, co0, block;
@@ -85,254 +60,203 @@ __device__ __forceinline__ W2Item w2_item(int bx, int by, int nco, int item) {
     return it;
 }
 
-// Persistent workgroups: 8 waves, one work item = a 16x16-pixel output block (8x8 tiles of 2x2) x 64 output channels after
-// the other. While item i is being multiplied the input patch and the first filter group of item i + 1 stream into LDS.
-__global__ __launch_bounds__(512, 2) void wino2f_kernel(const W2Params p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// ================================================================================================================
+// Forward / data-gradient kernel: the transformed filters stay in REGISTERS. A wave owns two of the 16
+// Winograd components (row I = wave / 2, columns J0, J0 + 1, J0 = 2 (wave & 1)) for ALL tiles and ALL output channels:
+//   * its filters U[xi][co][ci] for the two components are 2 x 64 x 64 values = 128 registers per lane, loaded once per kernel
+//     (row operand of v_mfma_f32_16x16x4_f32: lane = (co mod 16, ci quad)); no filter traffic through LDS, no DMA for it;
+//   * per group of 16 tiles (two tile rows) and per 16 input channels a lane reads 2 patch rows x 3 columns of its tile and
+//     forms its two components of B^T d B with 5 additions; 32 products follow (2 components x 4 output-channel blocks x 4);
+//   * the products of a tile group, M[xi][tile][co], meet in LDS (64 KB, XOR-swizzled by tile): every wave writes its two
+//     components, one barrier, then a lane reads the 12 components one output row of its (tile, 4 channels) needs, applies
+//     A^T . A, bias / add / ReLU, stores 16 bytes (a wave instruction covers whole 256-byte pixel rows of the output);
+//   * the input patch is refilled by LDS-DMA in two row bands (patch rows 0..7 while tile rows 4..7 are multiplied, rows
+//     8..17 during the next item's tile rows 0..3).
+constexpr int S_MB_SLOTS = 16 * 16 * 16;                     // M of a tile group: [xi][tile][co quad ^ tile] float4
+constexpr int S_RED_BYTES = 8 * 2 * 64 * 4;                  // batch-norm sums of the 8 waves
+constexpr int S_LDS_BYTES = P_BYTES + S_MB_SLOTS * 16 + S_RED_BYTES;     // 163 840: all of it
+// the 7 DMA pieces of a patch plane: slots 0, 64, 96 (rows 0..7 = slots 0..159: the first band) and 160, 224, 288, 296 (rows
+// 8..17); pieces 2 and 6 overlap their predecessors with the same values
+__host__ __device__ constexpr int sp_start(int k) { return k == 0 ? 0 : k == 1 ? 64 : k == 2 ? 96 : k == 3 ? 160 : k == 4 ? 224 : k == 5 ? 288 : 296; }
+
+template <int I, int J0>
+__device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
     f32x4* P = (f32x4*)smem;
-    f32x4* UA = (f32x4*)(smem + P_BYTES);
-    f32x4* UB = UA + UH_SLOTS;
-    float* red = (float*)(smem + P_BYTES + 2 * UH_SLOTS * 16);
-#ifdef W2F_TRACE
-    unsigned* trc = (unsigned*)(smem + LDS_BYTES);
-    int iter = 0;
-    bool trace_on = false;
-#endif
+    f32x4* MB = (f32x4*)(smem + P_BYTES);
+    float* red = (float*)(smem + P_BYTES + S_MB_SLOTS * 16);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: addresses derived from it stay scalar
-    const int t = lane & 15, q = lane >> 4;          // tile inside the wave's 16, channel quad inside a group of 16
-    const int tg = wave & 3, nh = wave >> 2;         // tile rows 2tg, 2tg+1 of the block; output-channel half
-    const int ty = 2 * tg + (t >> 3), tx = t & 7;
-    const int ucol = 32 * nh + t;                    // + 16 nb: the lane's row of the filter operand
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = lane & 15, kk = lane >> 4;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
 
-    // ---- LDS-DMA pieces (one wave instruction = 64 lanes x 16 B into 64 consecutive slots) -------------------------------
-    // filters: a half = 32 rows (xi8, q) of 64 output channels; wave w moves rows 4w .. 4w+3, piece k = row 4w + k
-    auto u_piece = [&](f32x4* dst, int h, int g, int co0, int k) {
-        const int r = wave * 4 + k;
-        const int xi8 = r >> 2, qq = r & 3;
-        const float* src = p.U + ((long)(8 * h + xi8) * p.Co + co0 + lane) * CI + 16 * g + 4 * qq;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + (xi8 * 4 + qq) * 64), 16, 0, 0);
-    };
-    // input patch: plane (channel quad) c of the 18 x 18 pixels = 6 pieces of 64 slots; the 24 pieces of channel group g
-    // are spread over the waves: wave w moves plane 4g + w/2, pieces 3 (w & 1) + j, j = 0..2. A lane's slot -> (row, column)
-    // does not depend on the item; image borders and the padding slots come back as zeros from the buffer bounds check.
-    // Piece 5 of a plane starts at slot 296 = 360 - 64 (it rewrites 24 slots of piece 4 with the same values): every piece is
-    // a full wave instruction, no lane mask, no branch.
-    int pc[3];                                       // row | column << 8; column 255: not a pixel
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int k = 3 * (wave & 1) + j;
-        const int sl = (k == 5 ? P_USED - 64 : 64 * k) + lane;
-        const int row = sl / P_ROW, r = sl - row * P_ROW, par = r / P_PAR, col = r - par * P_PAR;
-        pc[j] = row | ((col < 9 ? 2 * col + par : 255) << 8);
-    }
-    auto patch_piece = [&](int g, int j, const W2Item& it) {
-        const int plane = 4 * g + (wave >> 1);
-        const int k = 3 * (wave & 1) + j;
-        const int iy = it.oy0 - 1 + (pc[j] & 255), ix = it.ox0 - 1 + (pc[j] >> 8);
-        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && (pc[j] >> 8) != 255;
+    // piece n = 0..13 of this wave: plane 2 w + n / 7, piece n % 7. The slot -> pixel arithmetic is redone per piece (a dozen
+    // integer instructions, 14 pieces per item) rather than kept in registers: the filters leave none to spare.
+    auto piece = [&](int n, const W2Item& it) {
+        const int plane = 2 * wave + n / 7, k = n % 7;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                // opaque: keeps this arithmetic here instead of hoisted into 14 register sets
+        const int sl = sp_start(k) + ln;
+        const int row = (sl * 3277) >> 16;           // sl / 20 for sl < 1 << 14
+        const int r = sl - row * P_ROW;
+        const int par = r >= P_PAR ? 1 : 0, col = r - par * P_PAR;
+        const int iy = it.oy0 - 1 + row, ix = it.ox0 - 1 + 2 * col + par;
+        const bool ok = col < 9 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         const int off = (((it.n * p.H + iy) * p.W + ix) * CI + plane * 4) * 4;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(P + plane * P_PLANE + (k == 5 ? P_USED - 64 : 64 * k)), 16,
-                                                 ok ? off : OOB, 0, 0, 0);
-    };
-
-    // t = B^T d, row i of the lane's tile for its 4 channels of group g: a combination of two patch rows
-    //   row 0 = d0 - d2, row 1 = d1 + d2, row 2 = d2 - d1, row 3 = d1 - d3
-    auto load_tt = [&](f32x4 (&tt)[4], int g, int i) {
-        const int ra = i == 0 ? 0 : 1, rb = i == 3 ? 3 : 2;
-        const f32x4* Pp = P + (4 * g + q) * P_PLANE + (2 * ty) * P_ROW + tx;
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-            const f32x4* c = Pp + (bb & 1) * P_PAR + (bb >> 1);
-            const f32x4 ea = c[ra * P_ROW], eb = c[rb * P_ROW];
-            tt[bb] = i == 0 ? ea - eb : i == 1 ? ea + eb : i == 2 ? eb - ea : ea - eb;
-        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(P + plane * P_PLANE + sp_start(k)), 16, ok ? off : OOB, 0, 0, 0);
     };
 
     int item = blockIdx.x;
     if (item >= p.items) return;
-#ifdef W2F_TRACE
-    trace_on = blockIdx.x == 0;
-    W2_MARK(26);
-#endif
     W2Item cur = w2_item(p.bx, p.by, p.nco, item);
-    // prologue: channel groups 0..2 of the first patch (group 3 comes with the first half, like every later one) and the
-    // first filter half
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+    for (int n = 0; n < 14; ++n) piece(n, cur);
+
+    // the two components' filters: row operand, lane = (co = 16 cb + t, ci = 16 r + 4 kk + j)
+    f32x4 Ur[2][4][4];
+    int u_co0 = -1;
+    auto load_u = [&](int co0) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) patch_piece(g, j, cur);
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) u_piece(UA, 0, 0, cur.co0, k);
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Ur[a][cb][r] = *(const f32x4*)(p.U + ((long)(4 * I + J0 + a) * p.Co + co0 + 16 * cb + t) * CI + 16 * r + 4 * kk);
+        u_co0 = co0;
+    };
+    load_u(cur.co0);
+
+    constexpr int RA = I == 0 ? 0 : I == 2 ? 2 : 1, RB = I == 0 ? 2 : I == 1 ? 2 : I == 2 ? 1 : 3;
+    constexpr float SG = I == 1 ? 1.f : -1.f;                  // t[I] = d[RA] + SG d[RB]
+    constexpr int C0 = J0 == 0 ? 0 : 1;                        // columns C0, C0 + 1, C0 + 2 of t
+    // the lane's tile of a group: tile row 2 g + (t >> 3), column t & 7; patch reads of round r: plane 4 r + kk
+    const f32x4* Pl = P + kk * P_PLANE + (2 * (t >> 3)) * P_ROW + (t & 7);
+    auto load_d = [&](int g, int r, f32x4 (&d)[2][3]) {
+        const f32x4* c = Pl + 4 * r * P_PLANE + 4 * g * P_ROW;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int bb = C0 + b;
+            d[0][b] = c[RA * P_ROW + (bb & 1) * P_PAR + (bb >> 1)];
+            d[1][b] = c[RB * P_ROW + (bb & 1) * P_PAR + (bb >> 1)];
+        }
+    };
+    // output phase: lane = (4 output channels tq = t, tile 2 w + (kk & 1) of the group, output row oi = kk >> 1)
+    const int otile = 2 * wave + (kk & 1), oi = kk >> 1;
+    const f32x4* Mo = MB + (4 * oi * 16 + otile) * 16 + (t ^ otile);
+    const float osg = oi ? -1.f : 1.f;
+    f32x4* const Mw0 = MB + ((4 * I + J0) * 16 + t) * 16;       // + a * 256 + ((4 cb + kk) ^ t)
+
     W2_BARRIER(0);
-
-    // Software pipeline over the halves h = (item, group g, A | B); half h multiplies components 8 (h & 1) .. + 7 of group g
-    // out of buffer UA (A) / UB (B) in 8 steps of 8 products:
-    //   steps 0-1  the 4 DMA pieces of the NEXT half's filters go into the other buffer
-    //   steps 2-4  (A halves) 3 pieces refill the patch planes of the previous channel group for the next item
-    //   step  5    the filter operands of steps 6-7 are read into registers: no wave reads this buffer after the barrier
-    //   step  6    wait for the own pieces, ONE barrier: the other buffer is complete, this one may be refilled next half
-    //   steps 6-7  the first row of t = B^T d and the first filter operands of the next half are read: it starts without
-    //              an LDS round trip (its second row is read during its first steps)
-    f32x4 tt[4], uc0, uc1;                           // first row + operands: carried from half to half (across the epilogue)
-    load_tt(tt, 0, 0);
-    uc0 = UA[q * 64 + ucol];
-    uc1 = UA[q * 64 + ucol + 16];
-
+    f32x4 d[2][3];
+    load_d(0, 0, d);
+    f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
     while (true) {
         const int next = item + gridDim.x;
         const bool has_next = next < p.items;
         const W2Item nxt = w2_item(p.bx, p.by, p.nco, has_next ? next : item);
-#ifdef W2F_TRACE
-        trace_on = blockIdx.x == 0 && iter == 2;
-        ++iter;
-#endif
-        W2_MARK(0);
-
-        f32x4 acc[16][2];                            // started by the first product of channel group 0 (C operand 0)
-
-        auto half = [&](auto G, auto HB) {
-            constexpr int g = decltype(G)::value;
-            constexpr int hb = decltype(HB)::value;              // 0: half A, 1: half B
-            constexpr int i0 = 2 * hb;
-            const f32x4* up = (hb ? UB : UA) + q * 64 + ucol;
-            f32x4* const other = hb ? UA : UB;
-            // what the next half is. The pipeline has no branches: past the last item the pieces and reads repeat this item's
-            // (`nxt` = `cur`), into buffers that nobody reads again.
-            constexpr int ng = hb ? (g + 1) & 3 : g;
-            const int nco0 = (hb && g == 3) ? nxt.co0 : cur.co0;
-            f32x4 U0[8], U1[8], t2[4], tn[4], un0, un1;  // filter operands per step: read one step ahead
-            U0[0] = uc0;
-            U1[0] = uc1;
+        if (cur.co0 != u_co0) load_u(cur.co0);
+#pragma unroll 1
+        for (int g = 0; g < 4; ++g) {
+            f32x4 acc[2][4];
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                const int i = i0 + ii;
-                const f32x4 (&tr)[4] = ii ? t2 : tt;
-                f32x4 V[4];
-                V[0] = tr[0] - tr[2];
-                V[1] = tr[1] + tr[2];
-                V[2] = tr[2] - tr[1];
-                V[3] = tr[1] - tr[3];
+            for (int r = 0; r < 4; ++r) {
+                f32x4 V[2];
+                {
+                    f32x4 tc[3];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int st = ii * 4 + j;
-#ifdef W2F_PRIO
-                    // the two waves of a SIMD (nh = 0, 1) take turns at the higher issue priority, step by step: the older one
-                    // would otherwise run ahead and leave the other to finish the half alone
-                    if ((st + nh) & 1) __builtin_amdgcn_s_setprio(1);
-                    else __builtin_amdgcn_s_setprio(0);
-#endif
-                    if (st < 5) {
-                        U0[st + 1] = up[(st + 1) * 256];
-                        U1[st + 1] = up[(st + 1) * 256 + 16];
-                    } else if (st == 5) {            // the last reads of this buffer, before the barrier of step 6
-                        U0[6] = up[6 * 256];
-                        U1[6] = up[6 * 256 + 16];
-                        U0[7] = up[7 * 256];
-                        U1[7] = up[7 * 256 + 16];
+                    for (int b = 0; b < 3; ++b) tc[b] = d[0][b] + SG * d[1][b];
+                    if (J0 == 0) {
+                        V[0] = tc[0] - tc[2];
+                        V[1] = tc[1] + tc[2];
+                    } else {
+                        V[0] = tc[1] - tc[0];
+                        V[1] = tc[0] - tc[2];
                     }
-                    if (st == 1) load_tt(t2, g, i0 + 1);         // the second row of this half, used from step 4 on
-                    const f32x4 u0 = U0[st], u1 = U1[st];
-                    if (st < 2) {
-                        u_piece(other, hb ^ 1, ng, nco0, 2 * st);
-                        u_piece(other, hb ^ 1, ng, nco0, 2 * st + 1);
-                    } else if (st < 5 && !hb) {
-                        // patch refill in A halves: group g - 1 for the next item; g = 0: group 3 for THIS item (its planes
-                        // were last read in the previous item's half B of group 3)
-                        patch_piece((g + 3) & 3, st - 2, g == 0 ? cur : nxt);
-                    }
-                    if (st == 6) {
-                        W2_MARK(1 + (2 * g + hb) * 3);
-                        if (!hb) W2_BARRIER(3)       // the 3 patch pieces, issued after the filter pieces, may still fly
-                        else W2_BARRIER(0)
-                        W2_MARK(2 + (2 * g + hb) * 3);
-                        load_tt(tn, ng, hb ? 0 : 2); // the first row of the next half
-                        un0 = other[q * 64 + ucol];
-                        un1 = other[q * 64 + ucol + 16];
-                    }
-                    // the two accumulators alternate: a dependent v_mfma_f32_16x16x4_f32 issues after 40 cycles, an
-                    // independent one after 32
-                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const bool start = g == 0 && c == 0;
-                        acc[4 * i + j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u0[c], V[j][c], start ? zero : acc[4 * i + j][0], 0, 0, 0);
-                        acc[4 * i + j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u1[c], V[j][c], start ? zero : acc[4 * i + j][1], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);           // the steps stay in this order
                 }
+                // the next round's patch values (after the last round of the item: the next item's first, whose band landed
+                // before the barrier of tile group 3)
+                if (r < 3) load_d(g, r + 1, d);
+                // patch refill, two pieces per round: rows 8..17 (pieces 3..6 of the wave's two planes) for THIS item during its
+                // tile group 0 (the first item came complete), rows 0..7 for the NEXT item during tile group 2
+                if (g == 0 && item != (int)blockIdx.x) {
+                    piece(3 + r, cur);
+                    piece(7 + 3 + r, cur);
+                }
+                if (g == 2 && has_next && r < 3) {
+                    piece(r, nxt);
+                    piece(7 + r, nxt);
+                }
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int cb = 0; cb < 4; ++cb)
+                            acc[a][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ur[a][cb][r][j], V[a][j], (r == 0 && j == 0) ? zero : acc[a][cb], 0, 0, 0);
             }
-            W2_MARK(3 + (2 * g + hb) * 3);
+            // every wave has read the previous group's M; this group's goes in
+            W2_BARRIER(63);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) tt[b] = tn[b];
-            uc0 = un0;
-            uc1 = un1;
-        };
-        half(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        half(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-        half(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
-        half(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-        half(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
-        half(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
-        half(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
-        half(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
-
-        // ---- epilogue: Y = A^T M A per (tile, 4 output channels), + bias, + add; 16-byte stores -------------------------
-        const long pix = ((long)cur.n * p.H + cur.oy0 + 2 * ty) * p.W + cur.ox0 + 2 * tx;
-        f32x4 ssum[2], ssq[2];
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const int ch = cur.co0 + 32 * nh + 16 * nb + 4 * q;
-            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) bias4 = *(const f32x4*)(p.bias + ch);
-            f32x4 addv[4];
-            if (p.add) {
+                for (int cb = 0; cb < 4; ++cb) Mw0[a * 256 + ((4 * cb + kk) ^ t)] = acc[a][cb];
+            // all 16 components are there. The band pieces issued during this group (8 in group 0, 6 in group 2) may still fly;
+            // the barriers of groups 1 and 3 wait for them (they are then more than a tile group old)
+            if (g == 0) W2_BARRIER(8)
+            else if (g == 2) W2_BARRIER(6)
+            else W2_BARRIER(0)
+            // the next group's first patch values (group 3: the next item's)
+            load_d((g + 1) & 3, 0, d);
+            // ---- output phase: Y row oi of the lane's tile = A^T M A, + bias, + add, ReLU; 2 pixels x 4 channels ---------------
+            {
+                f32x4 sv[4];
 #pragma unroll
-                for (int ij = 0; ij < 4; ++ij) addv[ij] = *(const f32x4*)(p.add + (pix + (ij >> 1) * p.W + (ij & 1)) * p.Co + ch);
-            }
-            f32x4 s[2][4];
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                s[0][bb] = acc[0 + bb][nb] + acc[4 + bb][nb] + acc[8 + bb][nb];
-                s[1][bb] = acc[4 + bb][nb] - acc[8 + bb][nb] - acc[12 + bb][nb];
-            }
-            ssum[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            ssq[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ij = 0; ij < 4; ++ij) {
-                const int i = ij >> 1;
-                f32x4 yv = (ij & 1) ? (s[i][1] - s[i][2] - s[i][3]) : (s[i][0] + s[i][1] + s[i][2]);
-                yv += bias4;
-                if (p.add) yv += addv[ij];
-                if (p.relu) yv = __builtin_elementwise_max(yv, f32x4{0.f, 0.f, 0.f, 0.f});
-                *(f32x4*)(p.y + (pix + i * p.W + (ij & 1)) * p.Co + ch) = yv;
-                ssum[nb] += yv;
-                ssq[nb] += yv * yv;
+                for (int jj = 0; jj < 4; ++jj) {
+                    const f32x4 m0 = Mo[(0 * 4 + jj) * 256], m1 = Mo[(1 * 4 + jj) * 256], m2 = Mo[(2 * 4 + jj) * 256];
+                    sv[jj] = m0 + osg * (m1 + m2);
+                }
+                f32x4 y0 = sv[0] + sv[1] + sv[2];
+                f32x4 y1 = sv[1] - sv[2] - sv[3];
+                if (p.bias) {
+                    const f32x4 bias4 = *(const f32x4*)(p.bias + cur.co0 + 4 * t);
+                    y0 += bias4;
+                    y1 += bias4;
+                }
+                const int ty = 2 * g + (otile >> 3), tx = otile & 7;
+                const long o = (((long)cur.n * p.H + cur.oy0 + 2 * ty + oi) * p.W + cur.ox0 + 2 * tx) * p.Co + cur.co0 + 4 * t;
+                if (p.add) {
+                    y0 += *(const f32x4*)(p.add + o);
+                    y1 += *(const f32x4*)(p.add + o + p.Co);
+                }
+                if (p.relu) {
+                    y0 = __builtin_elementwise_max(y0, f32x4{0.f, 0.f, 0.f, 0.f});
+                    y1 = __builtin_elementwise_max(y1, f32x4{0.f, 0.f, 0.f, 0.f});
+                }
+                *(f32x4*)(p.y + o) = y0;
+                *(f32x4*)(p.y + o + p.Co) = y1;
+                ssum += y0 + y1;
+                ssq += y0 * y0 + y1 * y1;
             }
         }
         if (p.stats) {
-            // batch-norm column sums of this block: over the 16 tiles of a wave (lanes t), then over the 4 tile-row waves
+            // batch-norm column sums of this block: over the lanes of a wave that share the channels (kk), then over the waves
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
+            for (int off = 16; off < 64; off <<= 1)
 #pragma unroll
-                for (int off = 8; off > 0; off >>= 1)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        ssum[nb][c] += __shfl_xor(ssum[nb][c], off, 64);
-                        ssq[nb][c] += __shfl_xor(ssq[nb][c], off, 64);
-                    }
-                if (t == 0) {
-                    const int cl = 32 * nh + 16 * nb + 4 * q;
-                    *(f32x4*)(red + (tg * 2 + 0) * 64 + cl) = ssum[nb];
-                    *(f32x4*)(red + (tg * 2 + 1) * 64 + cl) = ssq[nb];
+                for (int c = 0; c < 4; ++c) {
+                    ssum[c] += __shfl_xor(ssum[c], off, 64);
+                    ssq[c] += __shfl_xor(ssq[c], off, 64);
                 }
+            if (kk == 0) {
+                *(f32x4*)(red + (wave * 2 + 0) * 64 + 4 * t) = ssum;
+                *(f32x4*)(red + (wave * 2 + 1) * 64 + 4 * t) = ssq;
             }
-            W2_BARRIER(63);                          // LDS only: nothing in flight is waited for
+            W2_BARRIER(63);
             if (tid < 64) {
                 double a = 0.0, bq = 0.0;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
+                for (int w = 0; w < 8; ++w) {
                     a += (double)red[(w * 2 + 0) * 64 + tid];
                     bq += (double)red[(w * 2 + 1) * 64 + tid];
                 }
@@ -340,21 +264,30 @@ __global__ __launch_bounds__(512, 2) void wino2f_kernel(const W2Params p) {
                 ps[cur.co0 + tid] = a;
                 ps[p.Co + cur.co0 + tid] = bq;
             }
+            ssum = f32x4{0.f, 0.f, 0.f, 0.f};
+            ssq = f32x4{0.f, 0.f, 0.f, 0.f};
+            W2_BARRIER(63);                          // `red` is free again
         }
-        W2_MARK(25);
         if (!has_next) break;
         item = next;
         cur = nxt;
     }
-    __builtin_amdgcn_s_waitcnt(0);                   // no LDS-DMA piece may land after the workgroup has released its LDS
-#ifdef W2F_TRACE
-    trace_on = blockIdx.x == 0;
-    W2_MARK(27);
-    __syncthreads();
-    if (blockIdx.x == 0 && tid < 256) g_w2f_trace[tid] = trc[tid];
-#endif
+    __builtin_amdgcn_s_waitcnt(0);
 }
 
+__global__ __launch_bounds__(512, 2) void wino2f_ws_kernel(const W2Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
+        case 0: w2s_run<0, 0>(p, smem); break;
+        case 1: w2s_run<0, 2>(p, smem); break;
+        case 2: w2s_run<1, 0>(p, smem); break;
+        case 3: w2s_run<1, 2>(p, smem); break;
+        case 4: w2s_run<2, 0>(p, smem); break;
+        case 5: w2s_run<2, 2>(p, smem); break;
+        case 6: w2s_run<3, 0>(p, smem); break;
+        default: w2s_run<3, 2>(p, smem); break;
+    }
+}
 
 // ================================================================================================================
 // Filter gradient of the same layers (64 -> 64 channels), fused: dw = G^T dU G with dU[xi][k][c] = sum over all 2x2 tiles of
@@ -620,10 +553,6 @@ __global__ __launch_bounds__(256) void w2g_dfilter_kernel(const float* __restric
 
 }  // namespace
 
-#ifdef W2F_TRACE
-extern "C" int denet_w2f_trace(unsigned* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w2f_trace), sizeof(unsigned) * 256); }
-#endif
-
 // geometry this kernel covers
 extern "C" int denet_conv_wino2f_ok(int N, int H, int W, int Ci, int Co) {
     return (Ci == 64 && Co > 0 && Co % 64 == 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0 && N > 0 &&
@@ -654,9 +583,9 @@ extern "C" int denet_conv_wino2f(const float* x, const float* u, const float* bi
     }
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)wino2f_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALLOC);
+        hipError_t e = hipFuncSetAttribute((const void*)wino2f_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
         if (e != hipSuccess) {
-            denet_set_error("conv_wino2f: hipFuncSetAttribute(%d B LDS): %s", LDS_BYTES, hipGetErrorString(e));
+            denet_set_error("conv_wino2f: hipFuncSetAttribute(%d B LDS): %s", S_LDS_BYTES, hipGetErrorString(e));
             return -(int)e;
         }
         attr_set = true;
@@ -673,7 +602,7 @@ extern "C" int denet_conv_wino2f(const float* x, const float* u, const float* bi
         cus = prop.multiProcessorCount;
     }
     const int grid = p.items < cus ? p.items : cus;
-    hipLaunchKernelGGL(wino2f_kernel, dim3((unsigned)grid), dim3(512), LDS_ALLOC, stream, p);
+    hipLaunchKernelGGL(wino2f_ws_kernel, dim3((unsigned)grid), dim3(512), S_LDS_BYTES, stream, p);
     DENET_CHECK_LAUNCH("conv_wino2f");
     return DENET_OK;
 }
