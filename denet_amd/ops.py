@@ -305,7 +305,7 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
     # with a launch of the chosen one (run-to-run determinism)
     tile = _wino_tile(0, g, direct, lambda t: conv_wino_fwd(x, w, bias, add, out=y, tile=t, relu=relu))
     if tile:
-        if PROFILE is not None:
+        if PROFILE is not None and tile != FUSED2:      # (the fused kernels are no igemm launches: not in this profile)
             PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])     # the FLOPs its batched GEMM really executes
         u = v_keep = None
         if cache is not None:
@@ -588,7 +588,7 @@ def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None,
 
     tile = _wino_tile(1, g, direct, lambda t: conv_wino_dgrad(dy, w, add, out=dx, tile=t))
     if tile:
-        if PROFILE is not None:
+        if PROFILE is not None and tile != FUSED2:      # (the fused kernels are no igemm launches: not in this profile)
             PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])
         u = None
         if cache is not None:
@@ -615,7 +615,7 @@ def conv_wgrad(x, dy, w_shape, stride=1, pad=0, s_real=None, out=None, logical=N
 
     tile = _wino_tile(2, g, direct, lambda t: conv_wino_wgrad(x, dy, out=dw, tile=t))
     if tile:
-        if PROFILE is not None:
+        if PROFILE is not None and tile != FUSED2:      # (the fused kernels are no igemm launches: not in this profile)
             PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])
         v = None
         if cache is not None and cache.get("V_tile") == tile:
