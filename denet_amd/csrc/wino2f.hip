@@ -418,7 +418,7 @@ __device__ __forceinline__ void w2g_run(const W2GParams& p, char* smem) {
             const int next = item + gridDim.x;
             const bool has_next = next < p.items;
             const W2Item nxt = w2_item(p.bx, p.by, 1, has_next ? next : item);
-#pragma unroll 1
+#pragma unroll 2
             for (int s = 0; s < 16; ++s) {
                 // this step's operands from the values read one step ago
                 f32x4 V[2], M[2];
