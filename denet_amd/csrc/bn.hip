@@ -33,6 +33,47 @@ BnMap bn_map(long M, int C) {
     return m;
 }
 
+// ---- a max pool directly behind a BN + ReLU layer (the ResNet stem: convolution.py -> batch_norm_relu.py -> pool.py:38) ----
+// Forward: y = relu(bn(x)) is never written - the pooled maximum (and its argmax tap, pool.hip's rule: first maximum in scan
+// order) is taken over values formed on the fly. Backward: the gradient of y at an input position is the sum of the pooled
+// gradients of the windows that selected it (the gather of pool.hip's maxpool_bwd_kernel, same loop order: bit-identical
+// values), evaluated inside the two batch-norm gradient passes instead of being written and read back twice.
+struct PoolGeom {
+    int H, W, OH, OW, k, s, pad;
+};
+
+__device__ __forceinline__ f32x4 pool_gather(const float* __restrict__ dyp, const unsigned char* __restrict__ arg, const PoolGeom& g,
+                                             long r, int C, int c) {
+    const int ix = (int)(r % g.W);
+    const long t = r / g.W;
+    const int iy = (int)(t % g.H);
+    const int n = (int)(t / g.H);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int oy_lo = (iy + g.pad - g.k + 1 + g.s - 1);
+    oy_lo = oy_lo < 0 ? 0 : oy_lo / g.s;
+    int oy_hi = (iy + g.pad) / g.s;
+    if (oy_hi > g.OH - 1) oy_hi = g.OH - 1;
+    int ox_lo = (ix + g.pad - g.k + 1 + g.s - 1);
+    ox_lo = ox_lo < 0 ? 0 : ox_lo / g.s;
+    int ox_hi = (ix + g.pad) / g.s;
+    if (ox_hi > g.OW - 1) ox_hi = g.OW - 1;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        const int ky = iy - (oy * g.s - g.pad);
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            const int kx = ix - (ox * g.s - g.pad);
+            const int tap = ky * g.k + kx;
+            const long o = (((long)n * g.OH + oy) * g.OW + ox) * C + c;
+            const uchar4 a = *(const uchar4*)(arg + o);
+            const f32x4 v = *(const f32x4*)(dyp + o);
+            acc[0] += (a.x == tap) ? v[0] : 0.f;
+            acc[1] += (a.y == tap) ? v[1] : 0.f;
+            acc[2] += (a.z == tap) ? v[2] : 0.f;
+            acc[3] += (a.w == tap) ? v[3] : 0.f;
+        }
+    }
+    return acc;
+}
+
 // partial[gy][2][C] : sum(x), sum(x*x)
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, long M, int C, int LC,
                                                                double* __restrict__ partial) {
@@ -161,16 +202,64 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
 }
 
+// pooled[n][oy][ox][c] = max over the window of relu(gamma*(x-mean)*invstd + beta), arg = its tap (first maximum in scan
+// order, padded taps skipped): bn_apply_kernel + maxpool_fwd_kernel without the tensor in between
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restrict__ x, float* __restrict__ yp,
+                                                            unsigned char* __restrict__ arg, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, int N, int C, PoolGeom g) {
+    const int C4 = C / 4;
+    const long total = (long)N * g.OH * g.OW * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        long t = i / C4;
+        const int ox = (int)(t % g.OW);
+        t /= g.OW;
+        const int oy = (int)(t % g.OH);
+        const int n = (int)(t / g.OH);
+        float sc[4], sh[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sc[e] = gamma[c + e] * invstd[c + e];
+            sh[e] = beta[c + e] - mean[c + e] * sc[e];
+        }
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        for (int ky = 0; ky < g.k; ++ky) {
+            const int iy = oy * g.s - g.pad + ky;
+            if ((unsigned)iy >= (unsigned)g.H) continue;
+            for (int kx = 0; kx < g.k; ++kx) {
+                const int ix = ox * g.s - g.pad + kx;
+                if ((unsigned)ix >= (unsigned)g.W) continue;
+                const f32x4 v = *(const f32x4*)(x + (((long)n * g.H + iy) * g.W + ix) * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float yv = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
+                    if (yv > best[e]) {
+                        best[e] = yv;
+                        bi[e] = ky * g.k + kx;
+                    }
+                }
+            }
+        }
+        *(f32x4*)(yp + i * 4) = best;
+        *(uchar4*)(arg + i * 4) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+    }
+}
+
 // partial[gy][2][C] : sum(g), sum(g*xhat)  with g = dy * (relu ? y>0 : 1)
 // relu mask: y > 0 when the forward output is given (residual-fused blocks), else recomputed from x with the
 // forward's own expression fmaf(x, gamma*invstd, beta - mean*gamma*invstd) > 0 (bit-identical, saves a pass)
+// POOL: dy is the gradient of the max pool behind this layer (dy [N,OH,OW,C], arg its taps): g is gathered on the fly
+template <bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                              const float* __restrict__ dy,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, long M, int C, int LC,
-                                                             int relu, double* __restrict__ partial) {
+                                                             int relu, double* __restrict__ partial,
+                                                             const unsigned char* __restrict__ arg, PoolGeom pg) {
     __shared__ double red[256 * 8];
     const int tid = threadIdx.x;
     const int cl = tid % LC, rsub = tid / LC, RS = 256 / LC;
@@ -187,7 +276,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     for (long r = (long)blockIdx.y * RS + rsub; r < M; r += (long)gridDim.y * RS) {
         const long o = r * C + c;
         const f32x4 xv = *(const f32x4*)(x + o);
-        f32x4 g = *(const f32x4*)(dy + o);
+        f32x4 g = POOL ? pool_gather(dy, arg, pg, r, C, c) : *(const f32x4*)(dy + o);
         if (relu) {
             if (y) {
                 const f32x4 yv = *(const f32x4*)(y + o);
@@ -252,6 +341,7 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restr
 }
 
 // dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) ; optional dres = g
+template <bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy,
                                                            const float* __restrict__ gamma,
@@ -259,7 +349,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ coef, float* __restrict__ dx,
-                                                           float* __restrict__ dres, long M, int C, int LC, int relu) {
+                                                           float* __restrict__ dres, long M, int C, int LC, int relu,
+                                                           const unsigned char* __restrict__ arg, PoolGeom pg) {
     const int tid = threadIdx.x;
     const int cl = tid % LC, rsub = tid / LC, RS = 256 / LC;
     const int c = (blockIdx.x * LC + cl) * 4;
@@ -276,7 +367,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     for (long r = (long)blockIdx.y * RS + rsub; r < M; r += (long)gridDim.y * RS) {
         const long o = r * C + c;
         const f32x4 xv = *(const f32x4*)(x + o);
-        f32x4 g = *(const f32x4*)(dy + o);
+        f32x4 g = POOL ? pool_gather(dy, arg, pg, r, C, c) : *(const f32x4*)(dy + o);
         if (relu) {
             if (y) {
                 const f32x4 yv = *(const f32x4*)(y + o);
@@ -398,13 +489,68 @@ extern "C" int denet_bn_bwd(const float* x, const float* y, const float* dy, con
     BnMap m = bn_map(M, C);
     double* partial = (double*)workspace;
     float* coef = (float*)(partial + (size_t)m.gy * 2 * C);
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, gamma, beta, save_mean,
-                       save_invstd, M, C, m.LC, relu, partial);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, gamma, beta, save_mean,
+                       save_invstd, M, C, m.LC, relu, partial, (const unsigned char*)nullptr, PoolGeom{});
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, m.gy, M, C, dgamma,
                        dbeta, coef);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, gamma, beta, save_mean,
-                       save_invstd, coef, dx, dres, M, C, m.LC, relu);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, gamma, beta, save_mean,
+                       save_invstd, coef, dx, dres, M, C, m.LC, relu, (const unsigned char*)nullptr, PoolGeom{});
     DENET_CHECK_LAUNCH("bn_bwd");
+    return DENET_OK;
+}
+
+// BN + ReLU + max pool in one (training): statistics as denet_bn_fwd_train (partial = NULL: measured here, workspace =
+// denet_bn_workspace_bytes(M, C)) or denet_bn_fwd_train_pre (partial / rows from the convolution in front); the pooled
+// output y_pool [N,OH,OW,C] and its argmax taps are written, relu(bn(x)) itself is not (batch_norm_relu.py:34-48 + pool.py:38)
+extern "C" int denet_bn_relu_pool_fwd_train(const float* x, float* y_pool, unsigned char* argmax, const float* gamma,
+                                            const float* beta, float* run_mean, float* run_stdinv, float* save_mean,
+                                            float* save_invstd, const double* partial, int rows, void* workspace, int N, int H,
+                                            int W, int C, int OH, int OW, int k, int stride, int pad, float momentum, float eps,
+                                            hipStream_t stream) {
+    DENET_CHECK_ARG(x && y_pool && argmax && gamma && beta && save_mean && save_invstd && (partial || workspace),
+                    "bn_relu_pool_fwd_train: null pointer");
+    DENET_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k > 0 && k * k <= 255 && stride > 0 && pad >= 0 && pad < k,
+                    "bn_relu_pool_fwd_train: bad arguments");
+    const long M = (long)N * H * W;
+    BnMap m = bn_map(M, C);
+    if (!partial) {
+        double* p = (double*)workspace;
+        hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, M, C, m.LC, p);
+        partial = p;
+        rows = m.gy;
+    }
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, rows, M, C, eps,
+                       momentum, save_mean, save_invstd, run_mean, run_stdinv);
+    const PoolGeom g = {H, W, OH, OW, k, stride, pad};
+    const long total = (long)N * OH * OW * (C / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(bn_apply_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y_pool, argmax, gamma, beta,
+                       save_mean, save_invstd, N, C, g);
+    DENET_CHECK_LAUNCH("bn_relu_pool_fwd_train");
+    return DENET_OK;
+}
+
+// its gradient: dy_pool [N,OH,OW,C] + argmax -> dx [N,H,W,C], dgamma, dbeta (masked BN gradient of the gathered pool gradient)
+extern "C" int denet_bn_relu_pool_bwd(const float* x, const float* dy_pool, const unsigned char* argmax, const float* gamma,
+                                      const float* beta, const float* save_mean, const float* save_invstd, float* dx,
+                                      float* dgamma, float* dbeta, void* workspace, int N, int H, int W, int C, int OH, int OW,
+                                      int k, int stride, int pad, hipStream_t stream) {
+    DENET_CHECK_ARG(x && dy_pool && argmax && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta && workspace,
+                    "bn_relu_pool_bwd: null pointer");
+    DENET_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k > 0 && stride > 0 && pad >= 0, "bn_relu_pool_bwd: bad arguments");
+    const long M = (long)N * H * W;
+    BnMap m = bn_map(M, C);
+    double* partial = (double*)workspace;
+    float* coef = (float*)(partial + (size_t)m.gy * 2 * C);
+    const PoolGeom g = {H, W, OH, OW, k, stride, pad};
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(m.gx, m.gy), dim3(256), 0, stream, x, (const float*)nullptr, dy_pool,
+                       gamma, beta, save_mean, save_invstd, M, C, m.LC, 1, partial, argmax, g);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, m.gy, M, C, dgamma,
+                       dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(m.gx, m.gy), dim3(256), 0, stream, x, (const float*)nullptr, dy_pool,
+                       gamma, beta, save_mean, save_invstd, coef, dx, (float*)nullptr, M, C, m.LC, 1, argmax, g);
+    DENET_CHECK_LAUNCH("bn_relu_pool_bwd");
     return DENET_OK;
 }
 

@@ -90,6 +90,19 @@ class BatchNormLayer(AbstractLayer):
             # per-channel sums already written by the convolution that produced x (ConvLayer.forward), valid for this tensor only
             pre = getattr(self.input, "stats", None)
             self.input.stats = None
+            pool = getattr(self, "pool_behind", None)
+            if pool is not None and ctx is not None and relu and res is None and out_act is self.output and ops.BN_POOL_FUSE:
+                # a max pool is the only reader of this layer's output (ModelCNN.build_train_func links it): one pass
+                # writes the pooled tensor, relu(bn(x)) itself is never materialised (its gradient neither)
+                k, s, p = pool.size[0], pool.stride[0], pool.pad[0]
+                yp, arg, sm, si = ops.bn_relu_pool_fwd_train(x, self.omega.dev, self.beta.dev, self.mean.dev, self.stdinv.dev,
+                                                             k, s, p, self.momentum, self.eps, pre=pre)
+                pool.output.data, pool._arg, pool._fused_in = yp, arg, ctx      # valid for this pass (ctx) only
+                out_act.data = None
+                self._save = (sm, si, relu, out_act, False)
+                self._pooled = True
+                return
+            self._pooled = False
             y, sm, si = ops.bn_fwd_train(x, self.omega.dev, self.beta.dev, self.mean.dev, self.stdinv.dev,
                                          self.momentum, self.eps, relu=relu, res=res, pre=pre)
             self._save = (sm, si, relu, out_act, res is not None)
@@ -102,6 +115,13 @@ class BatchNormLayer(AbstractLayer):
         if not self.enabled:
             return None
         sm, si, relu, out_act, has_res = self._save
+        if getattr(self, "_pooled", False):
+            pool = self.pool_behind
+            k, s, p = pool.size[0], pool.stride[0], pool.pad[0]
+            dx, _, _ = ops.bn_relu_pool_bwd(self.input.data, pool.output.grad, pool._arg, self.omega.dev, self.beta.dev, sm, si,
+                                            k, s, p, dgamma=self.omega.grad, dbeta=self.beta.grad)
+            self.input.add_grad(dx)
+            return None
         # without a residual input the relu mask is recomputed from x in the kernel (no read of y)
         y = out_act.data if (relu and has_res) else None
         dx, dres, _, _ = ops.bn_bwd(self.input.data, y, out_act.grad, self.omega.dev, sm, si, relu=relu,

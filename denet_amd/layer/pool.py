@@ -53,6 +53,8 @@ class PoolLayer(AbstractLayer):
 
     def forward(self, ctx):
         k, s, p = self.size[0], self.stride[0], self.pad[0]
+        if ctx is not None and getattr(self, "_fused_in", None) is ctx:
+            return                               # the BN + ReLU layer in front has already written output and argmax (this pass)
         if self.mode == "max":
             self.output.data, self._arg = ops.maxpool_fwd(self.input.data, k, s, p)
         else:
@@ -60,6 +62,9 @@ class PoolLayer(AbstractLayer):
 
     def backward(self, ctx):
         k, s, p = self.size[0], self.stride[0], self.pad[0]
+        if ctx is not None and getattr(self, "_fused_in", None) is ctx:
+            self._fused_in = None                # the BN + ReLU layer in front gathers this layer's gradient itself
+            return
         shape = tuple(self.input.data.shape)
         if self.mode == "max":
             self.input.add_grad(ops.maxpool_bwd(self.output.grad, self._arg, shape, k, s, p))

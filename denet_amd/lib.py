@@ -57,6 +57,8 @@ SIGNATURES = {
     "denet_bn_workspace_bytes": (Z, [L, I]),
     "denet_bn_fwd_train": (I, [P] * 10 + [L, I, F, F, I, P]),
     "denet_bn_fwd_train_pre": (I, [P] * 10 + [I, L, I, F, F, I, P]),
+    "denet_bn_relu_pool_fwd_train": (I, [P] * 10 + [I, P] + [I] * 9 + [F, F, P]),
+    "denet_bn_relu_pool_bwd": (I, [P] * 11 + [I] * 9 + [P]),
     "denet_bn_fold": (I, [P] * 6 + [F, P, P, I, L, P]),
     "denet_bn_fwd_test": (I, [P] * 8 + [I, L, I, F, I, P]),
     "denet_bn_bwd": (I, [P] * 12 + [L, I, I, P]),

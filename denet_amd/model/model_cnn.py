@@ -291,6 +291,12 @@ class ModelCNN:
         if self.gradient_clip > 0.0:
             raise NotImplementedError("gradient clipping is outside the hot path")
         self.use_split_mode = False   # split points are identities here (288 GB of HBM)
+        # a max pool that is the only reader of a BN + ReLU layer's output (the ResNet stem): the two run as one pass in training
+        for a, b in zip(self.layers[:-1], self.layers[1:]):
+            a.pool_behind = None
+            if a.type_name == "batchnorm-relu" and b.type_name == "pool" and b.mode == "max" and b.input is a.output \
+                    and self._consumers(a.output) == 1:
+                a.pool_behind = b
         if not skip_build:
             self.pack_device()
         self.func["train_step"] = self._device_step

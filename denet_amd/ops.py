@@ -700,6 +700,39 @@ def bn_bwd(x, y, dy, gamma, save_mean, save_invstd, relu=False, want_dres=False,
     return dx, dres, dgamma, dbeta
 
 
+BN_POOL_FUSE = os.environ.get("DENET_BN_POOL_FUSE", "1") != "0"    # training: BN + ReLU + max pool without the tensor in between
+
+
+def bn_relu_pool_fwd_train(x, gamma, beta, run_mean, run_stdinv, k, stride, pad, momentum=0.9, eps=1e-5, pre=None):
+    """relu(bn(x)) max-pooled, without writing relu(bn(x)): returns (y_pool, argmax, save_mean, save_invstd); values and
+    argmax taps are those of bn_fwd_train(relu=True) + maxpool_fwd"""
+    N, H, W, C = x.shape
+    OH = (H + 2 * pad - k) // stride + 1
+    OW = (W + 2 * pad - k) // stride + 1
+    y = empty(N, OH, OW, C)
+    arg = torch.empty((N, OH, OW, C), dtype=torch.uint8, device="cuda")
+    save_mean, save_invstd = empty(C), empty(C)
+    ws = None if pre is not None else _bn_ws(N * H * W, C)
+    check(_L().denet_bn_relu_pool_fwd_train(ptr(x), ptr(y), ptr(arg), ptr(gamma), ptr(beta), ptr(run_mean), ptr(run_stdinv),
+                                            ptr(save_mean), ptr(save_invstd), ptr(pre[0]) if pre is not None else None,
+                                            int(pre[1]) if pre is not None else 0, ptr(ws), N, H, W, C, OH, OW, k, stride, pad,
+                                            momentum, eps, stream_ptr()), "bn_relu_pool_fwd_train")
+    return y, arg, save_mean, save_invstd
+
+
+def bn_relu_pool_bwd(x, dy_pool, arg, gamma, beta, save_mean, save_invstd, k, stride, pad, dgamma=None, dbeta=None):
+    """gradient of bn_relu_pool_fwd_train: (dx, dgamma, dbeta); bit-identical to maxpool_bwd + bn_bwd(relu=True)"""
+    N, H, W, C = x.shape
+    OH, OW = dy_pool.shape[1], dy_pool.shape[2]
+    dx = torch.empty_like(x)
+    dgamma = dgamma if dgamma is not None else empty(C)
+    dbeta = dbeta if dbeta is not None else empty(C)
+    check(_L().denet_bn_relu_pool_bwd(ptr(x), ptr(dy_pool), ptr(arg), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_invstd),
+                                      ptr(dx), ptr(dgamma), ptr(dbeta), ptr(_bn_ws(N * H * W, C)), N, H, W, C, OH, OW, k, stride,
+                                      pad, stream_ptr()), "bn_relu_pool_bwd")
+    return dx, dgamma, dbeta
+
+
 def maxpool_fwd(x, k, stride, pad):
     N, H, W, C = x.shape
     OH = (H + 2 * pad - k) // stride + 1

@@ -178,6 +178,19 @@ int denet_bn_fold(const float* w, const float* conv_bias, const float* gamma, co
 int denet_bn_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                  const float* save_mean, const float* save_invstd, float* dx, float* dres, float* dgamma, float* dbeta,
                  void* workspace, long M, int C, int relu, hipStream_t stream);
+/* A max pool directly behind a BN + ReLU layer (batch_norm_relu.py:34-48 -> pool.py:38, the ResNet stem), training: the
+ * normalised tensor is never written. Forward: statistics from `partial` / `rows` (denet_conv_fwd_stats) or, partial = NULL,
+ * measured here (workspace = denet_bn_workspace_bytes(N*H*W, C)); writes y_pool [N,OH,OW,C] and the argmax taps (first maximum
+ * in scan order, as denet_maxpool_fwd). Backward: dy_pool + argmax -> dx [N,H,W,C], dgamma, dbeta; bit-identical to
+ * denet_maxpool_bwd followed by denet_bn_bwd. */
+int denet_bn_relu_pool_fwd_train(const float* x, float* y_pool, unsigned char* argmax, const float* gamma, const float* beta,
+                                 float* run_mean, float* run_stdinv, float* save_mean, float* save_invstd, const double* partial,
+                                 int rows, void* workspace, int N, int H, int W, int C, int OH, int OW, int k, int stride, int pad,
+                                 float momentum, float eps, hipStream_t stream);
+int denet_bn_relu_pool_bwd(const float* x, const float* dy_pool, const unsigned char* argmax, const float* gamma,
+                           const float* beta, const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
+                           float* dbeta, void* workspace, int N, int H, int W, int C, int OH, int OW, int k, int stride, int pad,
+                           hipStream_t stream);
 
 /* ---- pooling  (denet/layer/pool.py:28-40 dnn_pool max / average_inc_pad;
  *      denet/layer/pool_inv_op.py:38-63 k_pool_inv, :144-169 k_pool_inv_grad)                             */

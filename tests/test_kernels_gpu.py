@@ -182,6 +182,30 @@ def test_fused_winograd_f2_kernel(hip, case):
         ops._WINO.update(saved[1])
 
 
+@pytest.mark.parametrize("case", [(2, 32, 32, 64, 3, 2, 1), (3, 17, 23, 32, 3, 2, 1), (2, 16, 16, 128, 2, 2, 0), (1, 15, 15, 32, 3, 1, 1)])
+def test_bn_relu_pool_fused_equals_separate_passes(hip, case):
+    """BN + ReLU + max pool in one pass (bn.hip: denet_bn_relu_pool_fwd_train / _bwd; batch_norm_relu.py:34-54 -> pool.py:38)
+    against bn_fwd_train(relu) + maxpool_fwd and maxpool_bwd + bn_bwd: bit-identical output, argmax taps (ties between the
+    many zeros behind the ReLU included), statistics, dx, dgamma, dbeta"""
+    from denet_amd import ops
+    N, H, W, C, k, s, p = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, H, W, C, generator=g).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.5).cuda()
+    rm, rs = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    rm2, rs2 = rm.clone(), rs.clone()
+    y, sm, si = ops.bn_fwd_train(x, gamma, beta, rm, rs, relu=True)
+    yp, arg = ops.maxpool_fwd(y, k, s, p)
+    yp2, arg2, sm2, si2 = ops.bn_relu_pool_fwd_train(x, gamma, beta, rm2, rs2, k, s, p)
+    assert torch.equal(yp, yp2) and torch.equal(arg, arg2)
+    assert torch.equal(sm, sm2) and torch.equal(si, si2) and torch.equal(rm, rm2) and torch.equal(rs, rs2)
+    dyp = torch.randn(*yp.shape, generator=g).cuda()
+    dy = ops.maxpool_bwd(dyp, arg, tuple(x.shape), k, s, p)
+    dx, _, dg, db = ops.bn_bwd(x, None, dy, gamma, sm, si, relu=True, beta=beta)
+    dx2, dg2, db2 = ops.bn_relu_pool_bwd(x, dyp, arg2, gamma, beta, sm2, si2, k, s, p)
+    assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+
+
 def test_conv_stem_small_c(hip):
     """7x7/2 stem: C=3 padded to 4, S padded 7->8 (zero tap); wgrad must leave the padded tap at 0."""
     from denet_amd import ops

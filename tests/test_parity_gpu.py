@@ -118,6 +118,21 @@ def test_build_samples_exact_ties(hip):
     assert total == 16 and ties > 0
 
 
+@pytest.fixture(autouse=True)
+def _materialised_stem_activation(request):
+    """The teacher-forced comparisons read EVERY layer's output; training normally never writes relu(bn(x)) of a BN + ReLU layer
+    whose only reader is a max pool (ops.BN_POOL_FUSE, bit-identical to the separate passes: test_kernels_gpu.py and
+    test_bn_pool_fusion_leaves_training_unchanged below). The full-size property tests keep the product's default."""
+    name = request.node.name
+    if "full_size" in name or "fusion" in name or "cli" in name:
+        yield
+        return
+    saved = ops.BN_POOL_FUSE
+    ops.BN_POOL_FUSE = False
+    yield
+    ops.BN_POOL_FUSE = saved
+
+
 def _product_acts(model):
     out = {}
     for i, layer in enumerate(model.layers[1:], 1):
@@ -582,6 +597,30 @@ def test_direct_and_measured_paths_agree(hip):
         ops.AUTOTUNE = saved[0]
         ops._WINO.clear()
         ops._WINO.update(saved[1])
+
+
+def test_bn_pool_fusion_leaves_training_unchanged(hip):
+    """two training steps of DeNet-34 skip with the stem's BN + ReLU + max pool as one pass and as three: bit-identical state"""
+    res = []
+    saved = ops.BN_POOL_FUSE
+    try:
+        for fuse in (True, False):
+            ops.BN_POOL_FUSE = fuse
+            random.seed(7)
+            model = zoo.warm_corner_head(zoo.denet34(2, "skip", 128, class_num=80, seed=1), 4.0, 0.3)
+            model.build_train_func("nesterov")
+            stem_bn = [l for l in model.layers if getattr(l, "pool_behind", None) is not None]
+            assert len(stem_bn) == 1
+            x, metas = zoo.synthetic_batch(2, 128, seed=11)
+            costs = [model.train_step(x, metas, 0, it, 0.02, [0.9], 1e-4)[0] for it in range(2)]
+            torch.cuda.synchronize()
+            assert (stem_bn[0].output.data is None) == fuse
+            res.append((model.P.clone(), model.M.clone(), model.S.clone(), costs))
+    finally:
+        ops.BN_POOL_FUSE = saved
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(a, b)
+    assert res[0][3] == res[1][3]
 
 
 def test_acc_mode_accumulates_and_averages(hip):
