@@ -140,6 +140,29 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
     }
 }
 
+// first of two stages for long partial lists (a stem convolution leaves 16 384 rows = 16 MB, which the C/8 workgroups of the
+// final kernel would walk alone): slice `blockIdx.y` of the rows -> out[slice][2][C]
+__global__ __launch_bounds__(256) void bn_stats_fold_kernel(const double* __restrict__ partial, int gy, int per, int C,
+                                                            double* __restrict__ out) {
+    __shared__ double red[2][FJ][FC];
+    const int cl = threadIdx.x % FC, jl = threadIdx.x / FC;
+    const int c = blockIdx.x * FC + cl;
+    const int j0 = blockIdx.y * per;
+    const int n = gy - j0 < per ? gy - j0 : per;
+    double s, ss;
+    reduce_partials(partial + (long)j0 * 2 * C, n, C, c, jl, s, ss);
+    red[0][jl][cl] = s;
+    red[1][jl][cl] = ss;
+    __syncthreads();
+    if (jl != 0 || c >= C) return;
+    for (int j = 1; j < FJ; ++j) {
+        s += red[0][j][cl];
+        ss += red[1][j][cl];
+    }
+    out[(long)blockIdx.y * 2 * C + c] = s;
+    out[(long)blockIdx.y * 2 * C + C + c] = ss;
+}
+
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ partial, int gy, long M, int C,
                                                              float eps, float momentum, float* __restrict__ save_mean,
                                                              float* __restrict__ save_invstd,
@@ -424,8 +447,8 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ 
 extern "C" size_t denet_bn_workspace_bytes(long M, int C) {
     if (C <= 0 || C % 4) return 0;
     BnMap m = bn_map(M, C);
-    // partials + 2*C floats of coefficients (backward) / test-mode coefficients
-    return (size_t)m.gy * 2 * C * sizeof(double) + (size_t)2 * C * sizeof(float);
+    // partials (at least the 64 rows of a folded list) + 2*C floats of coefficients (backward) / test-mode coefficients
+    return (size_t)(m.gy > 64 ? m.gy : 64) * 2 * C * sizeof(double) + (size_t)2 * C * sizeof(float);
 }
 
 extern "C" int denet_bn_fwd_train(const float* x, const float* res, float* y, const float* gamma, const float* beta,
@@ -500,7 +523,8 @@ extern "C" int denet_bn_bwd(const float* x, const float* y, const float* dy, con
 }
 
 // BN + ReLU + max pool in one (training): statistics as denet_bn_fwd_train (partial = NULL: measured here, workspace =
-// denet_bn_workspace_bytes(M, C)) or denet_bn_fwd_train_pre (partial / rows from the convolution in front); the pooled
+// denet_bn_workspace_bytes(M, C)) or denet_bn_fwd_train_pre (partial / rows from the convolution in front; workspace optional:
+// with it a list of more than 2048 rows is folded in two stages); the pooled
 // output y_pool [N,OH,OW,C] and its argmax taps are written, relu(bn(x)) itself is not (batch_norm_relu.py:34-48 + pool.py:38)
 extern "C" int denet_bn_relu_pool_fwd_train(const float* x, float* y_pool, unsigned char* argmax, const float* gamma,
                                             const float* beta, float* run_mean, float* run_stdinv, float* save_mean,
@@ -518,6 +542,14 @@ extern "C" int denet_bn_relu_pool_fwd_train(const float* x, float* y_pool, unsig
         hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, M, C, m.LC, p);
         partial = p;
         rows = m.gy;
+    } else if (rows > 2048 && workspace) {
+        // a long list from the convolution's epilogue (one row per 128 output pixels): folded to 64 rows by 64 x C/8 workgroups first
+        const int per = (rows + 63) / 64;
+        const int slices = (rows + per - 1) / per;
+        double* folded = (double*)workspace;
+        hipLaunchKernelGGL(bn_stats_fold_kernel, dim3((C + FC - 1) / FC, slices), dim3(256), 0, stream, partial, rows, per, C, folded);
+        partial = folded;
+        rows = slices;
     }
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, rows, M, C, eps,
                        momentum, save_mean, save_invstd, run_mean, run_stdinv);

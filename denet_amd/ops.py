@@ -712,7 +712,7 @@ def bn_relu_pool_fwd_train(x, gamma, beta, run_mean, run_stdinv, k, stride, pad,
     y = empty(N, OH, OW, C)
     arg = torch.empty((N, OH, OW, C), dtype=torch.uint8, device="cuda")
     save_mean, save_invstd = empty(C), empty(C)
-    ws = None if pre is not None else _bn_ws(N * H * W, C)
+    ws = _bn_ws(N * H * W, C)
     check(_L().denet_bn_relu_pool_fwd_train(ptr(x), ptr(y), ptr(arg), ptr(gamma), ptr(beta), ptr(run_mean), ptr(run_stdinv),
                                             ptr(save_mean), ptr(save_invstd), ptr(pre[0]) if pre is not None else None,
                                             int(pre[1]) if pre is not None else 0, ptr(ws), N, H, W, C, OH, OW, k, stride, pad,
