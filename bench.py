@@ -146,8 +146,9 @@ def main():
                                "MSCOCO, full train step (targets, fwd, bwd, nesterov), %s corner regime" % args.regime,
                    "global_batch": BATCH_PER_GPU * world, "batch_per_gpu": BATCH_PER_GPU, "classes": 80,
                    "rois_per_image": 576, "parallelism": "dp%d" % world, "solver": "nesterov",
-                   "conv_algorithms": "fp32 throughout; per layer and pass the faster of the direct implicit GEMM and "
-                                      "Winograd F(2x2,3x3)/F(4x4,3x3), as measured once by tools/tune.py and stored in "
+                   "conv_algorithms": "fp32 throughout; per layer and pass the fastest of the direct implicit GEMM, "
+                                      "Winograd F(2x2,3x3)/F(4x4,3x3) and (64 input channels) F(2x2,3x3) fused into one "
+                                      "kernel, as measured once by tools/tune.py and stored in "
                                       "denet_amd/tuned/gfx950.json (every process runs the same kernels; geometries not "
                                       "in the file are measured on the first step; DENET_WINOGRAD=0: direct kernels only)",
                    "input": "fp32 NCHW batch resident in HBM before the timed region",
