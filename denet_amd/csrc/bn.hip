@@ -40,22 +40,29 @@ BnMap bn_map(long M, int C) {
 // values), evaluated inside the two batch-norm gradient passes instead of being written and read back twice.
 struct PoolGeom {
     int H, W, OH, OW, k, s, pad;
+    FastDiv fw, fh, fow, foh, fs, fc; // row index -> (n, y, x) without 64-bit divisions (N*H*W < 2^31 is checked by the callers)
 };
+
+PoolGeom pool_geom(int H, int W, int OH, int OW, int k, int s, int pad, int C) {
+    PoolGeom g = {H, W, OH, OW, k, s, pad, {}, {}, {}, {}, {}, {}};
+    g.fw.init(W); g.fh.init(H); g.fow.init(OW); g.foh.init(OH); g.fs.init(s); g.fc.init(C / 4);
+    return g;
+}
 
 __device__ __forceinline__ f32x4 pool_gather(const float* __restrict__ dyp, const unsigned char* __restrict__ arg, const PoolGeom& g,
                                              long r, int C, int c) {
-    const int ix = (int)(r % g.W);
-    const long t = r / g.W;
-    const int iy = (int)(t % g.H);
-    const int n = (int)(t / g.H);
+    const uint32_t t = g.fw.div((uint32_t)r);
+    const int ix = (int)((uint32_t)r - t * (uint32_t)g.W);
+    const int n = (int)g.fh.div(t);
+    const int iy = (int)(t - (uint32_t)n * (uint32_t)g.H);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     int oy_lo = (iy + g.pad - g.k + 1 + g.s - 1);
-    oy_lo = oy_lo < 0 ? 0 : oy_lo / g.s;
-    int oy_hi = (iy + g.pad) / g.s;
+    oy_lo = oy_lo < 0 ? 0 : (int)g.fs.div((uint32_t)oy_lo);
+    int oy_hi = (int)g.fs.div((uint32_t)(iy + g.pad));
     if (oy_hi > g.OH - 1) oy_hi = g.OH - 1;
     int ox_lo = (ix + g.pad - g.k + 1 + g.s - 1);
-    ox_lo = ox_lo < 0 ? 0 : ox_lo / g.s;
-    int ox_hi = (ix + g.pad) / g.s;
+    ox_lo = ox_lo < 0 ? 0 : (int)g.fs.div((uint32_t)ox_lo);
+    int ox_hi = (int)g.fs.div((uint32_t)(ix + g.pad));
     if (ox_hi > g.OW - 1) ox_hi = g.OW - 1;
     for (int oy = oy_lo; oy <= oy_hi; ++oy) {
         const int ky = iy - (oy * g.s - g.pad);
@@ -234,12 +241,12 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restr
     const int C4 = C / 4;
     const long total = (long)N * g.OH * g.OW * C4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4) * 4;
-        long t = i / C4;
-        const int ox = (int)(t % g.OW);
-        t /= g.OW;
-        const int oy = (int)(t % g.OH);
-        const int n = (int)(t / g.OH);
+        const uint32_t q = g.fc.div((uint32_t)i);            // pooled pixel
+        const int c = (int)((uint32_t)i - q * (uint32_t)C4) * 4;
+        const uint32_t t = g.fow.div(q);
+        const int ox = (int)(q - t * (uint32_t)g.OW);
+        const int n = (int)g.foh.div(t);
+        const int oy = (int)(t - (uint32_t)n * (uint32_t)g.OH);
         float sc[4], sh[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -533,8 +540,8 @@ extern "C" int denet_bn_relu_pool_fwd_train(const float* x, float* y_pool, unsig
                                             hipStream_t stream) {
     DENET_CHECK_ARG(x && y_pool && argmax && gamma && beta && save_mean && save_invstd && (partial || workspace),
                     "bn_relu_pool_fwd_train: null pointer");
-    DENET_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k > 0 && k * k <= 255 && stride > 0 && pad >= 0 && pad < k,
-                    "bn_relu_pool_fwd_train: bad arguments");
+    DENET_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k > 0 && k * k <= 255 && stride > 0 && pad >= 0 && pad < k &&
+                    (long)N * H * W < (1L << 31), "bn_relu_pool_fwd_train: bad arguments");
     const long M = (long)N * H * W;
     BnMap m = bn_map(M, C);
     if (!partial) {
@@ -553,7 +560,7 @@ extern "C" int denet_bn_relu_pool_fwd_train(const float* x, float* y_pool, unsig
     }
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, rows, M, C, eps,
                        momentum, save_mean, save_invstd, run_mean, run_stdinv);
-    const PoolGeom g = {H, W, OH, OW, k, stride, pad};
+    const PoolGeom g = pool_geom(H, W, OH, OW, k, stride, pad, C);
     const long total = (long)N * OH * OW * (C / 4);
     long blocks = (total + 255) / 256;
     if (blocks > 65536) blocks = 65536;
@@ -570,12 +577,13 @@ extern "C" int denet_bn_relu_pool_bwd(const float* x, const float* dy_pool, cons
                                       int k, int stride, int pad, hipStream_t stream) {
     DENET_CHECK_ARG(x && dy_pool && argmax && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta && workspace,
                     "bn_relu_pool_bwd: null pointer");
-    DENET_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k > 0 && stride > 0 && pad >= 0, "bn_relu_pool_bwd: bad arguments");
+    DENET_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k > 0 && stride > 0 && pad >= 0 && (long)N * H * W < (1L << 31),
+                    "bn_relu_pool_bwd: bad arguments");
     const long M = (long)N * H * W;
     BnMap m = bn_map(M, C);
     double* partial = (double*)workspace;
     float* coef = (float*)(partial + (size_t)m.gy * 2 * C);
-    const PoolGeom g = {H, W, OH, OW, k, stride, pad};
+    const PoolGeom g = pool_geom(H, W, OH, OW, k, stride, pad, C);
     hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(m.gx, m.gy), dim3(256), 0, stream, x, (const float*)nullptr, dy_pool,
                        gamma, beta, save_mean, save_invstd, M, C, m.LC, 1, partial, argmax, g);
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, m.gy, M, C, dgamma,
