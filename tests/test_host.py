@@ -284,6 +284,35 @@ def test_cabi_exports_every_declared_symbol():
     assert b"multiple of 32" in lib.denet_last_error()
 
 
+def test_committed_launch_configurations_are_consistent():
+    """denet_amd/tuned/gfx950.json (tools/tune.py): every record has the 11-field key + 3 values denet_tune_import expects, and a
+    direct / Winograd / fused decision only names an algorithm whose kernel covers that geometry (an ineligible entry would make
+    the pass fail at launch on every process that loads the file)"""
+    import json
+    path = os.path.join(ROOT, "denet_amd", "tuned", "gfx950.json")
+    d = json.load(open(path))
+    assert d["kernels"] and all(len(r) == 14 and all(isinstance(v, int) for v in r) for r in d["kernels"])
+    assert len({tuple(r[:11]) for r in d["kernels"]}) == len(d["kernels"])
+    seen = set()
+    n_fused = 0
+    for mode, g, tile in d["winograd"]:
+        assert mode in (0, 1, 2) and len(g) == 12 and tile in (0, 2, 4, 22)
+        assert (mode, tuple(g)) not in seen
+        seen.add((mode, tuple(g)))
+        N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
+        if tile:
+            assert (R, S, s_real, stride, pad) == (3, 3, 3, 1, 1) and (OH, OW) == (H, W)
+        if tile in (2, 4):
+            assert H % tile == 0 and W % tile == 0 and C % 32 == 0 and K % 32 == 0
+        if tile == 22:                                  # csrc/wino2f.hip: denet_conv_wino2f_ok / _wgrad_ok
+            n_fused += 1
+            ci, co = (C, K) if mode == 0 else (K, C)
+            assert H % 16 == 0 and W % 16 == 0 and ci == 64 and co % 64 == 0
+            if mode == 2:
+                assert C == 64 and K == 64
+    assert n_fused >= 3                                 # the 64-channel stage of the benchmark configuration, all three passes
+
+
 def test_product_fails_loudly_without_library(monkeypatch):
     monkeypatch.setattr(dlib, "_lib", None)
     monkeypatch.setattr(dlib, "LIB_PATH", "/nonexistent/libdenet_hip.so")
