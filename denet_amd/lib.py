@@ -127,6 +127,10 @@ def load():
         raise DenetHipError(
             "libdenet_hip.so is missing (%s): run `python -m denet_amd.build` / __graft_entry__.build() first. "
             "The DeNet hot path has no CPU fallback." % LIB_PATH)
+    # torch first: its wheel carries the HIP runtime (libamdhip64) that owns the streams and the memory this library is handed;
+    # loaded the other way round the dynamic linker would bind the library to a second copy of the runtime (/opt/rocm) in which
+    # torch's streams do not exist ("no ROCm-capable device" at the first launch)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
