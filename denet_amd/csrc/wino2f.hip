@@ -70,14 +70,17 @@ __device__ __forceinline__ W2Item w2_item(int bx, int by, int nco, int item) {
 //   * the products of a tile group, M[xi][tile][co], meet in LDS (64 KB, XOR-swizzled by tile): every wave writes its two
 //     components, one barrier, then a lane reads the 12 components one output row of its (tile, 4 channels) needs, applies
 //     A^T . A, bias / add / ReLU, stores 16 bytes (a wave instruction covers whole 256-byte pixel rows of the output);
-//   * the input patch is refilled by LDS-DMA in two row bands (patch rows 0..7 while tile rows 4..7 are multiplied, rows
-//     8..17 during the next item's tile rows 0..3).
+//   * the input patch is refilled by LDS-DMA in three row bands, each one tile group after its last reader (below).
 constexpr int S_MB_SLOTS = 16 * 16 * 16;                     // M of a tile group: [xi][tile][co quad ^ tile] float4
 constexpr int S_RED_BYTES = 8 * 2 * 64 * 4;                  // batch-norm sums of the 8 waves
 constexpr int S_LDS_BYTES = P_BYTES + S_MB_SLOTS * 16 + S_RED_BYTES;     // 163 840: all of it
-// the 7 DMA pieces of a patch plane: slots 0, 64, 96 (rows 0..7 = slots 0..159: the first band) and 160, 224, 288, 296 (rows
-// 8..17); pieces 2 and 6 overlap their predecessors with the same values
-__host__ __device__ constexpr int sp_start(int k) { return k == 0 ? 0 : k == 1 ? 64 : k == 2 ? 96 : k == 3 ? 160 : k == 4 ? 224 : k == 5 ? 288 : 296; }
+// The patch is refilled for the next item in three row bands, each as soon as no tile group reads it any more and at least one
+// whole tile group before it is read again (tile group g reads patch rows 4 g .. 4 g + 5):
+//   band A = rows 0..7   (slots   0..159: pieces at 0, 64, 96)    last read by group 1, refilled during group 2
+//   band B = rows 8..9   (slots 160..199: one piece at 136)       last read by group 2, refilled during group 3
+//   band C = rows 10..17 (slots 200..359: pieces at 200, 264, 296) last read by group 3, refilled during the next item's group 0
+// (pieces 2, 3 and 6 overlap their neighbours with the same values of the same item)
+__host__ __device__ constexpr int sp_start(int k) { return k == 0 ? 0 : k == 1 ? 64 : k == 2 ? 96 : k == 3 ? 136 : k == 4 ? 200 : k == 5 ? 264 : 296; }
 
 template <int I, int J0>
 __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
@@ -176,15 +179,19 @@ __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
                 // the next round's patch values (after the last round of the item: the next item's first, whose band landed
                 // before the barrier of tile group 3)
                 if (r < 3) load_d(g, r + 1, d);
-                // patch refill, two pieces per round: rows 8..17 (pieces 3..6 of the wave's two planes) for THIS item during its
-                // tile group 0 (the first item came complete), rows 0..7 for the NEXT item during tile group 2
-                if (g == 0 && item != (int)blockIdx.x) {
-                    piece(3 + r, cur);
-                    piece(7 + 3 + r, cur);
+                // patch refill, two pieces per round (the wave's two planes): band C of THIS item during its tile group 0 (the first
+                // item came complete), bands A and B of the NEXT item during tile groups 2 and 3
+                if (g == 0 && r < 3 && item != (int)blockIdx.x) {
+                    piece(4 + r, cur);
+                    piece(7 + 4 + r, cur);
                 }
-                if (g == 2 && has_next && r < 3) {
+                if (g == 2 && r < 3 && has_next) {
                     piece(r, nxt);
                     piece(7 + r, nxt);
+                }
+                if (g == 3 && r == 0 && has_next) {
+                    piece(3, nxt);
+                    piece(7 + 3, nxt);
                 }
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -201,10 +208,11 @@ __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) Mw0[a * 256 + ((4 * cb + kk) ^ t)] = acc[a][cb];
-            // all 16 components are there. The band pieces issued during this group (8 in group 0, 6 in group 2) may still fly;
-            // the barriers of groups 1 and 3 wait for them (they are then more than a tile group old)
-            if (g == 0) W2_BARRIER(8)
-            else if (g == 2) W2_BARRIER(6)
+            // all 16 components are there. The band pieces issued during this group (6 in groups 0 and 2, 2 in group 3) may still
+            // fly: a later barrier waits for them, when they are more than a tile group old and before their rows are read (band
+            // A, issued in group 2, by the barrier of group 3; band B by that of the next item's group 0; band C by that of group 1)
+            if (g == 0 || g == 2) W2_BARRIER(6)
+            else if (g == 3) W2_BARRIER(2)
             else W2_BARRIER(0)
             // the next group's first patch values (group 3: the next item's)
             load_d((g + 1) & 3, 0, d);

@@ -119,11 +119,12 @@ def test_conv_epilogue_batch_norm_sums(hip, case):
         ops._WINO.update(saved[1])
 
 
-@pytest.mark.parametrize("case", [(1, 16, 16, 64), (2, 32, 48, 64), (1, 16, 32, 128), (5, 128, 128, 64), (3, 128, 64, 128)])
+@pytest.mark.parametrize("case", [(1, 16, 16, 64), (2, 32, 48, 64), (1, 16, 32, 128), (5, 128, 128, 64), (3, 128, 64, 128), (14, 128, 128, 64)])
 def test_fused_winograd_f2_kernel(hip, case):
     """csrc/wino2f.hip through ops (algorithm ops.FUSED2) against an fp64 convolution: forward with bias / add / ReLU / the
     batch-norm sums, and the data gradient with the accumulated add. (5,128,128,64) = 320 work items on 256 persistent
-    workgroups (uneven loop), (3,128,64,128) = two output-channel chunks per block. F(2x2) in fp32: <= 1e-6 max-norm."""
+    workgroups (uneven loop), (3,128,64,128) = two output-channel chunks per block, (14,128,128,64) = 3-4 items per workgroup
+    (every LDS band refilled several times). F(2x2) in fp32: <= 1e-6 max-norm."""
     import torch.nn.functional as Fn
     from denet_amd import ops
     N, H, W, Co = case
