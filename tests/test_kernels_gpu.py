@@ -183,6 +183,47 @@ def test_fused_winograd_f2_kernel(hip, case):
         ops._WINO.update(saved[1])
 
 
+def test_fused_winograd_f2_kernels_under_memory_pressure(hip):
+    """the LDS refill protocol of csrc/wino2f.hip (row bands streamed in by LDS-DMA while the previous item is multiplied, waits
+    that leave younger pieces in flight) against stretched memory latencies: random batch / image sizes with several work items
+    per workgroup, a second stream saturating HBM meanwhile; every pass against the direct implicit-GEMM kernel"""
+    import random
+    from denet_amd import ops
+    ops.init_streams()
+    rng = random.Random(5)
+    side = torch.cuda.Stream()
+    big_a = torch.empty(1 << 27, device="cuda")
+    big_b = torch.empty(1 << 27, device="cuda")
+    saved = (ops.AUTOTUNE, dict(ops._WINO), set(ops._TUNED))
+    try:
+        ops.AUTOTUNE = False
+        for it in range(24):
+            N, H, W = rng.choice([8, 9, 17, 24, 40]), rng.choice([64, 96, 128]), rng.choice([64, 128, 144])
+            g = torch.Generator().manual_seed(it)
+            x = torch.randn(N, H, W, 64, generator=g).cuda()
+            dy = torch.randn(N, H, W, 64, generator=g).cuda()
+            w = (torch.randn(64, 3, 3, 64, generator=g) * 0.06).cuda()
+            geom = ops.conv_geom(x.shape, w.shape, 1, 1, None)
+            res = {}
+            for algo in (0, ops.FUSED2):
+                for mode in range(3):
+                    ops._WINO[(mode, geom)] = algo
+                if algo and it % 2:
+                    with torch.cuda.stream(side):
+                        for _ in range(6):
+                            big_b.copy_(big_a, non_blocking=True)
+                res[algo] = (ops.conv_fwd(x, w, stride=1, pad=1), ops.conv_dgrad(dy, w, tuple(x.shape), stride=1, pad=1),
+                             ops.conv_wgrad(x, dy, tuple(w.shape), stride=1, pad=1))
+            torch.cuda.synchronize()
+            for k in range(3):
+                a, b = res[0][k], res[ops.FUSED2][k]
+                assert float((a - b).abs().max() / a.abs().max()) < 1e-5, (it, N, H, W, k)
+    finally:
+        ops.AUTOTUNE = saved[0]
+        ops._WINO.clear()
+        ops._WINO.update(saved[1])
+
+
 @pytest.mark.parametrize("case", [(2, 32, 32, 64, 3, 2, 1), (3, 17, 23, 32, 3, 2, 1), (2, 16, 16, 128, 2, 2, 0), (1, 15, 15, 32, 3, 1, 1)])
 def test_bn_relu_pool_fused_equals_separate_passes(hip, case):
     """BN + ReLU + max pool in one pass (bn.hip: denet_bn_relu_pool_fwd_train / _bwd; batch_norm_relu.py:34-54 -> pool.py:38)
