@@ -232,19 +232,22 @@ __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
                     y1 += bias4;
                 }
                 const int ty = 2 * g + (otile >> 3), tx = otile & 7;
-                const long o = (((long)cur.n * p.H + cur.oy0 + 2 * ty + oi) * p.W + cur.ox0 + 2 * tx) * p.Co + cur.co0 + 4 * t;
-                if (p.add) {
-                    y0 += *(const f32x4*)(p.add + o);
-                    y1 += *(const f32x4*)(p.add + o + p.Co);
+                const int oy = cur.oy0 + 2 * ty + oi, ox = cur.ox0 + 2 * tx;
+                if (oy < p.H && ox < p.W) {          // blocks at the right / bottom edge of a map that is no multiple of 16 (W even)
+                    const long o = (((long)cur.n * p.H + oy) * p.W + ox) * p.Co + cur.co0 + 4 * t;
+                    if (p.add) {
+                        y0 += *(const f32x4*)(p.add + o);
+                        y1 += *(const f32x4*)(p.add + o + p.Co);
+                    }
+                    if (p.relu) {
+                        y0 = __builtin_elementwise_max(y0, f32x4{0.f, 0.f, 0.f, 0.f});
+                        y1 = __builtin_elementwise_max(y1, f32x4{0.f, 0.f, 0.f, 0.f});
+                    }
+                    *(f32x4*)(p.y + o) = y0;
+                    *(f32x4*)(p.y + o + p.Co) = y1;
+                    ssum += y0 + y1;
+                    ssq += y0 * y0 + y1 * y1;
                 }
-                if (p.relu) {
-                    y0 = __builtin_elementwise_max(y0, f32x4{0.f, 0.f, 0.f, 0.f});
-                    y1 = __builtin_elementwise_max(y1, f32x4{0.f, 0.f, 0.f, 0.f});
-                }
-                *(f32x4*)(p.y + o) = y0;
-                *(f32x4*)(p.y + o + p.Co) = y1;
-                ssum += y0 + y1;
-                ssq += y0 * y0 + y1 * y1;
             }
         }
         if (p.stats) {
@@ -358,7 +361,7 @@ __device__ __forceinline__ void w2g_run(const W2GParams& p, char* smem) {
             pcl[j] |= (row | ((col < 9 ? 2 * col + par : 255) << 8)) << (16 * hlf);
         }
     }
-    const int dyl = ((lane >> 4) * p.W + 2 * (lane & 7) + ((lane >> 3) & 1)) * CI * 4;   // dy pieces: lane part of the offset
+    const int dy_row = lane >> 4, dy_col = 2 * (lane & 7) + ((lane >> 3) & 1);             // dy pieces: the lane's pixel of a 4-row piece
     // piece numbers 0..13 = patch (plane 2w + n / 7, piece n % 7), 14..21 = dy (plane 2w + (n - 14) / 4, piece (n - 14) % 4).
     // The 7 patch pieces of a plane start at slots 0, 64, 128, 136 (rows 0..9 = slots 0..199: the FIRST HALF) and 200, 264, 296
     // (rows 10..17: the second half); pieces 3 and 6 overlap their predecessors with the same values.
@@ -373,8 +376,11 @@ __device__ __forceinline__ void w2g_run(const W2GParams& p, char* smem) {
         } else {
             const int m = n - 14;
             const int plane = 2 * wave + m / 4, k = m % 4;
-            const int base = (((it.n * p.H + it.oy0 + 4 * k) * p.W + it.ox0) * CI + plane * 4) * 4;      // wave-uniform
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(D + plane * GD_PLANE + 64 * k), 16, dyl, base, 0, 0);
+            const int iy = it.oy0 + 4 * k + dy_row, ix = it.ox0 + dy_col;
+            const int off = (((it.n * p.H + iy) * p.W + ix) * CI + plane * 4) * 4;
+            // pixels past the right / bottom edge (maps that are no multiple of 16) read as zeros: they add nothing to dU
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(D + plane * GD_PLANE + 64 * k), 16,
+                                                     iy < p.H && ix < p.W ? off : OOB, 0, 0, 0);
         }
     };
     // The first half of the LDS image (patch rows 0..9, dy rows 0..7) serves tile rows 0..3 and the top of tile row 4; it is
@@ -563,22 +569,22 @@ __global__ __launch_bounds__(256) void w2g_dfilter_kernel(const float* __restric
 
 // geometry this kernel covers
 extern "C" int denet_conv_wino2f_ok(int N, int H, int W, int Ci, int Co) {
-    return (Ci == 64 && Co > 0 && Co % 64 == 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0 && N > 0 &&
+    return (Ci == 64 && Co > 0 && Co % 64 == 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && N > 0 &&
             (long)N * H * W * 64 * 4 < 0xF0000000L) ? 1 : 0;
 }
 
 // y = conv3x3(x) stride 1 pad 1 (+ bias) (+ add) from the F(2x2) transformed filters u = [16][Co][64]
 // (denet_conv_wino_filter with tile 2: dgrad = 0 for the forward pass, 1 for the data gradient, where x = dy, Co = C).
-// stats_partial (optional): [N*(H/16)*(W/16)][2][Co] doubles, the batch-norm column sums of y (see denet_conv_fwd_stats).
+// stats_partial (optional): [N*ceil(H/16)*ceil(W/16)][2][Co] doubles, the batch-norm column sums of y (see denet_conv_fwd_stats).
 extern "C" int denet_conv_wino2f(const float* x, const float* u, const float* bias, const float* add, float* y, int relu,
                                  double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int Ci,
                                  int Co, hipStream_t stream) {
     DENET_CHECK_ARG(x && u && y, "conv_wino2f: null pointer");
-    DENET_CHECK_ARG(denet_conv_wino2f_ok(N, H, W, Ci, Co), "conv_wino2f: needs Ci = 64, Co %% 64 = 0, H, W multiples of 16");
+    DENET_CHECK_ARG(denet_conv_wino2f_ok(N, H, W, Ci, Co), "conv_wino2f: needs Ci = 64, Co %% 64 = 0, even H and W");
     W2Params p = {};
     p.x = x; p.U = u; p.bias = bias; p.add = add; p.y = y;
     p.N = N; p.H = H; p.W = W; p.Co = Co;
-    p.by = H / 16; p.bx = W / 16;
+    p.by = (H + 15) / 16; p.bx = (W + 15) / 16;
     p.nco = Co / 64;
     p.relu = relu;
     p.x_bytes = (unsigned)((size_t)N * H * W * 64 * 4);
@@ -617,7 +623,7 @@ extern "C" int denet_conv_wino2f(const float* x, const float* u, const float* bi
 
 // geometry the fused filter-gradient kernel covers
 extern "C" int denet_conv_wino2f_wgrad_ok(int N, int H, int W, int C, int K) {
-    return (C == 64 && K == 64 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0 && N > 0 &&
+    return (C == 64 && K == 64 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && N > 0 &&
             (long)N * H * W * 64 * 4 < 0xF0000000L) ? 1 : 0;
 }
 
@@ -629,7 +635,7 @@ static int w2g_grid(int N, int H, int W) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
         cus = prop.multiProcessorCount;
     }
-    const long items = (long)N * (H / 16) * (W / 16);
+    const long items = (long)N * ((H + 15) / 16) * ((W + 15) / 16);
     return (int)(items < cus ? items : cus);
 }
 
@@ -643,14 +649,14 @@ extern "C" size_t denet_conv_wino2f_wgrad_workspace_bytes(int N, int H, int W) {
 extern "C" int denet_conv_wino2f_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int N,
                                        int H, int W, int C, int K, hipStream_t stream) {
     DENET_CHECK_ARG(x && dy && dw && workspace, "conv_wino2f_wgrad: null pointer");
-    DENET_CHECK_ARG(denet_conv_wino2f_wgrad_ok(N, H, W, C, K), "conv_wino2f_wgrad: needs C = K = 64, H, W multiples of 16");
+    DENET_CHECK_ARG(denet_conv_wino2f_wgrad_ok(N, H, W, C, K), "conv_wino2f_wgrad: needs C = K = 64, even H and W");
     const int grid = w2g_grid(N, H, W);
     DENET_CHECK_ARG(grid > 0, "conv_wino2f_wgrad: cannot query the device");
     DENET_CHECK_ARG(workspace_bytes >= denet_conv_wino2f_wgrad_workspace_bytes(N, H, W), "conv_wino2f_wgrad: workspace too small");
     W2GParams p = {};
     p.x = x; p.dy = dy; p.part = (float*)workspace;
     p.N = N; p.H = H; p.W = W;
-    p.by = H / 16; p.bx = W / 16;
+    p.by = (H + 15) / 16; p.bx = (W + 15) / 16;
     p.items = N * p.by * p.bx;
     p.x_bytes = (unsigned)((size_t)N * H * W * 64 * 4);
     static bool attr_set = false;

@@ -106,10 +106,11 @@ int denet_conv_wino_fwd_stats(const float* x, const float* w, const float* u_cac
                               const float* add, float* y, double* stats_partial, size_t stats_bytes, int* stats_rows,
                               float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
                               hipStream_t stream);
-/* Fused F(2x2,3x3) convolution for Ci = 64 (stride 1, pad 1; H, W multiples of 16; Co a multiple of 64): transforms and the
+/* Fused F(2x2,3x3) convolution for Ci = 64 (stride 1, pad 1; H, W even; Co a multiple of 64): transforms and the
  * 16 component products in one kernel, x -> y only. u = denet_conv_wino_filter(tile 2) output: dgrad = 0 for the forward
  * pass (denet/layer/convolution.py:80-83), dgrad = 1 for the data gradient (x = dy; model_cnn.py:318). Optional bias [Co],
- * add [N,H,W,Co], relu (y = max(y, 0)) and batch-norm column sums stats_partial [N*(H/16)*(W/16)][2][Co] (doubles; *stats_rows = row count). */
+ * add [N,H,W,Co], relu (y = max(y, 0)) and batch-norm column sums stats_partial [N*ceil(H/16)*ceil(W/16)][2][Co] (doubles;
+ * *stats_rows = row count). Work items are 16x16-pixel blocks; maps that are no multiple of 16 waste the overhang. */
 int denet_conv_wino2f_ok(int N, int H, int W, int Ci, int Co);
 int denet_conv_wino2f(const float* x, const float* u, const float* bias, const float* add, float* y, int relu,
                       double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int Ci, int Co,

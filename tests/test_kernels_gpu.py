@@ -119,12 +119,13 @@ def test_conv_epilogue_batch_norm_sums(hip, case):
         ops._WINO.update(saved[1])
 
 
-@pytest.mark.parametrize("case", [(1, 16, 16, 64), (2, 32, 48, 64), (1, 16, 32, 128), (5, 128, 128, 64), (3, 128, 64, 128), (14, 128, 128, 64)])
+@pytest.mark.parametrize("case", [(1, 16, 16, 64), (2, 32, 48, 64), (1, 16, 32, 128), (5, 128, 128, 64), (3, 128, 64, 128), (14, 128, 128, 64),
+                                  (2, 56, 56, 64), (3, 24, 40, 128), (1, 2, 6, 64)])
 def test_fused_winograd_f2_kernel(hip, case):
     """csrc/wino2f.hip through ops (algorithm ops.FUSED2) against an fp64 convolution: forward with bias / add / ReLU / the
     batch-norm sums, and the data gradient with the accumulated add. (5,128,128,64) = 320 work items on 256 persistent
     workgroups (uneven loop), (3,128,64,128) = two output-channel chunks per block, (14,128,128,64) = 3-4 items per workgroup
-    (every LDS band refilled several times). F(2x2) in fp32: <= 1e-6 max-norm."""
+    (every LDS band refilled several times); (2,56,56), (3,24,40), (1,2,6): maps that are no multiple of the 16x16 block. F(2x2) in fp32: <= 1e-6 max-norm."""
     import torch.nn.functional as Fn
     from denet_amd import ops
     N, H, W, Co = case
@@ -152,7 +153,7 @@ def test_fused_winograd_f2_kernel(hip, case):
         r2 = r + bias.double() + addt.double()
         assert float((y2.double() - r2).abs().max()) / float(r2.abs().max()) <= 1e-6
         buf, rows = cache["bn_stats"]
-        assert rows == N * (H // 16) * (W // 16)
+        assert rows == N * ((H + 15) // 16) * ((W + 15) // 16)
         part = buf[:rows * 2 * Co].view(rows, 2, Co).sum(0)
         rr = r2.reshape(-1, Co)
         assert float((part[0] - rr.sum(0)).abs().max() / rr.abs().sum(0).max()) <= 1e-6
