@@ -106,6 +106,11 @@ int denet_conv_wino_fwd_stats(const float* x, const float* w, const float* u_cac
                               const float* add, float* y, double* stats_partial, size_t stats_bytes, int* stats_rows,
                               float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
                               hipStream_t stream);
+/* OPT-IN, not the fp32 path: C[M][N] = A[M][K] B[N][K]^T (+ bias[N]) with every product as a 3-term bf16 split on the bf16
+ * matrix cores (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulation): the forward pass of a 1x1 stride-1 convolution
+ * (convolution.py:80-83; the detection head) at ~1e-6 relative error instead of the exact fp32 FMA chain of denet_conv_fwd. */
+int denet_gemm_bf16x3_ok(int M, int N, int K);
+int denet_gemm_bf16x3_nt(const float* a, const float* b, const float* bias, float* c, int M, int N, int K, hipStream_t stream);
 /* Fused F(2x2,3x3) convolution for Ci = 64 (stride 1, pad 1; H, W even; Co a multiple of 64): transforms and the
  * 16 component products in one kernel, x -> y only. u = denet_conv_wino_filter(tile 2) output: dgrad = 0 for the forward
  * pass (denet/layer/convolution.py:80-83), dgrad = 1 for the data gradient (x = dy; model_cnn.py:318). Optional bias [Co],
