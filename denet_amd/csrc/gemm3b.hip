@@ -162,6 +162,25 @@ __global__ __launch_bounds__(256, 3) void gemm3b_nt_kernel(const G3Params p) {
     }
 }
 
+// dst[c][r] = src[r][c] (fp32): brings the operands of the data / filter gradient into the K-contiguous form the kernel above
+// takes (w^T for the data gradient; dy^T and x^T, contraction over pixels, for the filter gradient). 64 x 64 tiles through LDS.
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + ty + 4 * i, c = c0 + tx;
+        tile[ty + 4 * i][tx] = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i, r = r0 + tx;
+        if (r < R && c < C) dst[(long)c * R + r] = tile[tx][ty + 4 * i];
+    }
+}
+
 }  // namespace
 
 extern "C" int denet_gemm_bf16x3_ok(int M, int N, int K) {
@@ -178,5 +197,12 @@ extern "C" int denet_gemm_bf16x3_nt(const float* a, const float* b, const float*
     const unsigned tiles = (unsigned)(((M + BM - 1) / BM) * (N / BN));
     hipLaunchKernelGGL(gemm3b_nt_kernel, dim3(tiles), dim3(256), 0, stream, p);
     DENET_CHECK_LAUNCH("gemm_bf16x3_nt");
+    return DENET_OK;
+}
+
+extern "C" int denet_transpose_f32(const float* src, float* dst, int R, int C, hipStream_t stream) {
+    DENET_CHECK_ARG(src && dst && R > 0 && C > 0, "transpose_f32: bad arguments");
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, stream, src, dst, R, C);
+    DENET_CHECK_LAUNCH("transpose_f32");
     return DENET_OK;
 }

@@ -44,6 +44,7 @@ SIGNATURES = {
     "denet_conv_wino_dgrad": (I, [P] * 6 + [Z] + [I] * 6 + [P]),
     "denet_gemm_bf16x3_ok": (I, [I] * 3),
     "denet_gemm_bf16x3_nt": (I, [P] * 4 + [I] * 3 + [P]),
+    "denet_transpose_f32": (I, [P, P, I, I, P]),
     "denet_conv_wino2f_ok": (I, [I] * 5),
     "denet_conv_wino2f": (I, [P] * 5 + [I, P, Z, P] + [I] * 5 + [P]),
     "denet_conv_wino2f_wgrad_ok": (I, [I] * 5),

@@ -275,6 +275,29 @@ def _tune_first(mode, g, a, b, bias, add, out, ws):
     return True
 
 
+# OPT-IN (DENET_HEAD_BF16X3=1, or ops.HEAD_BF16X3 = True): the 1x1 stride-1 convolutions with >= 512 input channels (the detection
+# head) as 3-term bf16-split GEMMs on the bf16 matrix cores (csrc/gemm3b.hip): ~1e-6 relative error instead of the exact fp32
+# FMA chain, 2x the speed. Never on by default; bench.py reports it under its own key.
+HEAD_BF16X3 = os.environ.get("DENET_HEAD_BF16X3", "0") == "1"
+
+
+def _bf16x3_geom(g):
+    N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
+    return HEAD_BF16X3 and R == 1 and S == 1 and stride == 1 and pad == 0 and C >= 512 and C % 128 == 0 and K % 128 == 0 \
+        and (N * H * W) % 32 == 0
+
+
+def _gemm_bf16x3(a, b, bias, out, M, N, K):
+    check(_L().denet_gemm_bf16x3_nt(ptr(a), ptr(b), ptr(bias), ptr(out), M, N, K, stream_ptr()), "gemm_bf16x3_nt")
+    return out
+
+
+def _transpose(src, R, C):
+    dst = empty(C, R)
+    check(_L().denet_transpose_f32(ptr(src), ptr(dst), R, C, stream_ptr()), "transpose_f32")
+    return dst
+
+
 def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, logical=None, cache=None, relu=False,
              bn_stats=False):
     """bn_stats (training, the layer behind is a batch norm): the epilogue of the pass also writes the per-channel sums of y;
@@ -282,6 +305,11 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
     g = conv_geom(x.shape, w.shape, stride, pad, s_real)
     N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
     y = out if out is not None else empty(N, OH, OW, K)
+    if add is None and not relu and _bf16x3_geom(g):
+        if cache is not None:
+            cache["fwd_tile"] = 0
+            cache["bn_stats"] = None               # the batch norm behind measures its own statistics
+        return _gemm_bf16x3(x, w, bias, y, N * H * W, K, C)
     _tune_first(0, g, x, w, bias, add, y, None)
     st = None
     if bn_stats and cache is not None and not relu:
@@ -581,6 +609,11 @@ def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None,
     g = conv_geom(x_shape, w.shape, stride, pad, s_real)
     assert tuple(dy.shape) == (g[0], g[10], g[11], g[4]), (dy.shape, g)
     dx = out if out is not None else empty(*x_shape)
+    if add is None and _bf16x3_geom(g):
+        N, H, W, C, K = g[0], g[1], g[2], g[3], g[4]
+        if cache is not None:
+            cache["dgrad_tile"] = 0
+        return _gemm_bf16x3(dy, _transpose(w, K, C), None, dx, N * H * W, C, K)       # dx[pix][c] = dy[pix][k] (w^T)[c][k]^T
     _tune_first(1, g, dy, w, None, add, dx, None)
 
     def direct():
@@ -607,6 +640,10 @@ def conv_wgrad(x, dy, w_shape, stride=1, pad=0, s_real=None, out=None, logical=N
     g = conv_geom(x.shape, w_shape, stride, pad, s_real)
     assert tuple(dy.shape) == (g[0], g[10], g[11], g[4]), (dy.shape, g)
     dw = out if out is not None else empty(*w_shape)
+    if _bf16x3_geom(g):
+        N, H, W, C, K = g[0], g[1], g[2], g[3], g[4]
+        M = N * H * W                                                                   # dw[k][c] = sum over pixels dy^T[k][pix] x^T[c][pix]
+        return _gemm_bf16x3(_transpose(dy, M, K), _transpose(x, M, C), None, dw, K, C, M)
     ws = WS.get("wgrad", WGRAD_WS_BYTES)
     _tune_first(2, g, x, dy, None, None, dw, ws)
 

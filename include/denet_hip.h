@@ -111,6 +111,8 @@ int denet_conv_wino_fwd_stats(const float* x, const float* w, const float* u_cac
  * (convolution.py:80-83; the detection head) at ~1e-6 relative error instead of the exact fp32 FMA chain of denet_conv_fwd. */
 int denet_gemm_bf16x3_ok(int M, int N, int K);
 int denet_gemm_bf16x3_nt(const float* a, const float* b, const float* bias, float* c, int M, int N, int K, hipStream_t stream);
+/* dst [C][R] = src [R][C]^T (fp32): operands of the data / filter gradient in the K-contiguous form of the call above */
+int denet_transpose_f32(const float* src, float* dst, int R, int C, hipStream_t stream);
 /* Fused F(2x2,3x3) convolution for Ci = 64 (stride 1, pad 1; H, W even; Co a multiple of 64): transforms and the
  * 16 component products in one kernel, x -> y only. u = denet_conv_wino_filter(tile 2) output: dgrad = 0 for the forward
  * pass (denet/layer/convolution.py:80-83), dgrad = 1 for the data gradient (x = dy; model_cnn.py:318). Optional bias [Co],

@@ -184,6 +184,37 @@ def test_fused_winograd_f2_kernel(hip, case):
         ops._WINO.update(saved[1])
 
 
+@pytest.mark.parametrize("case", [(2, 24, 24, 1536, 1024), (1, 24, 24, 768, 512), (3, 8, 12, 512, 128)])
+def test_opt_in_bf16_split_head_gemms(hip, case):
+    """OPT-IN ops.HEAD_BF16X3 (csrc/gemm3b.hip): the head's 1x1 convolutions as 3-term bf16-split GEMMs - forward, data gradient
+    (w transposed) and filter gradient (dy, x transposed; contraction over the pixels) against fp64. Not the exact fp32 chain:
+    the bound is 2e-5 max-norm (measured 2-4e-6; the exact fp32 kernels give 1-2.5e-6), far inside the 1e-3 activation budget."""
+    from denet_amd import ops
+    N, H, W, C, K = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, H, W, C, generator=g).cuda()
+    w = (torch.randn(K, 1, 1, C, generator=g) * (2.0 / C) ** 0.5).cuda()
+    bias = torch.randn(K, generator=g).cuda()
+    dy = torch.randn(N, H, W, K, generator=g).cuda()
+    x2, w2, dy2 = x.double().reshape(-1, C), w.double().reshape(K, C), dy.double().reshape(-1, K)
+    ref = {"y": x2 @ w2.T + bias.double(), "dx": dy2 @ w2, "dw": dy2.T @ x2}
+    saved = ops.HEAD_BF16X3
+    try:
+        got = {}
+        for flag in (False, True):
+            ops.HEAD_BF16X3 = flag
+            got[flag] = {"y": ops.conv_fwd(x, w, bias=bias).reshape(-1, K), "dx": ops.conv_dgrad(dy, w, tuple(x.shape)).reshape(-1, C),
+                         "dw": ops.conv_wgrad(x, dy, tuple(w.shape)).reshape(K, C)}
+        for k, r in ref.items():
+            s = float(r.abs().max())
+            e_exact = float((got[False][k].double() - r).abs().max()) / s
+            e_split = float((got[True][k].double() - r).abs().max()) / s
+            assert e_exact <= 5e-6 and e_split <= 2e-5, (k, e_exact, e_split)
+            assert not torch.equal(got[False][k], got[True][k])           # the flag really switches the arithmetic
+    finally:
+        ops.HEAD_BF16X3 = saved
+
+
 def test_fused_winograd_f2_kernels_under_memory_pressure(hip):
     """the LDS refill protocol of csrc/wino2f.hip (row bands streamed in by LDS-DMA while the previous item is multiplied, waits
     that leave younger pieces in flight) against stretched memory latencies: random batch / image sizes with several work items
