@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-warm", action="store_true", help="skip the warm-corner-regime leg (rank 0, N=1)")
+    ap.add_argument("--no-split-bf16", action="store_true",
+                    help="skip the leg of the OPT-IN variant (head GEMMs as 3-term bf16 splits; own key, never the headline)")
     ap.add_argument("--regime", default="cold", choices=["cold", "warm"],
                     help="cold = weights as initialised (corner bias +5: no detector RoIs, SURVEY §8d); warm = corner "
                          "head re-biased so that ~1%% of the cells fire")
@@ -85,6 +87,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs the torch.distributed.run launcher (one rank per GPU)" % args.gpus)
     torch.cuda.set_device(local_rank)
+    ops.HEAD_BF16X3 = False      # the headline is fp32 MFMA whatever the environment says; the opt-in variant has its own leg below
     dp = None
     if world > 1 or os.environ.get("DENET_FORCE_DP") == "1":      # DENET_FORCE_DP: exercise the RCCL path on 1 GPU
         from denet_amd.multi import DataParallel
@@ -220,6 +223,44 @@ def main():
                               "final_cost": round(float(wcost), 5),
                               "note": "same step, DNC corner head re-biased (zoo.warm_corner_head) so that ~1 % of the cells "
                                       "fire; the proposal replaces the reference's host pair search (denet_sparse.cc:337-373)"}
+
+    if rank == 0 and world == 1 and not args.no_split_bf16:
+        # OPT-IN variant (ops.HEAD_BF16X3, csrc/gemm3b.hip): the same step with the 1x1 convolutions of the detection head (fwd,
+        # data and filter gradient; 4736 -> 1536 -> 1024 -> 768 -> 512) as 3-term bf16-split GEMMs on the bf16 matrix cores. Its
+        # products are NOT the exact fp32 FMA chain (relative error ~1e-6 of a sum): own key, own number.
+        torch.cuda.empty_cache()
+        costs = {}
+        sdt = None
+        for flag in (False, True):
+            ops.HEAD_BF16X3 = flag
+            ms = zoo.denet34(BATCH_PER_GPU, "skip", 512, class_num=80, seed=1)
+            ms.build_train_func("nesterov")
+            random.seed(1)
+            sit = 0
+            c1, _ = ms.train_step(xd, metas, 0, sit, lr, mom, decay)       # first step from identical weights: cost fp32 vs split
+            costs[flag] = float(c1)
+            sit += 1
+            if flag:
+                for _ in range(max(args.warmup, 2)):
+                    ms.train_step(xd, metas, 0, sit, lr, mom, decay)
+                    sit += 1
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    scost, _ = ms.train_step(xd, metas, 0, sit, lr, mom, decay)
+                    sit += 1
+                torch.cuda.synchronize()
+                sdt = time.perf_counter() - t0
+            del ms
+            torch.cuda.empty_cache()
+        ops.HEAD_BF16X3 = False
+        out["split_bf16"] = {"value": round(BATCH_PER_GPU * args.steps / sdt, 2), "unit": "images/sec",
+                             "ms_per_step": round(1e3 * sdt / args.steps, 3), "dtype": "f32 storage; head GEMM products bf16 x 3",
+                             "first_step_cost_fp32": round(costs[False], 6), "first_step_cost_split": round(costs[True], 6),
+                             "final_cost": round(float(scost), 5),
+                             "note": "opt-in (DENET_HEAD_BF16X3=1), NOT the headline: a b ~= a_hi b_hi + a_hi b_lo + a_lo b_hi on "
+                                     "v_mfma_f32_32x32x16_bf16, fp32 accumulation; 2-4e-6 max-norm error per GEMM against fp64 "
+                                     "(the exact fp32 kernels: 1-2.5e-6); everything else as in `value`"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import model as OM
