@@ -3,6 +3,7 @@
 The library is built IN-TREE (denet_amd/csrc/libdenet_hip.so) so that it travels with the repository
 snapshot to the GPU box; hipcc cross-compiles gfx950 code objects without a GPU present.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -18,33 +19,66 @@ NO_CONTRACT = {"dss.hip", "samples.hip", "detect.hip", "augment.hip", "image.hip
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
+def _hipcc_version(hipcc):
+    try:
+        return subprocess.run([hipcc, "--version"], check=True, capture_output=True, text=True).stdout
+    except (OSError, subprocess.CalledProcessError):
+        return "unknown"
+
+
+def _digest(parts, files):
+    """content hash of (command line, compiler version, every input file): mtimes say nothing after an rsync / checkout"""
+    h = hashlib.sha256()
+    for p in parts:
+        h.update(p.encode())
+        h.update(b"\0")
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(hashlib.sha256(fh.read()).digest())
+    return h.hexdigest()
+
+
+def _stale(target, digest):
+    """a target is current iff it exists and the digest recorded next to it (<target>.sha256) is the one of its inputs"""
+    stamp = target + ".sha256"
+    if not (os.path.exists(target) and os.path.exists(stamp)):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(stamp) as f:
+        return f.read().strip() != digest
+
+
+def _stamp(target, digest):
+    with open(target + ".sha256", "w") as f:
+        f.write(digest + "\n")
 
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
+    version = _hipcc_version(hipcc)
     objs = []
     headers = [os.path.join(CSRC, "common.h")]
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + COMMON + (["-ffp-contract=off"] if src in NO_CONTRACT else []) + ["-c", s, "-o", o]
+        flags = COMMON + (["-ffp-contract=off"] if src in NO_CONTRACT else [])
+        digest = _digest([version] + flags, [s] + headers)
+        if force or _stale(o, digest):
+            cmd = [hipcc] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+            _stamp(o, digest)
+    link = ["--offload-arch=gfx950", "-shared", "-fPIC"]
+    digest = _digest([version] + link, objs)
+    if force or _stale(LIB, digest):
+        cmd = [hipcc] + link + ["-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        _stamp(LIB, digest)
     return LIB
 
 

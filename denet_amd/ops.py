@@ -313,7 +313,10 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
     _tune_first(0, g, x, w, bias, add, y, None)
     st = None
     if bn_stats and cache is not None and not relu:
-        rows = max((N * OH * OW + 127) // 128, (N * (OH // 2 + 1) * (OW // 2 + 1) * (K // 4) + 255) // 256)
+        # rows of partial sums: direct tiles of 128 pixels, the F(2x2) output transform, the fused 64-channel kernel (one
+        # row per 16x16-pixel block) - whichever implementation runs, the buffer holds its rows
+        rows = max((N * OH * OW + 127) // 128, (N * (OH // 2 + 1) * (OW // 2 + 1) * (K // 4) + 255) // 256,
+                   N * ((OH + 15) // 16) * ((OW + 15) // 16))
         st = cache.get("bn_stats_buf")
         if st is None or st.numel() < rows * 2 * K:
             st = cache["bn_stats_buf"] = torch.empty(rows * 2 * K, dtype=torch.float64, device="cuda")
