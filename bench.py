@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — images/sec of one DeNet-34 skip training step at 512x512 (BASELINE.json metric) on N MI355X.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: starts its own N ranks, see self_launch)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
          bench.py --gpus N --steps K --warmup W
 
@@ -60,6 +60,125 @@ def host_cores():
     return n
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks (one per GPU) under
+    torch.distributed.run on a free local port, pass the ranks' output through and exit with the job's status. The reference's
+    driver spawns its own workers too (denet/model/train_multi.py:96-145, denet/multi/worker.py:138-243)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: the only mode the host driver supports
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def regime_leg(args, xd, metas, target_cells, lr, mom, decay):
+    """The headline step with the corner head of DNC held in a firing regime: `target_cells` cells per corner type and image
+    above the corner threshold. The corner rows of the DNC convolution (random weights, zoo.warm_corner_head) get the bias
+    that gives the target on this batch (bisection over steps with learning rate 0) and are then FROZEN: after every step
+    their weights / bias are restored and their momentum zeroed (two tiny copies) - the corner cost would otherwise train
+    the head cold within the warm-up steps (lr 0.1 x cost factor) and the leg would time a second cold regime. Everything
+    else trains as in `value`: same kernels, same host work."""
+    import math
+    import torch
+    from denet_amd import ops
+    from denet_amd.model import zoo
+    m = zoo.warm_corner_head(zoo.denet34(BATCH_PER_GPU, "skip", 512, class_num=80, seed=1))
+    m.build_train_func("nesterov")
+    dnc = [l for l in m.layers if l.type_name == "denet-corner"][0]
+    dns = [l for l in m.layers if l.type_name == "denet-sparse"][0]
+    conv, cn = dnc.layers[-1], dnc.corner_num
+    log_thr = math.log(dns.corner_threshold)
+    random.seed(1)
+    it = [0]
+
+    def step(rate):
+        c, _ = m.train_step(xd, metas, 0, it[0], rate, mom, decay)
+        it[0] += 1
+        return c
+
+    def cells():
+        # corner_pr [B, 2, types, H, W] log-probabilities, plane 1 = "corner" (denet_sparse.cc:503-511)
+        return (dnc.corner_pr[:, 1] > log_thr).sum(dim=(2, 3)).float()
+
+    lo, hi = -4.0, 14.0            # bias: more cells <-> fewer cells
+    for _ in range(12):
+        mid = 0.5 * (lo + hi)
+        conv.beta.dev[:cn].fill_(mid)
+        step(0.0)
+        if float(cells().mean()) > target_cells:
+            lo = mid
+        else:
+            hi = mid
+    conv.beta.dev[:cn].fill_(lo)
+    keep_w, keep_b = conv.omega.dev[:cn].clone(), conv.beta.dev[:cn].clone()
+
+    def hold():
+        conv.omega.dev[:cn].copy_(keep_w)
+        conv.beta.dev[:cn].copy_(keep_b)
+        conv.omega.mom[:cn].zero_()
+        conv.beta.mom[:cn].zero_()
+
+    for _ in range(max(args.warmup, 2)):
+        step(lr)
+        hold()
+    torch.cuda.synchronize()
+    rois, ncell, nkept, ncand, phases = [], [], [], [], {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cost = step(lr)
+        hold()
+        raw = getattr(dns, "_raw_samples", None)
+        rois.append(float(raw[1].mean()) if raw is not None else 0.0)
+        for k, v in dns.phase_ms.items():
+            phases[k] = phases.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # diagnostics of the regime, outside the timed region: three further steps
+    for _ in range(3):
+        step(lr)
+        hold()
+        c = cells()
+        kept, cand = ops.build_samples_stats(dnc.corner_pr, dns.proposal_count, dns.corner_max)
+        ncell.append((float(c.mean()), float(c.min()), float(c.max())))
+        nkept.append(float(kept.float().mean()))
+        ncand.append(float(cand.float().mean()))
+    # the RoI proposal alone (corner_select + pair_* kernels) on the last corner map, event-timed on its stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ops.build_samples(dnc.corner_pr, dns.corner_threshold, dns.proposal_count, dns.corner_max, dns.local_max)
+    e0.record()
+    for _ in range(10):
+        ops.build_samples(dnc.corner_pr, dns.corner_threshold, dns.proposal_count, dns.corner_max, dns.local_max)
+    e1.record()
+    torch.cuda.synchronize()
+    mean_rois = sum(rois) / len(rois)
+    if mean_rois < 50:
+        raise RuntimeError("corner head left the regime: %.1f detector RoIs per image (%.0f cells per type)"
+                           % (mean_rois, ncell[-1][0]))
+    if not math.isfinite(cost):
+        raise RuntimeError("non-finite cost %r" % cost)
+    return {"value": round(BATCH_PER_GPU * args.steps / dt, 2), "unit": "images/sec",
+            "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "target_cells_above_threshold_per_type": target_cells,
+            "cells_above_threshold_per_type": {"mean": round(sum(c[0] for c in ncell) / len(ncell), 1),
+                                               "min": min(c[1] for c in ncell), "max": max(c[2] for c in ncell)},
+            "corners_kept_per_type": round(sum(nkept) / len(nkept), 1), "max_corners": dns.corner_max,
+            "truncation_branch_taken": bool(max(c[2] for c in ncell) > dns.corner_max),
+            "pair_candidates_per_image": round(sum(ncand) / len(ncand), 1),
+            "detector_rois_per_image": round(mean_rois, 1), "rois_per_image_cap": dns.proposal_count,
+            "roi_proposal_kernels_ms": round(e0.elapsed_time(e1) / 10, 4),
+            # host phases of the RoI hand-off per step, the reference's names (denet_sparse.py:127-161): model = queue the proposal
+            # + wait for the device (forward pass up to the corner map included), build = host epilogue of build_samples
+            "host_phase_ms_per_step": {k: round(v / args.steps, 3) for k, v in sorted(phases.items())},
+            "corner_bias": round(lo, 4), "final_cost": round(float(cost), 5),
+            "note": "same step as `value`; corner rows of the DNC convolution frozen at a bias calibrated on this batch"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,13 +186,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-warm", action="store_true", help="skip the warm-corner-regime leg (rank 0, N=1)")
+    ap.add_argument("--no-warm", action="store_true", help="skip the warm / stress corner-regime legs (rank 0, N=1)")
     ap.add_argument("--no-split-bf16", action="store_true",
                     help="skip the leg of the OPT-IN variant (head GEMMs as 3-term bf16 splits; own key, never the headline)")
     ap.add_argument("--regime", default="cold", choices=["cold", "warm"],
                     help="cold = weights as initialised (corner bias +5: no detector RoIs, SURVEY §8d); warm = corner "
                          "head re-biased so that ~1%% of the cells fire")
+    ap.add_argument("--share-gpu", action="store_true", default=os.environ.get("DENET_BENCH_SHARE_GPU") == "1",
+                    help="LAUNCH-PATH DEBUG MODE, never a scaling measurement: all N ranks run on cuda:0 and torch.distributed "
+                         "uses gloo (one GPU cannot host two RCCL ranks); exercises launcher, rendezvous, bucketed "
+                         "all-reduce and the rank-0 JSON line on a one-GPU box")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)          # does not return
 
     import numpy
     import torch
@@ -84,15 +209,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (one rank per GPU)" % args.gpus)
-    torch.cuda.set_device(local_rank)
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    share = args.share_gpu
+    if not share and world > torch.cuda.device_count():
+        raise SystemExit("--gpus %d but %d HIP devices are visible (one rank per GPU; --share-gpu is the launch-path "
+                         "debug mode)" % (world, torch.cuda.device_count()))
+    torch.cuda.set_device(0 if share else local_rank)
     ops.HEAD_BF16X3 = False      # the headline is fp32 MFMA whatever the environment says; the opt-in variant has its own leg below
     dp = None
     if world > 1 or os.environ.get("DENET_FORCE_DP") == "1":      # DENET_FORCE_DP: exercise the RCCL path on 1 GPU
         from denet_amd.multi import DataParallel
-        dp = DataParallel(backend="nccl")
+        dp = DataParallel(backend="gloo" if share else "nccl")      # "nccl" is RCCL on ROCm
         dp.force_collectives = os.environ.get("DENET_FORCE_DP") == "1"
+        world = dp.world_size          # what the process group itself reports
 
     # identical initial weights on every rank (seed), per-rank data shard (seed + rank)
     model = zoo.denet34(BATCH_PER_GPU, "skip", 512, class_num=80, seed=1)
@@ -108,9 +237,10 @@ def main():
     lr, mom, decay = 0.1, [0.9], 1e-4     # papers/dss/denet34.sh:43
 
     def sync():
+        torch.cuda.synchronize()
         if dp is not None:
             dp.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     it = 0
     # launch configurations are measured during the first two steps (one-off setup, like kernel compilation): they are
@@ -119,14 +249,30 @@ def main():
         model.train_step(xd, metas, 0, it, lr, mom, decay)
         it += 1
     sync()
+    if dp is not None:
+        dp.start_timing()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         cost, _ = model.train_step(xd, metas, 0, it, lr, mom, decay)
         it += 1
     sync()
-    dt = time.perf_counter() - t0
+    dt_rank = dt = time.perf_counter() - t0
+    dp_info = None
     if dp is not None:
-        dt = dp.max_over_ranks(dt)
+        dt = dp.max_over_ranks(dt_rank)
+        per_rank = dp.gather_floats(1e3 * dt_rank / args.steps)
+        exposed = dp.gather_floats(dp.exposed_ms_per_step())
+        dp_info = {"backend": dp.backend + (" (RCCL)" if dp.backend == "nccl" else ""),
+                   "world_size": dp.world_size, "ms_per_step_per_rank": [round(v, 3) for v in per_rank],
+                   "allreduce_bytes_per_step": dp.bytes_per_step(), "collectives_per_step": dp.collectives_per_step(),
+                   "bucket_bytes": [4 * (hi - lo) for lo, hi, _ in (dp._buckets or [])],
+                   # time the compute stream stood waiting for collectives after its last backward kernel (HIP events
+                   # around the wait in DataParallel.finish_step): the part of the exchange the backward pass did not hide
+                   "exposed_collective_ms_per_step_per_rank": [round(v, 3) for v in exposed]}
+        if share:
+            dp_info["launch_path_test_only"] = ("all %d ranks share cuda:0 and gloo carries the tensors through the host: this "
+                                                "line proves the launch / rendezvous / exchange path, it is NOT a scaling "
+                                                "measurement" % dp.world_size)
     if not numpy.isfinite(cost):
         raise SystemExit("non-finite cost %r" % cost)
     images = BATCH_PER_GPU * world * args.steps
@@ -159,8 +305,13 @@ def main():
         # rate in FLOPs of the reference's direct algorithm (164.3 GFLOP per image and step); layers that run Winograd
         # execute fewer, so this is an effective rate - the MFMA utilisation of the kernels is in `roofline`
         "step_tflops_algorithmic": round(value * FLOP_PER_IMAGE_STEP / 1e12, 2),
-        "step_frac_of_fp32_mfma_peak": round(value * FLOP_PER_IMAGE_STEP / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
+        # NOT a utilisation: FLOPs of the reference's direct algorithm / time / peak; exceeds what the matrix cores execute by
+        # the Winograd saving and can pass 1.0. The utilisation of the step is `step_mfma_util_executed` (roofline leg).
+        "step_effective_frac_algorithmic": round(value * FLOP_PER_IMAGE_STEP / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world), 4),
     }
+
+    if dp_info is not None:
+        out["data_parallel"] = dp_info
 
     if rank == 0 and world == 1 and not args.no_roofline:
         prof = ops.KernelProfile()
@@ -174,6 +325,11 @@ def main():
         name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
         avg_ms = a["ms"] / a["launches"]
         achieved = (a["flops"] / a["launches"]) / (avg_ms * 1e-3) / 1e12
+        # FLOPs the matrix cores really execute in one step (every implicit-GEMM launch and the fused F(2x2) kernels, Winograd
+        # layers counted with their reduced products) / the timed step / peak: the step-level MFMA utilisation
+        executed = sum(v["flops"] for v in agg.values()) / nprof
+        out["step_gflop_executed"] = round(executed / 1e9, 1)
+        out["step_mfma_util_executed"] = round(executed / (dt / args.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
         out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2),
                            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(name),
@@ -185,44 +341,18 @@ def main():
                                          for k, v in sorted(agg.items())}}
 
     if rank == 0 and world == 1 and not args.no_warm and args.regime == "cold":
-        # the headline regime has no detector RoIs (cold corner head); the same step with a firing corner head
-        # exercises the RoI proposal for real (pair enumeration of a few hundred corners per type, top-576 selection)
+        # the headline regime has no detector RoIs (cold corner head). The same step with a firing corner head
+        # exercises the RoI proposal for real: "warm" = a few hundred corners per type and image (pair search of
+        # denet_sparse.cc:337-373, top-576 selection, random.sample trim), "stress" = more than max_corners = 1024 cells per
+        # type above the threshold (the truncation branch, denet_sparse.cc:526-530, then up to 2 x 1024^2 pairs per image)
         del model
         torch.cuda.empty_cache()
-        mw = zoo.warm_corner_head(zoo.denet34(BATCH_PER_GPU, "skip", 512, class_num=80, seed=1))
-        mw.build_train_func("nesterov")
-        random.seed(1)
-        wit = 0
-        for _ in range(max(args.warmup, 2)):
-            mw.train_step(xd, metas, 0, wit, lr, mom, decay)
-            wit += 1
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        rois = []
-        for _ in range(args.steps):
-            wcost, _ = mw.train_step(xd, metas, 0, wit, lr, mom, decay)
-            wit += 1
-            dns = [l for l in mw.layers if l.type_name == "denet-sparse"][0]
-            raw = getattr(dns, "_raw_samples", None)
-            rois.append(float(raw[1].mean()) if raw is not None else 0.0)
-        torch.cuda.synchronize()
-        wdt = time.perf_counter() - t0
-        # the RoI proposal alone (corner_select + pair_* kernels) on the last corner map, event-timed on its stream
-        dnc = [l for l in mw.layers if l.type_name == "denet-corner"][0]
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ops.build_samples(dnc.corner_pr, dns.corner_threshold, dns.proposal_count, 1024, dns.local_max)
-        e0.record()
-        for _ in range(10):
-            ops.build_samples(dnc.corner_pr, dns.corner_threshold, dns.proposal_count, 1024, dns.local_max)
-        e1.record()
-        torch.cuda.synchronize()
-        out["warm_regime"] = {"value": round(BATCH_PER_GPU * args.steps / wdt, 2), "unit": "images/sec",
-                              "ms_per_step": round(1e3 * wdt / args.steps, 3),
-                              "detector_rois_per_image": round(sum(rois) / len(rois), 1),
-                              "roi_proposal_kernels_ms": round(e0.elapsed_time(e1) / 10, 4),
-                              "final_cost": round(float(wcost), 5),
-                              "note": "same step, DNC corner head re-biased (zoo.warm_corner_head) so that ~1 % of the cells "
-                                      "fire; the proposal replaces the reference's host pair search (denet_sparse.cc:337-373)"}
+        for key, target in (("warm_regime", 40.0), ("stress_regime", 1400.0)):
+            try:
+                out[key] = regime_leg(args, xd, metas, target, lr, mom, decay)
+            except Exception as exc:          # an extra leg must never cost the headline line
+                out[key] = {"error": repr(exc)[:300]}
+            torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not args.no_split_bf16:
         try:

@@ -25,6 +25,12 @@ def _emit(level, args):
         sys.stdout.flush()
 
 
+def verbose_enabled():
+    """True once a driver has configured the logger (init) and it passes VERBOSE records: per-step timing lines of the hot
+    path (denet_sparse.py:145) are formatted only then"""
+    return _logger is not None and _logger.isEnabledFor(VERBOSE)
+
+
 def debug(*args):
     _emit(_logging.DEBUG, args)
 

@@ -28,6 +28,11 @@ void denet_set_error(const char* fmt, ...);
         }                                                                          \
     } while (0)
 
+// live per-launch timing (bench.py's roofline leg, denet_conv_profile; records live in igemm.hip): bracket a launch with
+// begin / end on its stream. begin returns -1 while profiling is off.
+int denet_prof_begin(int mode, int bm, int bn, int nbuf, hipStream_t stream);
+void denet_prof_end(int idx, hipStream_t stream);
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -738,6 +738,24 @@ struct ProfRec {
 std::vector<ProfRec> g_prof;
 bool g_prof_on = false;
 
+// opens a record (event on `stream` before the launch); -1 when profiling is off or an event cannot be created
+int prof_begin(int mode, int bm, int bn, int nbuf, hipStream_t stream) {
+    if (!g_prof_on) return -1;
+    ProfRec rec;
+    rec.cfg[0] = mode; rec.cfg[1] = bm; rec.cfg[2] = bn; rec.cfg[3] = nbuf;
+    if (hipEventCreate(&rec.a) != hipSuccess) return -1;
+    if (hipEventCreate(&rec.b) != hipSuccess) {
+        (void)hipEventDestroy(rec.a);
+        return -1;
+    }
+    (void)hipEventRecord(rec.a, stream);
+    g_prof.push_back(rec);
+    return (int)g_prof.size() - 1;
+}
+void prof_end(int idx, hipStream_t stream) {
+    if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, stream);
+}
+
 template <int MODE, int BM, int BN, int WM, int WN, int NBUF = 2>
 int launch_igemm(const IgemmParams& p, int splits, hipStream_t stream) {
     g_last_cfg[0] = MODE; g_last_cfg[1] = BM; g_last_cfg[2] = BN; g_last_cfg[3] = NBUF; g_last_cfg[4] = splits;
@@ -759,20 +777,9 @@ int launch_igemm(const IgemmParams& p, int splits, hipStream_t stream) {
     // wgrad folds the split slices into grid.x (see the id decode in the kernel); dgrad: y = stride parity classes
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n) * (MODE == MODE_WGRAD ? (unsigned)splits : 1u),
               MODE == MODE_WGRAD ? (unsigned)(p.batch > 1 ? p.batch : 1) : (unsigned)splits, 1);
-    ProfRec rec;
-    if (g_prof_on) {
-        rec.cfg[0] = MODE; rec.cfg[1] = BM; rec.cfg[2] = BN; rec.cfg[3] = NBUF;
-        if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) {
-            denet_set_error("igemm: hipEventCreate failed");
-            return DENET_ERR_ARG;
-        }
-        (void)hipEventRecord(rec.a, stream);
-    }
+    const int prof = prof_begin(MODE, BM, BN, NBUF, stream);
     hipLaunchKernelGGL((igemm_kernel<MODE, BM, BN, WM, WN, NBUF>), grid, dim3(256), lds, stream, p);
-    if (g_prof_on) {
-        (void)hipEventRecord(rec.b, stream);
-        g_prof.push_back(rec);
-    }
+    prof_end(prof, stream);
     DENET_CHECK_LAUNCH("igemm");
     return DENET_OK;
 }
@@ -977,6 +984,10 @@ int wgrad_dispatch(IgemmParams& p, int K, float* dw, float* workspace, size_t wo
 }
 
 }  // namespace
+
+// the same live timing for the kernels of other files (wino2f.hip: mode 10 = wino2f_ws_kernel, 11 = wino2f_wgrad_kernel)
+int denet_prof_begin(int mode, int bm, int bn, int nbuf, hipStream_t stream) { return prof_begin(mode, bm, bn, nbuf, stream); }
+void denet_prof_end(int idx, hipStream_t stream) { prof_end(idx, stream); }
 
 extern "C" int denet_conv_profile(int enable) {
     for (auto& r : g_prof) {

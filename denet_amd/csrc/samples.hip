@@ -499,6 +499,30 @@ extern "C" int denet_build_samples(const float* corner_pr, int* out_box, float* 
     return DENET_OK;
 }
 
+// Diagnostic read-out of the LAST denet_build_samples call on this workspace (same geometry arguments): corners kept per
+// (image, type) after the max_corners truncation (denet_sparse.cc:526-530) and candidate boxes generated per image by the
+// pair search (:337-373, before the top-sample_count cut). Device-to-device copies on `stream`; ncorner_out [B*Cn] int32,
+// candidates_out [B] uint32 (device).
+extern "C" int denet_build_samples_stats(const void* workspace, size_t workspace_bytes, int B, int Cn, int H, int W,
+                                         int max_corners, int sample_count, int* ncorner_out, unsigned* candidates_out,
+                                         hipStream_t stream) {
+    DENET_CHECK_ARG(workspace && ncorner_out && candidates_out, "build_samples_stats: null pointer");
+    DENET_CHECK_ARG(B > 0 && (Cn == 4 || Cn == 5) && H > 0 && W > 0 && max_corners > 0 && sample_count > 0,
+                    "build_samples_stats: bad geometry");
+    const WsLayout l = ws_layout(B, Cn, H, W, max_corners, sample_count);
+    DENET_CHECK_ARG(workspace_bytes >= l.total, "build_samples_stats: workspace too small");
+    const char* ws = (const char*)workspace;
+    hipError_t e = hipMemcpyAsync(ncorner_out, ws + l.ncorner, (size_t)B * Cn * sizeof(int), hipMemcpyDeviceToDevice, stream);
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(candidates_out, sizeof(unsigned), ws + l.state + offsetof(ImgState, total), sizeof(ImgState),
+                             sizeof(unsigned), (size_t)B, hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) {
+        denet_set_error("build_samples_stats: copy: %s", hipGetErrorString(e));
+        return -(int)e;
+    }
+    return DENET_OK;
+}
+
 // Host epilogue: turns the integer boxes + |d| of denet_build_samples (copied to the host) into the
 // reference's sample tuples (pr, x0, y0, x1, y1) with the reference's exact host arithmetic
 // (denet_sparse.cc:306-307): pr = (float)(1.0 / (1.0 + std::exp(fabs(d)))) with the fp32 exp overload,

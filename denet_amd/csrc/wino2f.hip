@@ -616,7 +616,9 @@ extern "C" int denet_conv_wino2f(const float* x, const float* u, const float* bi
         cus = prop.multiProcessorCount;
     }
     const int grid = p.items < cus ? p.items : cus;
+    const int prof = denet_prof_begin(10, 0, 0, 0, stream);
     hipLaunchKernelGGL(wino2f_ws_kernel, dim3((unsigned)grid), dim3(512), S_LDS_BYTES, stream, p);
+    denet_prof_end(prof, stream);
     DENET_CHECK_LAUNCH("conv_wino2f");
     return DENET_OK;
 }
@@ -669,7 +671,9 @@ extern "C" int denet_conv_wino2f_wgrad(const float* x, const float* dy, float* d
         attr_set = true;
     }
     float* dU = p.part + (size_t)grid * 16 * 4096;
+    const int prof = denet_prof_begin(11, 0, 0, 0, stream);
     hipLaunchKernelGGL(wino2f_wgrad_kernel, dim3(grid), dim3(512), G_LDS_BYTES, stream, p);
+    denet_prof_end(prof, stream);
     hipLaunchKernelGGL(w2g_reduce_kernel, dim3(16 * 64), dim3(256), 0, stream, p.part, grid, dU);
     hipLaunchKernelGGL(w2g_dfilter_kernel, dim3(16), dim3(256), 0, stream, dU, dw);
     DENET_CHECK_LAUNCH("conv_wino2f_wgrad");

@@ -16,6 +16,7 @@ import numpy
 
 from . import AbstractLayer, Act, get_train
 from .. import common
+from ..common import logging
 from .. import ops
 
 TAP_THEANO = 0   # denet_sparse.py:72-84 (Theano CPU path, canonical per north star)
@@ -129,6 +130,7 @@ class DeNetSparseLayer(AbstractLayer):
         self._taps = None
         self._pinned = None
         self.coverage = (0, 0)
+        self.phase_ms = {}         # host phases of the last RoI hand-off in ms, the reference's names (denet_sparse.py:127-161)
 
     @staticmethod
     def parse_desc(layers, name, tags, params):
@@ -158,6 +160,10 @@ class DeNetSparseLayer(AbstractLayer):
         import torch
         cl = self.corner_layer
         assert cl.corner_pr is not None, "run the model forward up to the corner layer first"
+        # the reference's phases (denet_sparse.py:127-145): "model" = the corner function (here: queueing the proposal kernels
+        # and waiting until the device has run the forward pass up to the corner map + the proposal), "build" = the host
+        # part of build_samples (here only its epilogue: libm score, box arithmetic, optional clustering)
+        timer = common.Timer()
         B, S = self.batch_size, self.proposal_count
         words = B * S * 5 + B
         if getattr(self, "_res_dev", None) is None:
@@ -173,11 +179,13 @@ class DeNetSparseLayer(AbstractLayer):
             cl.sample_shared = cl.conv.output.data
         self._res_host.copy_(r, non_blocking=True)
         ops.wait_stream()
+        timer.mark()
         h = self._res_host
         hcount = h[B * S * 5:]
         self._raw_samples = None
         if int(hcount.sum()) == 0:        # cold detector: nothing proposed
             empty_pr, empty_bx = numpy.zeros((0,)), numpy.zeros((0, 4))
+            self._log_get_samples(timer)
             return [empty_pr] * B, [empty_bx] * B
         hbox = h[:B * S * 4].view(B, S, 4)
         habsd = h[B * S * 4:B * S * 5].view(torch.float32).view(B, S)
@@ -186,6 +194,7 @@ class DeNetSparseLayer(AbstractLayer):
         if self.cluster:
             raw, hcount = ops.cluster_samples_host(raw, hcount, self.nms_threshold, self.sample_count)
         self._raw_samples = (raw, hcount)
+        self._log_get_samples(timer)
         if raw_only:
             return None, None
         samples = raw.astype(numpy.float64)
@@ -193,6 +202,16 @@ class DeNetSparseLayer(AbstractLayer):
         prs = [samples[b, :counts[b], 0] for b in range(B)]
         boxes = [samples[b, :counts[b], 1:5] for b in range(B)]
         return prs, boxes
+
+    def _log_get_samples(self, timer):
+        timer.mark()
+        # phase_ms: last value of every host phase of the RoI hand-off, under the reference's names
+        self.phase_ms["get_samples"] = timer.current_ms()
+        self.phase_ms["get_samples.model"] = timer.delta_ms(0)
+        self.phase_ms["get_samples.build"] = timer.delta_ms(1)
+        if logging.verbose_enabled():
+            logging.verbose("Took %i ms to get_samples (%i model, %i build, %i max corners) "
+                            % (timer.current_ms(), timer.delta_ms(0), timer.delta_ms(1), self.corner_max))
 
     def get_samples(self, data_x, train=False, store_shared=False):
         """list[B] of list[(pr, (x0, y0, x1, y1))], the return shape of c_code.build_samples
@@ -362,13 +381,22 @@ class DeNetSparseLayer(AbstractLayer):
         return S <= setsize and not self.log_coverage and len(metas) == self.batch_size
 
     def get_target(self, model, data_x, metas):
+        timer = common.Timer()
         native = self._native_edit_ok(metas)
         prs, boxes = self._device_samples(raw_only=native)
+        timer.mark()
         if native:
             self._edit_and_upload_native(metas)
         else:
             self.sample_pr, self.sample_boxes = self.edit_samples(prs, boxes, metas)
             self._upload_boxes()
+        timer.mark()
+        # the reference logs get_bbox_array and set_samples separately (denet_sparse.py:148-161); here the RoI editing
+        # writes the bbox array straight into the pinned upload buffer, so the two are one phase
+        self.phase_ms["set_samples"] = timer.delta_ms(1)
+        self.phase_ms["get_target"] = timer.current_ms()
+        if logging.verbose_enabled():
+            logging.debug("Took %i ms to set_samples" % timer.delta_ms(1))
         return None
 
     def export_json(self):

@@ -109,6 +109,7 @@ SIGNATURES = {
     "denet_soft_nms_host": (I, [P, P, I, F, P, P, P]),
     "denet_build_samples_workspace_bytes": (Z, [I] * 6),
     "denet_build_samples": (I, [P, P, P, P, P, Z] + [I] * 4 + [F, I, I, I, P]),
+    "denet_build_samples_stats": (I, [P, Z] + [I] * 6 + [P, P, P]),
     "denet_host_cluster_samples": (I, [P, I, F, I, P, P]),
     "denet_samples_finish_host": (I, [P, P, P, I, I, I, I, P]),
 }

@@ -18,7 +18,7 @@ import numpy
 
 from .. import common
 from .. import layer as layer_mod
-from ..common import json_util
+from ..common import json_util, logging
 from ..layer import Act, InitialLayer, round_up
 from ..layer.layer_types import layer_types
 
@@ -489,11 +489,17 @@ class ModelCNN:
         index_num = math.ceil(dataset_size / self.batch_size)
         total_cost = 0
         for index in range(index_num):
+            timer = common.Timer()
             data_x = dataset_x[index * self.batch_size:(index + 1) * self.batch_size]
             data_m = dataset_m[index * self.batch_size:(index + 1) * self.batch_size]
             cost, _ = self.train_step(data_x, data_m, epoch, self.iteration, learning_rate, momentum, decay)
             if math.isnan(cost):
                 raise Exception("ERROR: Cost is NaN")
+            # model_cnn.py:466. train_step returns once the costs are on the host; the device may still be in the backward
+            # sweep, so "took" is the host's time per step (the steady-state step time once the queue is full)
+            if logging.verbose_enabled():
+                logging.verbose("Batch %i.%i - iteration: %i cost:" % (epoch, index * self.batch_size, self.iteration), cost,
+                                "took: %i ms" % timer.current_ms())
             total_cost += cost
             self.iteration += 1
         return total_cost

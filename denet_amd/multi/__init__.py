@@ -44,6 +44,44 @@ class DataParallel:
         self.force_collectives = False     # run the collectives even at world_size 1 (single-GPU smoke of the path)
         self._buckets = None
         self._pending = []
+        self._timing = None                # [(event before the wait, event after)] per step while start_timing() is on
+        self._step_bytes = 0
+        self._step_colls = 0
+
+    # ---- instrumentation (bench.py) ----------------------------------------------------------------------
+    def start_timing(self):
+        """from now on finish_step brackets its wait for the collectives with two HIP events on the compute stream"""
+        self._timing = []
+
+    def exposed_ms_per_step(self):
+        """mean time the compute stream stood in finish_step's wait: collective time the backward pass did not hide"""
+        if not self._timing:
+            return 0.0
+        import torch
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._timing) / len(self._timing)
+
+    def bytes_per_step(self):
+        return int(self._step_bytes)
+
+    def collectives_per_step(self):
+        return int(self._step_colls)
+
+    def gather_floats(self, value):
+        """[value of rank 0, value of rank 1, ...] on every rank"""
+        import torch
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        mine = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+        if self.world_size == 1:
+            return [float(value)]
+        got = [torch.zeros_like(mine) for _ in range(self.world_size)]
+        self.dist.all_gather(got, mine)
+        return [float(t.item()) for t in got]
+
+    def _all_reduce(self, t):
+        self._step_bytes += t.numel() * t.element_size()
+        self._step_colls += 1
+        return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, async_op=True)
 
     # ---- setup -------------------------------------------------------------------------------------------
     def broadcast_state(self, model):
@@ -97,6 +135,8 @@ class DataParallel:
             for lo, hi, layer in self._buckets:
                 self._trigger[id(layer)] = (lo, hi)
         self._pending = []
+        self._step_bytes = 0
+        self._step_colls = 0
 
     def layer_done(self, model, layer):
         r = self._trigger.get(id(layer))
@@ -105,7 +145,7 @@ class DataParallel:
             # the bucket holds convolution weight gradients only: they are produced on the wgrad stream, so the
             # collective is ordered behind THAT stream and the data-gradient chain on the compute stream never waits
             with self._wgrad_ctx():
-                self._pending.append(self.dist.all_reduce(model.G[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True))
+                self._pending.append(self._all_reduce(model.G[lo:hi]))
 
     @staticmethod
     def _wgrad_ctx():
@@ -121,12 +161,19 @@ class DataParallel:
         if self.world_size > 1 or self.force_collectives:
             d = self.dist
             if model.n_trainable > model.n_weights:
-                self._pending.append(d.all_reduce(model.G[model.n_weights:model.n_trainable], op=d.ReduceOp.SUM,
-                                                  async_op=True))
-            self._pending.append(d.all_reduce(model.S, op=d.ReduceOp.SUM, async_op=True))
+                self._pending.append(self._all_reduce(model.G[model.n_weights:model.n_trainable]))
+            self._pending.append(self._all_reduce(model.S))
+            ev = None
+            if self._timing is not None:
+                import torch
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             for w in self._pending:
                 w.wait()
             self._scale(model.S, 1.0 / self.world_size)
+            if ev is not None:
+                ev[1].record()
+                self._timing.append(ev)
         self._pending = []
 
     def _scale(self, t, s):

@@ -57,12 +57,13 @@ class KernelProfile:
         torch.cuda.synchronize()
         L = _L()
         n = L.denet_conv_profile_count()
-        assert n == len(self.flops), "igemm launches (%d) != convolution calls (%d)" % (n, len(self.flops))
+        assert n == len(self.flops), "profiled launches (%d) != convolution calls (%d)" % (n, len(self.flops))
         agg = {}
         ms, v = ctypes.c_float(), [ctypes.c_int() for _ in range(4)]
         for i, flops in enumerate(self.flops):
             check(L.denet_conv_profile_read(i, ctypes.byref(ms), *[ctypes.byref(x) for x in v]), "conv_profile_read")
-            name = "igemm_kernel<%d, %d, %d, 2, 2, %d>" % tuple(x.value for x in v)
+            name = {10: "wino2f_ws_kernel", 11: "wino2f_wgrad_kernel"}.get(v[0].value) or \
+                "igemm_kernel<%d, %d, %d, 2, 2, %d>" % tuple(x.value for x in v)
             a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
             a["launches"] += 1
             a["ms"] += ms.value
@@ -336,7 +337,7 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
     # with a launch of the chosen one (run-to-run determinism)
     tile = _wino_tile(0, g, direct, lambda t: conv_wino_fwd(x, w, bias, add, out=y, tile=t, relu=relu))
     if tile:
-        if PROFILE is not None and tile != FUSED2:      # (the fused kernels are no igemm launches: not in this profile)
+        if PROFILE is not None:
             PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])     # the FLOPs its batched GEMM really executes
         u = v_keep = None
         if cache is not None:
@@ -624,7 +625,7 @@ def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None,
 
     tile = _wino_tile(1, g, direct, lambda t: conv_wino_dgrad(dy, w, add, out=dx, tile=t))
     if tile:
-        if PROFILE is not None and tile != FUSED2:      # (the fused kernels are no igemm launches: not in this profile)
+        if PROFILE is not None:
             PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])
         u = None
         if cache is not None:
@@ -655,7 +656,7 @@ def conv_wgrad(x, dy, w_shape, stride=1, pad=0, s_real=None, out=None, logical=N
 
     tile = _wino_tile(2, g, direct, lambda t: conv_wino_wgrad(x, dy, out=dw, tile=t))
     if tile:
-        if PROFILE is not None and tile != FUSED2:      # (the fused kernels are no igemm launches: not in this profile)
+        if PROFILE is not None:
             PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])
         v = None
         if cache is not None and cache.get("V_tile") == tile:
@@ -1031,6 +1032,19 @@ def build_samples(corner_pr, corner_threshold, sample_count, max_corners=1024, l
                                    corner_threshold, sample_count, max_corners, local_max, stream_ptr()),
           "build_samples")
     return box, absd, count
+
+
+def build_samples_stats(corner_pr, sample_count, max_corners=1024):
+    """diagnostics of the last build_samples call of this geometry: (corners kept [B, Cn] int32, pair candidates [B] int64),
+    host tensors (synchronises)"""
+    B, _, cn, H, W = corner_pr.shape
+    nbytes = _L().denet_build_samples_workspace_bytes(B, cn, H, W, max_corners, sample_count)
+    ws = WS.get("samples", nbytes)
+    nc = torch.empty((B, cn), dtype=torch.int32, device="cuda")
+    cand = torch.empty((B,), dtype=torch.int32, device="cuda")
+    check(_L().denet_build_samples_stats(ptr(ws), ws.numel(), B, cn, H, W, max_corners, sample_count, ptr(nc), ptr(cand),
+                                         stream_ptr()), "build_samples_stats")
+    return nc.cpu(), cand.cpu().to(torch.int64) & 0xFFFFFFFF
 
 
 def samples_finish_host(box, absd, count, H, W):

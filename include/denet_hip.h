@@ -354,6 +354,11 @@ size_t denet_build_samples_workspace_bytes(int B, int Cn, int H, int W, int max_
 int denet_build_samples(const float* corner_pr, int* out_box, float* out_absd, int* out_count, void* workspace,
                         size_t workspace_bytes, int B, int Cn, int H, int W, float corner_threshold, int sample_count,
                         int max_corners, int local_max, hipStream_t stream);
+/* diagnostics of the LAST denet_build_samples call on `workspace` (same geometry): corners kept per (image, type) after the
+ * max_corners truncation (denet_sparse.cc:526-530) -> ncorner_out [B*Cn] int32, candidate boxes generated per image by the
+ * pair search (:337-373) -> candidates_out [B] uint32; device buffers, copies on `stream`. */
+int denet_build_samples_stats(const void* workspace, size_t workspace_bytes, int B, int Cn, int H, int W, int max_corners,
+                              int sample_count, int* ncorner_out, unsigned* candidates_out, hipStream_t stream);
 int denet_host_cluster_samples(const float* samples_host, int n, float threshold, int output_num, float* out_host,
                                int* out_count);
 int denet_samples_finish_host(const int* box_host, const float* absd_host, const int* count_host, int B,

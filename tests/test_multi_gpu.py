@@ -196,3 +196,33 @@ def test_two_rank_state_averaging_equals_emulation(hip, tmp_path, heuristic_kern
         ref = ((getattr(reps[0]["m"], k) + getattr(reps[1]["m"], k)) * 0.5).cpu()
         err = float((got[0][k] - ref).abs().max() / (ref.abs().max() + 1e-30))
         assert err <= 1e-6, "%s differs from the emulated averaging: %.2e" % (k, err)
+
+
+def test_bench_self_launches_two_ranks_on_a_shared_gpu():
+    """LAUNCH-PATH test, never a scaling measurement. `python bench.py --gpus 2` WITHOUT a launcher must start its own two
+    ranks (the reference's driver spawns its workers itself, denet/model/train_multi.py:96-145, denet/multi/worker.py:138-243),
+    rendezvous on a free local port, run the bucketed gradient exchange inside the step and have rank 0 print ONE JSON line
+    whose n_gpus is the process group's world size. A one-GPU box cannot host two RCCL ranks, so `--share-gpu` puts both
+    ranks on cuda:0 and lets gloo carry the tensors; everything else (full-size DeNet-34 skip, B = 32 per rank, buckets,
+    event-timed exposed collective time, max over ranks) is the code path of an 8-GPU run."""
+    import json
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--share-gpu"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=840)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    dp = d["data_parallel"]
+    assert dp["world_size"] == 2 and dp["backend"] == "gloo" and "launch_path_test_only" in dp
+    assert len(dp["ms_per_step_per_rank"]) == 2 and len(dp["exposed_collective_ms_per_step_per_rank"]) == 2
+    # the whole flat gradient (~137 MB for DeNet-34 skip) + the BN running statistics cross the exchange every step
+    assert dp["allreduce_bytes_per_step"] > 100e6 and dp["collectives_per_step"] >= 4
+    assert abs(sum(dp["bucket_bytes"]) + 0 - dp["allreduce_bytes_per_step"]) < 0.05 * dp["allreduce_bytes_per_step"]
+    for k in ("roofline", "cpu_baseline", "warm_regime"):          # rank 0 at N = 1 only
+        assert k not in d
