@@ -14,6 +14,10 @@ Extra legs (rank 0, N=1 only; outside the timed region):
   roofline      the dominant kernel (implicit-GEMM convolution instantiation with the largest total time) is timed
                 live with HIP events on the launch stream over `steps` further instrumented steps;
                 achieved = algorithmic FLOPs per launch / average launch duration; peak = fp32 MFMA 157.3 TFLOP/s.
+  warm_regime / stress_regime
+                the same step with the corner head held in a firing regime (40 / 1400 cells per corner type and image above
+                the threshold; the second takes the max_corners truncation branch): RoI proposal on the GPU, host hand-off
+                phases under the reference's names.
   cpu_baseline  the numpy/C++ oracle (oracle/, a CPU restatement of the reference path, kind "port") runs ONE
                 training step of the same model at batch 1 on the host cores.
 """
@@ -79,11 +83,11 @@ def self_launch(n):
 
 def regime_leg(args, xd, metas, target_cells, lr, mom, decay):
     """The headline step with the corner head of DNC held in a firing regime: `target_cells` cells per corner type and image
-    above the corner threshold. The corner rows of the DNC convolution (random weights, zoo.warm_corner_head) get the bias
-    that gives the target on this batch (bisection over steps with learning rate 0) and are then FROZEN: after every step
-    their weights / bias are restored and their momentum zeroed (two tiny copies) - the corner cost would otherwise train
-    the head cold within the warm-up steps (lr 0.1 x cost factor) and the leg would time a second cold regime. Everything
-    else trains as in `value`: same kernels, same host work."""
+    above the corner threshold. The corner rows of the DNC convolution (random weights, zoo.warm_corner_head) are FROZEN: after every step
+    their weights are restored, their momentum zeroed and their bias re-set by a controller (hold() below; a few tiny device
+    ops, no host synchronisation) - the corner cost would otherwise train the head cold within the warm-up steps (lr 0.1 x
+    cost factor) and the leg would time a second cold regime. Everything else trains as in `value`: same kernels, same
+    host work."""
     import math
     import torch
     from denet_amd import ops
@@ -94,6 +98,12 @@ def regime_leg(args, xd, metas, target_cells, lr, mom, decay):
     dns = [l for l in m.layers if l.type_name == "denet-sparse"][0]
     conv, cn = dnc.layers[-1], dnc.corner_num
     log_thr = math.log(dns.corner_threshold)
+    # The synthetic batch has no image content a corner head could learn, so its cost can only push every logit towards "no
+    # corner" - through the frozen rows into the backbone, 10 logit units within 20 steps (measured: the bias controller below
+    # ran away to -39 and the regime collapsed). The corner cost factor (DNC costFactor, denet_corner.py:24) is therefore 0 in
+    # these legs: its loss and gradient kernels run as always and write a zero gradient; the backbone trains on the detection
+    # cost alone.
+    dnc.cost_factor = 0.0
     random.seed(1)
     it = [0]
 
@@ -106,24 +116,30 @@ def regime_leg(args, xd, metas, target_cells, lr, mom, decay):
         # corner_pr [B, 2, types, H, W] log-probabilities, plane 1 = "corner" (denet_sparse.cc:503-511)
         return (dnc.corner_pr[:, 1] > log_thr).sum(dim=(2, 3)).float()
 
-    lo, hi = -4.0, 14.0            # bias: more cells <-> fewer cells
-    for _ in range(12):
-        mid = 0.5 * (lo + hi)
-        conv.beta.dev[:cn].fill_(mid)
-        step(0.0)
-        if float(cells().mean()) > target_cells:
-            lo = mid
-        else:
-            hi = mid
-    conv.beta.dev[:cn].fill_(lo)
-    keep_w, keep_b = conv.omega.dev[:cn].clone(), conv.beta.dev[:cn].clone()
+    rows = conv.omega.dev_shape[0]             # filters are [Kp][R][S][Cp] inside the flat parameter buffer: row = output channel
+    w_dev, w_mom = conv.omega.dev.view(rows, -1), conv.omega.mom.view(rows, -1)
+    keep_w = w_dev[:cn].clone()
+    bias = conv.beta.dev[:cn].clone()
+    kth = max(1, int(round(target_cells * BATCH_PER_GPU)))
+    x_thr = 0.5 * math.log(math.expm1(-log_thr))
 
     def hold():
-        conv.omega.dev[:cn].copy_(keep_w)
-        conv.beta.dev[:cn].copy_(keep_b)
-        conv.omega.mom[:cn].zero_()
+        """frozen corner rows + a one-step bias controller, all on the device (no host synchronisation): the backbone keeps
+        training (detection cost), its features drift, so the bias of each corner type follows - it is set to the value that
+        puts the target number of cells of THIS step's corner map above the threshold (plane 1 = log sigmoid(-2x): the k-th largest log-probability v of a type corresponds to the
+        logit x_v = log(expm1(-v)) / 2, and the bias moves by x_thr - x_v)"""
+        w_dev[:cn].copy_(keep_w)
+        w_mom[:cn].zero_()
         conv.beta.mom[:cn].zero_()
+        plane = dnc.corner_pr[:, 1].transpose(0, 1).reshape(cn, -1)                 # [types, B*H*W]
+        v = torch.sort(plane, dim=1, descending=True).values[:, kth - 1].clamp(max=-1e-6)
+        x_v = (0.5 * torch.log(torch.expm1(-v))).clamp(min=-12.0, max=12.0)
+        bias.add_(x_thr - x_v)
+        conv.beta.dev[:cn].copy_(bias)
 
+    for _ in range(4):             # calibration on this batch: no learning, the controller alone
+        step(0.0)
+        hold()
     for _ in range(max(args.warmup, 2)):
         step(lr)
         hold()
@@ -175,8 +191,10 @@ def regime_leg(args, xd, metas, target_cells, lr, mom, decay):
             # host phases of the RoI hand-off per step, the reference's names (denet_sparse.py:127-161): model = queue the proposal
             # + wait for the device (forward pass up to the corner map included), build = host epilogue of build_samples
             "host_phase_ms_per_step": {k: round(v / args.steps, 3) for k, v in sorted(phases.items())},
-            "corner_bias": round(lo, 4), "final_cost": round(float(cost), 5),
-            "note": "same step as `value`; corner rows of the DNC convolution frozen at a bias calibrated on this batch"}
+            "corner_bias_per_type": [round(float(b), 3) for b in bias.tolist()], "final_cost": round(float(cost), 5),
+            "note": "same step and kernels as `value`; corner rows of the DNC convolution frozen, their bias follows a one-step "
+                    "on-device controller that keeps the target number of cells above the threshold, corner cost factor 0 "
+                    "(regime_leg in bench.py says why)"}
 
 
 def main():
