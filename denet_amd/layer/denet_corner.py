@@ -59,36 +59,34 @@ class DeNetCornerLayer(AbstractLayer):
         return json
 
     def get_target(self, model, samples, metas):
-        corner_pr = numpy.zeros(self.corner_shape, dtype=numpy.float32)
-        for b, meta in enumerate(metas):
-            for bbox in meta["bbox"]:
-                x0 = int(round(bbox[0] * self.width))
-                y0 = int(round(bbox[1] * self.height))
-                x1 = max(x0, int(round(bbox[2] * self.width)) - 1)
-                y1 = max(y0, int(round(bbox[3] * self.height)) - 1)
-                x0_valid = (x0 >= 0 and x0 < self.width)
-                y0_valid = (y0 >= 0 and y0 < self.height)
-                x1_valid = (x1 >= 0 and x1 < self.width)
-                y1_valid = (y1 >= 0 and y1 < self.height)
-                if x0_valid and y0_valid:
-                    corner_pr[b, 1, 0, y0, x0] = 1.0
-                if x1_valid and y0_valid:
-                    corner_pr[b, 1, 1, y0, x1] = 1.0
-                if x0_valid and y1_valid:
-                    corner_pr[b, 1, 2, y1, x0] = 1.0
-                if x1_valid and y1_valid:
-                    corner_pr[b, 1, 3, y1, x1] = 1.0
-                if self.use_center:
-                    cx = int(round((bbox[0] + bbox[2]) * 0.5 * self.width))
-                    cy = int(round((bbox[1] + bbox[3]) * 0.5 * self.height))
-                    if cx >= 0 and cx < self.width and cy >= 0 and cy < self.height:
-                        corner_pr[b, 1, 4, cy, cx] = 1.0
-
-        corner_pr[:, 0, :, :, :] = 1.0 - corner_pr[:, 1, :, :, :]
-        corner_pr /= self.width * self.height * self.corner_num
+        """corner-target map of denet_corner.py:81-123, rasterised for all boxes of the batch at once: cell =
+        round-half-to-even(coordinate * size) (numpy.rint == Python's round), far corner = max(near, cell - 1), a corner is
+        written when both of its cells are on the map; plane 1 = corner, plane 0 = 1 - plane 1, everything divided by
+        W * H * corner_num. Pinned against the reference's own method (tests/golden/make_layer_method_fixtures.py)."""
+        B, _, cn, H, W = self.corner_shape
+        pos = numpy.zeros((B, cn, H, W), dtype=numpy.float32)
+        counts = [len(m["bbox"]) for m in metas]
+        if sum(counts) > 0:
+            box = numpy.concatenate([numpy.asarray(m["bbox"], dtype=numpy.float64).reshape(-1, 4) for m in metas], axis=0)
+            img = numpy.repeat(numpy.arange(len(metas)), counts)
+            x0 = numpy.rint(box[:, 0] * W).astype(numpy.int64)
+            y0 = numpy.rint(box[:, 1] * H).astype(numpy.int64)
+            x1 = numpy.maximum(x0, numpy.rint(box[:, 2] * W).astype(numpy.int64) - 1)
+            y1 = numpy.maximum(y0, numpy.rint(box[:, 3] * H).astype(numpy.int64) - 1)
+            points = [(x0, y0), (x1, y0), (x0, y1), (x1, y1)]                    # TL, TR, BL, BR
+            if self.use_center:
+                points.append((numpy.rint((box[:, 0] + box[:, 2]) * 0.5 * W).astype(numpy.int64),
+                               numpy.rint((box[:, 1] + box[:, 3]) * 0.5 * H).astype(numpy.int64)))
+            for kind, (px, py) in enumerate(points):
+                on = (px >= 0) & (px < W) & (py >= 0) & (py < H)
+                pos[img[on], kind, py[on], px[on]] = 1.0
+        corner_pr = numpy.empty(self.corner_shape, dtype=numpy.float32)
+        corner_pr[:, 1] = pos
+        corner_pr[:, 0] = 1.0 - pos
+        corner_pr /= W * H * cn
         if self.dropout > 0.0:
-            mask = numpy.random.binomial(1, 1.0 - self.dropout, (self.corner_shape[0], self.corner_shape[2],
-                                                                 self.corner_shape[3], self.corner_shape[4])).astype(numpy.float32)
+            # denet_corner.py:113-116: one Bernoulli(1 - dropout) mask per cell and corner type from numpy's global generator
+            mask = numpy.random.binomial(1, 1.0 - self.dropout, (B, cn, H, W)).astype(numpy.float32)
             corner_pr *= mask[:, None, :, :, :] / (1.0 - self.dropout)
         return numpy.array([], dtype=numpy.int64), corner_pr.flatten()
 

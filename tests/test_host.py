@@ -536,3 +536,109 @@ def test_train_multi_sharding():
     pads = [random.randint(0, 39) for _ in range(48 - 40)]
     assert (parts[0] + parts[1])[:0] == [] and sorted(parts[0][:18] + parts[1][:18]) == list(range(36))
     assert parts[0][18:] == [36, 37, 38, 39] + pads[:2] and parts[1][18:] == pads[2:]
+
+
+# ---- methods of the reference's layer classes, executed in the build container (tests/golden/make_layer_method_fixtures.py) ----
+def _layer_method_fixtures():
+    with open(os.path.join(ROOT, "tests", "golden", "layer_method_fixtures.json")) as f:
+        return json.load(f)
+
+
+def test_corner_target_matches_executed_reference_method():
+    """DeNetCornerLayer.get_target of the build against the reference's own method (denet_corner.py:81-123), which the fixture
+    script compiled from its AST node and ran: positive cells, the two distinct target values, and the oracle's restatement"""
+    fix = _layer_method_fixtures()["corner_target"]
+    m = zoo.denet34(1, "skip", 128)
+    dnc = [l for l in m.layers if l.type_name == "denet-corner"][0]
+    assert len(fix["cases"]) >= 5
+    for c in fix["cases"]:
+        B, H, W, cn = c["B"], c["H"], c["W"], 5 if c["use_center"] else 4
+        dnc.corner_shape, dnc.width, dnc.height, dnc.use_center, dnc.corner_num = (B, 2, cn, H, W), W, H, c["use_center"], cn
+        for got in (dnc.get_target(m, None, c["metas"])[1].reshape(B, 2, cn, H, W), OL.corner_target(c["metas"], (B, 2, cn, H, W))):
+            assert got.dtype == np.float32
+            assert np.argwhere(got[:, 1] > 0).tolist() == c["positive_cells"]
+            assert np.array_equal(got[:, 0] > 0, ~(got[:, 1] > 0))
+            assert sorted(set(float(v) for v in np.unique(got))) == c["distinct_values"]
+            assert float(got.astype(np.float64).sum()) == c["sum"]
+
+
+def _fixture_model(sn, random_sample, sample_gt, B, class_num=80, dnd="DND[0.5,1,1]"):
+    head = zoo.DENET34_SKIP_DESC.replace("DNS[7,24,0.01,0.1]", "DNS%s[7,%d,0.01,%r]" % ("" if sample_gt else ".G", sn, random_sample))
+    return zoo.denet34(B, "skip", 128, class_num=class_num, head_desc=head.replace("DND[0.5,1,1]", dnd))
+
+
+def test_roi_editing_matches_executed_reference_method():
+    """the training-time RoI list editing (random.sample trim, random boxes, ground truth from the tail) of the build - the
+    Python path, the native host call and the oracle - against DeNetSparseLayer.get_target of the reference itself
+    (denet_sparse.py:164-207, executed by the fixture script): edited lists value for value, and the stdlib generator must
+    stand at the same position afterwards"""
+    fix = _layer_method_fixtures()["sparse_get_target"]
+    assert len(fix["cases"]) >= 6
+    for c in fix["cases"]:
+        sn, B = c["sample_num"], len(c["metas"])
+        S = sn * sn
+        m = _fixture_model(sn, c["random_sample"], c["sample_gt"], B)
+        dns = [l for l in m.layers if l.type_name == "denet-sparse"][0]
+        assert dns.sample_count == S and dns.sample_gt == c["sample_gt"] and dns.random_sample == c["random_sample"]
+        want = [[(p, tuple(bx)) for p, bx in l] for l in c["edited"]]
+        prs = [np.array([s[0] for s in l], dtype=np.float64) for l in c["samples"]]
+        boxes = [np.array([s[1] for s in l], dtype=np.float64).reshape(-1, 4) for l in c["samples"]]
+        # Python path
+        random.seed(c["seed"])
+        out_pr, out_bx = dns.edit_samples(prs, boxes, c["metas"])
+        assert [random.random() for _ in range(3)] == c["random_after"]
+        got = [[(float(p), tuple(b)) for p, b in zip(pr.tolist(), bx.tolist())] for pr, bx in zip(out_pr, out_bx)]
+        assert got == want
+        # native host call (denet_host_edit_samples): the detector rows are float32 there, like the reference's C++ hand-over
+        det = np.zeros((B, S, 5), dtype=np.float32)
+        cnt = np.zeros(B, dtype=np.int32)
+        for b, l in enumerate(c["samples"]):
+            cnt[b] = len(l)
+            for i, (p, bx) in enumerate(l):
+                det[b, i, 0], det[b, i, 1:] = p, bx
+        if dns._native_edit_ok(c["metas"]):
+            random.seed(c["seed"])
+            f32 = np.zeros((B * S, 4), dtype=np.float32)
+            n_pr, n_bx = dns.edit_samples_native(det, cnt, c["metas"], f32)
+            assert [random.random() for _ in range(3)] == c["random_after"]
+            for b in range(B):
+                w_pr = np.array([s[0] for s in want[b]])
+                w_bx = np.array([s[1] for s in want[b]])
+                from_det = w_pr != 1.0                    # detector / random rows passed through float32; ground truth is exact
+                assert np.array_equal(n_pr[b], w_pr)
+                assert np.array_equal(n_bx[b][~from_det], w_bx[~from_det])
+                assert np.array_equal(n_bx[b][from_det].astype(np.float32), w_bx[from_det].astype(np.float32))
+            np.testing.assert_array_equal(f32.reshape(B, S, 4), np.array([[s[1] for s in l] for l in want], dtype=np.float32))
+        # the oracle's restatement
+        random.seed(c["seed"])
+        ol = OL.edit_samples([[(p, tuple(bx)) for p, bx in l] for l in c["samples"]], c["metas"], S, c["random_sample"], c["sample_gt"])
+        assert [random.random() for _ in range(3)] == c["random_after"]
+        assert [[(float(p), tuple(float(v) for v in bx)) for p, bx in l] for l in ol] == want
+
+
+def test_detect_targets_match_executed_reference_method():
+    """RoI -> class / fitness / box-regression targets: DeNetDetectLayer.get_target of the build (native host path and numpy
+    path) and the oracle against the reference's own method loop (denet_detect.py:147-236, executed by the fixture script with
+    the IoU matrix of theano_util.py:38-59 evaluated in numpy float32), byte for byte"""
+    fix = _layer_method_fixtures()["detect_target"]
+    assert len(fix["cases"]) >= 5
+    for c in fix["cases"]:
+        sn, ncls, B = c["sample_num"], c["class_num"], len(c["metas"])
+        dnd_desc = "DND%s[0.5,1,%d%s]" % (".J" if c["use_jointfit"] else "", 1 if c["use_bbox_reg"] else 0, ",0.5" if c["use_indfit"] else "")
+        m = _fixture_model(sn, 0.1, True, B, class_num=ncls, dnd=dnd_desc)
+        dns = [l for l in m.layers if l.type_name == "denet-sparse"][0]
+        dnd = [l for l in m.layers if l.type_name == "denet-detect"][0]
+        dnd.overlap_threshold = tuple(c["overlap_threshold"])
+        assert (dnd.use_jointfit, dnd.use_bbox_reg, dnd.use_indfit) == (c["use_jointfit"], c["use_bbox_reg"], c["use_indfit"])
+        lists = [[(p, tuple(bx)) for p, bx in l] for l in c["sample_bbox_list"]]
+        dns.sample_pr, dns.sample_boxes = dns._from_lists(lists)
+        want = np.frombuffer(bytes.fromhex(c["yt_value_f32_hex"]), dtype="<f4")
+        assert want.size == c["yt_len"]
+        idx, val = dnd.get_target(m, None, c["metas"])
+        assert idx.size == 0 and val.dtype == np.float32
+        np.testing.assert_array_equal(val, want)
+        tg = OL.detect_target(c["metas"], lists, B, sn, ncls, tuple(c["overlap_threshold"]), c["use_bbox_reg"], c["use_jointfit"],
+                              c["use_indfit"])
+        parts = [tg[0].flatten()] + ([tg[1].flatten(), tg[2].flatten()] if c["use_bbox_reg"] else []) + \
+                ([tg[3].flatten()] if c["use_indfit"] else [])
+        np.testing.assert_array_equal(np.concatenate(parts), want)

@@ -63,10 +63,13 @@ def _assert_same_ranking(cpp_rows, cpp_boxes, naive_full, count, tag):
         assert np.float32(row[0]) == w[0], (tag, i, row[0], w[0])
     full_groups = NV.tie_groups(naive_full)
     pos = 0
+    stats = {"multi": 0, "cut": 0}         # tie groups with > 1 member inside the list / a group straddling the top-K cut
     for score, members in full_groups:
         if pos >= len(cpp_rows):
             break
         n = min(len(members), len(cpp_rows) - pos)
+        stats["multi"] += int(len(members) > 1)
+        stats["cut"] += int(n < len(members))
         got = {tuple(int(v) for v in cpp_boxes[pos + k]) for k in range(n)}
         assert len(got) == n, (tag, "duplicate boxes inside a tie group")
         if n == len(members):
@@ -80,6 +83,7 @@ def _assert_same_ranking(cpp_rows, cpp_boxes, naive_full, count, tag):
             assert tuple(np.float32(v) for v in b) == (np.float32(x0 / W), np.float32(y0 / H), np.float32((x1 + 1) / W),
                                                       np.float32((y1 + 1) / H)), (tag, pos + k)
         pos += n
+    return stats
 
 
 def test_build_samples_cpp_vs_independent_naive_implementation():
@@ -90,6 +94,7 @@ def test_build_samples_cpp_vs_independent_naive_implementation():
     from oracle import build_samples_naive as NV
     rng = np.random.RandomState(20260928)
     n_cases = 0
+    tally = {k: {False: 0, True: 0} for k in ("images", "images_with_tie_groups", "images_with_cut_tie_group")}
     for case in range(260):
         Cn = 5 if case % 5 == 4 else 4
         H = int(rng.randint(6, 21))
@@ -109,10 +114,19 @@ def test_build_samples_cpp_vs_independent_naive_implementation():
         for b in range(B):
             corners = [NV.find_corners(pr, b, ci, NV._logf(np.float32(thr)), max_corners, local_max) for ci in range(Cn)]
             full = NV.rank(NV.search_corners(pr, b, corners))
-            _assert_same_ranking(out[b, :cnt[b]], box[b, :cnt[b]], full, sample_num * sample_num,
-                                 (case, b, Cn, H, W, mu, quant, local_max, max_corners, sample_num, thr))
+            st = _assert_same_ranking(out[b, :cnt[b]], box[b, :cnt[b]], full, sample_num * sample_num,
+                                      (case, b, Cn, H, W, mu, quant, local_max, max_corners, sample_num, thr))
             n_cases += 1
+            tally["images_with_tie_groups"][bool(quant)] += int(st["multi"] > 0)
+            tally["images_with_cut_tie_group"][bool(quant)] += int(st["cut"] > 0)
+            tally["images"][bool(quant)] += 1
     assert n_cases >= 380
+    # How far "RoI lists bit-identical to the reference" reaches: inside a group of exactly equal fp32
+    # scores the reference's std::partial_sort leaves the order - and, for a group cut by the top-K limit, the membership -
+    # unspecified, so such groups are compared as sets above. Continuous random maps: distinct |pr_f - pr_t| still collide
+    # in fp32 now and then, and the cut hits such a group only rarely; quantised maps (built to tie) do both often.
+    print("tie-group tally (continuous maps / quantised maps):", {k: (v[False], v[True]) for k, v in tally.items()})
+    assert tally["images_with_cut_tie_group"][True] > 0, "the quantised maps no longer exercise a tie group at the cut"
 
 
 def test_build_samples_clustering_cpp_vs_naive():
