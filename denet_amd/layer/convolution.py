@@ -181,12 +181,18 @@ class ConvLayer(AbstractLayer):
         x = self.input.data
         st, pad, sr = self.stride[0], self.pad, self.filter_shape[3]
         if self.enabled and self.omega.grad is not None:
+            # the first layer of the network has no data gradient: its filter gradient is the tail of the backward sweep on the
+            # second stream, and the bias column sums (a pass over the largest tensor of the network) run beside it on the
+            # compute stream, which has nothing left to do, instead of behind it
+            tail = not getattr(self.input, "requires_grad", True)
             with ops.wgrad_stream():        # independent of the data-gradient chain below
                 ops.conv_wgrad(x, dy, self.omega.dev_shape, stride=st, pad=pad, s_real=sr,
                                out=self.omega.grad.view(self.omega.dev_shape), logical=self._logical(),
                                cache=self._cache())
-                if self.use_bias:
+                if self.use_bias and not tail:
                     ops.colsum(dy.view(-1, self.kp), out=self.beta.grad)
+            if self.use_bias and tail:
+                ops.colsum(dy.view(-1, self.kp), out=self.beta.grad)
         if getattr(self.input, "requires_grad", True):
             self.input.grad = ops.conv_dgrad(dy, self._w(), tuple(x.shape), add=self.input.grad, stride=st, pad=pad,
                                              s_real=sr, logical=self._logical(), cache=self._cache())

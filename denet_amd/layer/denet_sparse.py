@@ -23,6 +23,10 @@ TAP_THEANO = 0   # denet_sparse.py:72-84 (Theano CPU path, canonical per north s
 TAP_CUDA = 1     # denet_sparse_op.py:65-71
 
 
+# the cold-detector outcome of the RoI hand-off is prepared ahead of time (DeNetSparseLayer._speculate_cold); 0 switches it off
+SPECULATE_COLD = os.environ.get("DENET_SPECULATE_COLD", "1") != "0"
+
+
 class PyRandomMirror:
     """Vectorised draws from the stdlib `random` stream. numpy's RandomState is the same MT19937 with the same
     53-bit double construction as CPython's `random`, so the generator state can be moved across, doubles drawn
@@ -327,15 +331,57 @@ class DeNetSparseLayer(AbstractLayer):
         else:
             prep["off"], prep["gt"] = numpy.zeros(len(metas) + 1, dtype=numpy.int32), numpy.zeros((1, 4))
         self._prep = prep
+        self._spec = None
+        if SPECULATE_COLD and get_train() and self._native_edit_ok(metas) and self._on_device():
+            self._speculate_cold(metas, prep)
+
+    @staticmethod
+    def _on_device():
+        import torch
+        return torch.cuda.is_available()
+
+    def _speculate_cold(self, metas, prep):
+        """The cold-detector case of the RoI hand-off, prepared while the device runs the backbone: if the corner detector
+        proposes nothing (the regime of the first training epochs) the edited list is all random boxes + ground
+        truth and depends on the stdlib generator's state only. It is built here on a COPY of that state (same native
+        call as the real path), uploaded on a side stream, and adopted in get_target when the device reports zero
+        proposals for every image and the generator has not moved meanwhile (PyRandomMirror.fresh) - the device then
+        waits for one small device-to-host copy instead of the whole host edit + upload. Any other outcome discards it."""
+        import torch
+        B, S = self.batch_size, self.sample_count
+        if getattr(self, "_pinned_spec", None) is None:
+            self._pinned_spec = torch.empty((B * S, 4), dtype=torch.float32).pin_memory()
+            self._zero_det = numpy.zeros((B, S, 5), dtype=numpy.float32)
+            self._zero_cnt = numpy.zeros(B, dtype=numpy.int32)
+        mirror = PyRandomMirror()
+        out_pr, out_box = self._native_edit(mirror, self._zero_det, self._zero_cnt, prep, self._pinned_spec.numpy())
+        side = ops.side_stream(2)
+        with torch.cuda.stream(side):
+            dev = self._pinned_spec.cuda(non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._spec = {"metas": metas, "mirror": mirror, "pr": out_pr, "box": out_box, "dev": dev, "ev": ev}
+
+    def _native_edit(self, mirror, det, cnt, prep, out_f32):
+        """denet_host_edit_samples on the generator state held by `mirror` (advanced in place)"""
+        from .. import lib as _lib
+        B, S = self.batch_size, self.sample_count
+        n_keep = S - math.floor(self.random_sample * S)
+        ws = numpy.empty(2 * S, dtype=numpy.int32)
+        off, gt = prep["off"], prep["gt"]
+        out_pr = numpy.empty((B, S), dtype=numpy.float64)
+        out_box = numpy.empty((B, S, 4), dtype=numpy.float64)
+        assert out_f32.dtype == numpy.float32 and out_f32.size == B * S * 4 and out_f32.flags.c_contiguous
+        _lib.check(_lib.load().denet_host_edit_samples(
+            mirror.key.ctypes.data, mirror.pos.ctypes.data, det.ctypes.data, cnt.ctypes.data, B, S, n_keep,
+            gt.ctypes.data, off.ctypes.data, int(bool(self.sample_gt)), ws.ctypes.data, out_pr.ctypes.data,
+            out_box.ctypes.data, out_f32.ctypes.data), "edit_samples")
+        return out_pr, out_box
 
     def edit_samples_native(self, det, cnt, metas, out_f32, defer_push=False):
         """edit_samples for the whole batch in one native host call (denet_host_edit_samples): same generator
         stream, same values. det [B,S,5] float32 rows (pr, box) of the detector, cnt [B]; out_f32 [B*S,4] float32
         receives the array build_bbox_array would produce. Returns (pr [B,S], boxes [B,S,4]) as float64."""
-        from .. import lib as _lib
-        B, S = self.batch_size, self.sample_count
-        n_keep = S - math.floor(self.random_sample * S)
-        ws = numpy.empty(2 * S, dtype=numpy.int32)
         det = numpy.ascontiguousarray(det, dtype=numpy.float32)
         cnt = numpy.ascontiguousarray(cnt, dtype=numpy.int32)
         prep = getattr(self, "_prep", None)
@@ -343,15 +389,8 @@ class DeNetSparseLayer(AbstractLayer):
             self.begin_step(metas)
             prep = self._prep
         self._prep = None
-        off, gt = prep["off"], prep["gt"]
-        out_pr = numpy.empty((B, S), dtype=numpy.float64)
-        out_box = numpy.empty((B, S, 4), dtype=numpy.float64)
-        assert out_f32.dtype == numpy.float32 and out_f32.size == B * S * 4 and out_f32.flags.c_contiguous
         mirror = prep["mirror"] if prep["mirror"].fresh() else PyRandomMirror()
-        _lib.check(_lib.load().denet_host_edit_samples(
-            mirror.key.ctypes.data, mirror.pos.ctypes.data, det.ctypes.data, cnt.ctypes.data, B, S, n_keep,
-            gt.ctypes.data, off.ctypes.data, int(bool(self.sample_gt)), ws.ctypes.data, out_pr.ctypes.data,
-            out_box.ctypes.data, out_f32.ctypes.data), "edit_samples")
+        out_pr, out_box = self._native_edit(mirror, det, cnt, prep, out_f32)
         if defer_push:
             self._pending_push = mirror      # handed back to the stdlib generator once the gather is queued
         else:
@@ -361,6 +400,19 @@ class DeNetSparseLayer(AbstractLayer):
     def _edit_and_upload_native(self, metas):
         import torch
         B, S = self.batch_size, self.sample_count
+        spec = self.__dict__.pop("_spec", None)
+        if self._raw_samples is None and spec is not None and spec["metas"] is metas and spec["mirror"].fresh():
+            # nothing proposed and the generator stands where the prepared list was drawn from: adopt it (see _speculate_cold)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(spec["ev"])
+            spec["dev"].record_stream(cur)
+            self.sample_pr, self.sample_boxes = list(spec["pr"]), list(spec["box"])
+            self.sample_bbox = spec["dev"]
+            self.sample_bbox_f32 = self._pinned_spec.numpy().reshape(B, S, 4)
+            self._pending_push = spec["mirror"]
+            self._prep = None
+            self.cold_hits = getattr(self, "cold_hits", 0) + 1
+            return
         if self._pinned is None:
             self._pinned = torch.empty((B * S, 4), dtype=torch.float32).pin_memory()
         if self._raw_samples is not None:

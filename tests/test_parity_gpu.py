@@ -623,6 +623,42 @@ def test_bn_pool_fusion_leaves_training_unchanged(hip):
     assert res[0][3] == res[1][3]
 
 
+def test_prepared_cold_roi_list_equals_the_hand_off_path(hip):
+    """DeNetSparseLayer._speculate_cold: with a cold corner detector (no proposals: weights as initialised) the edited RoI list
+    is prepared at the start of the step on a copy of the stdlib generator and adopted at the hand-off; a warm detector must
+    discard it. Three steps either way: the same RoI lists (reference loop: denet/layer/denet_sparse.py:184-201), the same
+    parameters bit for bit, the generator at the same position afterwards"""
+    from denet_amd.layer import denet_sparse as DS
+    res = {}
+    saved = DS.SPECULATE_COLD
+    try:
+        for warm in (False, True):
+            for spec in (True, False):
+                DS.SPECULATE_COLD = spec
+                random.seed(21)
+                model = zoo.denet34(2, "skip", 128, class_num=80, seed=1)
+                if warm:
+                    zoo.warm_corner_head(model, 4.0, 0.3)
+                model.build_train_func("nesterov")
+                dns = [l for l in model.layers if l.type_name == "denet-sparse"][0]
+                x, metas = zoo.synthetic_batch(2, 128, seed=11)
+                lists = []
+                for it in range(3):
+                    model.train_step(x, metas, 0, it, 0.0 if warm else 0.02, [0.9], 1e-4)      # lr 0: the warm head stays warm
+                    lists.append(dns.sample_bbox_list)
+                torch.cuda.synchronize()
+                hits = getattr(dns, "cold_hits", 0)
+                # (the first step may draw from the generator between the preparation and the hand-off - a layer seed - and
+                # then falls back to the ordinary path, which is the point of the freshness check)
+                assert (hits >= 2) if (spec and not warm) else (hits == 0), (warm, spec, hits)
+                res[(warm, spec)] = (model.P.clone(), lists, random.random())
+    finally:
+        DS.SPECULATE_COLD = saved
+    for warm in (False, True):
+        a, b = res[(warm, True)], res[(warm, False)]
+        assert torch.equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2], warm
+
+
 def test_acc_mode_accumulates_and_averages(hip):
     """--use-acc-mode (model_cnn.py:374-392): train_begin / F x train_step / train_end = ONE update with the mean gradient and
     the mean of the would-be batch-norm running statistics, every sub-step starting from the same parameters"""
