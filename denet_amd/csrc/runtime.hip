@@ -4,6 +4,7 @@
 #include "common.h"
 #include <stdarg.h>
 #include <math.h>
+#include <string.h>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -68,8 +69,39 @@ static inline uint32_t mt_next(uint32_t* mt, int* pos) {
     return y;
 }
 
+// where the 32-bit outputs come from: the live generator state, or a stretch of its outputs drawn ahead of time
+// (denet_host_mt_prefetch) that is consumed through a cursor
+struct MtLive {
+    uint32_t* mt;
+    int* pos;
+    bool ok() const { return true; }
+    uint32_t next() { return mt_next(mt, pos); }
+};
+struct MtStream {
+    const uint32_t* out;
+    long n, cursor;
+    bool good;
+    bool ok() const { return good; }
+    uint32_t next() {
+        if (cursor >= n) {       // ran dry (a long rejection run of random.sample): the caller redoes the batch on the live generator
+            good = false;
+            return 0u;
+        }
+        return out[cursor++];
+    }
+};
+
+template <class Src>
+static int py_random_sample_from(Src& src, int n, int k, int* pool_ws, int* out);
+
 extern "C" int denet_host_py_random_sample(uint32_t* mt, int* pos, int n, int k, int* pool_ws, int* out) {
     DENET_CHECK_ARG(mt && pos && pool_ws && out, "py_random_sample: null pointer");
+    MtLive src{mt, pos};
+    return py_random_sample_from(src, n, k, pool_ws, out);
+}
+
+template <class Src>
+static int py_random_sample_from(Src& src, int n, int k, int* pool_ws, int* out) {
     DENET_CHECK_ARG(n > 0 && k >= 0 && k <= n, "py_random_sample: need 0 <= k <= n");
     // setsize of random.sample (CPython Lib/random.py): 21, plus 4**ceil(log(3k, 4)) when k > 5
     long setsize = 21;
@@ -85,8 +117,9 @@ extern "C" int denet_host_py_random_sample(uint32_t* mt, int* pos, int n, int k,
         const uint32_t m = (uint32_t)(n - i);
         int bits = 0;
         while ((m >> bits) != 0) bits++;
-        uint32_t r = mt_next(mt, pos) >> (32 - bits);
-        while (r >= m) r = mt_next(mt, pos) >> (32 - bits);
+        uint32_t r = src.next() >> (32 - bits);
+        while (r >= m && src.ok()) r = src.next() >> (32 - bits);
+        if (!src.ok()) return DENET_OK;          // the caller checks the source
         out[i] = pool_ws[r];
         pool_ws[r] = pool_ws[n - i - 1];
     }
@@ -104,16 +137,17 @@ extern "C" int denet_host_py_random_sample(uint32_t* mt, int* pos, int n, int k,
 // gt_off[B+1]. Outputs: out_pr [B,S] and out_box [B,S,4] doubles (the values the reference's Python list would
 // hold) and out_box_f32 [B,S,4] (what build_bbox_array would upload). Pure host code.
 // ---------------------------------------------------------------------------------------------------------
-static inline double mt_random(uint32_t* mt, int* pos) {
-    const uint32_t a = mt_next(mt, pos) >> 5, b = mt_next(mt, pos) >> 6;
+template <class Src>
+static inline double mt_random(Src& src) {
+    const uint32_t a = src.next() >> 5, b = src.next() >> 6;
     return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);
 }
 
-extern "C" int denet_host_edit_samples(uint32_t* mt, int* pos, const float* det, const int* count, int B, int S,
-                                       int n_keep, const double* gt, const int* gt_off, int sample_gt, int* ws,
-                                       double* out_pr, double* out_box, float* out_box_f32) {
+template <class Src>
+static int edit_samples_from(Src& src, const float* det, const int* count, int B, int S, int n_keep, const double* gt,
+                             const int* gt_off, int sample_gt, int* ws, double* out_pr, double* out_box, float* out_box_f32) {
 #pragma clang fp contract(off)
-    DENET_CHECK_ARG(mt && pos && det && count && ws && out_pr && out_box && out_box_f32, "edit_samples: null pointer");
+    DENET_CHECK_ARG(det && count && ws && out_pr && out_box && out_box_f32, "edit_samples: null pointer");
     DENET_CHECK_ARG(B > 0 && S > 0 && n_keep >= 0 && n_keep <= S, "edit_samples: bad sizes");
     DENET_CHECK_ARG(!sample_gt || (gt_off && (gt || gt_off[B] == 0)), "edit_samples: ground truth missing");
     int* pool = ws;          // [S]
@@ -125,8 +159,9 @@ extern "C" int denet_host_edit_samples(uint32_t* mt, int* pos, const float* det,
         int n = count[b];
         DENET_CHECK_ARG(n >= 0 && n <= S, "edit_samples: count[%d] = %d out of range", b, n);
         if (n > n_keep) {
-            int rc = denet_host_py_random_sample(mt, pos, n, n_keep, pool, pick);
+            int rc = py_random_sample_from(src, n, n_keep, pool, pick);
             if (rc != DENET_OK) return rc;
+            if (!src.ok()) return DENET_OK;
             n = n_keep;
             for (int i = 0; i < n; ++i) {
                 const float* r = d + (size_t)pick[i] * 5;
@@ -140,10 +175,10 @@ extern "C" int denet_host_edit_samples(uint32_t* mt, int* pos, const float* det,
             }
         }
         for (int i = n; i < S; ++i) {
-            const double x0 = 0.0 + (1.0 - 0.0) * mt_random(mt, pos);
-            const double y0 = 0.0 + (1.0 - 0.0) * mt_random(mt, pos);
-            const double x1 = x0 + (1.0 - x0) * mt_random(mt, pos);
-            const double y1 = y0 + (1.0 - y0) * mt_random(mt, pos);
+            const double x0 = 0.0 + (1.0 - 0.0) * mt_random(src);
+            const double y0 = 0.0 + (1.0 - 0.0) * mt_random(src);
+            const double x1 = x0 + (1.0 - x0) * mt_random(src);
+            const double y1 = y0 + (1.0 - y0) * mt_random(src);
             pr[i] = 0.0;
             bx[i * 4 + 0] = x0; bx[i * 4 + 1] = y0; bx[i * 4 + 2] = x1; bx[i * 4 + 3] = y1;
         }
@@ -158,8 +193,56 @@ extern "C" int denet_host_edit_samples(uint32_t* mt, int* pos, const float* det,
         }
         float* f = out_box_f32 + (size_t)b * S * 4;
         for (int i = 0; i < S * 4; ++i) f[i] = (float)bx[i];
+        if (!src.ok()) return DENET_OK;
     }
     return DENET_OK;
+}
+
+extern "C" int denet_host_edit_samples(uint32_t* mt, int* pos, const float* det, const int* count, int B, int S,
+                                       int n_keep, const double* gt, const int* gt_off, int sample_gt, int* ws,
+                                       double* out_pr, double* out_box, float* out_box_f32) {
+    DENET_CHECK_ARG(mt && pos, "edit_samples: null generator state");
+    MtLive src{mt, pos};
+    return edit_samples_from(src, det, count, B, S, n_keep, gt, gt_off, sample_gt, ws, out_pr, out_box, out_box_f32);
+}
+
+// The generator's outputs drawn AHEAD of the hand-off (the RoI list editing waits for the device's proposal, but the numbers it
+// will draw do not): advances a COPY of the state (mt_host 624 words, *pos_host) by n outputs into out_host[n] and records the
+// state words after every refill: snaps_host[j][624], snap_first_host[j] = index in out_host of the first output drawn from
+// snapshot j (snapshot 0 = the state at entry, snap_first 0 = 0, its position word is the entry position; later snapshots
+// start at position 0). n_snaps_host receives the count (<= max_snaps, else an argument error).
+extern "C" int denet_host_mt_prefetch(uint32_t* mt, int* pos, long n, uint32_t* out, uint32_t* snaps, long* snap_first,
+                                      int max_snaps, int* n_snaps) {
+    DENET_CHECK_ARG(mt && pos && out && snaps && snap_first && n_snaps && n >= 0 && max_snaps >= 1, "mt_prefetch: bad arguments");
+    memcpy(snaps, mt, 624 * sizeof(uint32_t));
+    snap_first[0] = 0;
+    int ns = 1;
+    for (long i = 0; i < n; ++i) {
+        const bool refill = *pos >= 624;
+        out[i] = mt_next(mt, pos);
+        if (refill) {
+            DENET_CHECK_ARG(ns < max_snaps, "mt_prefetch: more than %d refills", max_snaps);
+            memcpy(snaps + (size_t)ns * 624, mt, 624 * sizeof(uint32_t));
+            snap_first[ns] = i;
+            ++ns;
+        }
+    }
+    *n_snaps = ns;
+    return DENET_OK;
+}
+
+// denet_host_edit_samples drawing from such a stretch: stream_host[n_stream], *cursor_host = outputs consumed (in: where to
+// start, out: where it stopped). *exhausted_host = 1 when the stretch ran dry: the outputs are then incomplete and the caller
+// repeats the batch with denet_host_edit_samples on the live generator (which has not been touched).
+extern "C" int denet_host_edit_samples_stream(const uint32_t* stream, long n_stream, long* cursor, int* exhausted, const float* det,
+                                              const int* count, int B, int S, int n_keep, const double* gt, const int* gt_off,
+                                              int sample_gt, int* ws, double* out_pr, double* out_box, float* out_box_f32) {
+    DENET_CHECK_ARG(stream && cursor && exhausted && *cursor >= 0 && *cursor <= n_stream, "edit_samples_stream: bad stream arguments");
+    MtStream src{stream, n_stream, *cursor, true};
+    const int rc = edit_samples_from(src, det, count, B, S, n_keep, gt, gt_off, sample_gt, ws, out_pr, out_box, out_box_f32);
+    *cursor = src.cursor;
+    *exhausted = src.good ? 0 : 1;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------------------

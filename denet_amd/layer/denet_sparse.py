@@ -25,6 +25,8 @@ TAP_CUDA = 1     # denet_sparse_op.py:65-71
 
 # the cold-detector outcome of the RoI hand-off is prepared ahead of time (DeNetSparseLayer._speculate_cold); 0 switches it off
 SPECULATE_COLD = os.environ.get("DENET_SPECULATE_COLD", "1") != "0"
+# the generator outputs of a step's RoI editing are drawn while the device runs the backbone (DeNetSparseLayer._prefetch_random)
+PREFETCH_RANDOM = os.environ.get("DENET_PREFETCH_RANDOM", "1") != "0"
 
 
 class PyRandomMirror:
@@ -332,8 +334,63 @@ class DeNetSparseLayer(AbstractLayer):
             prep["off"], prep["gt"] = numpy.zeros(len(metas) + 1, dtype=numpy.int32), numpy.zeros((1, 4))
         self._prep = prep
         self._spec = None
-        if SPECULATE_COLD and get_train() and self._native_edit_ok(metas) and self._on_device():
-            self._speculate_cold(metas, prep)
+        self._prefetch = None
+        if get_train() and self._native_edit_ok(metas):
+            if PREFETCH_RANDOM:
+                self._prefetch_random()
+            if SPECULATE_COLD and self._on_device():
+                self._speculate_cold(metas, prep)
+
+    def _prefetch_random(self):
+        """The editing draws 8 generator outputs per random box (4 doubles) and a few per element kept by random.sample; what it
+        draws does not depend on the device's proposal, only how much. The outputs of the step are therefore drawn HERE, while
+        the device runs the backbone (denet_host_mt_prefetch, on a copy of the state), and the hand-off only walks through
+        them (denet_host_edit_samples_stream: ~4x less host time between the device's proposal and the gather). The state
+        after the consumed outputs is handed back to `random`; if the generator moved meanwhile, or the stretch runs dry, the
+        ordinary path runs."""
+        import ctypes
+        from .. import lib as _lib
+        B, S = self.batch_size, self.sample_count
+        n = 8 * B * S + 8192
+        max_snaps = n // 624 + 3
+        buf = getattr(self, "_pf_buf", None)
+        if buf is None or buf[0].size != n:
+            buf = self._pf_buf = (numpy.empty(n, dtype=numpy.uint32), numpy.empty((max_snaps, 624), dtype=numpy.uint32),
+                                  numpy.empty(max_snaps, dtype=numpy.int64))
+        out, snaps, first = buf
+        mirror = PyRandomMirror()
+        key, pos = mirror.key.copy(), mirror.pos.copy()
+        ns = ctypes.c_int(0)
+        _lib.check(_lib.load().denet_host_mt_prefetch(key.ctypes.data, pos.ctypes.data, n, out.ctypes.data, snaps.ctypes.data,
+                                                      first.ctypes.data, max_snaps, ctypes.byref(ns)), "mt_prefetch")
+        self._prefetch = {"mirror": mirror, "n": n, "ns": ns.value, "pos0": int(mirror.pos[0])}
+
+    def _native_edit_stream(self, pf, det, cnt, prep, out_f32):
+        """the editing on the prefetched outputs; returns (out_pr, out_box, mirror holding the state after them) or None when the
+        stretch ran dry"""
+        import ctypes
+        from .. import lib as _lib
+        B, S = self.batch_size, self.sample_count
+        n_keep = S - math.floor(self.random_sample * S)
+        ws = numpy.empty(2 * S, dtype=numpy.int32)
+        off, gt = prep["off"], prep["gt"]
+        out_pr, out_box = self._edit_out()
+        out, snaps, first = self._pf_buf
+        cursor, dry = ctypes.c_long(0), ctypes.c_int(0)
+        _lib.check(_lib.load().denet_host_edit_samples_stream(
+            out.ctypes.data, pf["n"], ctypes.byref(cursor), ctypes.byref(dry), det.ctypes.data, cnt.ctypes.data, B, S, n_keep,
+            gt.ctypes.data, off.ctypes.data, int(bool(self.sample_gt)), ws.ctypes.data, out_pr.ctypes.data,
+            out_box.ctypes.data, out_f32.ctypes.data), "edit_samples_stream")
+        if dry.value:
+            return None
+        # the state after c outputs: the snapshot they ended in, with CPython's lazy refill (a position of 624 stays 624)
+        c = cursor.value
+        j = max(0, int(numpy.searchsorted(first[:pf["ns"]], c, side="left")) - 1)
+        mirror = pf["mirror"]
+        mirror.key = snaps[j].copy()
+        mirror.pos[0] = (pf["pos0"] if j == 0 else 0) + (c - int(first[j]))
+        assert 0 <= int(mirror.pos[0]) <= 624
+        return out_pr, out_box, mirror
 
     @staticmethod
     def _on_device():
@@ -362,6 +419,18 @@ class DeNetSparseLayer(AbstractLayer):
             ev.record(side)
         self._spec = {"metas": metas, "mirror": mirror, "pr": out_pr, "box": out_box, "dev": dev, "ev": ev}
 
+    def _edit_out(self):
+        """the (pr [B,S], box [B,S,4]) float64 arrays an editing call writes: four sets used in turn (fresh 0.7 MB allocations
+        cost page faults inside the hand-off; the lists of a step are read until its targets are built, long before the
+        set comes round again)"""
+        B, S = self.batch_size, self.sample_count
+        ring = self.__dict__.setdefault("_edit_ring", [])
+        if len(ring) < 4 or ring[0][0].shape != (B, S):
+            ring[:] = [(numpy.empty((B, S), dtype=numpy.float64), numpy.empty((B, S, 4), dtype=numpy.float64)) for _ in range(4)]
+            self._edit_turn = 0
+        self._edit_turn = (self._edit_turn + 1) % 4
+        return ring[self._edit_turn]
+
     def _native_edit(self, mirror, det, cnt, prep, out_f32):
         """denet_host_edit_samples on the generator state held by `mirror` (advanced in place)"""
         from .. import lib as _lib
@@ -369,8 +438,7 @@ class DeNetSparseLayer(AbstractLayer):
         n_keep = S - math.floor(self.random_sample * S)
         ws = numpy.empty(2 * S, dtype=numpy.int32)
         off, gt = prep["off"], prep["gt"]
-        out_pr = numpy.empty((B, S), dtype=numpy.float64)
-        out_box = numpy.empty((B, S, 4), dtype=numpy.float64)
+        out_pr, out_box = self._edit_out()
         assert out_f32.dtype == numpy.float32 and out_f32.size == B * S * 4 and out_f32.flags.c_contiguous
         _lib.check(_lib.load().denet_host_edit_samples(
             mirror.key.ctypes.data, mirror.pos.ctypes.data, det.ctypes.data, cnt.ctypes.data, B, S, n_keep,
@@ -389,8 +457,15 @@ class DeNetSparseLayer(AbstractLayer):
             self.begin_step(metas)
             prep = self._prep
         self._prep = None
-        mirror = prep["mirror"] if prep["mirror"].fresh() else PyRandomMirror()
-        out_pr, out_box = self._native_edit(mirror, det, cnt, prep, out_f32)
+        pf = self.__dict__.pop("_prefetch", None)
+        done = None
+        if pf is not None and pf["mirror"].fresh():
+            done = self._native_edit_stream(pf, det, cnt, prep, out_f32)
+        if done is not None:
+            out_pr, out_box, mirror = done
+        else:
+            mirror = prep["mirror"] if prep["mirror"].fresh() else PyRandomMirror()
+            out_pr, out_box = self._native_edit(mirror, det, cnt, prep, out_f32)
         if defer_push:
             self._pending_push = mirror      # handed back to the stdlib generator once the gather is queued
         else:

@@ -50,6 +50,19 @@ int denet_host_py_random_sample(unsigned* mt_host, int* pos_host, int n, int k, 
 int denet_host_edit_samples(unsigned* mt_host, int* pos_host, const float* det_host, const int* count_host, int B, int S,
                             int n_keep, const double* gt_host, const int* gt_off_host, int sample_gt, int* ws_host,
                             double* out_pr_host, double* out_box_host, float* out_box_f32_host);
+/* the same editing with the generator's outputs drawn AHEAD of the hand-off (the list editing has to wait for the device's
+ * proposal, the numbers it will draw do not). denet_host_mt_prefetch advances a COPY of the state by n 32-bit outputs into
+ * out_host[n] and records the state words after every refill: snaps_host[j][624], snap_first_host[j] = index of the first output
+ * drawn from snapshot j (snapshot 0 = the state at entry, which keeps the entry position; later ones start at position 0), so
+ * that the state after any number of consumed outputs can be handed back to `random`. denet_host_edit_samples_stream is
+ * denet_host_edit_samples reading that stretch through *cursor_host; *exhausted_host = 1: the stretch ran dry, the outputs are
+ * incomplete and the caller repeats the batch on the live generator. */
+int denet_host_mt_prefetch(unsigned* mt_host, int* pos_host, long n, unsigned* out_host, unsigned* snaps_host,
+                           long* snap_first_host, int max_snaps, int* n_snaps_host);
+int denet_host_edit_samples_stream(const unsigned* stream_host, long n_stream, long* cursor_host, int* exhausted_host,
+                                   const float* det_host, const int* count_host, int B, int S, int n_keep, const double* gt_host,
+                                   const int* gt_off_host, int sample_gt, int* ws_host, double* out_pr_host, double* out_box_host,
+                                   float* out_box_f32_host);
 /* detection targets of a batch (denet/layer/denet_detect.py:147-235) in RoI-major layout: fp32 IoU matrix in the
  * operation order of common/theano_util.py:38-59, class / class x fitness-bin targets for IoU > t0, box-regression
  * target of the arg-max ground truth for IoU > t1, rows normalised and divided by S. gt: concatenated [n,4] doubles,

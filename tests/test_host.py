@@ -616,6 +616,40 @@ def test_roi_editing_matches_executed_reference_method():
         assert [[(float(p), tuple(float(v) for v in bx)) for p, bx in l] for l in ol] == want
 
 
+def test_prefetched_generator_outputs_give_the_same_editing():
+    """DeNetSparseLayer._prefetch_random: the editing that walks through generator outputs drawn ahead of the hand-off
+    (denet_host_mt_prefetch / denet_host_edit_samples_stream) against the editing on the live generator: same lists, same
+    upload array and the stdlib generator in the identical state afterwards (trim / no trim / empty / full lists, several
+    steps in a row so that refills of the 624-word state fall at every kind of position)"""
+    from denet_amd.layer import denet_sparse as DS
+    saved = DS.PREFETCH_RANDOM
+    try:
+        for rs in (0.1, 0.5):
+            m = _fixture_model(24, rs, True, 4)
+            dns = [l for l in m.layers if l.type_name == "denet-sparse"][0]
+            _, metas = zoo.synthetic_batch(4, 128, 80, seed=1)
+            B, S = 4, 576
+            det = np.random.RandomState(3).rand(B, S, 5).astype(np.float32)
+            for counts in ([0, 0, 0, 0], [576, 10, 519, 520], [576, 576, 576, 576], [3, 0, 519, 1]):
+                cnt = np.array(counts, dtype=np.int32)
+                res = []
+                for pre in (True, False):
+                    DS.PREFETCH_RANDOM = pre
+                    random.seed(5)
+                    random.random()
+                    for _ in range(3):
+                        dns.begin_step(metas)
+                        assert (dns._prefetch is not None) == pre
+                        f32 = np.zeros((B * S, 4), dtype=np.float32)
+                        pr, bx = dns.edit_samples_native(det, cnt, metas, f32)
+                    res.append((pr.copy(), bx.copy(), f32.copy(), random.getstate()))
+                a, b = res
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (rs, counts)
+                assert a[3] == b[3], "generator state differs"
+    finally:
+        DS.PREFETCH_RANDOM = saved
+
+
 def test_detect_targets_match_executed_reference_method():
     """RoI -> class / fitness / box-regression targets: DeNetDetectLayer.get_target of the build (native host path and numpy
     path) and the oracle against the reference's own method loop (denet_detect.py:147-236, executed by the fixture script with
