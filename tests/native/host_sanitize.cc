@@ -136,6 +136,50 @@ static void test_edit_samples() {
     CHECK(denet_host_edit_samples(mt.p, pos.p, det.p, count.p, 1, 4, 4, gt.p, off.p, 1, ws.p, pr.p, bx.p, f32.p) != 0);
 }
 
+static void test_prefetch_stream() {
+    // outputs drawn ahead + the editing that walks through them == the editing on the live generator, state included
+    const int B = 3, S = 16, n_keep = 12;
+    for (int round = 0; round < 2; ++round) {
+        Buf<uint32_t> mt(624), mt2(624);
+        Buf<int> pos(1), pos2(1);
+        mt_seed(mt.p, pos.p, 777u + round);
+        pos[0] = round ? 620 : 624;                    // a refill right away / a few outputs before one
+        memcpy(mt2.p, mt.p, 624 * sizeof(uint32_t));
+        pos2[0] = pos[0];
+        const long n = round ? 40 : 8L * B * S + 64;   // round 1: far too short a stretch -> must report "dry", not overrun
+        const int max_snaps = (int)(n / 624) + 3;
+        Buf<uint32_t> out(n), snaps((size_t)max_snaps * 624);
+        Buf<long> first(max_snaps);
+        Buf<int> ns(1);
+        CHECK(denet_host_mt_prefetch(mt2.p, pos2.p, n, out.p, snaps.p, first.p, max_snaps, ns.p) == 0);
+        CHECK(ns[0] >= 1 && ns[0] <= max_snaps && first[0] == 0);
+        Buf<float> det((size_t)B * S * 5);
+        Buf<int> count(B), off(B + 1), ws(2 * S), dry(1);
+        count[0] = S; count[1] = 0; count[2] = 5;       // trim, empty, short
+        for (size_t i = 0; i < det.n; ++i) det[i] = (float)urand();
+        off[1] = 2; off[2] = 2; off[3] = 5;
+        Buf<double> gt(5 * 4), pr_a((size_t)B * S), bx_a((size_t)B * S * 4), pr_b((size_t)B * S), bx_b((size_t)B * S * 4);
+        for (size_t i = 0; i < gt.n; ++i) gt[i] = urand();
+        Buf<float> f_a((size_t)B * S * 4), f_b((size_t)B * S * 4);
+        Buf<long> cursor(1);
+        CHECK(denet_host_edit_samples_stream(out.p, n, cursor.p, dry.p, det.p, count.p, B, S, n_keep, gt.p, off.p, 1, ws.p, pr_a.p, bx_a.p, f_a.p) == 0);
+        CHECK(cursor[0] >= 0 && cursor[0] <= n);
+        if (round) { CHECK(dry[0] == 1); continue; }
+        CHECK(dry[0] == 0);
+        CHECK(denet_host_edit_samples(mt.p, pos.p, det.p, count.p, B, S, n_keep, gt.p, off.p, 1, ws.p, pr_b.p, bx_b.p, f_b.p) == 0);
+        CHECK(memcmp(pr_a.p, pr_b.p, pr_a.n * sizeof(double)) == 0 && memcmp(bx_a.p, bx_b.p, bx_a.n * sizeof(double)) == 0);
+        CHECK(memcmp(f_a.p, f_b.p, f_a.n * sizeof(float)) == 0);
+        // the live state after the batch == the snapshot the cursor ended in
+        int j = 0;
+        while (j + 1 < ns[0] && first[j + 1] < cursor[0]) ++j;
+        const long p = (j == 0 ? 624 : 0) + (cursor[0] - first[j]);
+        CHECK(p == pos[0] && memcmp(snaps.p + (size_t)j * 624, mt.p, 624 * sizeof(uint32_t)) == 0);
+        Buf<uint32_t> big(5000), two((size_t)2 * 624);
+        Buf<long> first2(2);
+        CHECK(denet_host_mt_prefetch(mt2.p, pos2.p, 5000, big.p, two.p, first2.p, 2, ns.p) != 0);     // too few snapshot slots: refused
+    }
+}
+
 static void test_detect_targets() {
     struct Case { int B, S, ncls, jointfit, reg, indfit; };
     const Case cases[] = {{3, 16, 5, 0, 1, 0}, {2, 576, 80, 0, 1, 0}, {2, 25, 3, 1, 1, 0}, {2, 16, 4, 0, 0, 1}, {1, 9, 6, 1, 0, 0}};
@@ -278,6 +322,7 @@ static void test_resample_coeffs() {
 int main() {
     test_random_sample();
     test_edit_samples();
+    test_prefetch_stream();
     test_detect_targets();
     test_samples_and_cluster();
     test_soft_nms();
