@@ -492,6 +492,55 @@ extern "C" int denet_bn_fwd_train_pre(const float* x, const float* res, float* y
     return DENET_OK;
 }
 
+extern "C" int denet_bn_stats_final(const double* partial, int rows, long M, int C, float momentum, float eps, float* run_mean,
+                                    float* run_stdinv, float* save_mean, float* save_invstd, hipStream_t stream) {
+    DENET_CHECK_ARG(partial && rows > 0 && save_mean && save_invstd && M > 0 && C > 0, "bn_stats_final: bad arguments");
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, rows, M, C, eps,
+                       momentum, save_mean, save_invstd, run_mean, run_stdinv);
+    DENET_CHECK_LAUNCH("bn_stats_final");
+    return DENET_OK;
+}
+
+extern "C" int denet_bn_apply(const float* x, const float* res, float* y, const float* gamma, const float* beta,
+                              const float* save_mean, const float* save_invstd, long M, int C, int relu, hipStream_t stream) {
+    DENET_CHECK_ARG(x && y && gamma && beta && save_mean && save_invstd, "bn_apply: null pointer");
+    DENET_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "bn_apply: bad shape M=%ld C=%d", M, C);
+    BnMap m = bn_map(M, C);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, res, y, gamma, beta, save_mean,
+                       save_invstd, M, C, m.LC, relu);
+    DENET_CHECK_LAUNCH("bn_apply");
+    return DENET_OK;
+}
+
+extern "C" int denet_bn_bwd_sums(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
+                                 const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef,
+                                 void* workspace, long M, int C, int relu, hipStream_t stream) {
+    DENET_CHECK_ARG(x && dy && gamma && save_mean && save_invstd && dgamma && dbeta && coef && workspace, "bn_bwd_sums: null pointer");
+    DENET_CHECK_ARG(!relu || y || beta, "bn_bwd_sums: the relu mask needs the forward output y, or beta to recompute it");
+    DENET_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "bn_bwd_sums: bad shape M=%ld C=%d", M, C);
+    BnMap m = bn_map(M, C);
+    double* partial = (double*)workspace;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, gamma, beta, save_mean,
+                       save_invstd, M, C, m.LC, relu, partial, (const unsigned char*)nullptr, PoolGeom{});
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, m.gy, M, C, dgamma,
+                       dbeta, coef);
+    DENET_CHECK_LAUNCH("bn_bwd_sums");
+    return DENET_OK;
+}
+
+extern "C" int denet_bn_bwd_apply(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
+                                  const float* save_mean, const float* save_invstd, const float* coef, float* dx, float* dres,
+                                  long M, int C, int relu, hipStream_t stream) {
+    DENET_CHECK_ARG(x && dy && gamma && save_mean && save_invstd && coef && dx, "bn_bwd_apply: null pointer");
+    DENET_CHECK_ARG(!relu || y || beta, "bn_bwd_apply: the relu mask needs the forward output y, or beta to recompute it");
+    DENET_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "bn_bwd_apply: bad shape M=%ld C=%d", M, C);
+    BnMap m = bn_map(M, C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, gamma, beta, save_mean,
+                       save_invstd, coef, dx, dres, M, C, m.LC, relu, (const unsigned char*)nullptr, PoolGeom{});
+    DENET_CHECK_LAUNCH("bn_bwd_apply");
+    return DENET_OK;
+}
+
 extern "C" int denet_bn_fwd_test(const float* x, const float* res, float* y, const float* gamma, const float* beta,
                                  const float* run_mean, const float* run_stdinv, float* coef, int coef_ready, long M, int C,
                                  float eps, int relu, hipStream_t stream) {

@@ -13,6 +13,7 @@
 // The data gradient of a stride-1 pad-1 3x3 convolution is the same convolution of dy with the taps rotated by 180
 // degrees and the channel roles swapped: wino_filter_kernel<true> writes U'[xi][c][k] from w[k][2-r][2-s][c].
 #include "common.h"
+#include "../../include/denet_hip.h"
 
 int denet_gemm_batched_nt(const float* a, const float* w, float* out, int batch, int M, int Nc, int Kc, long stride_a,
                           long stride_w, long stride_out, void* bws, size_t bws_bytes, hipStream_t stream);
@@ -109,6 +110,143 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
             WINO_DOT(acc, TS, WT::BT[j][l_], tt[i][l_]);
             *(f32x4*)(V + ((long)(TS * i + j) * T + t) * C + c4 * 4) = acc;
         }
+}
+
+// ---- transforms whose input is formed on the fly from a batch-norm layer -----------------------------------------------------
+// A Winograd pass that reads a tensor a batch norm has just written re-reads what a pointwise kernel produced one launch
+// earlier. These kernels evaluate the batch-norm expression while they gather the patch (same operations in the same order as
+// bn_apply_kernel / bn_bwd_apply_kernel of bn.hip, so every value is bit-identical to the separate passes) and write the tensor
+// the pointwise kernel would have written from the inner MO x MO pixels of each tile (each pixel belongs to exactly one tile):
+//   FWD  d = relu?(fma(x, gamma*invstd, beta - mean*gamma*invstd) (+ res));  out = d (the activation);  V = B^T d B
+//        replaces bn_apply_kernel + wino_input_kernel of the next convolution (batch_norm_relu.py:34-48 -> convolution.py:80-83)
+//   BWD  g = dy masked by the ReLU (y > 0, or recomputed from x), d = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat));
+//        out = g (residual-branch gradient, optional);  V = B^T d B (input of the data-gradient products);
+//        dM = A d A^T over the inner pixels (input of the filter-gradient products)
+//        replaces bn_bwd_apply_kernel + wino_input_kernel + wino_dout_kernel: d (the gradient of the convolution's output) is
+//        never written
+struct BnFoldDev {
+    const float* x;       // FWD: pre-normalisation tensor; BWD: the same (the convolution's output)
+    const float* aux;     // FWD: residual input or NULL; BWD: dy (gradient of the batch norm's output)
+    const float* y;       // BWD: forward output for the ReLU mask, or NULL (recomputed from x)
+    const float* gamma;
+    const float* beta;
+    const float* mean;
+    const float* invstd;
+    const float* coef;    // BWD: [2][C] mean(g), mean(g*xhat) (bn_bwd_final_kernel)
+    float* out;           // FWD: the activation; BWD: g or NULL
+    int relu;
+};
+
+template <int MO, bool BWD>
+__global__ __launch_bounds__(256) void wino_prep_kernel(BnFoldDev f, float* __restrict__ V, float* __restrict__ dM, int N, int H,
+                                                        int W, int C, int TH, int TW, long T) {
+    using WT = Wino<MO>;
+    constexpr int TS = WT::TS;
+    const int c4n = C / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= T * c4n) return;
+    const int c4 = (int)(idx % c4n);
+    const long t = idx / c4n;
+    const int tx = (int)(t % TW);
+    const int ty = (int)((t / TW) % TH);
+    const int n = (int)(t / ((long)TW * TH));
+    const int c = c4 * 4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    float mu[4], is[4], sc[4], sh[4], mg[4], mgx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mu[k] = f.mean[c + k];
+        is[k] = f.invstd[c + k];
+        sc[k] = f.gamma[c + k] * is[k];
+        sh[k] = (f.beta ? f.beta[c + k] : 0.f) - mu[k] * sc[k];
+        mg[k] = BWD ? f.coef[c + k] : 0.f;
+        mgx[k] = BWD ? f.coef[C + c + k] : 0.f;
+    }
+    // the value of the folded tensor at pixel (iy, ix); `inner`: this tile owns the pixel and writes `out`
+    auto value = [&](int iy, int ix, bool inner) -> f32x4 {
+        if (!(((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W))) return z;
+        const long o = (((long)n * H + iy) * W + ix) * C + c;
+        const f32x4 xv = ld4(f.x + o);
+        f32x4 d;
+        if (!BWD) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = fmaf(xv[k], sc[k], sh[k]);
+            if (f.aux) d += ld4(f.aux + o);
+            if (f.relu) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = fmaxf(d[k], 0.f);
+            }
+            if (inner) *(f32x4*)(f.out + o) = d;
+        } else {
+            f32x4 g = ld4(f.aux + o);
+            if (f.relu) {
+                if (f.y) {
+                    const f32x4 yv = ld4(f.y + o);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) g[k] = fmaf(xv[k], sc[k], sh[k]) > 0.f ? g[k] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (xv[k] - mu[k]) * is[k];
+                d[k] = sc[k] * (g[k] - mg[k] - xh * mgx[k]);
+            }
+            if (inner && f.out) *(f32x4*)(f.out + o) = g;
+        }
+        return d;
+    };
+    {
+        f32x4 tt[TS][TS];       // B^T d, built column by column
+#pragma unroll
+        for (int j = 0; j < TS; ++j) {
+            const int ix = MO * tx - 1 + j;
+            f32x4 d[TS];
+#pragma unroll
+            for (int i = 0; i < TS; ++i) d[i] = value(MO * ty - 1 + i, ix, i >= 1 && i <= MO && j >= 1 && j <= MO);
+#pragma unroll
+            for (int i = 0; i < TS; ++i) {
+                f32x4 acc = z;
+                WINO_DOT(acc, TS, WT::BT[i][l_], d[l_]);
+                tt[i][j] = acc;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TS; ++i)
+#pragma unroll
+            for (int j = 0; j < TS; ++j) {
+                f32x4 acc = z;
+                WINO_DOT(acc, TS, WT::BT[j][l_], tt[i][l_]);
+                *(f32x4*)(V + ((long)(TS * i + j) * T + t) * C + c) = acc;
+            }
+    }
+    if (BWD) {
+        // dM[xi][t][c] = (A d A^T)[xi] over the tile's own MO x MO pixels (wino_dout_kernel); the values are formed a second
+        // time from lines this thread has just read (cache hits) - keeping them through the first transform would spill
+        f32x4 a[TS][MO];
+#pragma unroll
+        for (int j = 0; j < MO; ++j) {
+            f32x4 d[MO];
+#pragma unroll
+            for (int i = 0; i < MO; ++i) d[i] = value(MO * ty + i, MO * tx + j, false);
+#pragma unroll
+            for (int i = 0; i < TS; ++i) {
+                f32x4 acc = z;
+                WINO_DOT(acc, MO, WT::AT[l_][i], d[l_]);
+                a[i][j] = acc;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TS; ++i)
+#pragma unroll
+            for (int j = 0; j < TS; ++j) {
+                f32x4 acc = z;
+                WINO_DOT(acc, MO, WT::AT[l_][j], a[i][l_]);
+                *(f32x4*)(dM + ((long)(TS * i + j) * T + t) * C + c) = acc;
+            }
+    }
 }
 
 // U[xi][k][c] = (G g G^T)[xi] (DGRAD = false) or U'[xi][c][k] from the rotated taps (DGRAD = true); thread per (k, c)
@@ -390,9 +528,11 @@ int wino_filter(int mo, bool dgrad, const float* w, float* U, int K, int C, hipS
 // input is written (NULL: inside the workspace) - the filter gradient of the same layer can reuse it
 int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u_cached, float* v_keep, const float* bias,
              const float* add, float* out, float* ws, size_t ws_bytes, int N, int H, int W, int Cin, int Cout,
-             hipStream_t stream, int relu = 0, double* stats = nullptr) {
+             hipStream_t stream, int relu = 0, double* stats = nullptr, const BnFoldDev* fold = nullptr, float* dm_out = nullptr,
+             hipEvent_t transform_done = nullptr) {
     // in: [N,H,W,Cin]   out: [N,H,W,Cout]   w: KRSC with (K,C) = dgrad ? (Cin,Cout) : (Cout,Cin)
-    DENET_CHECK_ARG(in && w && out && ws, "conv_wino: null pointer");
+    // fold: the input is formed on the fly from a batch-norm layer (wino_prep_kernel; dgrad: backward form, dm_out receives dM)
+    DENET_CHECK_ARG((in || fold) && w && out && ws, "conv_wino: null pointer");
     WinoDims d;
     int rc = wino_dims(mo, N, H, W, Cin, Cout, &d);
     if (rc) return rc;
@@ -411,8 +551,28 @@ int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u
         if (rc) return rc;
         U = Uw;
     }
-    WINO_LAUNCH(mo, wino_input_kernel, d.T * (Cin / 4), in, V, N, H, W, Cin, d.TH, d.TW, d.T);
+    if (fold) {
+        const unsigned blocks = (unsigned)((d.T * (Cin / 4) + 255) / 256);
+        if (dgrad) {
+            DENET_CHECK_ARG(dm_out, "conv_wino: the backward fold needs the dM buffer");
+            if (mo == 2) hipLaunchKernelGGL((wino_prep_kernel<2, true>), dim3(blocks), dim3(256), 0, stream, *fold, V, dm_out, N, H, W, Cin, d.TH, d.TW, d.T);
+            else hipLaunchKernelGGL((wino_prep_kernel<4, true>), dim3(blocks), dim3(256), 0, stream, *fold, V, dm_out, N, H, W, Cin, d.TH, d.TW, d.T);
+        } else {
+            if (mo == 2) hipLaunchKernelGGL((wino_prep_kernel<2, false>), dim3(blocks), dim3(256), 0, stream, *fold, V, (float*)nullptr, N, H, W, Cin, d.TH, d.TW, d.T);
+            else hipLaunchKernelGGL((wino_prep_kernel<4, false>), dim3(blocks), dim3(256), 0, stream, *fold, V, (float*)nullptr, N, H, W, Cin, d.TH, d.TW, d.T);
+        }
+    } else {
+        WINO_LAUNCH(mo, wino_input_kernel, d.T * (Cin / 4), in, V, N, H, W, Cin, d.TH, d.TW, d.T);
+    }
     DENET_CHECK_LAUNCH("conv_wino transforms");
+    if (transform_done) {
+        // dm_out is complete here: the filter-gradient chain of another stream may start while this one runs the products
+        const hipError_t e = hipEventRecord(transform_done, stream);
+        if (e != hipSuccess) {
+            denet_set_error("conv_wino: hipEventRecord: %s", hipGetErrorString(e));
+            return -(int)e;
+        }
+    }
     rc = denet_gemm_batched_nt(V, U, Mx, d.NX, (int)d.T, Cout, Cin, d.T * Cin, kc, d.T * Cout, bws, bws_bytes, stream);
     if (rc) return rc;
     WINO_LAUNCH(mo, wino_output_kernel, d.T * (Cout / 4), Mx, bias, add, out, N, H, W, Cout, d.TH, d.TW, d.T, relu, stats);
@@ -424,10 +584,10 @@ int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u
 
 // dw = filter gradient of the 3x3 stride-1 pad-1 convolution; x:[N,H,W,C] dy:[N,H,W,K] dw:[K,3,3,C].
 // workspace (denet_conv_wino_workspace_bytes): stream-K state | dU | V | dM; split_ws: the split-K slices of the batched product.
-extern "C" int denet_conv_wino_wgrad(const float* x, const float* dy, const float* v_cached, float* dw, float* workspace,
-                                     size_t workspace_bytes, float* split_ws, size_t split_ws_bytes, int tile, int N, int H,
-                                     int W, int C, int K, hipStream_t stream) {
-    DENET_CHECK_ARG(x && dy && dw && workspace, "conv_wino_wgrad: null pointer");
+static int wino_wgrad_run(const float* x, const float* dy, const float* dm_ready, const float* v_cached, float* dw,
+                          float* workspace, size_t workspace_bytes, float* split_ws, size_t split_ws_bytes, int tile, int N,
+                          int H, int W, int C, int K, hipStream_t stream) {
+    DENET_CHECK_ARG((x || v_cached) && (dy || dm_ready) && dw && workspace, "conv_wino_wgrad: null pointer");
     WinoDims d;
     int rc = wino_dims(tile, N, H, W, C, K, &d);
     if (rc) return rc;
@@ -441,13 +601,80 @@ extern "C" int denet_conv_wino_wgrad(const float* x, const float* dy, const floa
         WINO_LAUNCH(tile, wino_input_kernel, d.T * (C / 4), x, Vw, N, H, W, C, d.TH, d.TW, d.T);
         V = Vw;
     }
-    WINO_LAUNCH(tile, wino_dout_kernel, d.T * (K / 4), dy, dM, N, H, W, K, d.TH, d.TW, d.T);
+    const float* dMr = dm_ready;       // already formed by the backward fold of the data-gradient call (wino_prep_kernel)
+    if (!dMr) {
+        WINO_LAUNCH(tile, wino_dout_kernel, d.T * (K / 4), dy, dM, N, H, W, K, d.TH, d.TW, d.T);
+        dMr = dM;
+    }
     DENET_CHECK_LAUNCH("conv_wino_wgrad transforms");
-    rc = denet_wgrad_batched(V, dM, dU, split_ws, split_ws_bytes, d.NX, (int)d.T, C, K, stream);
+    rc = denet_wgrad_batched(V, dMr, dU, split_ws, split_ws_bytes, d.NX, (int)d.T, C, K, stream);
     if (rc) return rc;
     WINO_LAUNCH(tile, wino_dfilter_kernel, (long)K * C, dU, dw, K, C);
     DENET_CHECK_LAUNCH("conv_wino_wgrad filter");
     return DENET_OK;
+}
+
+extern "C" int denet_conv_wino_wgrad(const float* x, const float* dy, const float* v_cached, float* dw, float* workspace,
+                                     size_t workspace_bytes, float* split_ws, size_t split_ws_bytes, int tile, int N, int H,
+                                     int W, int C, int K, hipStream_t stream) {
+    DENET_CHECK_ARG(x && dy, "conv_wino_wgrad: null pointer");
+    return wino_wgrad_run(x, dy, nullptr, v_cached, dw, workspace, workspace_bytes, split_ws, split_ws_bytes, tile, N, H, W, C, K,
+                          stream);
+}
+
+// the filter gradient from dM = A dy A^T already formed by denet_conv_wino_dgrad_fold: dm [(tile+2)^2][T][K]
+extern "C" int denet_conv_wino_wgrad_dm(const float* x, const float* dm, const float* v_cached, float* dw, float* workspace,
+                                        size_t workspace_bytes, float* split_ws, size_t split_ws_bytes, int tile, int N, int H,
+                                        int W, int C, int K, hipStream_t stream) {
+    DENET_CHECK_ARG(dm, "conv_wino_wgrad_dm: null pointer");
+    return wino_wgrad_run(x, nullptr, dm, v_cached, dw, workspace, workspace_bytes, split_ws, split_ws_bytes, tile, N, H, W, C, K,
+                          stream);
+}
+
+static int fold_from(const denet_bn_link* bn, bool bwd, BnFoldDev* f) {
+    DENET_CHECK_ARG(bn && bn->x && bn->gamma && bn->mean && bn->invstd, "conv_wino fold: null pointer");
+    DENET_CHECK_ARG(bwd ? (bn->aux && bn->coef && (!bn->relu || bn->y || bn->beta)) : (bn->beta && bn->out),
+                    "conv_wino fold: incomplete batch-norm description");
+    f->x = bn->x; f->aux = bn->aux; f->y = bn->y; f->gamma = bn->gamma; f->beta = bn->beta; f->mean = bn->mean;
+    f->invstd = bn->invstd; f->coef = bn->coef; f->out = bn->out; f->relu = bn->relu;
+    return DENET_OK;
+}
+
+// denet_conv_wino_fwd (+ ReLU / batch-norm column sums of the output, as denet_conv_wino_fwd_act / _stats) whose input is the
+// output of the batch-norm layer `bn` evaluated on the fly; bn->out receives that activation (what denet_bn_fwd_train_pre
+// would have written: bit-identical)
+extern "C" int denet_conv_wino_fwd_fold(const denet_bn_link* bn, const float* w, const float* u_cached, float* v_keep,
+                                        const float* bias, const float* add, float* y, int relu, double* stats_partial,
+                                        size_t stats_bytes, int* stats_rows, float* workspace, size_t workspace_bytes, int tile,
+                                        int N, int H, int W, int C, int K, hipStream_t stream) {
+    BnFoldDev f;
+    int rc = fold_from(bn, false, &f);
+    if (rc) return rc;
+    double* st = nullptr;
+    if (stats_partial) {
+        DENET_CHECK_ARG(stats_rows && !relu, "conv_wino_fwd_fold: bad statistics arguments");
+        const int k4n = K / 4;
+        const long rows = ((long)N * (H / tile) * (W / tile) * k4n + 255) / 256;
+        const bool ok = k4n > 0 && k4n <= 256 && 256 % k4n == 0 && stats_bytes >= (size_t)rows * 2 * K * sizeof(double);
+        *stats_rows = ok ? (int)rows : 0;
+        st = ok ? stats_partial : nullptr;
+    }
+    return wino_run(tile, false, nullptr, w, u_cached, v_keep, bias, add, y, workspace, workspace_bytes, N, H, W, C, K, stream,
+                    relu ? 1 : 0, st, &f);
+}
+
+// denet_conv_wino_dgrad whose input dy is the gradient a batch-norm layer `bn` hands to this convolution's output, evaluated on
+// the fly (bn->x = the convolution's output, bn->aux = gradient of the batch norm's output, bn->coef from denet_bn_bwd_sums);
+// that gradient tensor is never written. dm_out [(tile+2)^2][T][K] receives A dy A^T for denet_conv_wino_wgrad_dm, bn->out (if
+// not NULL) the masked gradient for the residual branch (the `dres` of denet_bn_bwd)
+extern "C" int denet_conv_wino_dgrad_fold(const denet_bn_link* bn, float* dm_out, const float* w, const float* u_cached,
+                                          const float* add, float* dx, float* workspace, size_t workspace_bytes, int tile, int N,
+                                          int H, int W, int C, int K, void* transform_done_event, hipStream_t stream) {
+    BnFoldDev f;
+    int rc = fold_from(bn, true, &f);
+    if (rc) return rc;
+    return wino_run(tile, true, nullptr, w, u_cached, nullptr, nullptr, add, dx, workspace, workspace_bytes, N, H, W, K, C, stream,
+                    0, nullptr, &f, dm_out, (hipEvent_t)transform_done_event);
 }
 
 // measures the launch configuration of the component GEMMs of this geometry (all three passes); synchronises

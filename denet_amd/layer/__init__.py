@@ -61,8 +61,61 @@ class Act:
         self.shape = tuple(int(s) for s in shape)
         self.cp = int(cp) if cp is not None else round_up(self.shape[1], 32)
         self.name = name
-        self.data = None
-        self.grad = None
+        self._data = None
+        self._grad = None
+        self._pending_data = None       # ops.BnLink: the tensor is the output of a batch norm whose pointwise pass has not run
+        self._pending_grad = None       # ops.BnLink: the gradient is what a batch norm's backward pointwise pass would write
+
+    # `data` / `grad` may be PENDING: a batch-norm layer has reduced its statistics but left the pointwise pass to the consumer
+    # (a Winograd convolution evaluates it inside its input transform, ops.conv_fwd / conv_backward_linked). Any other reader
+    # simply takes .data / .grad, which runs the pointwise kernel then - the same kernel the batch norm would have launched.
+    @property
+    def data(self):
+        if self._data is None and self._pending_data is not None:
+            link, self._pending_data = self._pending_data, None
+            self._data = link.materialise()
+        return self._data
+
+    @data.setter
+    def data(self, v):
+        self._data = v
+        self._pending_data = None
+
+    @property
+    def grad(self):
+        if self._pending_grad is not None:
+            link, self._pending_grad = self._pending_grad, None
+            g = link.materialise()
+            self._grad = g if self._grad is None else self._add(self._grad, g)
+        return self._grad
+
+    @grad.setter
+    def grad(self, v):
+        self._grad = v
+        self._pending_grad = None
+
+    @staticmethod
+    def _add(a, b):
+        from .. import ops
+        return ops.add(a, b)
+
+    def set_pending_data(self, link):
+        self._data = None
+        self._pending_data = link
+
+    def take_pending_data(self):
+        """the pending batch-norm link, or None; the taker must store the tensor it materialises into .data"""
+        link, self._pending_data = self._pending_data, None
+        return link
+
+    def set_pending_grad(self, link):
+        """only valid while nothing else has flowed into this tensor's gradient"""
+        assert self._grad is None and self._pending_grad is None
+        self._pending_grad = link
+
+    def take_pending_grad(self):
+        link, self._pending_grad = self._pending_grad, None
+        return link
 
     def phys_shape(self):
         if len(self.shape) == 4:
@@ -80,6 +133,7 @@ class Act:
     def clear(self):
         self.data = None
         self.grad = None
+        self.stats = None
 
 
 class Param:

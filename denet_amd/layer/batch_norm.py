@@ -103,6 +103,14 @@ class BatchNormLayer(AbstractLayer):
                 self._pooled = True
                 return
             self._pooled = False
+            if pre is not None and ops.LINK_BN and ctx is not None:
+                # the statistics are reduced now; the pointwise pass is left to the reader of the output (a Winograd convolution
+                # runs it inside its input transform, anybody else triggers it by taking out_act.data - ops.BnLink)
+                link, sm, si = ops.bn_fwd_train_link(x, self.omega.dev, self.beta.dev, self.mean.dev, self.stdinv.dev, pre,
+                                                     self.momentum, self.eps, relu=relu, res=res)
+                self._save = (sm, si, relu, out_act, res is not None)
+                out_act.set_pending_data(link)
+                return
             y, sm, si = ops.bn_fwd_train(x, self.omega.dev, self.beta.dev, self.mean.dev, self.stdinv.dev,
                                          self.momentum, self.eps, relu=relu, res=res, pre=pre)
             self._save = (sm, si, relu, out_act, res is not None)
@@ -124,6 +132,13 @@ class BatchNormLayer(AbstractLayer):
             return None
         # without a residual input the relu mask is recomputed from x in the kernel (no read of y)
         y = out_act.data if (relu and has_res) else None
+        if ops.LINK_BN and self.input._grad is None and self.input._pending_grad is None:
+            # the two sums now; the gradient of the input is formed by whoever reads it - the convolution in front inside the
+            # transform of its data- and filter-gradient passes (ConvLayer.backward), anybody else through Act.grad
+            link, dres = ops.bn_bwd_link(self.input.data, y, out_act.grad, self.omega.dev, sm, si, relu=relu,
+                                         want_dres=want_dres, dgamma=self.omega.grad, dbeta=self.beta.grad, beta=self.beta.dev)
+            self.input.set_pending_grad(link)
+            return dres
         dx, dres, _, _ = ops.bn_bwd(self.input.data, y, out_act.grad, self.omega.dev, sm, si, relu=relu,
                                     want_dres=want_dres, dgamma=self.omega.grad, dbeta=self.beta.grad,
                                     beta=self.beta.dev)

@@ -150,14 +150,19 @@ class ConvLayer(AbstractLayer):
 
     def forward(self, ctx, add=None):
         from . import get_train
-        x = self.input.data
+        # the input may be the output of a batch norm whose pointwise pass is still pending (ops.BnLink): a Winograd pass runs it
+        # inside its input transform; whatever path conv_fwd takes, the activation exists afterwards and is stored back
+        link = self.input.take_pending_data()
+        x = self.input.data if link is None else None
         cache = self._cache()
         cache["train"] = bool(get_train()) and self.enabled and self.omega.grad is not None
         # a batch norm directly behind this layer (it flags its input Act) gets its statistics from this pass's epilogue
         want_stats = bool(get_train()) and getattr(self.output, "want_stats", False)
         self.output.data = ops.conv_fwd(x, self._w(), bias=self.beta.dev if self.use_bias else None, add=add,
                                         stride=self.stride[0], pad=self.pad, s_real=self.filter_shape[3],
-                                        logical=self._logical(), cache=cache, bn_stats=want_stats)
+                                        logical=self._logical(), cache=cache, bn_stats=want_stats, link=link)
+        if link is not None:
+            self.input.data = link.materialise()
         self.output.stats = cache.pop("bn_stats", None) if want_stats else None
 
     def forward_folded(self, ctx, bn, add=None, relu=False, out_act=None):
@@ -177,9 +182,23 @@ class ConvLayer(AbstractLayer):
         return y
 
     def backward(self, ctx):
-        dy = self.output.grad
         x = self.input.data
         st, pad, sr = self.stride[0], self.pad, self.filter_shape[3]
+        link = self.output.take_pending_grad()
+        if link is not None:
+            # the gradient of the output is the pending pointwise pass of a batch norm's backward (ops.BnLink): a 3x3 layer whose
+            # data- and filter-gradient passes are Winograd passes forms it inside ONE transform kernel that feeds both
+            fs = self.filter_shape
+            if (self.enabled and self.omega.grad is not None and getattr(self.input, "requires_grad", True) and not self.use_bias
+                    and fs[2] == 3 and fs[3] == 3 and st == 1 and self.stride[1] == 1 and pad == 1):
+                dx = ops.conv_backward_linked(link, x, self._w(), self.omega.dev_shape, self.input.grad,
+                                              self.omega.grad.view(self.omega.dev_shape), self._cache(), stride=st, pad=pad,
+                                              s_real=sr)
+                if dx is not None:
+                    self.input.grad = dx
+                    return
+            self.output.grad = link.materialise()
+        dy = self.output.grad
         if self.enabled and self.omega.grad is not None:
             # the first layer of the network has no data gradient: its filter gradient is the tail of the backward sweep on the
             # second stream, and the bias column sums (a pass over the largest tensor of the network) run beside it on the

@@ -181,6 +181,12 @@ class ResnetLayer(AbstractLayer):
             main[-1].backward(ctx)
         else:
             dres = main[-1].backward(ctx, want_dres=True)
+        done = None
+        if len(main) >= 2 and main[-2].output._pending_grad is not None:
+            # the last batch norm left its pointwise backward pass (which also writes dres) to the convolution in front of it
+            # (ops.BnLink): that convolution runs first, so that dres exists before the shortcut branch reads it
+            done = main[-2]
+            done.backward(ctx)
         if sc:
             sc[-1].output.grad = dres
             for l in reversed(sc):
@@ -188,4 +194,5 @@ class ResnetLayer(AbstractLayer):
         else:
             self.input.add_grad(dres)
         for l in reversed(main[:-1]):
-            l.backward(ctx)
+            if l is not done:
+                l.backward(ctx)

@@ -65,6 +65,13 @@ SIGNATURES = {
     "denet_bn_relu_pool_fwd_train": (I, [P] * 10 + [I, P] + [I] * 9 + [F, F, P]),
     "denet_bn_relu_pool_bwd": (I, [P] * 11 + [I] * 9 + [P]),
     "denet_bn_fold": (I, [P] * 6 + [F, P, P, I, L, P]),
+    "denet_bn_stats_final": (I, [P, I, L, I, F, F, P, P, P, P, P]),
+    "denet_bn_apply": (I, [P] * 7 + [L, I, I, P]),
+    "denet_bn_bwd_sums": (I, [P] * 11 + [L, I, I, P]),
+    "denet_bn_bwd_apply": (I, [P] * 10 + [L, I, I, P]),
+    "denet_conv_wino_fwd_fold": (I, [P] * 7 + [I, P, Z, P, P, Z] + [I] * 6 + [P]),
+    "denet_conv_wino_dgrad_fold": (I, [P] * 7 + [Z] + [I] * 6 + [P, P]),
+    "denet_conv_wino_wgrad_dm": (I, [P, P, P, P, P, Z, P, Z] + [I] * 6 + [P]),
     "denet_bn_fwd_test": (I, [P] * 8 + [I, L, I, F, I, P]),
     "denet_bn_bwd": (I, [P] * 12 + [L, I, I, P]),
     "denet_maxpool_fwd": (I, [P, P, P] + [I] * 9 + [P]),

@@ -282,6 +282,98 @@ def _tune_first(mode, g, a, b, bias, add, out, ws):
 HEAD_BF16X3 = os.environ.get("DENET_HEAD_BF16X3", "0") == "1"
 
 
+def _conv_wino_fwd_linked(link, g, tile, w, bias, add, out, cache, bn_stats):
+    """conv_fwd's Winograd branch with the input transform that evaluates the batch norm in front (denet_conv_wino_fwd_fold)"""
+    import ctypes
+    N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
+    y = out if out is not None else empty(N, OH, OW, K)
+    act = torch.empty_like(link.x)
+    st = None
+    rows = ctypes.c_int(0)
+    if bn_stats:
+        nrows = max((N * OH * OW + 127) // 128, (N * (OH // 2 + 1) * (OW // 2 + 1) * (K // 4) + 255) // 256,
+                    N * ((OH + 15) // 16) * ((OW + 15) // 16))
+        st = cache.get("bn_stats_buf")
+        if st is None or st.numel() < nrows * 2 * K:
+            st = cache["bn_stats_buf"] = torch.empty(nrows * 2 * K, dtype=torch.float64, device="cuda")
+        cache["bn_stats"] = None
+    cache["fwd_tile"] = tile
+    u = _cached_u(cache, 0, tile)
+    v_keep = None
+    if _WINO.get((2, g)) == tile:            # the filter gradient of this layer reuses the transformed input
+        v_keep = cache.get("V")
+        nv = (tile + 2) * (tile + 2) * (N * (H // tile) * (W // tile)) * C
+        if v_keep is None or v_keep.numel() != nv:
+            v_keep = cache["V"] = torch.empty(nv, dtype=torch.float32, device="cuda")
+        cache["V_tile"] = tile
+    ws = _wino_ws(tile, N, H, W, C, K)
+    bn = link.c_struct(act)
+    check(_L().denet_conv_wino_fwd_fold(ctypes.byref(bn), ptr(w), ptr(u), ptr(v_keep), ptr(bias), ptr(add), ptr(y), 0, ptr(st),
+                                        st.numel() * 8 if st is not None else 0, ctypes.byref(rows), ptr(ws), ws.numel(), tile,
+                                        N, H, W, C, K, stream_ptr()), "conv_wino_fwd_fold")
+    if st is not None:
+        cache["bn_stats"] = (st, rows.value) if rows.value > 0 else None
+    link.result = act
+    return y
+
+
+def conv_backward_linked(link, x, w, w_shape, add, dw_out, cache, stride=1, pad=1, s_real=None):
+    """Data gradient AND filter gradient of a 3x3 convolution whose output gradient is the (unwritten) result of a batch norm's
+    backward pointwise pass (BnLink): one transform kernel on the compute stream evaluates it and writes both transformed
+    tensors (denet_conv_wino_dgrad_fold), the filter-gradient products follow on the second stream (denet_conv_wino_wgrad_dm).
+    Returns dx, or None when this layer's passes are not both Winograd passes of one tile (the caller materialises the gradient
+    and takes the ordinary path)."""
+    import ctypes
+    g = conv_geom(x.shape, w_shape, stride, pad, s_real)
+    N, H, W, C, K = g[0], g[1], g[2], g[3], g[4]
+    tile = _WINO.get((1, g))
+    if not (LINK_BN and tile in (2, 4) and _WINO.get((2, g)) == tile and PROFILE is None and not _bf16x3_geom(g)):
+        return None
+    if cache is not None:
+        cache["dgrad_tile"] = tile
+    T = N * (H // tile) * (W // tile)
+    dm = torch.empty((tile + 2) * (tile + 2) * T * K, dtype=torch.float32, device="cuda")
+    dx = empty(N, H, W, C)
+    u = _cached_u(cache, 1, tile) if cache is not None else None
+    ws = _wino_ws(tile, N, H, W, C, K)
+    ev = cache.get("prep_event") if cache is not None else None
+    if ev is None:
+        ev = torch.cuda.Event()
+        ev.record()                                   # creates the handle the native call records on
+        if cache is not None:
+            cache["prep_event"] = ev
+    bn = link.c_struct(link.out)
+    check(_L().denet_conv_wino_dgrad_fold(ctypes.byref(bn), ptr(dm), ptr(w), ptr(u), ptr(add), ptr(dx), ptr(ws), ws.numel(), tile,
+                                          N, H, W, C, K, ev.cuda_event, stream_ptr()), "conv_wino_dgrad_fold")
+    v = None
+    if cache is not None and cache.get("V_tile") == tile:
+        v = cache.get("V")
+        cache["V_tile"] = None
+    global _ON_WGRAD_STREAM
+    if WGRAD_STREAM and _WGRAD_STREAM is None:
+        init_streams()
+    side = _WGRAD_STREAM if WGRAD_STREAM else None
+    if side is not None:
+        side.wait_event(ev)                           # only the transform kernel: the products of the two chains run side by side
+        dm.record_stream(side)
+        with torch.cuda.stream(side):
+            _ON_WGRAD_STREAM = True
+            try:
+                _wgrad_dm(x, dm, v, dw_out, tile, N, H, W, C, K)
+            finally:
+                _ON_WGRAD_STREAM = False
+    else:
+        _wgrad_dm(x, dm, v, dw_out, tile, N, H, W, C, K)
+    return dx
+
+
+def _wgrad_dm(x, dm, v, dw, tile, N, H, W, C, K):
+    ws = _wino_ws(tile, N, H, W, C, K)
+    sws = WS.get("wgrad", WGRAD_WS_BYTES)
+    check(_L().denet_conv_wino_wgrad_dm(ptr(x), ptr(dm), ptr(v), ptr(dw), ptr(ws), ws.numel(), ptr(sws), sws.numel(), tile, N, H, W,
+                                        C, K, stream_ptr()), "conv_wino_wgrad_dm")
+
+
 def _bf16x3_geom(g):
     N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
     return HEAD_BF16X3 and R == 1 and S == 1 and stride == 1 and pad == 0 and C >= 512 and C % 128 == 0 and K % 128 == 0 \
@@ -300,9 +392,20 @@ def _transpose(src, R, C):
 
 
 def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, logical=None, cache=None, relu=False,
-             bn_stats=False):
+             bn_stats=False, link=None):
     """bn_stats (training, the layer behind is a batch norm): the epilogue of the pass also writes the per-channel sums of y;
-    cache["bn_stats"] = (partial sums tensor, rows) for bn_fwd_train(pre=...), or None when the chosen kernel cannot"""
+    cache["bn_stats"] = (partial sums tensor, rows) for bn_fwd_train(pre=...), or None when the chosen kernel cannot.
+    link (BnLink, x = None): the input is the output of a batch norm whose pointwise pass has not run; a Winograd pass evaluates
+    it inside its input transform, every other implementation materialises it first. link.result is the activation afterwards."""
+    if link is not None:
+        g = conv_geom(link.x.shape, w.shape, stride, pad, s_real)
+        tile = _WINO.get((0, g))
+        if not (tile in (2, 4) and cache is not None and cache.get("train") and not relu and PROFILE is None
+                and not _bf16x3_geom(g)):
+            x = link.materialise()             # direct / fused-64 / undecided implementations read the tensor itself
+            link = None
+    if link is not None:
+        return _conv_wino_fwd_linked(link, g, tile, w, bias, add, out, cache, bn_stats)
     g = conv_geom(x.shape, w.shape, stride, pad, s_real)
     N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
     y = out if out is not None else empty(N, OH, OW, K)
@@ -689,6 +792,76 @@ def bn_fwd_train(x, gamma, beta, run_mean, run_stdinv, momentum=0.9, eps=1e-5, r
                                   ptr(save_mean), ptr(save_invstd), ptr(_bn_ws(M, C)), M, C, momentum, eps,
                                   int(relu), stream_ptr()), "bn_fwd_train")
     return y, save_mean, save_invstd
+
+
+# ---- batch norm whose pointwise pass is left to the consumer (include/denet_hip.h: denet_bn_link) -------------------------------
+# Measured (round 3, profiles/r03_*): correct and bit-identical, but the first version of the transform kernel gathers the
+# halo of every tile through L2 for two or three tensors instead of one and is 15-40 % SLOWER than the separate passes
+# (forward 1.35 vs 1.03 ms per step, backward 1.97 vs 1.81); off until the patch is staged through LDS.
+LINK_BN = os.environ.get("DENET_BN_LINK", "0") != "0"
+
+
+class BnLink:
+    """A batch-norm layer that has reduced its statistics (forward) / its two gradient sums (backward) and leaves the pointwise
+    pass to whoever reads the tensor next: a Winograd convolution evaluates it inside its input transform
+    (denet_conv_wino_fwd_fold / denet_conv_wino_dgrad_fold), anybody else calls materialise(), which launches the very kernel
+    the batch norm would have launched (denet_bn_apply / denet_bn_bwd_apply). Values are bit-identical either way."""
+
+    def __init__(self, backward, x, aux, y, gamma, beta, mean, invstd, coef, relu, out=None):
+        self.backward, self.x, self.aux, self.y = backward, x, aux, y
+        self.gamma, self.beta, self.mean, self.invstd, self.coef, self.relu = gamma, beta, mean, invstd, coef, bool(relu)
+        self.out = out            # backward: the residual-branch gradient buffer (dres) or None; forward: set by the taker
+        self.result = None        # the tensor the pointwise pass produces (forward: activation, backward: dx), once it exists
+
+    def c_struct(self, out):
+        import ctypes
+
+        class _C(ctypes.Structure):
+            _fields_ = [(n, ctypes.c_void_p) for n in ("x", "aux", "y", "gamma", "beta", "mean", "invstd", "coef", "out")] + \
+                       [("relu", ctypes.c_int)]
+        return _C(ptr(self.x), ptr(self.aux), ptr(self.y), ptr(self.gamma), ptr(self.beta), ptr(self.mean), ptr(self.invstd),
+                  ptr(self.coef), ptr(out), int(self.relu))
+
+    def materialise(self):
+        if self.result is not None:
+            return self.result
+        C = self.x.shape[-1]
+        M = self.x.numel() // C
+        r = torch.empty_like(self.x)
+        if not self.backward:
+            check(_L().denet_bn_apply(ptr(self.x), ptr(self.aux), ptr(r), ptr(self.gamma), ptr(self.beta), ptr(self.mean),
+                                      ptr(self.invstd), M, C, int(self.relu), stream_ptr()), "bn_apply")
+        else:
+            check(_L().denet_bn_bwd_apply(ptr(self.x), ptr(self.y), ptr(self.aux), ptr(self.gamma), ptr(self.beta), ptr(self.mean),
+                                          ptr(self.invstd), ptr(self.coef), ptr(r), ptr(self.out), M, C, int(self.relu),
+                                          stream_ptr()), "bn_bwd_apply")
+        self.result = r
+        return r
+
+
+def bn_fwd_train_link(x, gamma, beta, run_mean, run_stdinv, pre, momentum=0.9, eps=1e-5, relu=False, res=None):
+    """bn_fwd_train(pre=...) without the pointwise pass: coefficients + running statistics now, the activation when somebody
+    reads it (BnLink). Returns (link, save_mean, save_invstd)."""
+    C = x.shape[-1]
+    M = x.numel() // C
+    save_mean, save_invstd = empty(C), empty(C)
+    check(_L().denet_bn_stats_final(ptr(pre[0]), int(pre[1]), M, C, momentum, eps, ptr(run_mean), ptr(run_stdinv), ptr(save_mean),
+                                    ptr(save_invstd), stream_ptr()), "bn_stats_final")
+    return BnLink(False, x, res, None, gamma, beta, save_mean, save_invstd, None, relu), save_mean, save_invstd
+
+
+def bn_bwd_link(x, y, dy, gamma, save_mean, save_invstd, relu=False, want_dres=False, dgamma=None, dbeta=None, beta=None):
+    """bn_bwd without the pointwise pass: dgamma / dbeta / the two means now, dx (and dres) when somebody reads them. Returns
+    (link, dres buffer or None)."""
+    C = x.shape[-1]
+    M = x.numel() // C
+    dgamma = dgamma if dgamma is not None else empty(C)
+    dbeta = dbeta if dbeta is not None else empty(C)
+    coef = empty(2 * C)
+    check(_L().denet_bn_bwd_sums(ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_invstd), ptr(dgamma),
+                                 ptr(dbeta), ptr(coef), ptr(_bn_ws(M, C)), M, C, int(relu), stream_ptr()), "bn_bwd_sums")
+    dres = torch.empty_like(x) if want_dres else None
+    return BnLink(True, x, dy, y, gamma, beta, save_mean, save_invstd, coef, relu, out=dres), dres
 
 
 WEIGHTS_VERSION = 0       # bumped whenever parameters / running statistics change (solver step, set_value, packing)

@@ -141,6 +141,41 @@ int denet_conv_wino2f_wgrad_ok(int N, int H, int W, int C, int K);
 size_t denet_conv_wino2f_wgrad_workspace_bytes(int N, int H, int W);
 int denet_conv_wino2f_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int H,
                             int W, int C, int K, hipStream_t stream);
+/* ---- Winograd passes whose input is formed on the fly from the batch-norm layer next to them (csrc/winograd.hip,
+ *      wino_prep_kernel). Reference: the BN -> conv chains of the residual blocks (denet/layer/resnet.py:60-90,
+ *      batch_norm_relu.py:34-54): a pointwise pass writes a tensor the next convolution's input transform re-reads at once.
+ *      denet_bn_link describes the batch norm; all values are bit-identical to the separate passes.
+ *        forward  (denet_conv_wino_fwd_fold):  x = pre-normalisation tensor, aux = residual input or NULL, gamma / beta /
+ *                 mean / invstd = the layer's coefficients (denet_bn_stats_final), relu; out receives the activation.
+ *        backward (denet_conv_wino_dgrad_fold): x = the convolution's output (= the batch norm's input), aux = gradient of
+ *                 the batch norm's output, y = its forward output for the ReLU mask (NULL: recomputed from x, needs beta),
+ *                 coef = [2][C] from denet_bn_bwd_sums; out = NULL or the masked gradient (residual branch). The gradient
+ *                 of the convolution's output itself is never written: the call forms the transformed input of the
+ *                 data-gradient products and dm_out = A dy A^T for denet_conv_wino_wgrad_dm.                              */
+typedef struct denet_bn_link {
+    const float* x;
+    const float* aux;
+    const float* y;
+    const float* gamma;
+    const float* beta;
+    const float* mean;
+    const float* invstd;
+    const float* coef;
+    float* out;
+    int relu;
+} denet_bn_link;
+int denet_conv_wino_fwd_fold(const denet_bn_link* bn, const float* w, const float* u_cached, float* v_keep, const float* bias,
+                             const float* add, float* y, int relu, double* stats_partial, size_t stats_bytes, int* stats_rows,
+                             float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
+                             hipStream_t stream);
+/* transform_done_event: NULL or a hipEvent_t recorded on `stream` right behind the transform kernel (dm_out complete), so that
+ * the filter-gradient chain of a second stream can start while this call's products still run */
+int denet_conv_wino_dgrad_fold(const denet_bn_link* bn, float* dm_out, const float* w, const float* u_cached, const float* add,
+                               float* dx, float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
+                               void* transform_done_event, hipStream_t stream);
+int denet_conv_wino_wgrad_dm(const float* x, const float* dm, const float* v_cached, float* dw, float* workspace,
+                             size_t workspace_bytes, float* split_ws, size_t split_ws_bytes, int tile, int N, int H, int W, int C,
+                             int K, hipStream_t stream);
 int denet_conv_wino_dgrad(const float* dy, const float* w, const float* u_cached, const float* add, float* dx,
                           float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
                           hipStream_t stream);
@@ -187,6 +222,21 @@ int denet_bn_fwd_train(const float* x, const float* res, float* y, const float* 
 int denet_bn_fwd_train_pre(const float* x, const float* res, float* y, const float* gamma, const float* beta,
                            float* run_mean, float* run_stdinv, float* save_mean, float* save_invstd, const double* partial,
                            int rows, long M, int C, float momentum, float eps, int relu, hipStream_t stream);
+/* the pieces of the training passes on their own, for consumers that evaluate the pointwise part themselves
+ * (denet_conv_wino_fwd_fold / _dgrad_fold): statistics -> coefficients (+ running statistics), the pointwise forward pass
+ * given the coefficients, the two reductions of the backward pass (dgamma, dbeta, coef [2][C] = mean(g), mean(g*xhat)) and its
+ * pointwise part given coef. denet_bn_stats_final + denet_bn_apply == denet_bn_fwd_train_pre,
+ * denet_bn_bwd_sums + denet_bn_bwd_apply == denet_bn_bwd (same kernels). */
+int denet_bn_stats_final(const double* partial, int rows, long M, int C, float momentum, float eps, float* run_mean,
+                         float* run_stdinv, float* save_mean, float* save_invstd, hipStream_t stream);
+int denet_bn_apply(const float* x, const float* res, float* y, const float* gamma, const float* beta, const float* save_mean,
+                   const float* save_invstd, long M, int C, int relu, hipStream_t stream);
+int denet_bn_bwd_sums(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
+                      const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef,
+                      void* workspace, long M, int C, int relu, hipStream_t stream);
+int denet_bn_bwd_apply(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
+                       const float* save_mean, const float* save_invstd, const float* coef, float* dx, float* dres, long M,
+                       int C, int relu, hipStream_t stream);
 int denet_bn_fwd_test(const float* x, const float* res, float* y, const float* gamma, const float* beta,
                       const float* run_mean, const float* run_stdinv, float* coef, int coef_ready, long M, int C, float eps,
                       int relu, hipStream_t stream);
