@@ -13,6 +13,7 @@
 // The data gradient of a stride-1 pad-1 3x3 convolution is the same convolution of dy with the taps rotated by 180
 // degrees and the channel roles swapped: wino_filter_kernel<true> writes U'[xi][c][k] from w[k][2-r][2-s][c].
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/denet_hip.h"
 
 int denet_gemm_batched_nt(const float* a, const float* w, float* out, int batch, int M, int Nc, int Kc, long stride_a,
@@ -55,7 +56,22 @@ struct Wino<4> {
     static constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
 };
 
-// acc = sum_l coef[l] * v[l] with the compile-time coefficients folded (0 dropped, +-1 without a multiply)
+// one multiply-add of a transform, written as an explicit fused operation: left to the compiler, an expression like
+// 4*d0 - 5*d2 + d4 is contracted as fma(-5, d2, 4*d0) in one kernel and as fma(4, d0, -5*d2) in another (both legal, different
+// roundings) - with the explicit form every kernel that evaluates a transform produces the same bits (the transforms that
+// evaluate a batch norm on the fly, wino_prep_*, must equal wino_input_kernel / wino_dout_kernel exactly)
+__device__ __forceinline__ float wino_fma(float c, float v, float acc) { return __builtin_fmaf(c, v, acc); }
+__device__ __forceinline__ f32x4 wino_fma(float c, f32x4 v, f32x4 acc) {
+    f32x4 r;
+    r[0] = __builtin_fmaf(c, v[0], acc[0]);
+    r[1] = __builtin_fmaf(c, v[1], acc[1]);
+    r[2] = __builtin_fmaf(c, v[2], acc[2]);
+    r[3] = __builtin_fmaf(c, v[3], acc[3]);
+    return r;
+}
+
+// acc = sum_l coef[l] * v[l] with the compile-time coefficients folded (0 dropped): first product rounded, then one fused
+// multiply-add per further term, in index order
 #define WINO_DOT(acc, NL, COEF, VAL)                       \
     {                                                      \
         bool first_ = true;                                \
@@ -63,7 +79,7 @@ struct Wino<4> {
             const float c_ = (COEF);                       \
             if (c_ != 0.f) {                               \
                 if (first_) acc = c_ * (VAL);              \
-                else acc += c_ * (VAL);                    \
+                else acc = wino_fma(c_, (VAL), acc);       \
                 first_ = false;                            \
             }                                              \
         }                                                  \
@@ -247,6 +263,181 @@ __global__ __launch_bounds__(256) void wino_prep_kernel(BnFoldDev f, float* __re
                 *(f32x4*)(dM + ((long)(TS * i + j) * T + t) * C + c) = acc;
             }
     }
+}
+
+// The same passes with the patch staged through LDS: a workgroup owns a block of BT x BT tiles (BT*MO pixels square) and CQ
+// channel quads; it evaluates the folded tensor ONCE per pixel of the block + halo ((BT*MO+2)^2 pixels: 1.27x the block for
+// F(4x4), instead of the 2.25x of one-thread-per-tile gathers through L2, which made the version above slower than the passes
+// it replaces), writes the tensor the pointwise kernel would have written, and the threads then take their tiles from LDS.
+template <int MO, bool BWD>
+struct PrepLds {
+    static constexpr int BT = 4;                    // tiles per block edge
+    static constexpr int CQ = 8;                    // channel quads (32 channels) per workgroup
+    static constexpr int PB = BT * MO;              // pixels per block edge
+    static constexpr int PP = PB + 2;               // with halo
+    static constexpr int NT = BT * BT * CQ;         // threads
+    static constexpr int PS = CQ + 1;               // LDS pixel stride in float4 (odd: tiles of a wave fall into different banks)
+    static constexpr size_t LDS = (size_t)PP * PP * PS * sizeof(f32x4);
+};
+
+template <int MO, bool BWD>
+__global__ __launch_bounds__(128) void wino_prep_lds_kernel(BnFoldDev f, float* __restrict__ V, float* __restrict__ dM, int N,
+                                                            int H, int W, int C, int TH, int TW, long T, int BH, int BW) {
+    using WT = Wino<MO>;
+    using PL = PrepLds<MO, BWD>;
+    static_assert(PL::NT == 128, "launch bounds");
+    constexpr int TS = WT::TS, BT = PL::BT, CQ = PL::CQ, PB = PL::PB, PP = PL::PP, NT = PL::NT, PS = PL::PS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char prep_smem[];
+    f32x4* patch = (f32x4*)prep_smem;               // [PP][PP][PS]
+    const int tid = threadIdx.x;
+    const int cq = tid % CQ;
+    const int cblk = blockIdx.y;                    // channel block of 32
+    const int c = (cblk * CQ + cq) * 4;
+    int b = blockIdx.x;
+    const int bx = b % BW; b /= BW;
+    const int by = b % BH;
+    const int n = b / BH;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    float mu[4], is[4], sc[4], sh[4], mg[4], mgx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mu[k] = f.mean[c + k];
+        is[k] = f.invstd[c + k];
+        sc[k] = f.gamma[c + k] * is[k];
+        sh[k] = (f.beta ? f.beta[c + k] : 0.f) - mu[k] * sc[k];
+        mg[k] = BWD ? f.coef[c + k] : 0.f;
+        mgx[k] = BWD ? f.coef[C + c + k] : 0.f;
+    }
+    // phase 1: the folded tensor over the block + halo, one pixel x channel quad per thread and round. The loads of a batch of
+    // rounds are issued together, unconditionally (a pixel outside the image reads element 0 and is zeroed afterwards):
+    // with 1.5 waves per SIMD the latency of a dependent load -> LDS chain per round was the whole kernel time
+    const int y0 = by * PB - 1, x0 = bx * PB - 1;
+    constexpr int SLOTS = NT / CQ;                                   // pixels per round
+    constexpr int ROUNDS = (PP * PP + SLOTS - 1) / SLOTS;
+    constexpr int UB = 7;                                            // rounds per batch
+    for (int r0 = 0; r0 < ROUNDS; r0 += UB) {
+        f32x4 xv[UB], av[UB], yv[UB];
+        long off[UB];
+        int pix[UB];
+        bool ok[UB], inner[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int p = (r0 + u) * SLOTS + tid / CQ;
+            const int py = p / PP, px = p - py * PP;
+            const int iy = y0 + py, ix = x0 + px;
+            pix[u] = p;
+            ok[u] = p < PP * PP && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+            inner[u] = py >= 1 && py <= PB && px >= 1 && px <= PB;
+            off[u] = ok[u] ? (((long)n * H + iy) * W + ix) * C + c : (long)c;
+            xv[u] = ld4(f.x + off[u]);
+            if (BWD || f.aux) av[u] = ld4(f.aux + off[u]);
+            if (BWD && f.relu && f.y) yv[u] = ld4(f.y + off[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            f32x4 d = z;
+            if (!BWD) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = fmaf(xv[u][k], sc[k], sh[k]);
+                if (f.aux) d += av[u];
+                if (f.relu) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d[k] = fmaxf(d[k], 0.f);
+                }
+                if (ok[u] && inner[u]) *(f32x4*)(f.out + off[u]) = d;
+            } else {
+                f32x4 g = av[u];
+                if (f.relu) {
+                    if (f.y) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) g[k] = yv[u][k] > 0.f ? g[k] : 0.f;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) g[k] = fmaf(xv[u][k], sc[k], sh[k]) > 0.f ? g[k] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float xh = (xv[u][k] - mu[k]) * is[k];
+                    d[k] = sc[k] * (g[k] - mg[k] - xh * mgx[k]);
+                }
+                if (ok[u] && inner[u] && f.out) *(f32x4*)(f.out + off[u]) = g;
+            }
+            if (pix[u] < PP * PP) patch[pix[u] * PS + cq] = ok[u] ? d : z;
+        }
+    }
+    __syncthreads();
+    // phase 2: one thread per (tile, channel quad)
+    const int tl = tid / CQ;
+    const int tyl = tl / BT, txl = tl - tyl * BT;
+    const int ty = by * BT + tyl, tx = bx * BT + txl;
+    if (ty >= TH || tx >= TW) return;
+    const long t = ((long)n * TH + ty) * TW + tx;
+    {
+        f32x4 tt[TS][TS];
+#pragma unroll
+        for (int j = 0; j < TS; ++j) {
+            f32x4 d[TS];
+#pragma unroll
+            for (int i = 0; i < TS; ++i) d[i] = patch[((MO * tyl + i) * PP + MO * txl + j) * PS + cq];
+#pragma unroll
+            for (int i = 0; i < TS; ++i) {
+                f32x4 acc = z;
+                WINO_DOT(acc, TS, WT::BT[i][l_], d[l_]);
+                tt[i][j] = acc;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TS; ++i)
+#pragma unroll
+            for (int j = 0; j < TS; ++j) {
+                f32x4 acc = z;
+                WINO_DOT(acc, TS, WT::BT[j][l_], tt[i][l_]);
+                *(f32x4*)(V + ((long)(TS * i + j) * T + t) * C + c) = acc;
+            }
+    }
+    if (BWD) {
+        f32x4 a[TS][MO];
+#pragma unroll
+        for (int j = 0; j < MO; ++j) {
+            f32x4 d[MO];
+#pragma unroll
+            for (int i = 0; i < MO; ++i) d[i] = patch[((MO * tyl + 1 + i) * PP + MO * txl + 1 + j) * PS + cq];
+#pragma unroll
+            for (int i = 0; i < TS; ++i) {
+                f32x4 acc = z;
+                WINO_DOT(acc, MO, WT::AT[l_][i], d[l_]);
+                a[i][j] = acc;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TS; ++i)
+#pragma unroll
+            for (int j = 0; j < TS; ++j) {
+                f32x4 acc = z;
+                WINO_DOT(acc, MO, WT::AT[l_][j], a[i][l_]);
+                *(f32x4*)(dM + ((long)(TS * i + j) * T + t) * C + c) = acc;
+            }
+    }
+}
+
+template <int MO, bool BWD>
+int launch_prep_lds(const BnFoldDev& f, float* V, float* dM, int N, int H, int W, int C, int TH, int TW, long T, hipStream_t stream) {
+    using PL = PrepLds<MO, BWD>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute((const void*)wino_prep_lds_kernel<MO, BWD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)PL::LDS);
+        if (e != hipSuccess) {
+            denet_set_error("conv_wino fold: hipFuncSetAttribute(%zu B LDS): %s", PL::LDS, hipGetErrorString(e));
+            return -(int)e;
+        }
+        attr_set = true;
+    }
+    const int BH = (TH + PL::BT - 1) / PL::BT, BW = (TW + PL::BT - 1) / PL::BT;
+    hipLaunchKernelGGL((wino_prep_lds_kernel<MO, BWD>), dim3((unsigned)(N * BH * BW), (unsigned)(C / (4 * PL::CQ))), dim3(PL::NT),
+                       PL::LDS, stream, f, V, dM, N, H, W, C, TH, TW, T, BH, BW);
+    return DENET_OK;
 }
 
 // U[xi][k][c] = (G g G^T)[xi] (DGRAD = false) or U'[xi][c][k] from the rotated taps (DGRAD = true); thread per (k, c)
@@ -551,7 +742,15 @@ int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u
         if (rc) return rc;
         U = Uw;
     }
-    if (fold) {
+    static const int prep_lds = [] { const char* e = getenv("DENET_PREP_LDS"); return e ? atoi(e) : 1; }();
+    if (fold && prep_lds && Cin % 32 == 0 && (long)N * ((d.TH + 3) / 4) * ((d.TW + 3) / 4) < 0x7FFFFFFFL) {
+        DENET_CHECK_ARG(!dgrad || dm_out, "conv_wino: the backward fold needs the dM buffer");
+        if (dgrad) rc = mo == 2 ? launch_prep_lds<2, true>(*fold, V, dm_out, N, H, W, Cin, d.TH, d.TW, d.T, stream)
+                                : launch_prep_lds<4, true>(*fold, V, dm_out, N, H, W, Cin, d.TH, d.TW, d.T, stream);
+        else rc = mo == 2 ? launch_prep_lds<2, false>(*fold, V, nullptr, N, H, W, Cin, d.TH, d.TW, d.T, stream)
+                          : launch_prep_lds<4, false>(*fold, V, nullptr, N, H, W, Cin, d.TH, d.TW, d.T, stream);
+        if (rc) return rc;
+    } else if (fold) {
         const unsigned blocks = (unsigned)((d.T * (Cin / 4) + 255) / 256);
         if (dgrad) {
             DENET_CHECK_ARG(dm_out, "conv_wino: the backward fold needs the dM buffer");

@@ -314,6 +314,7 @@ def _conv_wino_fwd_linked(link, g, tile, w, bias, add, out, cache, bn_stats):
     if st is not None:
         cache["bn_stats"] = (st, rows.value) if rows.value > 0 else None
     link.result = act
+    LINK_COUNT[0] += 1
     return y
 
 
@@ -364,6 +365,7 @@ def conv_backward_linked(link, x, w, w_shape, add, dw_out, cache, stride=1, pad=
                 _ON_WGRAD_STREAM = False
     else:
         _wgrad_dm(x, dm, v, dw_out, tile, N, H, W, C, K)
+    LINK_COUNT[1] += 1
     return dx
 
 
@@ -795,10 +797,13 @@ def bn_fwd_train(x, gamma, beta, run_mean, run_stdinv, momentum=0.9, eps=1e-5, r
 
 
 # ---- batch norm whose pointwise pass is left to the consumer (include/denet_hip.h: denet_bn_link) -------------------------------
-# Measured (round 3, profiles/r03_*): correct and bit-identical, but the first version of the transform kernel gathers the
-# halo of every tile through L2 for two or three tensors instead of one and is 15-40 % SLOWER than the separate passes
-# (forward 1.35 vs 1.03 ms per step, backward 1.97 vs 1.81); off until the patch is staged through LDS.
-LINK_BN = os.environ.get("DENET_BN_LINK", "0") != "0"
+# Measured (round 3): the first form of the transform kernel (one thread per tile gathering the halo through L2 for two or three
+# tensors) was 15-40 % slower than the passes it replaced; with the patch staged through LDS and the loads of a batch of rounds
+# issued together it is faster: 965 -> 979 img/s for the whole step. DENET_BN_LINK=0 restores the separate passes.
+LINK_BN = os.environ.get("DENET_BN_LINK", "1") != "0"
+
+
+LINK_COUNT = [0, 0]        # forward / backward passes that took the linked transform (tests)
 
 
 class BnLink:

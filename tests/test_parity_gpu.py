@@ -623,6 +623,52 @@ def test_bn_pool_fusion_leaves_training_unchanged(hip):
     assert res[0][3] == res[1][3]
 
 
+@pytest.mark.parametrize("img,tile", [(128, 4), (256, 4), (128, 2)])
+def test_batch_norm_linked_into_winograd_transforms_is_bit_identical(hip, img, tile):
+    """ops.LINK_BN: the pointwise pass of a batch norm evaluated inside the input transform of the Winograd convolution next to
+    it (forward: denet_conv_wino_fwd_fold; backward: denet_conv_wino_dgrad_fold + denet_conv_wino_wgrad_dm, the gradient tensor
+    between batch norm and convolution is never written) against the separate kernels: training steps of DeNet-34 skip,
+    parameters / momentum / running statistics bit for bit. Reference chain: conv -> BN(+ReLU) -> conv of the residual blocks
+    (denet/layer/resnet.py:60-90, batch_norm_relu.py:34-54). Every 3x3 stride-1 layer is put on the un-fused Winograd passes of
+    one tile size (all three passes), so that the linked forms run for whole blocks; 128: maps of 4x4 ... 16x16 cells (partial
+    tile blocks of the LDS-staged transform), 256: full blocks"""
+    res = []
+    saved = (ops.LINK_BN, dict(ops._WINO))
+
+    def build():
+        model = zoo.warm_corner_head(zoo.denet34(2, "skip", img, class_num=80, seed=1), 4.0, 0.3)
+        model.build_train_func("nesterov")
+        return model
+    try:
+        # every launch configuration is decided once, on a throwaway model (the measurement of a first step may pick different
+        # implementations from run to run at these sizes); then all eligible layers are put on one Winograd tile
+        ops.LINK_BN = False
+        x, metas = zoo.synthetic_batch(2, img, seed=11)
+        build().train_step(x, metas, 0, 0, 0.02, [0.9], 1e-4)
+        for (mode, g) in list(ops._WINO):
+            if ops.conv_wino_ok(g, tile):
+                ops._WINO[(mode, g)] = tile
+        for link in (True, False):
+            ops.LINK_BN = link
+            ops.LINK_COUNT[:] = [0, 0]
+            random.seed(7)
+            model = build()
+            costs = [model.train_step(x, metas, 0, it, 0.02, [0.9], 1e-4)[0] for it in range(3)]
+            torch.cuda.synchronize()
+            if link:
+                assert ops.LINK_COUNT[0] >= 16 and ops.LINK_COUNT[1] >= 16, ops.LINK_COUNT
+            else:
+                assert ops.LINK_COUNT == [0, 0]
+            res.append((model.P.clone(), model.M.clone(), model.S.clone(), costs))
+    finally:
+        ops.LINK_BN = saved[0]
+        ops._WINO.clear()
+        ops._WINO.update(saved[1])
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(a, b)
+    assert res[0][3] == res[1][3]
+
+
 def test_prepared_cold_roi_list_equals_the_hand_off_path(hip):
     """DeNetSparseLayer._speculate_cold: with a cold corner detector (no proposals: weights as initialised) the edited RoI list
     is prepared at the start of the step on a copy of the stdlib generator and adopted at the hand-off; a warm detector must
