@@ -1029,42 +1029,15 @@ extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, floa
                                 int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad,
                                 int OH, int OW, hipStream_t stream);
 
-size_t denet_bgemm_workspace_bytes();
-int denet_bgemm(const float* a, const float* b, float* c, int batch, int M, int N, int K, long stride_a, long stride_b,
-                long stride_c, void* workspace, size_t workspace_bytes, int tile, int wg_per_cu, hipStream_t stream);
-
 // Batch of `batch` independent GEMMs out_b[M,Nc] = a_b[M,Kc] * w_b[Nc,Kc]^T (all row-major, K contiguous): the component
-// products of the Winograd path (winograd.hip). Strides in elements. bws (denet_bgemm_workspace_bytes, flags zeroed once
-// by the caller) enables the persistent stream-K kernel of bgemm.hip; a measured choice (denet_gemm_batched_tune) is
-// TuneVal{tile, nbuf, 0} with nbuf = 1 | 2: forward implicit-GEMM kernel, nbuf = 10 + workgroups per CU: bgemm.hip.
+// products of the Winograd path (winograd.hip). Strides in elements. A measured choice (denet_gemm_batched_tune) is
+// TuneVal{tile, nbuf, 0}: tile 0 = 128 x 128, 1 = 128 x 64; nbuf = loop structure. (Round 2's persistent stream-K kernel for
+// these products - 10-17 % faster alone, neutral inside the training step in every measurement incl. round 3's - is gone.)
 int denet_gemm_batched_nt(const float* a, const float* w, float* out, int batch, int M, int Nc, int Kc, long stride_a,
-                          long stride_w, long stride_out, void* bws, size_t bws_bytes, hipStream_t stream) {
+                          long stride_w, long stride_out, hipStream_t stream) {
     DENET_CHECK_ARG(a && w && out && batch > 0 && batch <= 65535 && M > 0, "gemm_batched: bad arguments");
     DENET_CHECK_ARG(Nc % 32 == 0 && Kc % 32 == 0, "gemm_batched: Nc, Kc must be multiples of 32");
     DENET_CHECK_ARG((long)M * Kc * 4 < 0xF0000000L && (long)Nc * Kc * 4 < 0xF0000000L, "gemm_batched: operand too large");
-    {
-        TuneVal tv;
-        const bool have = tuned_choice(tune_key(3, batch, 1, M, Kc, Nc, 1, 1, 1, 1, 0), &tv);
-        static int use_bgemm = -1;
-        if (use_bgemm < 0) {
-            // DENET_BGEMM=1 adds the persistent stream-K kernel (bgemm.hip) to the candidates. Measured (round 2): alone it
-            // runs the component GEMMs 10-17 % faster than this file's kernel (l2 108 vs 125 us, l3 94 vs 110, l4 90 vs 97),
-            // inside a training step it is neutral to -2 % (its fixed set of resident workgroups cannot interleave with the
-            // kernels of the second stream), so it stays opt-in
-            const char* e = getenv("DENET_BGEMM");
-            use_bgemm = e ? atoi(e) : 0;
-        }
-        if (bws && use_bgemm && (have ? tv.nbuf >= 10 : true)) {
-            g_last_cfg[0] = 3; g_last_cfg[1] = 128; g_last_cfg[2] = (have ? tv.tile == 0 : false) && Nc >= 128 ? 128 : 64;
-            g_last_cfg[3] = have ? tv.nbuf : 12; g_last_cfg[4] = batch;
-            return denet_bgemm(a, w, out, batch, M, Nc, Kc, stride_a, stride_w, stride_out, bws, bws_bytes, have ? tv.tile : 1,
-                               have ? tv.nbuf - 10 : 2, stream);
-        }
-        if (have && tv.nbuf >= 10) {
-            denet_set_error("gemm_batched: the measured configuration needs the stream-K workspace");
-            return DENET_ERR_ARG;
-        }
-    }
     IgemmParams p = {};
     p.act = a; p.wgt = w; p.out = out;
     p.N = 1; p.H = 1; p.W = M; p.C = Kc; p.OH = 1; p.OW = M; p.K = Nc;
@@ -1078,7 +1051,7 @@ int denet_gemm_batched_nt(const float* a, const float* w, float* out, int batch,
     int nbuf = (p.ksteps >= 24) ? 2 : 1;
     bool big = Nc >= 128 && (long)p.tiles_m * ceil_div(Nc, 128) * batch >= 1024;
     TuneVal tv;
-    if (tuned_choice(tune_key(3, batch, 1, M, Kc, Nc, 1, 1, 1, 1, 0), &tv)) {
+    if (tuned_choice(tune_key(3, batch, 1, M, Kc, Nc, 1, 1, 1, 1, 0), &tv) && tv.nbuf < 10) {      // (>= 10: a stream-K record of round 2)
         nbuf = tv.nbuf;
         big = (tv.tile == 0) && Nc >= 128;
     }
@@ -1154,7 +1127,7 @@ int denet_wgrad_batched_tune(const float* x, const float* dy, float* dw, float* 
 
 // measures the launch configuration of the batched GEMM for these sizes (synchronises the stream)
 int denet_gemm_batched_tune(const float* a, const float* w, float* out, int batch, int M, int Nc, int Kc, long stride_a,
-                            long stride_w, long stride_out, void* bws, size_t bws_bytes, hipStream_t stream) {
+                            long stride_w, long stride_out, hipStream_t stream) {
     const TuneKey key = tune_key(3, batch, 1, M, Kc, Nc, 1, 1, 1, 1, 0);
     if (g_tuned.count(key)) return DENET_OK;
     hipEvent_t e0, e1;
@@ -1170,17 +1143,15 @@ int denet_gemm_batched_tune(const float* a, const float* w, float* out, int batc
     std::vector<TuneVal> cand;
     for (int t = (Nc >= 128 ? 0 : 1); t < 2; ++t) {
         for (int nbuf = 1; nbuf <= 2; ++nbuf) cand.push_back(TuneVal{t, nbuf, 0});
-        if (bws && getenv("DENET_BGEMM") != nullptr && atoi(getenv("DENET_BGEMM")) != 0)
-            for (int wg = 1; wg <= 2; ++wg) cand.push_back(TuneVal{t, 10 + wg, 0});
     }
     for (const TuneVal& c : cand) {
         if (rc) break;
         t_try = c;
-        rc = denet_gemm_batched_nt(a, w, out, batch, M, Nc, Kc, stride_a, stride_w, stride_out, bws, bws_bytes, stream);
+        rc = denet_gemm_batched_nt(a, w, out, batch, M, Nc, Kc, stride_a, stride_w, stride_out, stream);
         float ms_min = 1e30f;
         for (int rep = 0; rep < 3 && !rc; ++rep) {
             (void)hipEventRecord(e0, stream);
-            rc = denet_gemm_batched_nt(a, w, out, batch, M, Nc, Kc, stride_a, stride_w, stride_out, bws, bws_bytes, stream);
+            rc = denet_gemm_batched_nt(a, w, out, batch, M, Nc, Kc, stride_a, stride_w, stride_out, stream);
             (void)hipEventRecord(e1, stream);
             if (hipEventSynchronize(e1) != hipSuccess) rc = DENET_ERR_ARG;
             float ms = 0.f;

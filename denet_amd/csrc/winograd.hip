@@ -17,10 +17,9 @@
 #include "../../include/denet_hip.h"
 
 int denet_gemm_batched_nt(const float* a, const float* w, float* out, int batch, int M, int Nc, int Kc, long stride_a,
-                          long stride_w, long stride_out, void* bws, size_t bws_bytes, hipStream_t stream);
+                          long stride_w, long stride_out, hipStream_t stream);
 int denet_gemm_batched_tune(const float* a, const float* w, float* out, int batch, int M, int Nc, int Kc, long stride_a,
-                            long stride_w, long stride_out, void* bws, size_t bws_bytes, hipStream_t stream);
-size_t denet_bgemm_workspace_bytes();
+                            long stride_w, long stride_out, hipStream_t stream);
 
 int denet_wgrad_batched(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes, int batch,
                         int T, int Cc, int Kr, hipStream_t stream);
@@ -727,12 +726,10 @@ int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u
     WinoDims d;
     int rc = wino_dims(mo, N, H, W, Cin, Cout, &d);
     if (rc) return rc;
-    // workspace: [stream-K state of the component GEMMs (fixed position: its flags are zeroed once) | U | V | M]
-    const size_t bws_bytes = denet_bgemm_workspace_bytes();
-    DENET_CHECK_ARG(ws_bytes >= bws_bytes + (d.nU + d.nV + d.nM) * sizeof(float), "conv_wino: workspace too small (%zu < %zu)",
-                    ws_bytes, bws_bytes + (d.nU + d.nV + d.nM) * sizeof(float));
-    void* bws = ws;
-    float* Uw = (float*)((char*)ws + bws_bytes);
+    // workspace: [U | V | M]
+    DENET_CHECK_ARG(ws_bytes >= (d.nU + d.nV + d.nM) * sizeof(float), "conv_wino: workspace too small (%zu < %zu)",
+                    ws_bytes, (d.nU + d.nV + d.nM) * sizeof(float));
+    float* Uw = ws;
     float* V = v_keep ? v_keep : Uw + d.nU;
     float* Mx = Uw + d.nU + d.nV;
     const long kc = (long)Cin * Cout;
@@ -772,7 +769,7 @@ int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u
             return -(int)e;
         }
     }
-    rc = denet_gemm_batched_nt(V, U, Mx, d.NX, (int)d.T, Cout, Cin, d.T * Cin, kc, d.T * Cout, bws, bws_bytes, stream);
+    rc = denet_gemm_batched_nt(V, U, Mx, d.NX, (int)d.T, Cout, Cin, d.T * Cin, kc, d.T * Cout, stream);
     if (rc) return rc;
     WINO_LAUNCH(mo, wino_output_kernel, d.T * (Cout / 4), Mx, bias, add, out, N, H, W, Cout, d.TH, d.TW, d.T, relu, stats);
     DENET_CHECK_LAUNCH("conv_wino output");
@@ -782,7 +779,7 @@ int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u
 }  // namespace
 
 // dw = filter gradient of the 3x3 stride-1 pad-1 convolution; x:[N,H,W,C] dy:[N,H,W,K] dw:[K,3,3,C].
-// workspace (denet_conv_wino_workspace_bytes): stream-K state | dU | V | dM; split_ws: the split-K slices of the batched product.
+// workspace (denet_conv_wino_workspace_bytes): dU | V | dM; split_ws: the split-K slices of the batched product.
 static int wino_wgrad_run(const float* x, const float* dy, const float* dm_ready, const float* v_cached, float* dw,
                           float* workspace, size_t workspace_bytes, float* split_ws, size_t split_ws_bytes, int tile, int N,
                           int H, int W, int C, int K, hipStream_t stream) {
@@ -790,9 +787,8 @@ static int wino_wgrad_run(const float* x, const float* dy, const float* dm_ready
     WinoDims d;
     int rc = wino_dims(tile, N, H, W, C, K, &d);
     if (rc) return rc;
-    const size_t bws_bytes = denet_bgemm_workspace_bytes();
-    DENET_CHECK_ARG(workspace_bytes >= bws_bytes + (d.nU + d.nV + d.nM) * sizeof(float), "conv_wino_wgrad: workspace too small");
-    float* dU = (float*)((char*)workspace + bws_bytes);
+    DENET_CHECK_ARG(workspace_bytes >= (d.nU + d.nV + d.nM) * sizeof(float), "conv_wino_wgrad: workspace too small");
+    float* dU = workspace;
     const float* V = v_cached;
     float* dM = dU + d.nU + d.nV;
     if (!V) {      // v_cached: the transformed input the forward pass of this layer kept (same tile)
@@ -883,16 +879,14 @@ extern "C" int denet_conv_wino_tune(float* workspace, size_t workspace_bytes, fl
     WinoDims d;
     int rc = wino_dims(tile, N, H, W, C, K, &d);
     if (rc) return rc;
-    const size_t bws_bytes = denet_bgemm_workspace_bytes();
-    DENET_CHECK_ARG(workspace_bytes >= bws_bytes + (d.nU + d.nV + d.nM) * sizeof(float), "conv_wino_tune: workspace too small");
-    void* bws = workspace;
-    float* U = (float*)((char*)workspace + bws_bytes);
+    DENET_CHECK_ARG(workspace_bytes >= (d.nU + d.nV + d.nM) * sizeof(float), "conv_wino_tune: workspace too small");
+    float* U = workspace;
     (void)hipMemsetAsync(U, 0, (d.nU + d.nV + d.nM) * sizeof(float), stream);
     const long T = d.T;
     // forward: V [T x C] -> M [T x K];  data gradient: V [T x K] -> M [T x C]
-    rc = denet_gemm_batched_tune(U + d.nU, U, U + d.nU + d.nV, d.NX, (int)T, K, C, T * C, (long)C * K, T * K, bws, bws_bytes, stream);
+    rc = denet_gemm_batched_tune(U + d.nU, U, U + d.nU + d.nV, d.NX, (int)T, K, C, T * C, (long)C * K, T * K, stream);
     if (rc) return rc;
-    rc = denet_gemm_batched_tune(U + d.nU + d.nV, U, U + d.nU, d.NX, (int)T, C, K, T * K, (long)C * K, T * C, bws, bws_bytes, stream);
+    rc = denet_gemm_batched_tune(U + d.nU + d.nV, U, U + d.nU, d.NX, (int)T, C, K, T * K, (long)C * K, T * C, stream);
     if (rc || !split_ws) return rc;
     return denet_wgrad_batched_tune(U + d.nU, U + d.nU + d.nV, U, split_ws, split_ws_bytes, d.NX, (int)T, C, K, stream);
 }
@@ -900,7 +894,7 @@ extern "C" int denet_conv_wino_tune(float* workspace, size_t workspace_bytes, fl
 extern "C" size_t denet_conv_wino_workspace_bytes(int tile, int N, int H, int W, int C, int K) {
     const size_t nx = (size_t)(tile + 2) * (tile + 2);
     const size_t T = (size_t)N * (H / tile) * (W / tile);
-    return denet_bgemm_workspace_bytes() + (nx * C * K + nx * T * C + nx * T * K) * sizeof(float);
+    return (nx * C * K + nx * T * C + nx * T * K) * sizeof(float);
 }
 
 // y = conv3x3(x, w) stride 1 pad 1 (+ bias) (+ add); x:[N,H,W,C] w:[K,3,3,C] y:[N,H,W,K]; tile = 2: F(2x2,3x3), 4: F(4x4,3x3)

@@ -193,7 +193,7 @@ class ConvLayer(AbstractLayer):
                     and fs[2] == 3 and fs[3] == 3 and st == 1 and self.stride[1] == 1 and pad == 1):
                 dx = ops.conv_backward_linked(link, x, self._w(), self.omega.dev_shape, self.input.grad,
                                               self.omega.grad.view(self.omega.dev_shape), self._cache(), stride=st, pad=pad,
-                                              s_real=sr)
+                                              s_real=sr, logical=self._logical())
                 if dx is not None:
                     self.input.grad = dx
                     return

@@ -29,8 +29,6 @@ class Workspace:
         nbytes = int(nbytes)
         buf = self.bufs.get(name)
         if buf is None or buf.numel() < nbytes:
-            # zero-filled: the stream-K component GEMMs keep hand-off flags at the start of the Winograd workspace, which
-            # must never hold a stale value that equals a launch epoch
             buf = torch.zeros(max(nbytes, 1), dtype=torch.uint8, device="cuda")
             self.bufs[name] = buf
         return buf
@@ -318,7 +316,7 @@ def _conv_wino_fwd_linked(link, g, tile, w, bias, add, out, cache, bn_stats):
     return y
 
 
-def conv_backward_linked(link, x, w, w_shape, add, dw_out, cache, stride=1, pad=1, s_real=None):
+def conv_backward_linked(link, x, w, w_shape, add, dw_out, cache, stride=1, pad=1, s_real=None, logical=None):
     """Data gradient AND filter gradient of a 3x3 convolution whose output gradient is the (unwritten) result of a batch norm's
     backward pointwise pass (BnLink): one transform kernel on the compute stream evaluates it and writes both transformed
     tensors (denet_conv_wino_dgrad_fold), the filter-gradient products follow on the second stream (denet_conv_wino_wgrad_dm).
@@ -328,8 +326,11 @@ def conv_backward_linked(link, x, w, w_shape, add, dw_out, cache, stride=1, pad=
     g = conv_geom(x.shape, w_shape, stride, pad, s_real)
     N, H, W, C, K = g[0], g[1], g[2], g[3], g[4]
     tile = _WINO.get((1, g))
-    if not (LINK_BN and tile in (2, 4) and _WINO.get((2, g)) == tile and PROFILE is None and not _bf16x3_geom(g)):
+    if not (LINK_BN and tile in (2, 4) and _WINO.get((2, g)) == tile and not _bf16x3_geom(g)):
         return None
+    if PROFILE is not None:          # two implicit-GEMM launches follow, in this order: data-gradient, filter-gradient products
+        PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])
+        PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])
     if cache is not None:
         cache["dgrad_tile"] = tile
     T = N * (H // tile) * (W // tile)
@@ -353,7 +354,7 @@ def conv_backward_linked(link, x, w, w_shape, add, dw_out, cache, stride=1, pad=
     global _ON_WGRAD_STREAM
     if WGRAD_STREAM and _WGRAD_STREAM is None:
         init_streams()
-    side = _WGRAD_STREAM if WGRAD_STREAM else None
+    side = _WGRAD_STREAM if (WGRAD_STREAM and PROFILE is None) else None      # a live kernel profile runs every kernel alone
     if side is not None:
         side.wait_event(ev)                           # only the transform kernel: the products of the two chains run side by side
         dm.record_stream(side)
@@ -402,11 +403,12 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
     if link is not None:
         g = conv_geom(link.x.shape, w.shape, stride, pad, s_real)
         tile = _WINO.get((0, g))
-        if not (tile in (2, 4) and cache is not None and cache.get("train") and not relu and PROFILE is None
-                and not _bf16x3_geom(g)):
+        if not (tile in (2, 4) and cache is not None and cache.get("train") and not relu and not _bf16x3_geom(g)):
             x = link.materialise()             # direct / fused-64 / undecided implementations read the tensor itself
             link = None
     if link is not None:
+        if PROFILE is not None:
+            PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])
         return _conv_wino_fwd_linked(link, g, tile, w, bias, add, out, cache, bn_stats)
     g = conv_geom(x.shape, w.shape, stride, pad, s_real)
     N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g

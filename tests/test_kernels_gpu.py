@@ -654,40 +654,6 @@ def test_sparse_tap_counting_sort(hip, case):
     assert L.denet_sparse_sort_workspace_bytes(1, 256, 256, 4, 2) == 0
 
 
-@pytest.mark.parametrize("shape", [(36, 2048, 256, 256), (36, 512, 512, 512), (16, 1000, 96, 160), (3, 70, 32, 32), (36, 8192, 128, 128)])
-def test_stream_k_batched_gemm(hip, shape):
-    """csrc/bgemm.hip (opt-in alternative for the component GEMMs of the Winograd passes, denet/layer/convolution.py:80-83):
-    persistent stream-K partition with in-launch fix-up of the tiles cut by a workgroup boundary - exact against fp64 to
-    fp32 rounding, bit-identical run to run, no hand-off timeout, for both tile shapes and 1 / 2 workgroups per CU"""
-    import ctypes
-    f = getattr(hip, "_Z11denet_bgemmPKfS0_PfiiiilllPvmiiP12ihipStream_t")
-    f.restype = ctypes.c_int
-    f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_long] * 3 + [ctypes.c_void_p, ctypes.c_size_t,
-                                                                                      ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-    wsb = getattr(hip, "_Z27denet_bgemm_workspace_bytesv")
-    wsb.restype = ctypes.c_size_t
-    nws = wsb()
-    ws = torch.zeros(nws, dtype=torch.uint8, device="cuda")
-    NX, M, N, K = shape
-    g = torch.Generator().manual_seed(M + N)
-    a = torch.randn(NX, M, K, generator=g).cuda()
-    b = (torch.randn(NX, N, K, generator=g) * 0.05).cuda()
-    ref = torch.bmm(a.double(), b.double().transpose(1, 2))
-    s = torch.cuda.current_stream().cuda_stream
-    for tile in (0, 1):
-        for wg in (1, 2):
-            outs = []
-            for rep in range(2):
-                c = torch.full((NX, M, N), float("nan"), device="cuda")
-                assert f(a.data_ptr(), b.data_ptr(), c.data_ptr(), NX, M, N, K, M * K, N * K, M * N, ws.data_ptr(), nws, tile, wg, s) == 0
-                torch.cuda.synchronize()
-                outs.append(c)
-            assert int(ws[16380:16384].view(torch.int32)[0]) == 0, "a fix-up hand-off timed out"
-            assert torch.equal(outs[0], outs[1])
-            err = float((outs[0].double() - ref).abs().max() / ref.abs().max())
-            assert err < 5e-6, (tile, wg, err)
-
-
 def test_side_streams_run_beside_the_compute_stream(hip):
     """ops.init_streams: the filter-gradient / side streams are picked by probing (two idle kernels) so that they sit on a
     hardware queue of their own - the HIP runtime multiplexes all streams of a process onto 4 queues, and a filter-gradient
