@@ -336,9 +336,14 @@ class ModelCNN:
             self.pack_device()
         for a in self.acts:
             a.grad = None
+        from .. import ops
+        step_begin = None
+        if train:
+            import torch
+            step_begin = torch.cuda.Event()      # everything before this step (the solver update of the weights) is behind it
+            step_begin.record()
         self._upload_input(data_x)
         ctx = StepContext(self)
-        from .. import ops
         fold = (not train) and ops.INFER_FOLD
         skip_next = False
         for i, layer in enumerate(self.layers[1:]):
@@ -365,7 +370,7 @@ class ModelCNN:
                 if convs is None:
                     convs = self._conv_layers = [l for l in walk_layers(self.layers) if l.type_name == "conv" and
                                                  getattr(l, "enabled", True)]
-                ops.wino_prefetch_filters([(l._cache(), l._w()) for l in convs])
+                ops.wino_prefetch_filters([(l._cache(), l._w()) for l in convs], after=step_begin)
             if train and data_m is not None and i == 0:
                 # host work that needs no device result (corner targets, ...): done while the first layer runs, so the
                 # device is not left idle in front of it

@@ -563,12 +563,12 @@ def _cached_u(cache, dgrad, tile):
     ent = cache.get(("u", dgrad))
     if ent is None or ent[0] != tile or not ent[2]:
         return None
-    wait_upload(cache.get("u_event"))
+    wait_upload(cache.get(("u_event", dgrad)))
     ent[2] = False                            # valid for one step: the solver changes the weights
     return ent[1]
 
 
-def wino_prefetch_filters(caches_and_weights):
+def wino_prefetch_filters(caches_and_weights, after=None):
     """For every convolution layer that runs Winograd passes: transform its filters for the forward and the data-gradient
     pass on a side stream, right at the start of a training step (the ~60 small launches leave the critical path)."""
     global _SIDE_FILTER
@@ -577,10 +577,18 @@ def wino_prefetch_filters(caches_and_weights):
         return
     if _SIDE_FILTER is None:
         init_streams()
-    _SIDE_FILTER.wait_stream(torch.cuda.current_stream())        # the solver update of the weights
+    # ordered behind the solver update of the weights only (after: the event recorded when the step began), not behind the
+    # kernels the forward pass has queued since - the ~300 small launches run beside the stem convolution; the forward
+    # filters of the first layers are transformed first and every GROUP of layers signals its own event, so that the first
+    # Winograd layer does not wait for the last layer's filters (round 3: with one event behind all launches the first
+    # 64-channel block started ~1 ms late)
+    if after is not None:
+        _SIDE_FILTER.wait_event(after)
+    else:
+        _SIDE_FILTER.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(_SIDE_FILTER):
-        for c, w in todo:
-            for dgrad, key in ((0, "fwd_tile"), (1, "dgrad_tile")):
+        def run(items, dgrad, key):
+            for c, w in items:
                 tile = c.get(key)
                 if not tile:
                     continue
@@ -591,10 +599,14 @@ def wino_prefetch_filters(caches_and_weights):
                     ent = c[("u", dgrad)] = [tile, torch.empty((ft + 2) * (ft + 2) * K * C, dtype=torch.float32, device="cuda"), False]
                 conv_wino_filter(w, ft, dgrad, out=ent[1])
                 ent[2] = True
-        ev = torch.cuda.Event()
-        ev.record(_SIDE_FILTER)
-    for c, _ in todo:
-        c["u_event"] = ev
+            ev = torch.cuda.Event()
+            ev.record(_SIDE_FILTER)
+            for c, _ in items:
+                c[("u_event", dgrad)] = ev
+        # forward filters in layer order, in groups of 8 layers; then the data-gradient filters (needed much later)
+        for i in range(0, len(todo), 8):
+            run(todo[i:i + 8], 0, "fwd_tile")
+        run(todo, 1, "dgrad_tile")
 
 
 _SIDE_FILTER = None
