@@ -528,6 +528,17 @@ extern "C" int denet_bn_bwd_sums(const float* x, const float* y, const float* dy
     return DENET_OK;
 }
 
+// the second stage of the two backward reductions alone: partial [rows][2][C] doubles (sum(g) | sum(g * xhat) over disjoint row
+// sets), written by bn_bwd_partial_kernel or by the data-gradient pass that produced the gradient (denet_conv_wino_dgrad_sums,
+// denet_conv_wino2f_sums) -> dgamma, dbeta, coef [2][C]
+extern "C" int denet_bn_bwd_final(const double* partial, int rows, long M, int C, float* dgamma, float* dbeta, float* coef,
+                                  hipStream_t stream) {
+    DENET_CHECK_ARG(partial && rows > 0 && dgamma && dbeta && coef && M > 0 && C > 0, "bn_bwd_final: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, rows, M, C, dgamma, dbeta, coef);
+    DENET_CHECK_LAUNCH("bn_bwd_final");
+    return DENET_OK;
+}
+
 extern "C" int denet_bn_bwd_apply(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                                   const float* save_mean, const float* save_invstd, const float* coef, float* dx, float* dres,
                                   long M, int C, int relu, hipStream_t stream) {

@@ -10,6 +10,7 @@
 // is multiplied): wino2f_ws_kernel (forward / data gradient) and wino2f_wgrad_kernel (filter gradient) + its two reducers.
 // Exact fp32 FMA chains; the association differs from the direct kernel (F(2x2): ~1e-6 relative).
 #include "common.h"
+#include "../../include/denet_hip.h"
 
 namespace {
 
@@ -23,6 +24,16 @@ struct W2Params {
     const float* add;    // [N,H,W,Co] or null
     float* y;            // [N,H,W,Co]
     double* stats;       // [blocks][2][Co] or null
+    // stats of the BACKWARD kind (bs_x != null; the kernel then computes a data gradient): the tensor written is the gradient of
+    // the output of a batch-norm layer whose input was bs_x; the sums are that layer's two reductions, sum(g) and
+    // sum(g * xhat) with g = y masked by the layer's ReLU (bs_y > 0, or recomputed from bs_x) - bn_bwd_partial_kernel's
+    const float* bs_x;
+    const float* bs_y;
+    const float* bs_gamma;
+    const float* bs_beta;
+    const float* bs_mean;
+    const float* bs_invstd;
+    int bs_relu;
     int N, H, W, Co;
     int by, bx;          // 16x16 output blocks per image
     int nco;             // Co / 64
@@ -245,8 +256,35 @@ __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
                     }
                     *(f32x4*)(p.y + o) = y0;
                     *(f32x4*)(p.y + o + p.Co) = y1;
-                    ssum += y0 + y1;
-                    ssq += y0 * y0 + y1 * y1;
+                    if (p.bs_x) {
+                        const int cq = cur.co0 + 4 * t;
+                        const f32x4 mu = *(const f32x4*)(p.bs_mean + cq), is = *(const f32x4*)(p.bs_invstd + cq);
+                        const f32x4 x0 = *(const f32x4*)(p.bs_x + o), x1 = *(const f32x4*)(p.bs_x + o + p.Co);
+                        f32x4 g0 = y0, g1 = y1;
+                        if (p.bs_relu) {
+                            if (p.bs_y) {
+                                const f32x4 v0 = *(const f32x4*)(p.bs_y + o), v1 = *(const f32x4*)(p.bs_y + o + p.Co);
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    g0[c] = v0[c] > 0.f ? g0[c] : 0.f;
+                                    g1[c] = v1[c] > 0.f ? g1[c] : 0.f;
+                                }
+                            } else {
+                                const f32x4 ga = *(const f32x4*)(p.bs_gamma + cq), be = *(const f32x4*)(p.bs_beta + cq);
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    const float sc = ga[c] * is[c], sh = be[c] - mu[c] * sc;
+                                    g0[c] = fmaf(x0[c], sc, sh) > 0.f ? g0[c] : 0.f;
+                                    g1[c] = fmaf(x1[c], sc, sh) > 0.f ? g1[c] : 0.f;
+                                }
+                            }
+                        }
+                        ssum += g0 + g1;
+                        ssq += g0 * ((x0 - mu) * is) + g1 * ((x1 - mu) * is);
+                    } else {
+                        ssum += y0 + y1;
+                        ssq += y0 * y0 + y1 * y1;
+                    }
                 }
             }
         }
@@ -576,9 +614,23 @@ extern "C" int denet_conv_wino2f_ok(int N, int H, int W, int Ci, int Co) {
 // y = conv3x3(x) stride 1 pad 1 (+ bias) (+ add) from the F(2x2) transformed filters u = [16][Co][64]
 // (denet_conv_wino_filter with tile 2: dgrad = 0 for the forward pass, 1 for the data gradient, where x = dy, Co = C).
 // stats_partial (optional): [N*ceil(H/16)*ceil(W/16)][2][Co] doubles, the batch-norm column sums of y (see denet_conv_fwd_stats).
+extern "C" int denet_conv_wino2f_sums(const float* x, const float* u, const float* bias, const float* add, float* y, int relu,
+                                      double* stats_partial, size_t stats_bytes, int* stats_rows, const denet_bn_link* sums_of,
+                                      int N, int H, int W, int Ci, int Co, hipStream_t stream);
+
 extern "C" int denet_conv_wino2f(const float* x, const float* u, const float* bias, const float* add, float* y, int relu,
                                  double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int Ci,
                                  int Co, hipStream_t stream) {
+    return denet_conv_wino2f_sums(x, u, bias, add, y, relu, stats_partial, stats_bytes, stats_rows, nullptr, N, H, W, Ci, Co, stream);
+}
+
+// the same; sums_of != NULL (a data-gradient call): the tensor written is the gradient of the OUTPUT of the batch-norm layer
+// sums_of describes (x = its input, y = its forward output or NULL, gamma / beta / mean / invstd, relu) and stats_partial
+// receives that layer's backward reductions per block: [rows][2][Co] doubles = sum(g), sum(g * xhat) - the input of
+// denet_bn_bwd_final instead of a pass of its own over three tensors (bn_bwd_partial_kernel)
+extern "C" int denet_conv_wino2f_sums(const float* x, const float* u, const float* bias, const float* add, float* y, int relu,
+                                      double* stats_partial, size_t stats_bytes, int* stats_rows, const denet_bn_link* sums_of,
+                                      int N, int H, int W, int Ci, int Co, hipStream_t stream) {
     DENET_CHECK_ARG(x && u && y, "conv_wino2f: null pointer");
     DENET_CHECK_ARG(denet_conv_wino2f_ok(N, H, W, Ci, Co), "conv_wino2f: needs Ci = 64, Co %% 64 = 0, even H and W");
     W2Params p = {};
@@ -594,6 +646,12 @@ extern "C" int denet_conv_wino2f(const float* x, const float* u, const float* bi
         DENET_CHECK_ARG(stats_rows && stats_bytes >= (size_t)blocks * 2 * Co * sizeof(double), "conv_wino2f: statistics buffer too small");
         *stats_rows = (int)blocks;
         p.stats = stats_partial;
+        if (sums_of) {
+            DENET_CHECK_ARG(sums_of->x && sums_of->mean && sums_of->invstd && (!sums_of->relu || sums_of->y || (sums_of->gamma && sums_of->beta)),
+                            "conv_wino2f: incomplete batch-norm description for the backward sums");
+            p.bs_x = sums_of->x; p.bs_y = sums_of->relu ? sums_of->y : nullptr; p.bs_gamma = sums_of->gamma; p.bs_beta = sums_of->beta;
+            p.bs_mean = sums_of->mean; p.bs_invstd = sums_of->invstd; p.bs_relu = sums_of->relu;
+        }
     }
     static bool attr_set = false;
     if (!attr_set) {

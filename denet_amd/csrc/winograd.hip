@@ -525,7 +525,7 @@ template <int MO>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias,
                                                           const float* __restrict__ add, float* __restrict__ y, int N,
                                                           int H, int W, int K, int TH, int TW, long T, int relu,
-                                                          double* __restrict__ stats) {
+                                                          double* __restrict__ stats, BnFoldDev bs) {
     using WT = Wino<MO>;
     constexpr int TS = WT::TS;
     __shared__ f32x4 red[2][256];
@@ -555,6 +555,16 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         }
         f32x4 b = z;
         if (bias) b = ld4(bias + k4 * 4);
+        float bs_mu[4] = {0.f, 0.f, 0.f, 0.f}, bs_is[4] = {0.f, 0.f, 0.f, 0.f}, bs_sc[4] = {0.f, 0.f, 0.f, 0.f}, bs_sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bs.x) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bs_mu[c] = bs.mean[k4 * 4 + c];
+                bs_is[c] = bs.invstd[k4 * 4 + c];
+                bs_sc[c] = (bs.gamma ? bs.gamma[k4 * 4 + c] : 1.f) * bs_is[c];
+                bs_sh[c] = (bs.beta ? bs.beta[k4 * 4 + c] : 0.f) - bs_mu[c] * bs_sc[c];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < MO; ++i)
 #pragma unroll
@@ -571,8 +581,28 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                     acc[3] = fmaxf(acc[3], 0.f);
                 }
                 *(f32x4*)(y + o) = acc;
-                ssum += acc;
-                ssq += acc * acc;
+                if (bs.x) {
+                    // backward sums of the batch norm whose OUTPUT gradient this pass writes (bn_bwd_partial_kernel): g = the value
+                    // masked by that layer's ReLU, sums of g and g * xhat
+                    const f32x4 xv = ld4(bs.x + o);
+                    f32x4 g = acc;
+                    if (bs.relu) {
+                        if (bs.y) {
+                            const f32x4 yv = ld4(bs.y + o);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) g[c] = yv[c] > 0.f ? g[c] : 0.f;
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) g[c] = fmaf(xv[c], bs_sc[c], bs_sh[c]) > 0.f ? g[c] : 0.f;
+                        }
+                    }
+                    ssum += g;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ssq[c] += g[c] * ((xv[c] - bs_mu[c]) * bs_is[c]);
+                } else {
+                    ssum += acc;
+                    ssq += acc * acc;
+                }
             }
     }
     if (!stats) return;
@@ -719,7 +749,7 @@ int wino_filter(int mo, bool dgrad, const float* w, float* U, int K, int C, hipS
 int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u_cached, float* v_keep, const float* bias,
              const float* add, float* out, float* ws, size_t ws_bytes, int N, int H, int W, int Cin, int Cout,
              hipStream_t stream, int relu = 0, double* stats = nullptr, const BnFoldDev* fold = nullptr, float* dm_out = nullptr,
-             hipEvent_t transform_done = nullptr) {
+             hipEvent_t transform_done = nullptr, const BnFoldDev* out_sums = nullptr) {
     // in: [N,H,W,Cin]   out: [N,H,W,Cout]   w: KRSC with (K,C) = dgrad ? (Cin,Cout) : (Cout,Cin)
     // fold: the input is formed on the fly from a batch-norm layer (wino_prep_kernel; dgrad: backward form, dm_out receives dM)
     DENET_CHECK_ARG((in || fold) && w && out && ws, "conv_wino: null pointer");
@@ -771,7 +801,10 @@ int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u
     }
     rc = denet_gemm_batched_nt(V, U, Mx, d.NX, (int)d.T, Cout, Cin, d.T * Cin, kc, d.T * Cout, stream);
     if (rc) return rc;
-    WINO_LAUNCH(mo, wino_output_kernel, d.T * (Cout / 4), Mx, bias, add, out, N, H, W, Cout, d.TH, d.TW, d.T, relu, stats);
+    // out_sums (with stats): the sums written are the backward reductions of the batch norm whose output gradient `out` is
+    BnFoldDev bs = {};
+    if (out_sums && stats) bs = *out_sums;
+    WINO_LAUNCH(mo, wino_output_kernel, d.T * (Cout / 4), Mx, bias, add, out, N, H, W, Cout, d.TH, d.TW, d.T, relu, stats, bs);
     DENET_CHECK_LAUNCH("conv_wino output");
     return DENET_OK;
 }
@@ -862,14 +895,54 @@ extern "C" int denet_conv_wino_fwd_fold(const denet_bn_link* bn, const float* w,
 // the fly (bn->x = the convolution's output, bn->aux = gradient of the batch norm's output, bn->coef from denet_bn_bwd_sums);
 // that gradient tensor is never written. dm_out [(tile+2)^2][T][K] receives A dy A^T for denet_conv_wino_wgrad_dm, bn->out (if
 // not NULL) the masked gradient for the residual branch (the `dres` of denet_bn_bwd)
+// statistics request of a data-gradient pass: dx is the gradient of the OUTPUT of the batch norm `sums_of` (x = its input,
+// y = its forward output or NULL, gamma / beta / mean / invstd, relu); the output transform then also writes that layer's two
+// backward reductions, stats_partial [rows][2][C] doubles (*stats_rows = 0: this channel count is not supported, no sums)
+static int sums_request(const denet_bn_link* sums_of, double* stats_partial, size_t stats_bytes, int* stats_rows, int tile, int N,
+                        int H, int W, int C, BnFoldDev* bs, double** st) {
+    *st = nullptr;
+    if (!sums_of) return DENET_OK;
+    DENET_CHECK_ARG(stats_partial && stats_rows, "conv_wino dgrad: the backward sums need a buffer");
+    DENET_CHECK_ARG(sums_of->x && sums_of->mean && sums_of->invstd && (!sums_of->relu || sums_of->y || (sums_of->gamma && sums_of->beta)),
+                    "conv_wino dgrad: incomplete batch-norm description for the backward sums");
+    const int k4n = C / 4;
+    const long rows = ((long)N * (H / tile) * (W / tile) * k4n + 255) / 256;
+    const bool ok = k4n > 0 && k4n <= 256 && 256 % k4n == 0 && stats_bytes >= (size_t)rows * 2 * C * sizeof(double);
+    *stats_rows = ok ? (int)rows : 0;
+    if (ok) {
+        *bs = BnFoldDev{};
+        bs->x = sums_of->x; bs->y = sums_of->relu ? sums_of->y : nullptr; bs->gamma = sums_of->gamma; bs->beta = sums_of->beta;
+        bs->mean = sums_of->mean; bs->invstd = sums_of->invstd; bs->relu = sums_of->relu;
+        *st = stats_partial;
+    }
+    return DENET_OK;
+}
+
 extern "C" int denet_conv_wino_dgrad_fold(const denet_bn_link* bn, float* dm_out, const float* w, const float* u_cached,
-                                          const float* add, float* dx, float* workspace, size_t workspace_bytes, int tile, int N,
-                                          int H, int W, int C, int K, void* transform_done_event, hipStream_t stream) {
-    BnFoldDev f;
+                                          const float* add, float* dx, const denet_bn_link* sums_of, double* stats_partial,
+                                          size_t stats_bytes, int* stats_rows, float* workspace, size_t workspace_bytes, int tile,
+                                          int N, int H, int W, int C, int K, void* transform_done_event, hipStream_t stream) {
+    BnFoldDev f, bs;
+    double* st;
     int rc = fold_from(bn, true, &f);
     if (rc) return rc;
+    rc = sums_request(sums_of, stats_partial, stats_bytes, stats_rows, tile, N, H, W, C, &bs, &st);
+    if (rc) return rc;
     return wino_run(tile, true, nullptr, w, u_cached, nullptr, nullptr, add, dx, workspace, workspace_bytes, N, H, W, K, C, stream,
-                    0, nullptr, &f, dm_out, (hipEvent_t)transform_done_event);
+                    0, st, &f, dm_out, (hipEvent_t)transform_done_event, st ? &bs : nullptr);
+}
+
+// denet_conv_wino_dgrad with such a statistics request
+extern "C" int denet_conv_wino_dgrad_sums(const float* dy, const float* w, const float* u_cached, const float* add, float* dx,
+                                          const denet_bn_link* sums_of, double* stats_partial, size_t stats_bytes, int* stats_rows,
+                                          float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
+                                          hipStream_t stream) {
+    BnFoldDev bs;
+    double* st;
+    int rc = sums_request(sums_of, stats_partial, stats_bytes, stats_rows, tile, N, H, W, C, &bs, &st);
+    if (rc) return rc;
+    return wino_run(tile, true, dy, w, u_cached, nullptr, nullptr, add, dx, workspace, workspace_bytes, N, H, W, K, C, stream, 0, st,
+                    nullptr, nullptr, nullptr, st ? &bs : nullptr);
 }
 
 // measures the launch configuration of the component GEMMs of this geometry (all three passes); synchronises

@@ -65,6 +65,8 @@ class Act:
         self._grad = None
         self._pending_data = None       # ops.BnLink: the tensor is the output of a batch norm whose pointwise pass has not run
         self._pending_grad = None       # ops.BnLink: the gradient is what a batch norm's backward pointwise pass would write
+        self.bn_producer = None         # the batch-norm layer whose forward pass (training) wrote this tensor
+        self.grad_sums = None           # ops.BnSums left by the data-gradient pass that wrote .grad LAST (cleared by any later write)
 
     # `data` / `grad` may be PENDING: a batch-norm layer has reduced its statistics but left the pointwise pass to the consumer
     # (a Winograd convolution evaluates it inside its input transform, ops.conv_fwd / conv_backward_linked). Any other reader
@@ -93,6 +95,7 @@ class Act:
     def grad(self, v):
         self._grad = v
         self._pending_grad = None
+        self.grad_sums = None
 
     @staticmethod
     def _add(a, b):
@@ -112,6 +115,7 @@ class Act:
         """only valid while nothing else has flowed into this tensor's gradient"""
         assert self._grad is None and self._pending_grad is None
         self._pending_grad = link
+        self.grad_sums = None
 
     def take_pending_grad(self):
         link, self._pending_grad = self._pending_grad, None

@@ -110,14 +110,28 @@ class BatchNormLayer(AbstractLayer):
                                                      self.momentum, self.eps, relu=relu, res=res)
                 self._save = (sm, si, relu, out_act, res is not None)
                 out_act.set_pending_data(link)
+                out_act.bn_producer = self
                 return
             y, sm, si = ops.bn_fwd_train(x, self.omega.dev, self.beta.dev, self.mean.dev, self.stdinv.dev,
                                          self.momentum, self.eps, relu=relu, res=res, pre=pre)
             self._save = (sm, si, relu, out_act, res is not None)
+            out_act.data = y
+            out_act.bn_producer = self
+            return
         else:
             y = ops.bn_fwd_test(x, self.omega.dev, self.beta.dev, self.mean.dev, self.stdinv.dev, self.eps, relu=relu,
                                 res=res, cache=self.__dict__.setdefault("_infer_cache", {}))
         out_act.data = y
+
+    def sums_request(self, act):
+        """for the data-gradient pass that writes the gradient of `act` (this layer's output of the current training step): the
+        description of this batch norm, so that the pass leaves the two backward reductions behind (ops.BnSums)"""
+        if not (self.enabled and self._save is not None and not getattr(self, "_pooled", False)):
+            return None
+        sm, si, relu, out_act, has_res = self._save
+        if out_act is not act:
+            return None
+        return ops.BnSums(self.input.data, out_act.data if (relu and has_res) else None, self.omega.dev, self.beta.dev, sm, si, relu)
 
     def backward(self, ctx, want_dres=False):
         if not self.enabled:
@@ -132,14 +146,23 @@ class BatchNormLayer(AbstractLayer):
             return None
         # without a residual input the relu mask is recomputed from x in the kernel (no read of y)
         y = out_act.data if (relu and has_res) else None
+        dy = out_act.grad
+        sums = out_act.grad_sums           # left by the data-gradient pass that wrote dy last (ConvLayer.backward)
+        pre = sums.partial if sums is not None else None
+        if pre is not None and not (ops.LINK_BN and self.input._grad is None and self.input._pending_grad is None):
+            link, dres = ops.bn_bwd_link(self.input.data, y, dy, self.omega.dev, sm, si, relu=relu, want_dres=want_dres,
+                                         dgamma=self.omega.grad, dbeta=self.beta.grad, beta=self.beta.dev, pre=pre)
+            self.input.add_grad(link.materialise())
+            return dres
         if ops.LINK_BN and self.input._grad is None and self.input._pending_grad is None:
             # the two sums now; the gradient of the input is formed by whoever reads it - the convolution in front inside the
             # transform of its data- and filter-gradient passes (ConvLayer.backward), anybody else through Act.grad
-            link, dres = ops.bn_bwd_link(self.input.data, y, out_act.grad, self.omega.dev, sm, si, relu=relu,
-                                         want_dres=want_dres, dgamma=self.omega.grad, dbeta=self.beta.grad, beta=self.beta.dev)
+            link, dres = ops.bn_bwd_link(self.input.data, y, dy, self.omega.dev, sm, si, relu=relu,
+                                         want_dres=want_dres, dgamma=self.omega.grad, dbeta=self.beta.grad, beta=self.beta.dev,
+                                         pre=pre)
             self.input.set_pending_grad(link)
             return dres
-        dx, dres, _, _ = ops.bn_bwd(self.input.data, y, out_act.grad, self.omega.dev, sm, si, relu=relu,
+        dx, dres, _, _ = ops.bn_bwd(self.input.data, y, dy, self.omega.dev, sm, si, relu=relu,
                                     want_dres=want_dres, dgamma=self.omega.grad, dbeta=self.beta.grad,
                                     beta=self.beta.dev)
         self.input.add_grad(dx)

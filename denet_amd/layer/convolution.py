@@ -184,6 +184,12 @@ class ConvLayer(AbstractLayer):
     def backward(self, ctx):
         x = self.input.data
         st, pad, sr = self.stride[0], self.pad, self.filter_shape[3]
+        # the batch norm (of this training step) whose output is this layer's input: the data-gradient pass below writes the
+        # gradient of that output, and a Winograd pass can leave that batch norm's two backward reductions behind (ops.BnSums)
+        sums = None
+        bn = self.input.bn_producer
+        if ops.BWD_SUMS and bn is not None and self._cache().get("train") and getattr(self.input, "requires_grad", True):
+            sums = bn.sums_request(self.input)
         link = self.output.take_pending_grad()
         if link is not None:
             # the gradient of the output is the pending pointwise pass of a batch norm's backward (ops.BnLink): a 3x3 layer whose
@@ -193,9 +199,10 @@ class ConvLayer(AbstractLayer):
                     and fs[2] == 3 and fs[3] == 3 and st == 1 and self.stride[1] == 1 and pad == 1):
                 dx = ops.conv_backward_linked(link, x, self._w(), self.omega.dev_shape, self.input.grad,
                                               self.omega.grad.view(self.omega.dev_shape), self._cache(), stride=st, pad=pad,
-                                              s_real=sr, logical=self._logical())
+                                              s_real=sr, logical=self._logical(), sums=sums)
                 if dx is not None:
                     self.input.grad = dx
+                    self.input.grad_sums = sums
                     return
             self.output.grad = link.materialise()
         dy = self.output.grad
@@ -214,4 +221,5 @@ class ConvLayer(AbstractLayer):
                 ops.colsum(dy.view(-1, self.kp), out=self.beta.grad)
         if getattr(self.input, "requires_grad", True):
             self.input.grad = ops.conv_dgrad(dy, self._w(), tuple(x.shape), add=self.input.grad, stride=st, pad=pad,
-                                             s_real=sr, logical=self._logical(), cache=self._cache())
+                                             s_real=sr, logical=self._logical(), cache=self._cache(), sums=sums)
+            self.input.grad_sums = sums

@@ -316,7 +316,7 @@ def _conv_wino_fwd_linked(link, g, tile, w, bias, add, out, cache, bn_stats):
     return y
 
 
-def conv_backward_linked(link, x, w, w_shape, add, dw_out, cache, stride=1, pad=1, s_real=None, logical=None):
+def conv_backward_linked(link, x, w, w_shape, add, dw_out, cache, stride=1, pad=1, s_real=None, logical=None, sums=None):
     """Data gradient AND filter gradient of a 3x3 convolution whose output gradient is the (unwritten) result of a batch norm's
     backward pointwise pass (BnLink): one transform kernel on the compute stream evaluates it and writes both transformed
     tensors (denet_conv_wino_dgrad_fold), the filter-gradient products follow on the second stream (denet_conv_wino_wgrad_dm).
@@ -345,8 +345,15 @@ def conv_backward_linked(link, x, w, w_shape, add, dw_out, cache, stride=1, pad=
         if cache is not None:
             cache["prep_event"] = ev
     bn = link.c_struct(link.out)
-    check(_L().denet_conv_wino_dgrad_fold(ctypes.byref(bn), ptr(dm), ptr(w), ptr(u), ptr(add), ptr(dx), ptr(ws), ws.numel(), tile,
-                                          N, H, W, C, K, ev.cuda_event, stream_ptr()), "conv_wino_dgrad_fold")
+    rows = ctypes.c_int(0)
+    sb = sums.buffer(cache, (T * (C // 4) + 255) // 256, C) if sums is not None else None
+    so = sums.c_struct() if sums is not None else None
+    check(_L().denet_conv_wino_dgrad_fold(ctypes.byref(bn), ptr(dm), ptr(w), ptr(u), ptr(add), ptr(dx),
+                                          ctypes.byref(so) if so is not None else None, ptr(sb), sb.numel() * 8 if sb is not None else 0,
+                                          ctypes.byref(rows), ptr(ws), ws.numel(), tile, N, H, W, C, K, ev.cuda_event, stream_ptr()),
+          "conv_wino_dgrad_fold")
+    if sums is not None:
+        sums.done(sb, rows.value)
     v = None
     if cache is not None and cache.get("V_tile") == tile:
         v = cache.get("V")
@@ -685,19 +692,33 @@ def conv_wino_fwd(x, w, bias=None, add=None, out=None, tile=2, u=None, v_keep=No
     return y
 
 
-def conv_wino_dgrad(dy, w, add=None, out=None, tile=2, u=None):
+def conv_wino_dgrad(dy, w, add=None, out=None, tile=2, u=None, sums=None, cache=None):
+    """sums (BnSums): dx is the gradient of that batch norm's output - its backward reductions are written along (sums.partial)"""
+    import ctypes
     N, H, W, K = dy.shape
     C = w.shape[3]
     dx = out if out is not None else empty(N, H, W, C)
+    rows = ctypes.c_int(0)
+    so = sums.c_struct() if sums is not None else None
     if tile == FUSED2:
-        import ctypes
         if u is None:
             u = conv_wino_filter(w, 2, dgrad=True)
-        rows = ctypes.c_int(0)
-        check(_L().denet_conv_wino2f(ptr(dy), ptr(u), None, ptr(add), ptr(dx), 0, None, 0, ctypes.byref(rows), N, H, W, K, C,
-                                     stream_ptr()), "conv_wino2f")
+        sb = sums.buffer(cache, N * ((H + 15) // 16) * ((W + 15) // 16), C) if sums is not None else None
+        check(_L().denet_conv_wino2f_sums(ptr(dy), ptr(u), None, ptr(add), ptr(dx), 0, ptr(sb), sb.numel() * 8 if sb is not None else 0,
+                                          ctypes.byref(rows), ctypes.byref(so) if so is not None else None, N, H, W, K, C,
+                                          stream_ptr()), "conv_wino2f")
+        if sums is not None:
+            sums.done(sb, rows.value)
         return dx
     ws = _wino_ws(tile, N, H, W, C, K)
+    if sums is not None:
+        T = N * (H // tile) * (W // tile)
+        sb = sums.buffer(cache, (T * (C // 4) + 255) // 256, C)
+        check(_L().denet_conv_wino_dgrad_sums(ptr(dy), ptr(w), ptr(u), ptr(add), ptr(dx), ctypes.byref(so), ptr(sb), sb.numel() * 8,
+                                              ctypes.byref(rows), ptr(ws), ws.numel(), tile, N, H, W, C, K, stream_ptr()),
+              "conv_wino_dgrad_sums")
+        sums.done(sb, rows.value)
+        return dx
     check(_L().denet_conv_wino_dgrad(ptr(dy), ptr(w), ptr(u), ptr(add), ptr(dx), ptr(ws), ws.numel(), tile, N, H, W, C, K,
                                      stream_ptr()), "conv_wino_dgrad")
     return dx
@@ -728,7 +749,7 @@ def conv_wino_filter(w, tile, dgrad, out=None):
     return u
 
 
-def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None, logical=None, cache=None):
+def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None, logical=None, cache=None, sums=None):
     g = conv_geom(x_shape, w.shape, stride, pad, s_real)
     assert tuple(dy.shape) == (g[0], g[10], g[11], g[4]), (dy.shape, g)
     dx = out if out is not None else empty(*x_shape)
@@ -750,7 +771,7 @@ def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None,
         if cache is not None:
             cache["dgrad_tile"] = tile
             u = _cached_u(cache, 1, tile)
-        return conv_wino_dgrad(dy, w, add, out=dx, tile=tile, u=u)
+        return conv_wino_dgrad(dy, w, add, out=dx, tile=tile, u=u, sums=sums, cache=cache)
     if cache is not None:
         cache["dgrad_tile"] = 0
     if PROFILE is not None:
@@ -818,6 +839,47 @@ LINK_BN = os.environ.get("DENET_BN_LINK", "1") != "0"
 
 
 LINK_COUNT = [0, 0]        # forward / backward passes that took the linked transform (tests)
+SUMS_COUNT = [0]           # data-gradient passes that also produced a batch norm's backward sums (tests)
+# the output transform of a Winograd data-gradient pass also writes the two backward reductions of the batch norm whose output
+# gradient it produces (denet_conv_wino_dgrad_sums / denet_conv_wino2f_sums): that layer's backward then needs no pass of its own
+# over (gradient, input, output) for them. The sums are accumulated per block in fp32 before they are widened (as the forward
+# statistics from the convolution epilogues are), so they differ from bn_bwd_partial_kernel's in the last bits. 0: off
+BWD_SUMS = os.environ.get("DENET_BN_BWD_SUMS", "1") != "0"
+
+
+def _bn_link_struct(x, aux, y, gamma, beta, mean, invstd, coef, out, relu):
+    import ctypes
+
+    class _C(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_void_p) for n in ("x", "aux", "y", "gamma", "beta", "mean", "invstd", "coef", "out")] + \
+                   [("relu", ctypes.c_int)]
+    return _C(ptr(x), ptr(aux), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(coef), ptr(out), int(relu))
+
+
+class BnSums:
+    """request to a data-gradient pass: `the tensor you write is the gradient of the output of this batch norm - leave its two
+    backward reductions behind` (x = the layer's input, y = its forward output if the ReLU mask needs it); partial = (float64
+    buffer [rows][2][C], rows) afterwards, or None when the pass that ran cannot"""
+
+    def __init__(self, x, y, gamma, beta, mean, invstd, relu):
+        self.x, self.y, self.gamma, self.beta, self.mean, self.invstd, self.relu = x, y, gamma, beta, mean, invstd, bool(relu)
+        self.partial = None
+
+    def c_struct(self):
+        return _bn_link_struct(self.x, None, self.y, self.gamma, self.beta, self.mean, self.invstd, None, None, self.relu)
+
+    def buffer(self, cache, rows, C):
+        buf = cache.get("bsum_buf") if cache is not None else None
+        if buf is None or buf.numel() < rows * 2 * C:
+            buf = torch.empty(rows * 2 * C, dtype=torch.float64, device="cuda")
+            if cache is not None:
+                cache["bsum_buf"] = buf
+        return buf
+
+    def done(self, buf, rows):
+        self.partial = (buf, rows) if rows > 0 else None
+        if rows > 0:
+            SUMS_COUNT[0] += 1
 
 
 class BnLink:
@@ -833,13 +895,7 @@ class BnLink:
         self.result = None        # the tensor the pointwise pass produces (forward: activation, backward: dx), once it exists
 
     def c_struct(self, out):
-        import ctypes
-
-        class _C(ctypes.Structure):
-            _fields_ = [(n, ctypes.c_void_p) for n in ("x", "aux", "y", "gamma", "beta", "mean", "invstd", "coef", "out")] + \
-                       [("relu", ctypes.c_int)]
-        return _C(ptr(self.x), ptr(self.aux), ptr(self.y), ptr(self.gamma), ptr(self.beta), ptr(self.mean), ptr(self.invstd),
-                  ptr(self.coef), ptr(out), int(self.relu))
+        return _bn_link_struct(self.x, self.aux, self.y, self.gamma, self.beta, self.mean, self.invstd, self.coef, out, self.relu)
 
     def materialise(self):
         if self.result is not None:
@@ -869,16 +925,21 @@ def bn_fwd_train_link(x, gamma, beta, run_mean, run_stdinv, pre, momentum=0.9, e
     return BnLink(False, x, res, None, gamma, beta, save_mean, save_invstd, None, relu), save_mean, save_invstd
 
 
-def bn_bwd_link(x, y, dy, gamma, save_mean, save_invstd, relu=False, want_dres=False, dgamma=None, dbeta=None, beta=None):
+def bn_bwd_link(x, y, dy, gamma, save_mean, save_invstd, relu=False, want_dres=False, dgamma=None, dbeta=None, beta=None,
+                pre=None):
     """bn_bwd without the pointwise pass: dgamma / dbeta / the two means now, dx (and dres) when somebody reads them. Returns
-    (link, dres buffer or None)."""
+    (link, dres buffer or None). pre = (partial sums float64 [rows][2][C], rows) left behind by the data-gradient pass that
+    produced dy (BnSums): the reduction pass over dy, x and y is skipped."""
     C = x.shape[-1]
     M = x.numel() // C
     dgamma = dgamma if dgamma is not None else empty(C)
     dbeta = dbeta if dbeta is not None else empty(C)
     coef = empty(2 * C)
-    check(_L().denet_bn_bwd_sums(ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_invstd), ptr(dgamma),
-                                 ptr(dbeta), ptr(coef), ptr(_bn_ws(M, C)), M, C, int(relu), stream_ptr()), "bn_bwd_sums")
+    if pre is not None:
+        check(_L().denet_bn_bwd_final(ptr(pre[0]), int(pre[1]), M, C, ptr(dgamma), ptr(dbeta), ptr(coef), stream_ptr()), "bn_bwd_final")
+    else:
+        check(_L().denet_bn_bwd_sums(ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_invstd), ptr(dgamma),
+                                     ptr(dbeta), ptr(coef), ptr(_bn_ws(M, C)), M, C, int(relu), stream_ptr()), "bn_bwd_sums")
     dres = torch.empty_like(x) if want_dres else None
     return BnLink(True, x, dy, y, gamma, beta, save_mean, save_invstd, coef, relu, out=dres), dres
 

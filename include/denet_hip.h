@@ -169,10 +169,23 @@ int denet_conv_wino_fwd_fold(const denet_bn_link* bn, const float* w, const floa
                              float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
                              hipStream_t stream);
 /* transform_done_event: NULL or a hipEvent_t recorded on `stream` right behind the transform kernel (dm_out complete), so that
- * the filter-gradient chain of a second stream can start while this call's products still run */
+ * the filter-gradient chain of a second stream can start while this call's products still run.
+ * sums_of (optional, also denet_conv_wino_dgrad_sums / denet_conv_wino2f_sums): dx is the gradient of the OUTPUT of another batch
+ * norm (x = that layer's input, y = its forward output or NULL, gamma / beta / mean / invstd, relu); the output transform then
+ * also writes that layer's two backward reductions sum(g), sum(g * xhat) (g = dx masked by its ReLU) as stats_partial
+ * [rows][2][C] doubles for denet_bn_bwd_final - instead of the pass over dx, x and y that bn_bwd_partial_kernel makes.
+ * *stats_rows = 0: channel count not supported, nothing written. */
 int denet_conv_wino_dgrad_fold(const denet_bn_link* bn, float* dm_out, const float* w, const float* u_cached, const float* add,
-                               float* dx, float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
+                               float* dx, const denet_bn_link* sums_of, double* stats_partial, size_t stats_bytes, int* stats_rows,
+                               float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
                                void* transform_done_event, hipStream_t stream);
+int denet_conv_wino_dgrad_sums(const float* dy, const float* w, const float* u_cached, const float* add, float* dx,
+                               const denet_bn_link* sums_of, double* stats_partial, size_t stats_bytes, int* stats_rows,
+                               float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
+                               hipStream_t stream);
+int denet_conv_wino2f_sums(const float* x, const float* u, const float* bias, const float* add, float* y, int relu,
+                           double* stats_partial, size_t stats_bytes, int* stats_rows, const denet_bn_link* sums_of, int N, int H,
+                           int W, int Ci, int Co, hipStream_t stream);
 int denet_conv_wino_wgrad_dm(const float* x, const float* dm, const float* v_cached, float* dw, float* workspace,
                              size_t workspace_bytes, float* split_ws, size_t split_ws_bytes, int tile, int N, int H, int W, int C,
                              int K, hipStream_t stream);
@@ -234,6 +247,8 @@ int denet_bn_apply(const float* x, const float* res, float* y, const float* gamm
 int denet_bn_bwd_sums(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                       const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* coef,
                       void* workspace, long M, int C, int relu, hipStream_t stream);
+int denet_bn_bwd_final(const double* partial, int rows, long M, int C, float* dgamma, float* dbeta, float* coef,
+                       hipStream_t stream);
 int denet_bn_bwd_apply(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
                        const float* save_mean, const float* save_invstd, const float* coef, float* dx, float* dres, long M,
                        int C, int relu, hipStream_t stream);

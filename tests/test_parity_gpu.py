@@ -681,6 +681,54 @@ def test_batch_norm_linked_into_winograd_transforms_is_bit_identical(hip, img, t
     assert res[0][3] == res[1][3]
 
 
+@pytest.mark.parametrize("img,tile", [(128, 4), (256, 22), (128, 2)])
+def test_batch_norm_backward_sums_from_the_data_gradient_pass(hip, img, tile):
+    """ops.BWD_SUMS: the output transform of a Winograd data-gradient pass (un-fused F(2x2) / F(4x4): wino_output_kernel; the fused
+    64-channel kernel: wino2f_ws_kernel) also writes the two backward reductions sum(g), sum(g * xhat) of the batch norm whose
+    output gradient it produces, and that layer's backward skips its own reduction pass (bn_bwd_partial_kernel). Reference:
+    the gradient of batch_norm.py:50-53 / batch_norm_relu.py:50-54 through model_cnn.py:318. The sums are accumulated per block
+    in fp32 before they are widened, so the comparison is numeric: all gradients of one step from identical parameters within
+    2e-5 max-norm relative, per parameter range"""
+    res = []
+    saved = (ops.BWD_SUMS, dict(ops._WINO))
+
+    def build():
+        model = zoo.warm_corner_head(zoo.denet34(2, "skip", img, class_num=80, seed=1), 4.0, 0.3)
+        model.build_train_func("nesterov")
+        return model
+    try:
+        ops.BWD_SUMS = False
+        x, metas = zoo.synthetic_batch(2, img, seed=11)
+        build().train_step(x, metas, 0, 0, 0.02, [0.9], 1e-4)                  # decides the launch configurations once
+        for (mode, g) in list(ops._WINO):
+            t = tile if tile != ops.FUSED2 else (ops.FUSED2 if ops.conv_wino2f_ok(mode, g) else 4)
+            if (t == ops.FUSED2) or ops.conv_wino_ok(g, t):
+                ops._WINO[(mode, g)] = t
+        for on in (True, False):
+            ops.BWD_SUMS = on
+            ops.SUMS_COUNT[0] = 0
+            random.seed(7)
+            model = build()
+            model.train_step(x, metas, 0, 0, 0.0, [0.9], 0.0)                  # learning rate 0: the gradients are what is compared
+            torch.cuda.synchronize()
+            assert (ops.SUMS_COUNT[0] >= 12) if on else (ops.SUMS_COUNT[0] == 0), ops.SUMS_COUNT
+            res.append((model, model.G.clone()))
+    finally:
+        ops.BWD_SUMS = saved[0]
+        ops._WINO.clear()
+        ops._WINO.update(saved[1])
+    (m, ga), (_, gb) = res
+    worst = 0.0
+    for layer, lo, hi in m.layer_weight_range:
+        ref = float(gb[lo:hi].abs().max())
+        if ref > 0:
+            worst = max(worst, float((ga[lo:hi] - gb[lo:hi]).abs().max()) / ref)
+    nb = m.n_trainable
+    bias_ref = float(gb[m.n_weights:nb].abs().max())
+    worst_b = float((ga[m.n_weights:nb] - gb[m.n_weights:nb]).abs().max()) / bias_ref
+    assert worst < 2e-5 and worst_b < 2e-5, (worst, worst_b)
+
+
 def test_prepared_cold_roi_list_equals_the_hand_off_path(hip):
     """DeNetSparseLayer._speculate_cold: with a cold corner detector (no proposals: weights as initialised) the edited RoI list
     is prepared at the start of the step on a copy of the stdlib generator and adopted at the hand-off; a warm detector must
