@@ -17,6 +17,7 @@
 //                 reduction order is a fixed permutation of k (legal: the sum is over the same terms).
 // Launch:         1-D grid over tiles with an XCD-aware remap (8 XCDs, private L2 each).
 #include "common.h"
+#include "../../include/denet_hip.h"
 #include <map>
 #include <vector>
 #include <type_traits>
@@ -53,6 +54,16 @@ struct IgemmParams {
     FastDiv div_row_w;  // fwd/wgrad: OW       dgrad: Wc
     int Hc, Wc;         // dgrad: H/stride, W/stride
     int wg_split_slow;  // wgrad: 1 = split slice is the slow (XCD-local) index of the linear workgroup id
+    // backward sums (bs_x != null, with `stats`): the tensor written is the gradient of the OUTPUT of a batch norm whose input
+    // was bs_x; the column sums become that layer's two backward reductions, sum(g) and sum(g * xhat), g = the value masked by
+    // the layer's ReLU (bs_y > 0, or recomputed from bs_x) - what bn_bwd_partial_kernel computes in a pass of its own
+    const float* bs_x;
+    const float* bs_y;
+    const float* bs_gamma;
+    const float* bs_beta;
+    const float* bs_mean;
+    const float* bs_invstd;
+    int bs_relu;
     long batch_act, batch_wgt, batch_out;  // fwd / wgrad: element strides of blockIdx.y (batched GEMMs of the Winograd path)
     int batch;          // wgrad: number of batch members (grid.y), 0 = 1
     unsigned act_bytes, wgt_bytes;  // extents of `act` / `wgt` (buffer descriptors: out-of-range lanes read 0)
@@ -612,7 +623,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
     float* out = p.out;
     if (MODE == MODE_WGRAD) out += (long)split_id * p.split_stride;
     if (MODE == MODE_FWD || MODE == MODE_WGRAD) out += by * p.batch_out;
-    if (MODE == MODE_FWD && p.stats) {
+    if ((MODE == MODE_FWD || MODE == MODE_DGRAD) && p.stats) {      // (data gradient: stride 1 only, checked by the host)
         // ---- store + batch-norm column sums. Lane (li, lh) holds row m and, per (j, g), 4 consecutive columns: the sums
         // over the rows of the tile are a reduction over li (shuffles inside each 32-lane half), then over the two waves
         // stacked along M (LDS), written as doubles: partial[tile_m][0][n] = sum, [1][n] = sum of squares.
@@ -628,6 +639,15 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
                 if (n < p.NC) {
                     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
                     if (p.bias) bias4 = *(const f32x4*)(p.bias + n);
+                    f32x4 bmu = {0.f, 0.f, 0.f, 0.f}, bis = bmu, bsc = bmu, bsh = bmu;
+                    if (p.bs_x) {
+                        bmu = *(const f32x4*)(p.bs_mean + n);
+                        bis = *(const f32x4*)(p.bs_invstd + n);
+                        if (p.bs_relu && !p.bs_y) {
+                            bsc = *(const f32x4*)(p.bs_gamma + n) * bis;
+                            bsh = *(const f32x4*)(p.bs_beta + n) - bmu * bsc;
+                        }
+                    }
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         const int m = m0 + (wm * TM + i) * 32 + li;
@@ -640,8 +660,25 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
                                 v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
                             }
                             *(f32x4*)(p.out + row + n) = v;
-                            sv += v;
-                            sq += v * v;
+                            if (p.bs_x) {
+                                const f32x4 xv = *(const f32x4*)(p.bs_x + row + n);
+                                f32x4 gq = v;
+                                if (p.bs_relu) {
+                                    if (p.bs_y) {
+                                        const f32x4 yv = *(const f32x4*)(p.bs_y + row + n);
+#pragma unroll
+                                        for (int c = 0; c < 4; ++c) gq[c] = yv[c] > 0.f ? gq[c] : 0.f;
+                                    } else {
+#pragma unroll
+                                        for (int c = 0; c < 4; ++c) gq[c] = fmaf(xv[c], bsc[c], bsh[c]) > 0.f ? gq[c] : 0.f;
+                                    }
+                                }
+                                sv += gq;
+                                sq += gq * ((xv - bmu) * bis);
+                            } else {
+                                sv += v;
+                                sq += v * v;
+                            }
                         }
                     }
                 }
@@ -1357,15 +1394,46 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
     }
 }
 
+static int conv_dgrad_impl(const float* dy, const float* w, const float* add, float* dx, const denet_bn_link* sums_of,
+                           double* stats, int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH,
+                           int OW, hipStream_t stream);
+
 extern "C" int denet_conv_dgrad(const float* dy, const float* w, const float* add, float* dx, int N, int H, int W,
                                 int C, int K, int R, int S, int S_real, int stride, int pad, int OH, int OW,
                                 hipStream_t stream) {
+    return conv_dgrad_impl(dy, w, add, dx, nullptr, nullptr, N, H, W, C, K, R, S, S_real, stride, pad, OH, OW, stream);
+}
+
+// denet_conv_dgrad of a stride-1 layer whose dx is the gradient of the OUTPUT of the batch norm `sums_of` (see
+// denet_conv_wino_dgrad_sums): the epilogue also writes that layer's backward reductions, stats_partial
+// [ceil(N*H*W / 128)][2][C] doubles, *stats_rows rows (0 and no sums for strides > 1)
+extern "C" int denet_conv_dgrad_sums(const float* dy, const float* w, const float* add, float* dx, const denet_bn_link* sums_of,
+                                     double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int C, int K,
+                                     int R, int S, int S_real, int stride, int pad, int OH, int OW, hipStream_t stream) {
+    DENET_CHECK_ARG(sums_of && stats_partial && stats_rows, "conv_dgrad_sums: null pointer");
+    DENET_CHECK_ARG(sums_of->x && sums_of->mean && sums_of->invstd && (!sums_of->relu || sums_of->y || (sums_of->gamma && sums_of->beta)),
+                    "conv_dgrad_sums: incomplete batch-norm description");
+    const long rows = ((long)N * H * W + 127) / 128;
+    const bool ok = stride == 1 && stats_bytes >= (size_t)rows * 2 * C * sizeof(double);
+    *stats_rows = ok ? (int)rows : 0;
+    return conv_dgrad_impl(dy, w, add, dx, ok ? sums_of : nullptr, ok ? stats_partial : nullptr, N, H, W, C, K, R, S, S_real, stride,
+                           pad, OH, OW, stream);
+}
+
+static int conv_dgrad_impl(const float* dy, const float* w, const float* add, float* dx, const denet_bn_link* sums_of,
+                           double* stats, int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH,
+                           int OW, hipStream_t stream) {
     int rc = check_geom(N, H, W, C, K, R, S, S_real, stride, pad, OH, OW);
     if (rc) return rc;
     DENET_CHECK_ARG(dy && w && dx, "conv_dgrad: null pointer");
     DENET_CHECK_ARG(C >= 32, "conv_dgrad: C < 32 not supported (first layer needs no data gradient)");
     IgemmParams p = {};
     p.act = dy; p.wgt = w; p.out = dx; p.bias = nullptr; p.add = add;
+    if (sums_of && stats) {
+        p.stats = stats;
+        p.bs_x = sums_of->x; p.bs_y = sums_of->relu ? sums_of->y : nullptr; p.bs_gamma = sums_of->gamma; p.bs_beta = sums_of->beta;
+        p.bs_mean = sums_of->mean; p.bs_invstd = sums_of->invstd; p.bs_relu = sums_of->relu;
+    }
     p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K;
     p.R = R; p.S = S; p.S_real = S_real; p.stride = stride; p.sshift = ilog2_exact(stride); p.pad = pad;
     DENET_CHECK_ARG(H % stride == 0 && W % stride == 0, "conv_dgrad: H, W must be multiples of the stride");

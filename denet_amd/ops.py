@@ -776,6 +776,17 @@ def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None,
         cache["dgrad_tile"] = 0
     if PROFILE is not None:
         PROFILE.add(_conv_flops(g, logical))
+    if sums is not None and g[8] == 1 and (int(BWD_SUMS) & 2):
+        # stride 1: the epilogue of the implicit-GEMM kernel leaves the batch norm's backward reductions behind as well
+        import ctypes
+        N, H, W, C = g[0], g[1], g[2], g[3]
+        rows = ctypes.c_int(0)
+        sb = sums.buffer(cache, (N * H * W + 127) // 128, C)
+        so = sums.c_struct()
+        check(_L().denet_conv_dgrad_sums(ptr(dy), ptr(w), ptr(add), ptr(dx), ctypes.byref(so), ptr(sb), sb.numel() * 8,
+                                         ctypes.byref(rows), *g, stream_ptr()), "conv_dgrad_sums")
+        sums.done(sb, rows.value)
+        return dx
     direct()
     return dx
 
@@ -844,7 +855,7 @@ SUMS_COUNT = [0]           # data-gradient passes that also produced a batch nor
 # gradient it produces (denet_conv_wino_dgrad_sums / denet_conv_wino2f_sums): that layer's backward then needs no pass of its own
 # over (gradient, input, output) for them. The sums are accumulated per block in fp32 before they are widened (as the forward
 # statistics from the convolution epilogues are), so they differ from bn_bwd_partial_kernel's in the last bits. 0: off
-BWD_SUMS = os.environ.get("DENET_BN_BWD_SUMS", "1") != "0"
+BWD_SUMS = int(os.environ.get("DENET_BN_BWD_SUMS", "3"))      # bit 0: Winograd passes, bit 1: direct stride-1 passes (1x1 head)
 
 
 def _bn_link_struct(x, aux, y, gamma, beta, mean, invstd, coef, out, relu):

@@ -183,6 +183,9 @@ int denet_conv_wino_dgrad_sums(const float* dy, const float* w, const float* u_c
                                const denet_bn_link* sums_of, double* stats_partial, size_t stats_bytes, int* stats_rows,
                                float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
                                hipStream_t stream);
+int denet_conv_dgrad_sums(const float* dy, const float* w, const float* add, float* dx, const denet_bn_link* sums_of,
+                          double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int C, int K, int R,
+                          int S, int S_real, int stride, int pad, int OH, int OW, hipStream_t stream);
 int denet_conv_wino2f_sums(const float* x, const float* u, const float* bias, const float* add, float* y, int relu,
                            double* stats_partial, size_t stats_bytes, int* stats_rows, const denet_bn_link* sums_of, int N, int H,
                            int W, int Ci, int Co, hipStream_t stream);

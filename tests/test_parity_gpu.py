@@ -684,7 +684,7 @@ def test_batch_norm_linked_into_winograd_transforms_is_bit_identical(hip, img, t
 @pytest.mark.parametrize("img,tile", [(128, 4), (256, 22), (128, 2)])
 def test_batch_norm_backward_sums_from_the_data_gradient_pass(hip, img, tile):
     """ops.BWD_SUMS: the output transform of a Winograd data-gradient pass (un-fused F(2x2) / F(4x4): wino_output_kernel; the fused
-    64-channel kernel: wino2f_ws_kernel) also writes the two backward reductions sum(g), sum(g * xhat) of the batch norm whose
+    64-channel kernel: wino2f_ws_kernel; the 1x1 layers of the RoI head: the implicit-GEMM epilogue) also writes the two backward reductions sum(g), sum(g * xhat) of the batch norm whose
     output gradient it produces, and that layer's backward skips its own reduction pass (bn_bwd_partial_kernel). Reference:
     the gradient of batch_norm.py:50-53 / batch_norm_relu.py:50-54 through model_cnn.py:318. The sums are accumulated per block
     in fp32 before they are widened, so the comparison is numeric: all gradients of one step from identical parameters within
@@ -697,7 +697,7 @@ def test_batch_norm_backward_sums_from_the_data_gradient_pass(hip, img, tile):
         model.build_train_func("nesterov")
         return model
     try:
-        ops.BWD_SUMS = False
+        ops.BWD_SUMS = 0
         x, metas = zoo.synthetic_batch(2, img, seed=11)
         build().train_step(x, metas, 0, 0, 0.02, [0.9], 1e-4)                  # decides the launch configurations once
         for (mode, g) in list(ops._WINO):
@@ -705,7 +705,7 @@ def test_batch_norm_backward_sums_from_the_data_gradient_pass(hip, img, tile):
             if (t == ops.FUSED2) or ops.conv_wino_ok(g, t):
                 ops._WINO[(mode, g)] = t
         for on in (True, False):
-            ops.BWD_SUMS = on
+            ops.BWD_SUMS = 3 if on else 0        # Winograd passes and the stride-1 implicit-GEMM passes (1x1 head)
             ops.SUMS_COUNT[0] = 0
             random.seed(7)
             model = build()
