@@ -90,7 +90,10 @@ def train(args, train_data, dp, log=None):
     for epoch in range(epoch_start, args.epochs):
         random.seed(args.seed + epoch)                 # same order on every rank (train_multi.py:44-46)
         train_data.shuffle()
-        for subset in range(train_data.subset_num):
+        # a restarted run continues the first epoch behind the subsets the checkpoint has seen (UpdateClient(epoch_start,
+        # subset_start, ...), train_multi.py:396-398); the shuffle above is the whole epoch's, so the data order is unchanged
+        first = int(getattr(args, "subset_start", 0)) if epoch == epoch_start else 0
+        for subset in range(first, train_data.subset_num):
             images = shard.images_of_subset(subset)
             if len(images) == 0:
                 continue
@@ -128,16 +131,19 @@ def train(args, train_data, dp, log=None):
 
 
 def find_restart(output_prefix):
-    """(model file, epoch_start) of the newest checkpoint of a run (load_restart_args, train_multi.py:242-268): a `_final`
-    file continues with the next epoch, a `_subsetMMM` file repeats its epoch"""
+    """(model file, epoch_start, subset_start) of the newest checkpoint of a run, with the arithmetic of load_restart_args
+    (train_multi.py:242-268): a `_final` file continues with the next epoch at subset 0; a `_subsetMMM` file continues ITS epoch
+    at subset MMM + 1. (The file number is already the finished subset + 1, train_multi.py:158, so the reference steps over one
+    subset when it restarts; mirrored as it is.)"""
     import glob
     files = sorted(glob.glob(output_prefix + "_epoch*.mdl.gz"))
     if not files:
         raise Exception("Could not find any intermediate models to continue training from!")
     v = os.path.basename(files[-1])
     v = v[:v.find(".")].split("_")
-    epoch = int(v[-2][5:]) + 1 if v[-1] == "final" else int(v[-2][5:])
-    return files[-1], epoch
+    if v[-1] == "final":
+        return files[-1], int(v[-2][5:]) + 1, 0
+    return files[-1], int(v[-2][5:]), int(v[-1][6:]) + 1
 
 
 def main(argv=None):
@@ -149,11 +155,12 @@ def main(argv=None):
                         help="Use model accumulation over multiple batches (with --batch-size-factor F > 1: the F local steps "
                              "of an iteration all start from the same parameters and their updates are averaged)")
     parser.add_argument("--epoch-start", type=int, default=0, help="Epoch to start from")
+    parser.add_argument("--subset-start", type=int, default=0, help="Subset to start from")
     parser.add_argument("--restart", default=False, action="store_true", help="Restart training of model")
     parser.add_argument("--save-subsets", default=False, action="store_true", help="checkpoint after every subset")
     args = parser.parse_args(argv)
     if args.restart:
-        args.model, args.epoch_start = find_restart(args.output_prefix)
+        args.model, args.epoch_start, args.subset_start = find_restart(args.output_prefix)
     from ..common import logging
     logging.init(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -489,11 +489,11 @@ def test_train_multi_restart_lookup(tmp_path):
         find_restart(prefix)
     for name in ("_epoch000_final", "_epoch001_subset003", "_epoch001_final", "_epoch002_subset001"):
         open(prefix + name + ".mdl.gz", "w").close()
-    assert find_restart(prefix) == (prefix + "_epoch002_subset001.mdl.gz", 2)
+    assert find_restart(prefix) == (prefix + "_epoch002_subset001.mdl.gz", 2, 2)
     os.remove(prefix + "_epoch002_subset001.mdl.gz")
-    assert find_restart(prefix) == (prefix + "_epoch001_subset003.mdl.gz", 1)      # sorted(): "subset" > "final", as in the reference
+    assert find_restart(prefix) == (prefix + "_epoch001_subset003.mdl.gz", 1, 4)      # sorted(): "subset" > "final", as in the reference
     os.remove(prefix + "_epoch001_subset003.mdl.gz")
-    assert find_restart(prefix) == (prefix + "_epoch001_final.mdl.gz", 2)
+    assert find_restart(prefix) == (prefix + "_epoch001_final.mdl.gz", 2, 0)
 
 
 def test_train_multi_sharding():

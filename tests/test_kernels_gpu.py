@@ -70,6 +70,43 @@ def test_conv_fwd_dgrad_wgrad(hip, case):
     _close(dx2, dx + addx)
 
 
+@pytest.mark.parametrize("ratio", [0.0, 3.0, 30.0])
+def test_conv_epilogue_statistics_with_a_large_channel_offset(hip, ratio):
+    """the statistics from the convolution epilogues accumulate sum and sum of squares of 128-256 values in fp32
+    before they are widened, and var = E[x^2] - mean^2 cancels: with a channel whose |mean| / std is `ratio`, the inverse
+    standard deviation carries a relative error of about 1e-7 x ratio^2 (the stand-alone pass sums every element in fp64; the
+    reference's cuDNN is two-pass). Measured here and bounded: DeNet's convolution outputs in front of a batch norm have
+    ratios of 0-3 (no bias in front of a BN: resnet.py:60-90), where the error is at the 1e-6 level; a ratio of 100 would
+    cost 3 digits - documented in DESIGN.md section 8 as a limit of the fused statistics."""
+    from denet_amd import ops
+    N, H, C, K = 4, 32, 64, 64
+    g = torch.Generator(device="cpu").manual_seed(int(ratio))
+    x = torch.randn(N, H, H, C, generator=g).cuda()
+    w = (torch.randn(K, 3, 3, C, generator=g) * 0.04).cuda()
+    gamma, beta = torch.ones(K).cuda(), torch.zeros(K).cuda()
+    y0 = ops.conv_fwd(x, w, stride=1, pad=1)
+    bias = (float(ratio) * y0.std()).item() * torch.ones(K).cuda()
+    saved = dict(ops._WINO)
+    try:
+        worst = 0.0
+        for force in (0, 2, 4):
+            geom = ops.conv_geom(x.shape, w.shape, 1, 1, None)
+            ops._WINO.clear()
+            ops._WINO[(0, geom)] = force
+            cache = {"train": True}
+            y = ops.conv_fwd(x, w, bias=bias, stride=1, pad=1, cache=cache, bn_stats=True)
+            st = cache.get("bn_stats")
+            assert st is not None
+            rm, rs = torch.zeros(K).cuda(), torch.ones(K).cuda()
+            _, _, si = ops.bn_fwd_train(y, gamma, beta, rm, rs, pre=st)
+            ref = 1.0 / torch.sqrt(y.double().reshape(-1, K).var(0, unbiased=False) + 1e-5)
+            worst = max(worst, float(((si.double() - ref) / ref).abs().max()))
+    finally:
+        ops._WINO.clear()
+        ops._WINO.update(saved)
+    assert worst < 3e-7 * (1.0 + ratio * ratio) + 2e-6, (ratio, worst)
+
+
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1), (3, 20, 12, 32, 160, 1, 1, 0), (2, 16, 16, 64, 128, 3, 2, 1),
                                   (1, 12, 12, 128, 128, 3, 1, 1), (2, 24, 24, 64, 96, 3, 1, 1)])
 def test_conv_epilogue_batch_norm_sums(hip, case):
