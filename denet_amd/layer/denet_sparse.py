@@ -195,7 +195,12 @@ class DeNetSparseLayer(AbstractLayer):
             return [empty_pr] * B, [empty_bx] * B
         hbox = h[:B * S * 4].view(B, S, 4)
         habsd = h[B * S * 4:B * S * 5].view(torch.float32).view(B, S)
-        raw = ops.samples_finish_host(hbox, habsd, hcount, cl.height, cl.width).numpy()
+        # two buffers in turn: the rows of a step are read until its detection targets are built, i.e. into the next forward pass
+        ring = self.__dict__.setdefault("_finish_ring", [None, None])
+        self._finish_turn = 1 - getattr(self, "_finish_turn", 0)
+        out = ops.samples_finish_host(hbox, habsd, hcount, cl.height, cl.width, out=ring[self._finish_turn])
+        ring[self._finish_turn] = out
+        raw = out.numpy()
         hcount = hcount.numpy()
         if self.cluster:
             raw, hcount = ops.cluster_samples_host(raw, hcount, self.nms_threshold, self.sample_count)

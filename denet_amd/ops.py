@@ -1311,10 +1311,12 @@ def build_samples_stats(corner_pr, sample_count, max_corners=1024):
     return nc.cpu(), cand.cpu().to(torch.int64) & 0xFFFFFFFF
 
 
-def samples_finish_host(box, absd, count, H, W):
-    """Host epilogue (libm expf, double box arithmetic exactly as the reference). CPU tensors in, CPU tensor out."""
+def samples_finish_host(box, absd, count, H, W, out=None):
+    """Host epilogue (libm expf, double box arithmetic exactly as the reference). CPU tensors in, CPU tensor out (`out`: a
+    buffer of the caller's to write into - a fresh 0.4 MB allocation costs ~0.1 ms of page faults inside the RoI hand-off)."""
     B, S, _ = box.shape
-    out = torch.empty((B, S, 5), dtype=torch.float32)
+    if out is None or tuple(out.shape) != (B, S, 5):
+        out = torch.empty((B, S, 5), dtype=torch.float32)
     check(_L().denet_samples_finish_host(box.data_ptr(), absd.data_ptr(), count.data_ptr(), B, S, H, W,
                                          out.data_ptr()), "samples_finish_host")
     return out
