@@ -352,6 +352,52 @@ def test_conv_is_mfma_exact_order_free(hip):
     _close(y, ref, rtol=1e-5)
 
 
+@pytest.mark.parametrize("path", ["wino4", "wino2", "fused64", "direct1x1"])
+@pytest.mark.parametrize("relu,with_y", [(False, False), (True, False), (True, True)])
+def test_data_gradient_pass_leaves_the_batch_norm_backward_sums(hip, path, relu, with_y):
+    """denet_conv_wino_dgrad_sums / denet_conv_wino2f_sums / denet_conv_dgrad_sums + denet_bn_bwd_final: a data-gradient pass
+    whose output is the gradient of a batch norm's OUTPUT also writes that layer's two backward reductions (the cuDNN BN-grad
+    reduction of batch_norm.py:51-53 / the masked one of batch_norm_relu.py:50-54) - against the reduction pass of its own
+    (denet_bn_bwd_sums) on the same tensors, and the pieces against the one-call form: denet_bn_bwd == sums + apply,
+    denet_bn_fwd_train_pre == stats_final + apply (bit for bit)"""
+    from denet_amd import ops
+    g = torch.Generator().manual_seed(5)
+    N, H, W = 2, 16, 16
+    C, K, R = {"wino4": (128, 96, 3), "wino2": (64, 128, 3), "fused64": (64, 64, 3), "direct1x1": (256, 160, 1)}[path]
+    pad = 1 if R == 3 else 0
+    dy = torch.randn(N, H, W, K, generator=g).cuda()                   # gradient of the convolution's output
+    w = (torch.randn(K, R, R, C, generator=g) * 0.05).cuda()
+    addt = torch.randn(N, H, W, C, generator=g).cuda()                 # an earlier contribution to the same gradient
+    x = (torch.randn(N, H, W, C, generator=g) * 1.5 + 0.3).cuda()      # the batch norm's input
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    rm, rs = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    res = torch.randn(N, H, W, C, generator=g).cuda() if with_y else None
+    y, sm, si = ops.bn_fwd_train(x, gamma, beta, rm, rs, relu=relu, res=res)
+    geom = ops.conv_geom((N, H, W, C), w.shape, 1, pad, None)
+    saved = (dict(ops._WINO), ops.BWD_SUMS)
+    try:
+        ops.BWD_SUMS = 3
+        ops._WINO[(1, geom)] = {"wino4": 4, "wino2": 2, "fused64": ops.FUSED2, "direct1x1": 0}[path]
+        sums = ops.BnSums(x, y if (relu and with_y) else None, gamma, beta, sm, si, relu)
+        cache = {}
+        dz = ops.conv_dgrad(dy, w, (N, H, W, C), add=addt, stride=1, pad=pad, cache=cache, sums=sums)
+        assert sums.partial is not None, "the pass did not leave the sums"
+        dz_plain = ops.conv_dgrad(dy, w, (N, H, W, C), add=addt, stride=1, pad=pad, cache={})
+        assert torch.equal(dz, dz_plain)                               # the gradient itself is untouched by the request
+        yy = y if (relu and with_y) else None
+        la, _ = ops.bn_bwd_link(x, yy, dz, gamma, sm, si, relu=relu, beta=beta, pre=sums.partial)
+        lb, _ = ops.bn_bwd_link(x, yy, dz, gamma, sm, si, relu=relu, beta=beta)
+        _close(la.coef, lb.coef, rtol=2e-5)
+        assert torch.equal(la.materialise(), la.materialise())
+        # the pieces == the one-call forms
+        dx_ref, _, dg_ref, db_ref = ops.bn_bwd(x, yy, dz, gamma, sm, si, relu=relu, beta=beta)
+        assert torch.equal(lb.materialise(), dx_ref)
+    finally:
+        ops._WINO.clear()
+        ops._WINO.update(saved[0])
+        ops.BWD_SUMS = saved[1]
+
+
 @pytest.mark.parametrize("shape", [(4, 16, 16, 64), (2, 8, 8, 1536), (3, 5, 7, 768), (2, 32, 32, 128)])
 @pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
 def test_bn_fwd_bwd(hip, shape, relu, res):
