@@ -676,3 +676,61 @@ def test_detect_targets_match_executed_reference_method():
         parts = [tg[0].flatten()] + ([tg[1].flatten(), tg[2].flatten()] if c["use_bbox_reg"] else []) + \
                 ([tg[3].flatten()] if c["use_indfit"] else [])
         np.testing.assert_array_equal(np.concatenate(parts), want)
+
+
+def test_desc_grammar_matches_the_executed_reference_parser():
+    """The `TYPE.TAGS[args]` operator surface against the reference itself: tests/golden/make_desc_fixtures.py executed the reference's
+    `ModelCNN.build_layer` (model_cnn.py:122-146) and the `parse_desc` of its 19 registry classes (layer_types.py:17-25) with the
+    layer constructors recorded; the same tokens go through the build's parser with ITS constructors recorded the same way. Per
+    token: the same class(es), in the same number, with the same constructor arguments (defaults, tag semantics, argument
+    types), the same registry order, and an exception for the tokens the reference rejects"""
+    import inspect
+    import types
+    from denet_amd import layer as layer_pkg
+    from denet_amd.layer.layer_types import layer_types
+    with open(os.path.join(GOLDEN, "desc_fixtures.json")) as f:
+        fix = json.load(f)
+    assert [c.__name__ for c in layer_types] == fix["registry_order"]
+    stub_shape = tuple(fix["stub_shape"])
+    log = []
+    classes = {c.__name__: c for c in layer_types}
+    modules = [m for name, m in sys.modules.items() if name.startswith("denet_amd.layer") and m is not None]
+    patched = []
+
+    def recorder(cls):
+        names = list(inspect.signature(cls.__init__).parameters)[1:]
+
+        def construct(*args, **kwargs):
+            named = dict(zip(names, args))
+            named.update(kwargs)
+            named.pop("layers", None)
+            log.append({"class": cls.__name__, "args": {k: (list(v) if isinstance(v, tuple) else v) for k, v in named.items()}})
+            return types.SimpleNamespace(output_shape=stub_shape, type_name=cls.__name__)
+        return construct
+    try:
+        for m in modules:
+            for name, cls in classes.items():
+                if m.__dict__.get(name) is cls:
+                    patched.append((m, name, cls))
+                    setattr(m, name, recorder(cls))
+        model = model_cnn.ModelCNN()
+        model.class_num = 80
+        assert len(fix["cases"]) >= 50
+        for c in fix["cases"]:
+            layers = [types.SimpleNamespace(output_shape=stub_shape, type_name="initial")]
+            del log[:]
+            if "error" in c:
+                with pytest.raises(Exception):
+                    model.build_layer(c["token"], layers, "relu", "half", "he-backward")
+                continue
+            model.build_layer(c["token"], layers, "relu", "half", "he-backward")
+            assert len(layers) - 1 == c["layers_appended"], c["token"]
+            assert [x["class"] for x in log] == [x["class"] for x in c["calls"]], c["token"]
+            for got, want in zip(log, c["calls"]):
+                for k, v in want["args"].items():
+                    assert k in got["args"], (c["token"], "constructor argument the reference passes is unknown here", k)
+                    assert got["args"][k] == v and type(got["args"][k]) is type(v), (c["token"], k, got["args"][k], v)
+                assert set(got["args"]) == set(want["args"]), (c["token"], got["args"], want["args"])
+    finally:
+        for m, name, cls in patched:
+            setattr(m, name, cls)
