@@ -8,7 +8,8 @@
 A "step" = one full training step of the hot path on one synthetic MSCOCO-shaped batch of 32 images per GPU:
 host targets -> forward (conv/BN stack, corner map, GPU RoI proposal, RoI editing, sparse gather, RoI head) ->
 costs -> backward -> (N>1: RCCL gradient all-reduce overlapped with backward) -> fused nesterov update.
-Inputs are resident in HBM before the timed region. Rank 0 prints ONE JSON line.
+Inputs are resident in HBM before the timed region. Rank 0 prints ONE JSON line. N > 1: key `data_parallel` (backend as the
+process group reports it, per-rank ms/step, all-reduce bytes and buckets per step, event-timed exposed collective time).
 
 Extra legs (rank 0, N=1 only; outside the timed region):
   roofline      the dominant kernel (implicit-GEMM convolution instantiation with the largest total time) is timed
@@ -18,6 +19,7 @@ Extra legs (rank 0, N=1 only; outside the timed region):
                 the same step with the corner head held in a firing regime (40 / 1400 cells per corner type and image above
                 the threshold; the second takes the max_corners truncation branch): RoI proposal on the GPU, host hand-off
                 phases under the reference's names.
+  split_bf16    OPT-IN variant, never the headline: the head GEMMs as 3-term bf16 splits (own key, own number).
   cpu_baseline  the numpy/C++ oracle (oracle/, a CPU restatement of the reference path, kind "port") runs ONE
                 training step of the same model at batch 1 on the host cores.
 """
