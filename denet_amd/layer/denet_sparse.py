@@ -415,6 +415,9 @@ class DeNetSparseLayer(AbstractLayer):
             self._pinned_spec = torch.empty((B * S, 4), dtype=torch.float32).pin_memory()
             self._zero_det = numpy.zeros((B, S, 5), dtype=numpy.float32)
             self._zero_cnt = numpy.zeros(B, dtype=numpy.int32)
+        prev = getattr(self, "_spec_upload", None)
+        if prev is not None:
+            prev.synchronize()          # the upload of the previous step's list out of this pinned buffer (a whole step old: done)
         mirror = PyRandomMirror()
         out_pr, out_box = self._native_edit(mirror, self._zero_det, self._zero_cnt, prep, self._pinned_spec.numpy())
         side = ops.side_stream(2)
@@ -422,6 +425,7 @@ class DeNetSparseLayer(AbstractLayer):
             dev = self._pinned_spec.cuda(non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(side)
+        self._spec_upload = ev
         self._spec = {"metas": metas, "mirror": mirror, "pr": out_pr, "box": out_box, "dev": dev, "ev": ev}
 
     def _edit_out(self):
