@@ -121,10 +121,19 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     }
 }
 
-// second stage: a workgroup reduces FC channels, FJ = 256/FC lanes stride over the partial rows. The stage is
-// latency bound (a few hundred KB, a chain of dependent row loads per lane): 8 channels x 32 row lanes keeps the
-// chain at gy/128 rounds of 4 loads in flight and spreads the work over C/8 workgroups.
-constexpr int FC = 8, FJ = 256 / FC;
+// second stage: a one-wave workgroup reduces FC channels, FJ = 64/FC lanes stride over the partial rows and a shuffle tree
+// adds them. The stage is latency bound (a few hundred KB, a chain of dependent row loads per lane): 32 row lanes keep the
+// chain at gy/128 rounds of 4 loads in flight, C/2 workgroups spread it over the chip. NO LDS on purpose: these kernels run
+// beside the persistent 64-channel Winograd kernels, whose workgroups hold a CU's whole LDS - a kernel that asks for any
+// waits for one of them to retire (measured: 165 us instead of 7 for the six layer-1 finals of a step).
+constexpr int FC = 2, FJ = 64 / FC, FINAL_NT = 64;
+__device__ __forceinline__ void reduce_row_lanes(double& s, double& ss) {
+#pragma unroll
+    for (int off = FC; off < 64; off <<= 1) {
+        s += __shfl_xor(s, off, 64);
+        ss += __shfl_xor(ss, off, 64);
+    }
+}
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partial, int gy, int C, int c, int jl,
                                                 double& s, double& ss) {
     s = 0;
@@ -149,45 +158,31 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
 
 // first of two stages for long partial lists (a stem convolution leaves 16 384 rows = 16 MB, which the C/8 workgroups of the
 // final kernel would walk alone): slice `blockIdx.y` of the rows -> out[slice][2][C]
-__global__ __launch_bounds__(256) void bn_stats_fold_kernel(const double* __restrict__ partial, int gy, int per, int C,
-                                                            double* __restrict__ out) {
-    __shared__ double red[2][FJ][FC];
+__global__ __launch_bounds__(FINAL_NT) void bn_stats_fold_kernel(const double* __restrict__ partial, int gy, int per, int C,
+                                                                 double* __restrict__ out) {
     const int cl = threadIdx.x % FC, jl = threadIdx.x / FC;
     const int c = blockIdx.x * FC + cl;
     const int j0 = blockIdx.y * per;
     const int n = gy - j0 < per ? gy - j0 : per;
     double s, ss;
     reduce_partials(partial + (long)j0 * 2 * C, n, C, c, jl, s, ss);
-    red[0][jl][cl] = s;
-    red[1][jl][cl] = ss;
-    __syncthreads();
+    reduce_row_lanes(s, ss);
     if (jl != 0 || c >= C) return;
-    for (int j = 1; j < FJ; ++j) {
-        s += red[0][j][cl];
-        ss += red[1][j][cl];
-    }
     out[(long)blockIdx.y * 2 * C + c] = s;
     out[(long)blockIdx.y * 2 * C + C + c] = ss;
 }
 
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double* __restrict__ partial, int gy, long M, int C,
+__global__ __launch_bounds__(FINAL_NT) void bn_stats_final_kernel(const double* __restrict__ partial, int gy, long M, int C,
                                                              float eps, float momentum, float* __restrict__ save_mean,
                                                              float* __restrict__ save_invstd,
                                                              float* __restrict__ run_mean,
                                                              float* __restrict__ run_stdinv) {
-    __shared__ double red[2][FJ][FC];
     const int cl = threadIdx.x % FC, jl = threadIdx.x / FC;
     const int c = blockIdx.x * FC + cl;
     double s, ss;
     reduce_partials(partial, gy, C, c, jl, s, ss);
-    red[0][jl][cl] = s;
-    red[1][jl][cl] = ss;
-    __syncthreads();
+    reduce_row_lanes(s, ss);
     if (jl != 0 || c >= C) return;
-    for (int j = 1; j < FJ; ++j) {
-        s += red[0][j][cl];
-        ss += red[1][j][cl];
-    }
     const double mean = s / (double)M;
     double var = ss / (double)M - mean * mean;  // biased variance (cuDNN)
     if (var < 0) var = 0;
@@ -348,22 +343,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 }
 
 // dbeta = sum g ; dgamma = sum g*xhat ; coef[0][c] = dbeta/M ; coef[1][c] = dgamma/M
-__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restrict__ partial, int gy, long M, int C,
+__global__ __launch_bounds__(FINAL_NT) void bn_bwd_final_kernel(const double* __restrict__ partial, int gy, long M, int C,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            float* __restrict__ coef) {
-    __shared__ double red[2][FJ][FC];
     const int cl = threadIdx.x % FC, jl = threadIdx.x / FC;
     const int c = blockIdx.x * FC + cl;
     double s, ss;
     reduce_partials(partial, gy, C, c, jl, s, ss);
-    red[0][jl][cl] = s;
-    red[1][jl][cl] = ss;
-    __syncthreads();
+    reduce_row_lanes(s, ss);
     if (jl != 0 || c >= C) return;
-    for (int j = 1; j < FJ; ++j) {
-        s += red[0][j][cl];
-        ss += red[1][j][cl];
-    }
     dbeta[c] = (float)s;
     dgamma[c] = (float)ss;
     coef[c] = (float)(s / (double)M);
@@ -467,7 +455,7 @@ extern "C" int denet_bn_fwd_train(const float* x, const float* res, float* y, co
     BnMap m = bn_map(M, C);
     double* partial = (double*)workspace;
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, M, C, m.LC, partial);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, m.gy, M, C, eps,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FC - 1) / FC), dim3(FINAL_NT), 0, stream, partial, m.gy, M, C, eps,
                        momentum, save_mean, save_invstd, run_mean, run_stdinv);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, res, y, gamma, beta, save_mean,
                        save_invstd, M, C, m.LC, relu);
@@ -484,7 +472,7 @@ extern "C" int denet_bn_fwd_train_pre(const float* x, const float* res, float* y
     DENET_CHECK_ARG(x && y && gamma && beta && save_mean && save_invstd && partial && rows > 0, "bn_fwd_train_pre: bad arguments");
     DENET_CHECK_ARG(M > 0 && C > 0 && C % 4 == 0, "bn_fwd_train_pre: bad shape M=%ld C=%d", M, C);
     BnMap m = bn_map(M, C);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, rows, M, C, eps,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FC - 1) / FC), dim3(FINAL_NT), 0, stream, partial, rows, M, C, eps,
                        momentum, save_mean, save_invstd, run_mean, run_stdinv);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(m.gx, m.gy), dim3(256), 0, stream, x, res, y, gamma, beta, save_mean,
                        save_invstd, M, C, m.LC, relu);
@@ -495,7 +483,7 @@ extern "C" int denet_bn_fwd_train_pre(const float* x, const float* res, float* y
 extern "C" int denet_bn_stats_final(const double* partial, int rows, long M, int C, float momentum, float eps, float* run_mean,
                                     float* run_stdinv, float* save_mean, float* save_invstd, hipStream_t stream) {
     DENET_CHECK_ARG(partial && rows > 0 && save_mean && save_invstd && M > 0 && C > 0, "bn_stats_final: bad arguments");
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, rows, M, C, eps,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FC - 1) / FC), dim3(FINAL_NT), 0, stream, partial, rows, M, C, eps,
                        momentum, save_mean, save_invstd, run_mean, run_stdinv);
     DENET_CHECK_LAUNCH("bn_stats_final");
     return DENET_OK;
@@ -522,7 +510,7 @@ extern "C" int denet_bn_bwd_sums(const float* x, const float* y, const float* dy
     double* partial = (double*)workspace;
     hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, gamma, beta, save_mean,
                        save_invstd, M, C, m.LC, relu, partial, (const unsigned char*)nullptr, PoolGeom{});
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, m.gy, M, C, dgamma,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FC - 1) / FC), dim3(FINAL_NT), 0, stream, partial, m.gy, M, C, dgamma,
                        dbeta, coef);
     DENET_CHECK_LAUNCH("bn_bwd_sums");
     return DENET_OK;
@@ -534,7 +522,7 @@ extern "C" int denet_bn_bwd_sums(const float* x, const float* y, const float* dy
 extern "C" int denet_bn_bwd_final(const double* partial, int rows, long M, int C, float* dgamma, float* dbeta, float* coef,
                                   hipStream_t stream) {
     DENET_CHECK_ARG(partial && rows > 0 && dgamma && dbeta && coef && M > 0 && C > 0, "bn_bwd_final: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, rows, M, C, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FC - 1) / FC), dim3(FINAL_NT), 0, stream, partial, rows, M, C, dgamma, dbeta, coef);
     DENET_CHECK_LAUNCH("bn_bwd_final");
     return DENET_OK;
 }
@@ -581,7 +569,7 @@ extern "C" int denet_bn_bwd(const float* x, const float* y, const float* dy, con
     float* coef = (float*)(partial + (size_t)m.gy * 2 * C);
     hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, gamma, beta, save_mean,
                        save_invstd, M, C, m.LC, relu, partial, (const unsigned char*)nullptr, PoolGeom{});
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, m.gy, M, C, dgamma,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FC - 1) / FC), dim3(FINAL_NT), 0, stream, partial, m.gy, M, C, dgamma,
                        dbeta, coef);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(m.gx, m.gy), dim3(256), 0, stream, x, y, dy, gamma, beta, save_mean,
                        save_invstd, coef, dx, dres, M, C, m.LC, relu, (const unsigned char*)nullptr, PoolGeom{});
@@ -614,11 +602,11 @@ extern "C" int denet_bn_relu_pool_fwd_train(const float* x, float* y_pool, unsig
         const int per = (rows + 63) / 64;
         const int slices = (rows + per - 1) / per;
         double* folded = (double*)workspace;
-        hipLaunchKernelGGL(bn_stats_fold_kernel, dim3((C + FC - 1) / FC, slices), dim3(256), 0, stream, partial, rows, per, C, folded);
+        hipLaunchKernelGGL(bn_stats_fold_kernel, dim3((C + FC - 1) / FC, slices), dim3(FINAL_NT), 0, stream, partial, rows, per, C, folded);
         partial = folded;
         rows = slices;
     }
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, rows, M, C, eps,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FC - 1) / FC), dim3(FINAL_NT), 0, stream, partial, rows, M, C, eps,
                        momentum, save_mean, save_invstd, run_mean, run_stdinv);
     const PoolGeom g = pool_geom(H, W, OH, OW, k, stride, pad, C);
     const long total = (long)N * OH * OW * (C / 4);
@@ -646,7 +634,7 @@ extern "C" int denet_bn_relu_pool_bwd(const float* x, const float* dy_pool, cons
     const PoolGeom g = pool_geom(H, W, OH, OW, k, stride, pad, C);
     hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(m.gx, m.gy), dim3(256), 0, stream, x, (const float*)nullptr, dy_pool,
                        gamma, beta, save_mean, save_invstd, M, C, m.LC, 1, partial, argmax, g);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FC - 1) / FC), dim3(256), 0, stream, partial, m.gy, M, C, dgamma,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FC - 1) / FC), dim3(FINAL_NT), 0, stream, partial, m.gy, M, C, dgamma,
                        dbeta, coef);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(m.gx, m.gy), dim3(256), 0, stream, x, (const float*)nullptr, dy_pool,
                        gamma, beta, save_mean, save_invstd, coef, dx, (float*)nullptr, M, C, m.LC, 1, argmax, g);

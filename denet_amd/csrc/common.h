@@ -33,6 +33,15 @@ void denet_set_error(const char* fmt, ...);
 int denet_prof_begin(int mode, int bm, int bn, int nbuf, hipStream_t stream);
 void denet_prof_end(int idx, hipStream_t stream);
 
+// the first layer's own kernels (stem.hip); the generic entry points of igemm.hip hand the geometry over when *_ok says so
+extern "C" int denet_conv_stem_ok(int pass, int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH,
+                                  int OW);
+extern "C" int denet_conv_stem_fwd(const float* x, const float* w, const float* bias, float* y, double* stats_partial,
+                                   size_t stats_bytes, int* stats_rows, int N, int H, int W, hipStream_t stream);
+extern "C" size_t denet_conv_stem_wgrad_workspace_bytes(void);
+extern "C" int denet_conv_stem_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes, int N,
+                                     int H, int W, hipStream_t stream);
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

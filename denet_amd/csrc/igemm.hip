@@ -1349,6 +1349,8 @@ extern "C" int denet_conv_fwd_stats(const float* x, const float* w, const float*
                                     double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int C,
                                     int K, int R, int S, int S_real, int stride, int pad, int OH, int OW, hipStream_t stream) {
     DENET_CHECK_ARG(stats_partial && stats_rows, "conv_fwd_stats: null pointer");
+    if (!add && denet_conv_stem_ok(0, N, H, W, C, K, R, S, S_real, stride, pad, OH, OW))
+        return denet_conv_stem_fwd(x, w, bias, y, stats_partial, stats_bytes, stats_rows, N, H, W, stream);
     const long rows = ((long)N * OH * OW + 127) / 128;
     DENET_CHECK_ARG(stats_bytes >= (size_t)rows * 2 * K * sizeof(double), "conv_fwd_stats: statistics buffer too small");
     *stats_rows = (int)rows;
@@ -1361,6 +1363,8 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
     int rc = check_geom(N, H, W, C, K, R, S, S_real, stride, pad, OH, OW);
     if (rc) return rc;
     DENET_CHECK_ARG(x && w && y, "conv_fwd: null pointer");
+    if (!add && !relu && !stats && denet_conv_stem_ok(0, N, H, W, C, K, R, S, S_real, stride, pad, OH, OW))
+        return denet_conv_stem_fwd(x, w, bias, y, nullptr, 0, nullptr, N, H, W, stream);
     IgemmParams p = {};
     p.act = x; p.wgt = w; p.out = y; p.bias = bias; p.add = add; p.relu = relu ? 1 : 0; p.stats = stats;
     p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K;
@@ -1477,6 +1481,9 @@ extern "C" int denet_conv_wgrad(const float* x, const float* dy, float* dw, floa
     int rc = check_geom(N, H, W, C, K, R, S, S_real, stride, pad, OH, OW);
     if (rc) return rc;
     DENET_CHECK_ARG(x && dy && dw, "conv_wgrad: null pointer");
+    if (workspace && workspace_bytes >= denet_conv_stem_wgrad_workspace_bytes() &&
+        denet_conv_stem_ok(1, N, H, W, C, K, R, S, S_real, stride, pad, OH, OW))
+        return denet_conv_stem_wgrad(x, dy, dw, workspace, workspace_bytes, N, H, W, stream);
     IgemmParams p = {};
     p.act = x; p.wgt = dy; p.bias = nullptr; p.add = nullptr;
     p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K;

@@ -23,7 +23,7 @@ struct W2Params {
     const float* bias;   // [Co] or null
     const float* add;    // [N,H,W,Co] or null
     float* y;            // [N,H,W,Co]
-    double* stats;       // [blocks][2][Co] or null
+    double* stats;       // Co = 64: [grid][2][64], a row per workgroup (the sums of all its blocks); else [blocks][2][Co]; or null
     // stats of the BACKWARD kind (bs_x != null; the kernel then computes a data gradient): the tensor written is the gradient of
     // the output of a batch-norm layer whose input was bs_x; the sums are that layer's two reductions, sum(g) and
     // sum(g * xhat) with g = y masked by the layer's ReLU (bs_y > 0, or recomputed from bs_x) - bn_bwd_partial_kernel's
@@ -164,6 +164,8 @@ __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
     f32x4 d[2][3];
     load_d(0, 0, d);
     f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+    if (p.stats && p.nco == 1 && tid < 64)
+        for (int c = tid; c < 2 * p.Co; c += 64) p.stats[(long)blockIdx.x * 2 * p.Co + c] = 0.0;
     while (true) {
         const int next = item + gridDim.x;
         const bool has_next = next < p.items;
@@ -309,9 +311,17 @@ __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
                     a += (double)red[(w * 2 + 0) * 64 + tid];
                     bq += (double)red[(w * 2 + 1) * 64 + tid];
                 }
-                double* ps = p.stats + (long)cur.block * 2 * p.Co;
-                ps[cur.co0 + tid] = a;
-                ps[p.Co + cur.co0 + tid] = bq;
+                if (p.nco == 1) {
+                    // one row per WORKGROUP (zeroed before the first item): lane tid owns its channel's two sums
+                    double* ps = p.stats + (long)blockIdx.x * 2 * p.Co;
+                    ps[tid] += a;
+                    ps[p.Co + tid] += bq;
+                } else {
+                    // several output-channel chunks per block: one row per block, each item writes its chunk of it
+                    double* ps = p.stats + (long)cur.block * 2 * p.Co;
+                    ps[cur.co0 + tid] = a;
+                    ps[p.Co + cur.co0 + tid] = bq;
+                }
             }
             ssum = f32x4{0.f, 0.f, 0.f, 0.f};
             ssq = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -613,7 +623,8 @@ extern "C" int denet_conv_wino2f_ok(int N, int H, int W, int Ci, int Co) {
 
 // y = conv3x3(x) stride 1 pad 1 (+ bias) (+ add) from the F(2x2) transformed filters u = [16][Co][64]
 // (denet_conv_wino_filter with tile 2: dgrad = 0 for the forward pass, 1 for the data gradient, where x = dy, Co = C).
-// stats_partial (optional): [N*ceil(H/16)*ceil(W/16)][2][Co] doubles, the batch-norm column sums of y (see denet_conv_fwd_stats).
+// stats_partial (optional): [rows][2][Co] doubles, the batch-norm column sums of y (see denet_conv_fwd_stats); rows = the launch's
+// workgroups for Co = 64, N*ceil(H/16)*ceil(W/16) otherwise (the most the buffer must hold); *stats_rows receives rows.
 extern "C" int denet_conv_wino2f_sums(const float* x, const float* u, const float* bias, const float* add, float* y, int relu,
                                       double* stats_partial, size_t stats_bytes, int* stats_rows, const denet_bn_link* sums_of,
                                       int N, int H, int W, int Ci, int Co, hipStream_t stream);
@@ -642,9 +653,22 @@ extern "C" int denet_conv_wino2f_sums(const float* x, const float* u, const floa
     p.x_bytes = (unsigned)((size_t)N * H * W * 64 * 4);
     const long blocks = (long)N * p.by * p.bx;
     p.items = (int)(blocks * p.nco);
+    // the LDS footprint allows one workgroup per CU: a persistent grid, work items strided over it
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            denet_set_error("conv_wino2f: cannot query the device");
+            return DENET_ERR_ARG;
+        }
+        cus = prop.multiProcessorCount;
+    }
+    const int grid = p.items < cus ? p.items : cus;
     if (stats_partial) {
-        DENET_CHECK_ARG(stats_rows && stats_bytes >= (size_t)blocks * 2 * Co * sizeof(double), "conv_wino2f: statistics buffer too small");
-        *stats_rows = (int)blocks;
+        const long rows = p.nco == 1 ? grid : blocks;
+        DENET_CHECK_ARG(stats_rows && stats_bytes >= (size_t)rows * 2 * Co * sizeof(double), "conv_wino2f: statistics buffer too small");
+        *stats_rows = (int)rows;
         p.stats = stats_partial;
         if (sums_of) {
             DENET_CHECK_ARG(sums_of->x && sums_of->mean && sums_of->invstd && (!sums_of->relu || sums_of->y || (sums_of->gamma && sums_of->beta)),
@@ -662,18 +686,6 @@ extern "C" int denet_conv_wino2f_sums(const float* x, const float* u, const floa
         }
         attr_set = true;
     }
-    // the LDS footprint allows one workgroup per CU: a persistent grid, work items strided over it
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-            denet_set_error("conv_wino2f: cannot query the device");
-            return DENET_ERR_ARG;
-        }
-        cus = prop.multiProcessorCount;
-    }
-    const int grid = p.items < cus ? p.items : cus;
     const int prof = denet_prof_begin(10, 0, 0, 0, stream);
     hipLaunchKernelGGL(wino2f_ws_kernel, dim3((unsigned)grid), dim3(512), S_LDS_BYTES, stream, p);
     denet_prof_end(prof, stream);

@@ -206,6 +206,15 @@ class ConvLayer(AbstractLayer):
                     return
             self.output.grad = link.materialise()
         dy = self.output.grad
+        need_dx = getattr(self.input, "requires_grad", True)
+        # two MFMA-bound GEMMs of hundreds of GFLOP gain nothing from sharing the chip (measured: the 4736 -> 1536 head layer's
+        # pair takes 4.9 ms side by side, 2.1 + 2.2 ms one after the other) and the data gradient is the one the backward sweep
+        # waits for: it goes first, the filter gradient follows on the second stream beside the HBM-bound passes that come next
+        first = need_dx and sr == 1 and st == 1 and 2e-9 * dy.numel() * x.shape[-1] >= ops.DGRAD_FIRST_GFLOP
+        if first:
+            self.input.grad = ops.conv_dgrad(dy, self._w(), tuple(x.shape), add=self.input.grad, stride=st, pad=pad,
+                                             s_real=sr, logical=self._logical(), cache=self._cache(), sums=sums)
+            self.input.grad_sums = sums
         if self.enabled and self.omega.grad is not None:
             # the first layer of the network has no data gradient: its filter gradient is the tail of the backward sweep on the
             # second stream, and the bias column sums (a pass over the largest tensor of the network) run beside it on the
@@ -219,7 +228,7 @@ class ConvLayer(AbstractLayer):
                     ops.colsum(dy.view(-1, self.kp), out=self.beta.grad)
             if self.use_bias and tail:
                 ops.colsum(dy.view(-1, self.kp), out=self.beta.grad)
-        if getattr(self.input, "requires_grad", True):
+        if need_dx and not first:
             self.input.grad = ops.conv_dgrad(dy, self._w(), tuple(x.shape), add=self.input.grad, stride=st, pad=pad,
                                              s_real=sr, logical=self._logical(), cache=self._cache(), sums=sums)
             self.input.grad_sums = sums

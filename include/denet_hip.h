@@ -129,8 +129,9 @@ int denet_transpose_f32(const float* src, float* dst, int R, int C, hipStream_t 
 /* Fused F(2x2,3x3) convolution for Ci = 64 (stride 1, pad 1; H, W even; Co a multiple of 64): transforms and the
  * 16 component products in one kernel, x -> y only. u = denet_conv_wino_filter(tile 2) output: dgrad = 0 for the forward
  * pass (denet/layer/convolution.py:80-83), dgrad = 1 for the data gradient (x = dy; model_cnn.py:318). Optional bias [Co],
- * add [N,H,W,Co], relu (y = max(y, 0)) and batch-norm column sums stats_partial [N*ceil(H/16)*ceil(W/16)][2][Co] (doubles;
- * *stats_rows = row count). Work items are 16x16-pixel blocks; maps that are no multiple of 16 waste the overhang. */
+ * add [N,H,W,Co], relu (y = max(y, 0)) and batch-norm column sums stats_partial [rows][2][Co] (doubles; Co = 64: a row per
+ * workgroup of the launch, else one per block; rows <= N*ceil(H/16)*ceil(W/16) = what the buffer must hold; *stats_rows =
+ * rows). Work items are 16x16-pixel blocks; maps that are no multiple of 16 waste the overhang. */
 int denet_conv_wino2f_ok(int N, int H, int W, int Ci, int Co);
 int denet_conv_wino2f(const float* x, const float* u, const float* bias, const float* add, float* y, int relu,
                       double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int Ci, int Co,
@@ -141,6 +142,19 @@ int denet_conv_wino2f_wgrad_ok(int N, int H, int W, int C, int K);
 size_t denet_conv_wino2f_wgrad_workspace_bytes(int N, int H, int W);
 int denet_conv_wino2f_wgrad(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int H,
                             int W, int C, int K, hipStream_t stream);
+/* ---- The first layer, `C.B[64,7,2]` on the 3-channel image (csrc/stem.hip; reference: denet/layer/convolution.py:80-83 with the
+ *      desc of examples/resnet34-imagenet.sh:7, filter gradient: tensor.grad, model_cnn.py:318), as kernels of their own: the
+ *      reduction walks the 147 real taps (padded to 160) instead of the 7 x 8 x 4 = 224 of the padded KRSC layout. denet_conv_fwd /
+ *      denet_conv_fwd_stats / denet_conv_wgrad hand this geometry over themselves when denet_conv_stem_ok(pass: 0 forward, 1
+ *      filter gradient) says so (x [N][H][W][4], w / dw [64][7][8][4], stride 2, pad 3, even H and W; DENET_STEM=0 keeps the
+ *      generic kernels). Forward: optional bias and batch-norm column sums, stats_partial [rows][2][64] doubles with rows =
+ *      the launch's workgroups (*stats_rows). Filter gradient: workspace = one partial per workgroup, added in a fixed order. */
+int denet_conv_stem_ok(int pass, int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH, int OW);
+int denet_conv_stem_fwd(const float* x, const float* w, const float* bias, float* y, double* stats_partial, size_t stats_bytes,
+                        int* stats_rows, int N, int H, int W, hipStream_t stream);
+size_t denet_conv_stem_wgrad_workspace_bytes(void);
+int denet_conv_stem_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes, int N, int H, int W,
+                          hipStream_t stream);
 /* ---- Winograd passes whose input is formed on the fly from the batch-norm layer next to them (csrc/winograd.hip,
  *      wino_prep_kernel). Reference: the BN -> conv chains of the residual blocks (denet/layer/resnet.py:60-90,
  *      batch_norm_relu.py:34-54): a pointwise pass writes a tensor the next convolution's input transform re-reads at once.
