@@ -46,14 +46,14 @@ constexpr int PART = 64 * KP;                              // floats of one work
     }
 
 struct StemParams {
-    const float* x;      // [N][H][W][4]
+    const float* x;      // [N][H][W][4], or planar [N][3][H][W] (the reference's own input layout)
     const float* w;      // [64][7][8][4] (forward)
     const float* bias;   // [64] or null
     float* y;            // [N][OH][OW][64] (forward)
     double* stats;       // [grid][2][64] or null
     const float* dy;     // [N][OH][OW][64] (filter gradient)
     float* part;         // [grid][PART]
-    int N, H, W, OH, OW, tiles_y, tiles_x, tiles;
+    int N, H, W, OH, OW, tiles_y, tiles_x, tiles, planar;
 };
 
 struct Block {
@@ -83,9 +83,16 @@ __device__ __forceinline__ f32x3 piece_load(const StemParams& p, const Block& b,
     const int rr = idx / IC, cc = idx - rr * IC;
     const int iy = 2 * b.oy0 - 3 + rr, ix = 2 * b.ox0 - 3 + cc;
     const int iyc = iy < 0 ? 0 : iy >= p.H ? p.H - 1 : iy, ixc = ix < 0 ? 0 : ix >= p.W ? p.W - 1 : ix;
-    const float* const src = p.x + (((long)b.n * p.H + iyc) * p.W + ixc) * 4;
     f32x3 v;
-    __builtin_memcpy(&v, src, 12);
+    if (p.planar) {
+        const float* const src = p.x + ((long)b.n * 3 * p.H + iyc) * p.W + ixc;
+        const long plane = (long)p.H * p.W;
+        v[0] = src[0];
+        v[1] = src[plane];
+        v[2] = src[2 * plane];
+    } else {
+        __builtin_memcpy(&v, p.x + (((long)b.n * p.H + iyc) * p.W + ixc) * 4, 12);
+    }
     return v;
 }
 __device__ __forceinline__ void piece_store(const StemParams& p, const Block& b, float* buf, int k, int tid, const f32x3 v) {
@@ -415,14 +422,26 @@ extern "C" int denet_conv_stem_ok(int pass, int N, int H, int W, int C, int K, i
            W % 2 == 0 && OH == H / 2 && OW == W / 2 && N > 0 && (long)N * H * W * 4 < (1L << 31);
 }
 
+extern "C" int denet_conv_stem_fwd_from(const float* x, int x_nchw, const float* w, const float* bias, float* y, double* stats_partial,
+                                        size_t stats_bytes, int* stats_rows, int N, int H, int W, hipStream_t stream);
+extern "C" int denet_conv_stem_wgrad_from(const float* x, int x_nchw, const float* dy, float* dw, float* workspace,
+                                          size_t workspace_bytes, int N, int H, int W, hipStream_t stream);
+
 // y = conv7x7/2(x) (+ bias) for x [N][H][W][4] (4th channel ignored), w [64][7][8][4]; stats_partial (optional): the batch-norm
 // column sums of y, [rows][2][64] doubles with rows = the launch's workgroups (<= 256 on this chip; *stats_rows receives it)
 extern "C" int denet_conv_stem_fwd(const float* x, const float* w, const float* bias, float* y, double* stats_partial,
                                    size_t stats_bytes, int* stats_rows, int N, int H, int W, hipStream_t stream) {
+    return denet_conv_stem_fwd_from(x, 0, w, bias, y, stats_partial, stats_bytes, stats_rows, N, H, W, stream);
+}
+
+// the same; x_nchw != 0: x is the image batch as the reference holds it, [N][3][H][W] (dataset/__init__.py:359, the layout
+// model_cnn.py feeds the first layer) - no NHWC copy of the input has to exist
+extern "C" int denet_conv_stem_fwd_from(const float* x, int x_nchw, const float* w, const float* bias, float* y, double* stats_partial,
+                                        size_t stats_bytes, int* stats_rows, int N, int H, int W, hipStream_t stream) {
     DENET_CHECK_ARG(x && w && y, "conv_stem_fwd: null pointer");
     DENET_CHECK_ARG(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "conv_stem_fwd: needs even H and W");
     StemParams p = {};
-    p.x = x; p.w = w; p.bias = bias; p.y = y;
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.planar = x_nchw ? 1 : 0;
     const int grid = fill(p, N, H, W);
     DENET_CHECK_ARG(grid > 0, "conv_stem_fwd: cannot query the device");
     if (stats_partial) {
@@ -454,10 +473,15 @@ extern "C" size_t denet_conv_stem_wgrad_workspace_bytes(void) {
 // dw [64][7][8][4] = the filter gradient of the same layer from x and dy [N][H/2][W/2][64]; workspace: one partial per workgroup
 extern "C" int denet_conv_stem_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes, int N,
                                      int H, int W, hipStream_t stream) {
+    return denet_conv_stem_wgrad_from(x, 0, dy, dw, workspace, workspace_bytes, N, H, W, stream);
+}
+
+extern "C" int denet_conv_stem_wgrad_from(const float* x, int x_nchw, const float* dy, float* dw, float* workspace,
+                                          size_t workspace_bytes, int N, int H, int W, hipStream_t stream) {
     DENET_CHECK_ARG(x && dy && dw && workspace, "conv_stem_wgrad: null pointer");
     DENET_CHECK_ARG(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "conv_stem_wgrad: needs even H and W");
     StemParams p = {};
-    p.x = x; p.dy = dy; p.part = workspace;
+    p.x = x; p.dy = dy; p.part = workspace; p.planar = x_nchw ? 1 : 0;
     const int grid = fill(p, N, H, W);
     DENET_CHECK_ARG(grid > 0, "conv_stem_wgrad: cannot query the device");
     DENET_CHECK_ARG(workspace_bytes >= (size_t)grid * PART * sizeof(float), "conv_stem_wgrad: workspace too small");

@@ -153,11 +153,23 @@ class ConvLayer(AbstractLayer):
         # the input may be the output of a batch norm whose pointwise pass is still pending (ops.BnLink): a Winograd pass runs it
         # inside its input transform; whatever path conv_fwd takes, the activation exists afterwards and is stored back
         link = self.input.take_pending_data()
-        x = self.input.data if link is None else None
         cache = self._cache()
         cache["train"] = bool(get_train()) and self.enabled and self.omega.grad is not None
         # a batch norm directly behind this layer (it flags its input Act) gets its statistics from this pass's epilogue
         want_stats = bool(get_train()) and getattr(self.output, "want_stats", False)
+        self._planar_x = None
+        if isinstance(link, ops.NchwLink):
+            # the network input, still in the reference's planar layout: the first layer's kernels read it as it is (forward and,
+            # in backward(), the filter gradient); anybody else who asks the Act for .data gets the NHWC tensor made then
+            self.input.set_pending_data(link)
+            if add is None and self.use_bias and ops.conv_stem_ok(link.x, self.omega.dev_shape, self.stride[0], self.pad,
+                                                                   self.filter_shape[3]):
+                self.output.data = ops.conv_stem_fwd(link.x, self._w(), self.beta.dev, cache, want_stats, logical=self._logical())
+                self.output.stats = cache.pop("bn_stats", None) if want_stats else None
+                self._planar_x = link.x
+                return
+            link = None
+        x = self.input.data if link is None else None
         self.output.data = ops.conv_fwd(x, self._w(), bias=self.beta.dev if self.use_bias else None, add=add,
                                         stride=self.stride[0], pad=self.pad, s_real=self.filter_shape[3],
                                         logical=self._logical(), cache=cache, bn_stats=want_stats, link=link)
@@ -182,7 +194,9 @@ class ConvLayer(AbstractLayer):
         return y
 
     def backward(self, ctx):
-        x = self.input.data
+        # (the first layer on the planar network input has no data gradient and reads the image as it is)
+        planar = getattr(self, "_planar_x", None) if not getattr(self.input, "requires_grad", True) else None
+        x = self.input.data if planar is None else None
         st, pad, sr = self.stride[0], self.pad, self.filter_shape[3]
         # the batch norm (of this training step) whose output is this layer's input: the data-gradient pass below writes the
         # gradient of that output, and a Winograd pass can leave that batch norm's two backward reductions behind (ops.BnSums)
@@ -221,9 +235,13 @@ class ConvLayer(AbstractLayer):
             # compute stream, which has nothing left to do, instead of behind it
             tail = not getattr(self.input, "requires_grad", True)
             with ops.wgrad_stream():        # independent of the data-gradient chain below
-                ops.conv_wgrad(x, dy, self.omega.dev_shape, stride=st, pad=pad, s_real=sr,
-                               out=self.omega.grad.view(self.omega.dev_shape), logical=self._logical(),
-                               cache=self._cache())
+                if planar is not None:
+                    ops.conv_stem_wgrad(planar, dy, self.omega.dev_shape, self.omega.grad.view(self.omega.dev_shape),
+                                        logical=self._logical())
+                else:
+                    ops.conv_wgrad(x, dy, self.omega.dev_shape, stride=st, pad=pad, s_real=sr,
+                                   out=self.omega.grad.view(self.omega.dev_shape), logical=self._logical(),
+                                   cache=self._cache())
                 if self.use_bias and not tail:
                     ops.colsum(dy.view(-1, self.kp), out=self.beta.grad)
             if self.use_bias and tail:

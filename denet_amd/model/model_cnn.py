@@ -315,7 +315,8 @@ class ModelCNN:
         else:
             x = torch.from_numpy(numpy.ascontiguousarray(data_x, dtype=numpy.float32)).cuda(non_blocking=True)
         assert tuple(x.shape) == self.get_input_shape(), (tuple(x.shape), self.get_input_shape())
-        self.input.data = ops.nchw_to_nhwc(x.contiguous(), self.input.cp)
+        # the NHWC copy is made when a layer asks for it: the first convolution's own kernels read the planar batch (ops.NchwLink)
+        self.input.set_pending_data(ops.NchwLink(x.contiguous(), self.input.cp))
 
     def _consumers(self, act):
         """number of layers (nested ones included) that read `act` as their input or as a skip tap"""

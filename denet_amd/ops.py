@@ -822,6 +822,56 @@ def conv_wgrad(x, dy, w_shape, stride=1, pad=0, s_real=None, out=None, logical=N
     return dw
 
 
+class NchwLink:
+    """the network input as the reference feeds it, [N,3,H,W] (dataset/__init__.py:359): the first layer's own kernels read it in
+    that layout (csrc/stem.hip), the NHWC tensor every other consumer expects is only made when somebody asks for it"""
+
+    def __init__(self, x, cp):
+        self.x, self.cp = x, cp
+
+    def materialise(self):
+        return nchw_to_nhwc(self.x, self.cp)
+
+
+def conv_stem_ok(x_nchw, w_shape, stride, pad, s_real):
+    """the first layer's kernels take this convolution straight from the planar image batch"""
+    N, C, H, W = x_nchw.shape
+    K, R, S, cp = w_shape
+    a = (N, H, W, cp, K, R, S, s_real, stride, pad, H // 2, W // 2)
+    return C == 3 and bool(_L().denet_conv_stem_ok(0, *a)) and bool(_L().denet_conv_stem_ok(1, *a))
+
+
+def conv_stem_fwd(x_nchw, w, bias, cache, bn_stats, logical=None):
+    """y = conv7x7/2(x) + bias from the planar image batch (+ the batch-norm column sums: cache["bn_stats"], see conv_fwd)"""
+    import ctypes
+    N, _, H, W = x_nchw.shape
+    K = w.shape[0]
+    g = conv_geom((N, H, W, w.shape[3]), tuple(w.shape), 2, 3, 7)
+    y = empty(N, H // 2, W // 2, K)
+    st, rows = None, ctypes.c_int(0)
+    if bn_stats:
+        st = cache.get("bn_stats_buf")
+        if st is None or st.numel() < 1024 * 2 * K:          # a row per workgroup: at most one per CU
+            st = cache["bn_stats_buf"] = torch.empty(1024 * 2 * K, dtype=torch.float64, device="cuda")
+    if PROFILE is not None:
+        PROFILE.add(_conv_flops(g, logical))
+    check(_L().denet_conv_stem_fwd_from(ptr(x_nchw), 1, ptr(w), ptr(bias), ptr(y), ptr(st), st.numel() * 8 if st is not None else 0,
+                                        ctypes.byref(rows), N, H, W, stream_ptr()), "conv_stem_fwd")
+    cache["bn_stats"] = (st, rows.value) if st is not None else None
+    return y
+
+
+def conv_stem_wgrad(x_nchw, dy, w_shape, out, logical=None):
+    N, _, H, W = x_nchw.shape
+    g = conv_geom((N, H, W, w_shape[3]), tuple(w_shape), 2, 3, 7)
+    ws = WS.get("wgrad", WGRAD_WS_BYTES)
+    if PROFILE is not None:
+        PROFILE.add(_conv_flops(g, logical))
+    check(_L().denet_conv_stem_wgrad_from(ptr(x_nchw), 1, ptr(dy), ptr(out), ptr(ws), ws.numel(), N, H, W, stream_ptr()),
+          "conv_stem_wgrad")
+    return out
+
+
 def _bn_ws(M, C):
     return WS.get("bn", _L().denet_bn_workspace_bytes(M, C))
 

@@ -152,6 +152,12 @@ int denet_conv_wino2f_wgrad(const float* x, const float* dy, float* dw, void* wo
 int denet_conv_stem_ok(int pass, int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH, int OW);
 int denet_conv_stem_fwd(const float* x, const float* w, const float* bias, float* y, double* stats_partial, size_t stats_bytes,
                         int* stats_rows, int N, int H, int W, hipStream_t stream);
+/* ..._from with x_nchw != 0: x is the image batch in the reference's own layout [N][3][H][W] (dataset/__init__.py:359) - the
+ * training step then never makes an NHWC copy of its input */
+int denet_conv_stem_fwd_from(const float* x, int x_nchw, const float* w, const float* bias, float* y, double* stats_partial,
+                             size_t stats_bytes, int* stats_rows, int N, int H, int W, hipStream_t stream);
+int denet_conv_stem_wgrad_from(const float* x, int x_nchw, const float* dy, float* dw, float* workspace, size_t workspace_bytes,
+                               int N, int H, int W, hipStream_t stream);
 size_t denet_conv_stem_wgrad_workspace_bytes(void);
 int denet_conv_stem_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes, int N, int H, int W,
                           hipStream_t stream);

@@ -388,6 +388,15 @@ def test_first_layer_kernels(hip, case):
         dws.append(dw)
     assert torch.equal(dws[0], dws[1])
     dw = dws[0]
+    # the planar image batch (the reference's input layout) read directly: bit-identical to the NHWC route
+    assert ops.conv_stem_ok(x, tuple(wn.shape), 2, 3, 7)
+    cache = {}
+    y3 = ops.conv_stem_fwd(x.contiguous(), wn, bias, cache, True)
+    assert torch.equal(y3, y)
+    st3, rows3 = cache["bn_stats"]
+    assert rows3 == rows.value and torch.equal(st3[:rows3 * 2 * K], st[:rows3 * 2 * K])
+    dw3 = ops.conv_stem_wgrad(x.contiguous(), dyn, tuple(wn.shape), torch.empty_like(dw))
+    assert torch.equal(dw3, dw)
     ref = wd.grad.permute(0, 2, 3, 1)
     assert float((dw[:, :, :7, :3].double() - ref).abs().max()) < 3e-6 * float(ref.abs().max())
     assert float(dw[:, :, 7, :].abs().max()) == 0.0 and float(dw[:, :, :, 3].abs().max()) == 0.0
