@@ -229,8 +229,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 
 // pooled[n][oy][ox][c] = max over the window of relu(gamma*(x-mean)*invstd + beta), arg = its tap (first maximum in scan
 // order, padded taps skipped): bn_apply_kernel + maxpool_fwd_kernel without the tensor in between
+// xh (optional): the normalised input (x - mean) * invstd AT the argmax - with it the two reductions of the layer's backward
+// are sums over the pooled tensors (denet_bn_relu_pool_bwd_sums), a quarter of the elements and no window gather
 __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restrict__ x, float* __restrict__ yp,
-                                                            unsigned char* __restrict__ arg, const float* __restrict__ gamma,
+                                                            unsigned char* __restrict__ arg, float* __restrict__ xh,
+                                                            const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, int N, int C, PoolGeom g) {
     const int C4 = C / 4;
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restr
             sc[e] = gamma[c + e] * invstd[c + e];
             sh[e] = beta[c + e] - mean[c + e] * sc[e];
         }
-        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, bx = {0.f, 0.f, 0.f, 0.f};
         int bi[4] = {0, 0, 0, 0};
         for (int ky = 0; ky < g.k; ++ky) {
             const int iy = oy * g.s - g.pad + ky;
@@ -262,6 +265,7 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restr
                     const float yv = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
                     if (yv > best[e]) {
                         best[e] = yv;
+                        bx[e] = v[e];
                         bi[e] = ky * g.k + kx;
                     }
                 }
@@ -269,6 +273,12 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restr
         }
         *(f32x4*)(yp + i * 4) = best;
         *(uchar4*)(arg + i * 4) = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+        if (xh) {
+            f32x4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (bx[e] - mean[c + e]) * invstd[c + e];     // bn_bwd_partial_kernel's expression
+            *(f32x4*)(xh + i * 4) = h;
+        }
     }
 }
 
@@ -581,11 +591,26 @@ extern "C" int denet_bn_bwd(const float* x, const float* y, const float* dy, con
 // denet_bn_workspace_bytes(M, C)) or denet_bn_fwd_train_pre (partial / rows from the convolution in front; workspace optional:
 // with it a list of more than 2048 rows is folded in two stages); the pooled
 // output y_pool [N,OH,OW,C] and its argmax taps are written, relu(bn(x)) itself is not (batch_norm_relu.py:34-48 + pool.py:38)
+extern "C" int denet_bn_relu_pool_fwd_train_xhat(const float* x, float* y_pool, unsigned char* argmax, float* xhat_pool,
+                                                 const float* gamma, const float* beta, float* run_mean, float* run_stdinv,
+                                                 float* save_mean, float* save_invstd, const double* partial, int rows,
+                                                 void* workspace, int N, int H, int W, int C, int OH, int OW, int k, int stride,
+                                                 int pad, float momentum, float eps, hipStream_t stream);
 extern "C" int denet_bn_relu_pool_fwd_train(const float* x, float* y_pool, unsigned char* argmax, const float* gamma,
                                             const float* beta, float* run_mean, float* run_stdinv, float* save_mean,
                                             float* save_invstd, const double* partial, int rows, void* workspace, int N, int H,
                                             int W, int C, int OH, int OW, int k, int stride, int pad, float momentum, float eps,
                                             hipStream_t stream) {
+    return denet_bn_relu_pool_fwd_train_xhat(x, y_pool, argmax, nullptr, gamma, beta, run_mean, run_stdinv, save_mean, save_invstd,
+                                             partial, rows, workspace, N, H, W, C, OH, OW, k, stride, pad, momentum, eps, stream);
+}
+
+// the same; xhat_pool (optional) [N,OH,OW,C]: the normalised input at each window's argmax, for denet_bn_relu_pool_bwd_sums
+extern "C" int denet_bn_relu_pool_fwd_train_xhat(const float* x, float* y_pool, unsigned char* argmax, float* xhat_pool,
+                                                 const float* gamma, const float* beta, float* run_mean, float* run_stdinv,
+                                                 float* save_mean, float* save_invstd, const double* partial, int rows,
+                                                 void* workspace, int N, int H, int W, int C, int OH, int OW, int k, int stride,
+                                                 int pad, float momentum, float eps, hipStream_t stream) {
     DENET_CHECK_ARG(x && y_pool && argmax && gamma && beta && save_mean && save_invstd && (partial || workspace),
                     "bn_relu_pool_fwd_train: null pointer");
     DENET_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k > 0 && k * k <= 255 && stride > 0 && pad >= 0 && pad < k &&
@@ -612,7 +637,7 @@ extern "C" int denet_bn_relu_pool_fwd_train(const float* x, float* y_pool, unsig
     const long total = (long)N * OH * OW * (C / 4);
     long blocks = (total + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(bn_apply_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y_pool, argmax, gamma, beta,
+    hipLaunchKernelGGL(bn_apply_pool_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, y_pool, argmax, xhat_pool, gamma, beta,
                        save_mean, save_invstd, N, C, g);
     DENET_CHECK_LAUNCH("bn_relu_pool_fwd_train");
     return DENET_OK;
@@ -639,6 +664,47 @@ extern "C" int denet_bn_relu_pool_bwd(const float* x, const float* dy_pool, cons
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(m.gx, m.gy), dim3(256), 0, stream, x, (const float*)nullptr, dy_pool,
                        gamma, beta, save_mean, save_invstd, coef, dx, (float*)nullptr, M, C, m.LC, 1, argmax, g);
     DENET_CHECK_LAUNCH("bn_relu_pool_bwd");
+    return DENET_OK;
+}
+
+// The backward pass of the same layer in two calls, its reductions over the POOLED tensors. With g[p] = the pool gradient routed
+// to input pixel p and masked by the ReLU: sum_p g[p] = sum_w dy_pool[w] * [y_pool[w] > 0] and sum_p g[p] * xhat[p] = sum_w
+// dy_pool[w] * [y_pool[w] > 0] * xhat_pool[w] (every window w sends its gradient to its argmax pixel, whose ReLU output IS
+// y_pool[w]): a quarter of the elements, no window gather. zeros / ones: [C] constant vectors (the kernel shared with
+// denet_bn_bwd_sums normalises its "x" - here already normalised - with mean 0, invstd 1). The sums may also come from the
+// data-gradient pass that wrote dy_pool (denet_conv_wino2f_sums with sums_of = {x: xhat_pool, y: y_pool, mean: zeros, invstd: ones,
+// relu}) and go through denet_bn_bwd_final(partial, rows, N*H*W, ...). coef [2][C]: the two means over the N*H*W INPUT pixels.
+extern "C" int denet_bn_relu_pool_bwd_sums(const float* xhat_pool, const float* y_pool, const float* dy_pool, const float* zeros,
+                                           const float* ones, float* dgamma, float* dbeta, float* coef, void* workspace, int N,
+                                           int H, int W, int C, int OH, int OW, hipStream_t stream) {
+    DENET_CHECK_ARG(xhat_pool && y_pool && dy_pool && zeros && ones && dgamma && dbeta && coef && workspace,
+                    "bn_relu_pool_bwd_sums: null pointer");
+    DENET_CHECK_ARG(N > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && C > 0 && C % 4 == 0, "bn_relu_pool_bwd_sums: bad arguments");
+    const long Mp = (long)N * OH * OW;
+    BnMap m = bn_map(Mp, C);
+    double* partial = (double*)workspace;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(m.gx, m.gy), dim3(256), 0, stream, xhat_pool, y_pool, dy_pool, ones,
+                       (const float*)nullptr, zeros, ones, Mp, C, m.LC, 1, partial, (const unsigned char*)nullptr, PoolGeom{});
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FC - 1) / FC), dim3(FINAL_NT), 0, stream, partial, m.gy, (long)N * H * W, C,
+                       dgamma, dbeta, coef);
+    DENET_CHECK_LAUNCH("bn_relu_pool_bwd_sums");
+    return DENET_OK;
+}
+
+// dx [N,H,W,C] from dy_pool + argmax and the two means in coef (denet_bn_relu_pool_bwd's pointwise pass)
+extern "C" int denet_bn_relu_pool_bwd_apply(const float* x, const float* dy_pool, const unsigned char* argmax, const float* gamma,
+                                            const float* beta, const float* save_mean, const float* save_invstd, const float* coef,
+                                            float* dx, int N, int H, int W, int C, int OH, int OW, int k, int stride, int pad,
+                                            hipStream_t stream) {
+    DENET_CHECK_ARG(x && dy_pool && argmax && gamma && beta && save_mean && save_invstd && coef && dx, "bn_relu_pool_bwd_apply: null pointer");
+    DENET_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k > 0 && stride > 0 && pad >= 0 && (long)N * H * W < (1L << 31),
+                    "bn_relu_pool_bwd_apply: bad arguments");
+    const long M = (long)N * H * W;
+    BnMap m = bn_map(M, C);
+    const PoolGeom g = pool_geom(H, W, OH, OW, k, stride, pad, C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(m.gx, m.gy), dim3(256), 0, stream, x, (const float*)nullptr, dy_pool,
+                       gamma, beta, save_mean, save_invstd, coef, dx, (float*)nullptr, M, C, m.LC, 1, argmax, g);
+    DENET_CHECK_LAUNCH("bn_relu_pool_bwd_apply");
     return DENET_OK;
 }
 

@@ -95,9 +95,13 @@ class BatchNormLayer(AbstractLayer):
                 # a max pool is the only reader of this layer's output (ModelCNN.build_train_func links it): one pass
                 # writes the pooled tensor, relu(bn(x)) itself is never materialised (its gradient neither)
                 k, s, p = pool.size[0], pool.stride[0], pool.pad[0]
-                yp, arg, sm, si = ops.bn_relu_pool_fwd_train(x, self.omega.dev, self.beta.dev, self.mean.dev, self.stdinv.dev,
-                                                             k, s, p, self.momentum, self.eps, pre=pre)
+                yp, arg, sm, si, xh = ops.bn_relu_pool_fwd_train(x, self.omega.dev, self.beta.dev, self.mean.dev, self.stdinv.dev,
+                                                                 k, s, p, self.momentum, self.eps, pre=pre, xhat=True)
                 pool.output.data, pool._arg, pool._fused_in = yp, arg, ctx      # valid for this pass (ctx) only
+                # the backward reductions of this layer are sums over the pooled tensors (ops.bn_relu_pool_bwd_pooled); the
+                # data-gradient pass that writes the pool output's gradient can leave them behind (sums_request)
+                pool._xhat = xh
+                pool.output.bn_producer = self
                 out_act.data = None
                 self._save = (sm, si, relu, out_act, False)
                 self._pooled = True
@@ -126,8 +130,16 @@ class BatchNormLayer(AbstractLayer):
     def sums_request(self, act):
         """for the data-gradient pass that writes the gradient of `act` (this layer's output of the current training step): the
         description of this batch norm, so that the pass leaves the two backward reductions behind (ops.BnSums)"""
-        if not (self.enabled and self._save is not None and not getattr(self, "_pooled", False)):
+        if not (self.enabled and self._save is not None):
             return None
+        if getattr(self, "_pooled", False):
+            # the fused BN + ReLU + max pool: `act` is the POOL's output; over the pooled tensors the layer looks like a batch norm
+            # with input xhat (already normalised: mean 0, invstd 1) and forward output y_pool
+            pool = self.pool_behind
+            if act is not pool.output or getattr(pool, "_xhat", None) is None:
+                return None
+            C = act.data.shape[-1]
+            return ops.BnSums(pool._xhat, act.data, self.omega.dev, self.beta.dev, ops.const_vec(0.0, C), ops.const_vec(1.0, C), True)
         sm, si, relu, out_act, has_res = self._save
         if out_act is not act:
             return None
@@ -140,8 +152,12 @@ class BatchNormLayer(AbstractLayer):
         if getattr(self, "_pooled", False):
             pool = self.pool_behind
             k, s, p = pool.size[0], pool.stride[0], pool.pad[0]
-            dx, _, _ = ops.bn_relu_pool_bwd(self.input.data, pool.output.grad, pool._arg, self.omega.dev, self.beta.dev, sm, si,
-                                            k, s, p, dgamma=self.omega.grad, dbeta=self.beta.grad)
+            dyp = pool.output.grad
+            sums = pool.output.grad_sums       # left by the data-gradient pass that wrote dyp last (ConvLayer.backward)
+            dx = ops.bn_relu_pool_bwd_pooled(self.input.data, pool._xhat, pool.output.data, dyp, pool._arg, self.omega.dev,
+                                             self.beta.dev, sm, si, k, s, p, self.omega.grad, self.beta.grad,
+                                             pre=sums.partial if sums is not None else None)
+            pool._xhat = None
             self.input.add_grad(dx)
             return None
         # without a residual input the relu mask is recomputed from x in the kernel (no read of y)

@@ -70,6 +70,9 @@ SIGNATURES = {
     "denet_bn_fwd_train_pre": (I, [P] * 10 + [I, L, I, F, F, I, P]),
     "denet_bn_relu_pool_fwd_train": (I, [P] * 10 + [I, P] + [I] * 9 + [F, F, P]),
     "denet_bn_relu_pool_bwd": (I, [P] * 11 + [I] * 9 + [P]),
+    "denet_bn_relu_pool_fwd_train_xhat": (I, [P] * 11 + [I, P] + [I] * 9 + [F, F, P]),
+    "denet_bn_relu_pool_bwd_sums": (I, [P] * 9 + [I] * 6 + [P]),
+    "denet_bn_relu_pool_bwd_apply": (I, [P] * 9 + [I] * 9 + [P]),
     "denet_bn_fold": (I, [P] * 6 + [F, P, P, I, L, P]),
     "denet_bn_stats_final": (I, [P, I, L, I, F, F, P, P, P, P, P]),
     "denet_bn_apply": (I, [P] * 7 + [L, I, I, P]),

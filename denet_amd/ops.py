@@ -1060,21 +1060,58 @@ def bn_bwd(x, y, dy, gamma, save_mean, save_invstd, relu=False, want_dres=False,
 BN_POOL_FUSE = os.environ.get("DENET_BN_POOL_FUSE", "1") != "0"    # training: BN + ReLU + max pool without the tensor in between
 
 
-def bn_relu_pool_fwd_train(x, gamma, beta, run_mean, run_stdinv, k, stride, pad, momentum=0.9, eps=1e-5, pre=None):
+def bn_relu_pool_fwd_train(x, gamma, beta, run_mean, run_stdinv, k, stride, pad, momentum=0.9, eps=1e-5, pre=None, xhat=False):
     """relu(bn(x)) max-pooled, without writing relu(bn(x)): returns (y_pool, argmax, save_mean, save_invstd); values and
-    argmax taps are those of bn_fwd_train(relu=True) + maxpool_fwd"""
+    argmax taps are those of bn_fwd_train(relu=True) + maxpool_fwd. xhat: also (x - mean) * invstd at each window's argmax, as a
+    fifth result - what bn_relu_pool_bwd_sums (the backward reductions over the pooled tensors) reads"""
     N, H, W, C = x.shape
     OH = (H + 2 * pad - k) // stride + 1
     OW = (W + 2 * pad - k) // stride + 1
     y = empty(N, OH, OW, C)
     arg = torch.empty((N, OH, OW, C), dtype=torch.uint8, device="cuda")
+    xh = empty(N, OH, OW, C) if xhat else None
     save_mean, save_invstd = empty(C), empty(C)
     ws = _bn_ws(N * H * W, C)
-    check(_L().denet_bn_relu_pool_fwd_train(ptr(x), ptr(y), ptr(arg), ptr(gamma), ptr(beta), ptr(run_mean), ptr(run_stdinv),
-                                            ptr(save_mean), ptr(save_invstd), ptr(pre[0]) if pre is not None else None,
-                                            int(pre[1]) if pre is not None else 0, ptr(ws), N, H, W, C, OH, OW, k, stride, pad,
-                                            momentum, eps, stream_ptr()), "bn_relu_pool_fwd_train")
-    return y, arg, save_mean, save_invstd
+    check(_L().denet_bn_relu_pool_fwd_train_xhat(ptr(x), ptr(y), ptr(arg), ptr(xh), ptr(gamma), ptr(beta), ptr(run_mean),
+                                                 ptr(run_stdinv), ptr(save_mean), ptr(save_invstd),
+                                                 ptr(pre[0]) if pre is not None else None, int(pre[1]) if pre is not None else 0,
+                                                 ptr(ws), N, H, W, C, OH, OW, k, stride, pad, momentum, eps, stream_ptr()),
+          "bn_relu_pool_fwd_train")
+    return (y, arg, save_mean, save_invstd, xh) if xhat else (y, arg, save_mean, save_invstd)
+
+
+_CONST_VEC = {}
+
+
+def const_vec(value, C):
+    """[C] floats of one value on the device (mean 0 / invstd 1 of an already normalised tensor)"""
+    v = _CONST_VEC.get((value, C))
+    if v is None:
+        v = _CONST_VEC[(value, C)] = torch.full((C,), float(value), dtype=torch.float32, device="cuda")
+    return v
+
+
+def bn_relu_pool_bwd_pooled(x, xhat_pool, y_pool, dy_pool, arg, gamma, beta, save_mean, save_invstd, k, stride, pad, dgamma, dbeta,
+                            pre=None):
+    """gradient of bn_relu_pool_fwd_train(xhat=True) with the two reductions taken over the POOLED tensors (every window sends its
+    gradient to its argmax pixel, whose ReLU output is y_pool): a quarter of the elements and no window gather. pre = (partial sums,
+    rows) left by the data-gradient pass that wrote dy_pool (BnSums on the pooled tensors): no reduction pass at all. Same sums as
+    bn_relu_pool_bwd up to the order of a double-precision summation. Returns dx."""
+    N, H, W, C = x.shape
+    OH, OW = dy_pool.shape[1], dy_pool.shape[2]
+    coef = empty(2 * C)
+    if pre is not None:
+        check(_L().denet_bn_bwd_final(ptr(pre[0]), int(pre[1]), N * H * W, C, ptr(dgamma), ptr(dbeta), ptr(coef), stream_ptr()),
+              "bn_bwd_final")
+    else:
+        check(_L().denet_bn_relu_pool_bwd_sums(ptr(xhat_pool), ptr(y_pool), ptr(dy_pool), ptr(const_vec(0.0, C)), ptr(const_vec(1.0, C)),
+                                               ptr(dgamma), ptr(dbeta), ptr(coef), ptr(_bn_ws(N * OH * OW, C)), N, H, W, C, OH, OW,
+                                               stream_ptr()), "bn_relu_pool_bwd_sums")
+    dx = torch.empty_like(x)
+    check(_L().denet_bn_relu_pool_bwd_apply(ptr(x), ptr(dy_pool), ptr(arg), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_invstd),
+                                            ptr(coef), ptr(dx), N, H, W, C, OH, OW, k, stride, pad, stream_ptr()),
+          "bn_relu_pool_bwd_apply")
+    return dx
 
 
 def bn_relu_pool_bwd(x, dy_pool, arg, gamma, beta, save_mean, save_invstd, k, stride, pad, dgamma=None, dbeta=None):

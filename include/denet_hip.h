@@ -300,6 +300,22 @@ int denet_bn_relu_pool_bwd(const float* x, const float* dy_pool, const unsigned 
                            const float* beta, const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                            float* dbeta, void* workspace, int N, int H, int W, int C, int OH, int OW, int k, int stride, int pad,
                            hipStream_t stream);
+/* The same backward pass with its two reductions taken over the POOLED tensors (a quarter of the elements, no window gather):
+ * every window sends its gradient to its argmax pixel, whose ReLU output is y_pool - so sum g = sum dy_pool * [y_pool > 0] and
+ * sum g * xhat = sum dy_pool * [y_pool > 0] * xhat_pool with xhat_pool = (x - mean) * invstd at the argmax, written by
+ * ..._fwd_train_xhat. ..._bwd_sums reduces them (zeros / ones: [C] constant vectors; coef [2][C] = the means over the N*H*W input
+ * pixels); they may instead come from the data-gradient pass that wrote dy_pool (denet_conv_wino2f_sums with sums_of = {x:
+ * xhat_pool, y: y_pool, mean: zeros, invstd: ones, relu: 1}) through denet_bn_bwd_final. ..._bwd_apply is the pointwise pass. */
+int denet_bn_relu_pool_fwd_train_xhat(const float* x, float* y_pool, unsigned char* argmax, float* xhat_pool, const float* gamma,
+                                      const float* beta, float* run_mean, float* run_stdinv, float* save_mean, float* save_invstd,
+                                      const double* partial, int rows, void* workspace, int N, int H, int W, int C, int OH, int OW,
+                                      int k, int stride, int pad, float momentum, float eps, hipStream_t stream);
+int denet_bn_relu_pool_bwd_sums(const float* xhat_pool, const float* y_pool, const float* dy_pool, const float* zeros,
+                                const float* ones, float* dgamma, float* dbeta, float* coef, void* workspace, int N, int H, int W,
+                                int C, int OH, int OW, hipStream_t stream);
+int denet_bn_relu_pool_bwd_apply(const float* x, const float* dy_pool, const unsigned char* argmax, const float* gamma,
+                                 const float* beta, const float* save_mean, const float* save_invstd, const float* coef, float* dx,
+                                 int N, int H, int W, int C, int OH, int OW, int k, int stride, int pad, hipStream_t stream);
 
 /* ---- pooling  (denet/layer/pool.py:28-40 dnn_pool max / average_inc_pad;
  *      denet/layer/pool_inv_op.py:38-63 k_pool_inv, :144-169 k_pool_inv_grad)                             */

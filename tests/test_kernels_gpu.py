@@ -316,6 +316,17 @@ def test_bn_relu_pool_fused_equals_separate_passes(hip, case):
     dx, _, dg, db = ops.bn_bwd(x, None, dy, gamma, sm, si, relu=True, beta=beta)
     dx2, dg2, db2 = ops.bn_relu_pool_bwd(x, dyp, arg2, gamma, beta, sm2, si2, k, s, p)
     assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+    # the backward reductions over the POOLED tensors (a window sends its gradient to its argmax pixel, whose ReLU output is the
+    # pooled value): the same sums in another order of a double-precision summation, from a pass over a quarter of the elements -
+    # or from partial sums somebody else left behind (here: the generic reduction kernel on the pooled tensors)
+    rm3, rs3 = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    yp3, arg3, sm3, si3, xh = ops.bn_relu_pool_fwd_train(x, gamma, beta, rm3, rs3, k, s, p, xhat=True)
+    assert torch.equal(yp3, yp) and torch.equal(arg3, arg) and torch.equal(sm3, sm)
+    dg3, db3 = torch.empty(C).cuda(), torch.empty(C).cuda()
+    dx3 = ops.bn_relu_pool_bwd_pooled(x, xh, yp3, dyp, arg3, gamma, beta, sm3, si3, k, s, p, dg3, db3)
+    torch.testing.assert_close(dg3, dg, rtol=2e-6, atol=2e-6 * float(dg.abs().max()))
+    torch.testing.assert_close(db3, db, rtol=2e-6, atol=2e-6 * float(db.abs().max()))
+    torch.testing.assert_close(dx3, dx, rtol=1e-5, atol=1e-6 * float(dx.abs().max()))
 
 
 def test_conv_stem_small_c(hip):

@@ -612,7 +612,10 @@ def test_direct_and_measured_paths_agree(hip):
 
 
 def test_bn_pool_fusion_leaves_training_unchanged(hip):
-    """two training steps of DeNet-34 skip with the stem's BN + ReLU + max pool as one pass and as three: bit-identical state"""
+    """two training steps of DeNet-34 skip with the stem's BN + ReLU + max pool as one pass and as three. The pooled form takes the
+    layer's two backward reductions over the pooled tensors (ops.bn_relu_pool_bwd_pooled: the same sums in another order of a
+    double-precision summation; the element values - output, argmax, statistics, dx given the sums - are bit-identical,
+    test_bn_relu_pool_fused_equals_separate_passes), so the states agree numerically: 1e-5 max-norm relative per buffer"""
     res = []
     saved = ops.BN_POOL_FUSE
     try:
@@ -631,8 +634,9 @@ def test_bn_pool_fusion_leaves_training_unchanged(hip):
     finally:
         ops.BN_POOL_FUSE = saved
     for a, b in zip(res[0][:3], res[1][:3]):
-        assert torch.equal(a, b)
-    assert res[0][3] == res[1][3]
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    for ca, cb in zip(res[0][3], res[1][3]):
+        assert abs(ca - cb) <= 1e-5 * abs(cb)
 
 
 @pytest.mark.parametrize("img,tile", [(128, 4), (256, 4), (128, 2)])
