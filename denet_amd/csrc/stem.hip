@@ -372,20 +372,42 @@ __global__ __launch_bounds__(NTH, 2) void stem_wgrad_kernel(const StemParams p) 
     for (int i = tid; i < PART; i += NTH) out[i] = red[i];
 }
 
-// dw[f][r][s][c] (KRSC with the padded 8th column and 4th channel zero) = sum over the workgroups' partials, in order
+// dw[f][r][s][c] (KRSC with the padded 8th column and 4th channel zero) = sum over the workgroups' partials in a FIXED order: a
+// workgroup takes 64 consecutive elements of the partial layout (one accumulator register of a wave's 32 x 32 block: element e of
+// block (i, j), lanes (lh, li)); its four waves sum a quarter of the partials each, one after the other, and the four quarter sums
+// are added in wave order
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ part, int grid, float* __restrict__ dw) {
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= 64 * 7 * 8 * 4) return;
-    const int c = o & 3, s = (o >> 2) & 7, r = (o >> 5) % 7, f = o / 224;
+    __shared__ float q[4][64];
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int row = blockIdx.x;                      // (5 i + j) * 16 + e
+    const int per = (grid + 3) / 4;
+    const int k0 = seg * per, k1 = k0 + per < grid ? k0 + per : grid;
+    const float* src = part + row * 64 + lane;
     float v = 0.f;
-    if (s < 7 && c < 3) {
-        const int t = (r * 7 + s) * 3 + c;
-        const int i = f >> 5, fr = f & 31, g = fr >> 3, lh = (fr >> 2) & 1, q = fr & 3;
-        const int j = t >> 5, li = t & 31;
-        const float* src = part + ((5 * i + j) * 16 + 4 * g + q) * 64 + lh * 32 + li;
-        for (int k = 0; k < grid; ++k) v += src[(long)k * PART];
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = src[(long)(k + u) * PART];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
     }
-    dw[o] = v;
+    for (; k < k1; ++k) v += src[(long)k * PART];
+    q[seg][lane] = v;
+    __syncthreads();
+    if (seg == 0) {
+        v = ((q[0][lane] + q[1][lane]) + q[2][lane]) + q[3][lane];
+        const int e = row & 15, blk = row >> 4, i = blk / 5, j = blk - 5 * i;
+        const int lh = lane >> 5, li = lane & 31;
+        const int f = 32 * i + 8 * (e >> 2) + 4 * lh + (e & 3), t = 32 * j + li;
+        if (t < TAPS) {
+            const int r = t / 21, w = t - 21 * r, sx = w / 3, c = w - 3 * sx;
+            dw[((f * 7 + r) * 8 + sx) * 4 + c] = v;
+        }
+    }
+    // the padding entries (8th column, 4th channel) are zero
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o < 64 * 224 && (((o >> 2) & 7) == 7 || (o & 3) == 3)) dw[o] = 0.f;
 }
 
 int stem_grid(int tiles) {
@@ -497,7 +519,7 @@ extern "C" int denet_conv_stem_wgrad_from(const float* x, int x_nchw, const floa
     const int prof = denet_prof_begin(13, 0, 0, 0, stream);
     hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)grid), dim3(NTH), G_LDS_BYTES, stream, p);
     denet_prof_end(prof, stream);
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * 224 + 255) / 256), dim3(256), 0, stream, workspace, grid, dw);
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(PART / 64), dim3(256), 0, stream, workspace, grid, dw);
     DENET_CHECK_LAUNCH("conv_stem_wgrad");
     return DENET_OK;
 }
