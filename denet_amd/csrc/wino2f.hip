@@ -39,7 +39,7 @@ struct W2Params {
     int nco;             // Co / 64
     int items;           // N * by * bx * nco work items: (block, 64 output channels)
     int relu;            // y = max(y, 0) (the inference fold of a ReLU layer)
-    unsigned x_bytes;
+    unsigned x_bytes, y_bytes;
 };
 
 constexpr int CI = 64;
@@ -93,7 +93,8 @@ constexpr int S_LDS_BYTES = P_BYTES + S_MB_SLOTS * 16 + S_RED_BYTES;     // 163 
 // (pieces 2, 3 and 6 overlap their neighbours with the same values of the same item)
 __host__ __device__ constexpr int sp_start(int k) { return k == 0 ? 0 : k == 1 ? 64 : k == 2 ? 96 : k == 3 ? 136 : k == 4 ? 200 : k == 5 ? 264 : 296; }
 
-template <int I, int J0>
+// PF: the launch has output operands to read (an `add`, the tensors of the backward sums): they are prefetched (below)
+template <int I, int J0, bool PF>
 __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
     f32x4* P = (f32x4*)smem;
     f32x4* MB = (f32x4*)(smem + P_BYTES);
@@ -102,6 +103,12 @@ __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t = lane & 15, kk = lane >> 4;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    // the output phase's global operands (residual / accumulated gradient `add`, the batch-norm input and output of the backward
+    // sums) come through buffer descriptors of their own: an absent tensor is a descriptor of 0 bytes, whose loads return zeros
+    // without touching memory - the loads are issued unconditionally, a whole matrix round ahead of their use (below)
+    const __amdgpu_buffer_rsrc_t radd = __builtin_amdgcn_make_buffer_rsrc((void*)p.add, 0, p.add ? p.y_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbx = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_x, 0, p.bs_x ? p.y_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rby = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_y, 0, (p.bs_x && p.bs_relu && p.bs_y) ? p.y_bytes : 0u, 0x00020000);
 
     // piece n = 0..13 of this wave: plane 2 w + n / 7, piece n % 7. The slot -> pixel arithmetic is redone per piece (a dozen
     // integer instructions, 14 pieces per item) rather than kept in registers: the filters leave none to spare.
@@ -174,6 +181,7 @@ __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
 #pragma unroll 1
         for (int g = 0; g < 4; ++g) {
             f32x4 acc[2][4];
+            f32x4 pf[6];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 f32x4 V[2];
@@ -192,6 +200,19 @@ __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
                 // the next round's patch values (after the last round of the item: the next item's first, whose band landed
                 // before the barrier of tile group 3)
                 if (r < 3) load_d(g, r + 1, d);
+                // last round: the patch registers are free until the next group - they carry this group's output operands, asked
+                // for now and used a matrix round and two barriers later
+                if (PF && r == 3) {
+                    const int ty = 2 * g + (otile >> 3), tx = otile & 7;
+                    const int oy = cur.oy0 + 2 * ty + oi, ox = cur.ox0 + 2 * tx;
+                    const int ob = (oy < p.H && ox < p.W) ? ((((cur.n * p.H + oy) * p.W + ox) * p.Co + cur.co0 + 4 * t) * 4) : OOB;
+                    pf[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(radd, ob, 0, 0));
+                    pf[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(radd, ob, p.Co * 4, 0));
+                    pf[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbx, ob, 0, 0));
+                    pf[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbx, ob, p.Co * 4, 0));
+                    pf[4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rby, ob, 0, 0));
+                    pf[5] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rby, ob, p.Co * 4, 0));
+                }
                 // patch refill, two pieces per round (the wave's two planes): band C of THIS item during its tile group 0 (the first
                 // item came complete), bands A and B of the NEXT item during tile groups 2 and 3
                 if (g == 0 && r < 3 && item != (int)blockIdx.x) {
@@ -224,11 +245,13 @@ __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
             // all 16 components are there. The band pieces issued during this group (6 in groups 0 and 2, 2 in group 3) may still
             // fly: a later barrier waits for them, when they are more than a tile group old and before their rows are read (band
             // A, issued in group 2, by the barrier of group 3; band B by that of the next item's group 0; band C by that of group 1)
-            if (g == 0 || g == 2) W2_BARRIER(6)
-            else if (g == 3) W2_BARRIER(2)
-            else W2_BARRIER(0)
-            // the next group's first patch values (group 3: the next item's)
-            load_d((g + 1) & 3, 0, d);
+            // (+ 6: the output operands asked for in the last round, younger than every piece)
+            if (g == 0 || g == 2) W2_BARRIER(PF ? 12 : 6)
+            else if (g == 3) W2_BARRIER(PF ? 8 : 2)
+            else W2_BARRIER(PF ? 6 : 0)
+            // the next group's first patch values (group 3: the next item's); with output operands in flight they sit in the
+            // patch registers until the output phase has used them, and the patch values are read after it
+            if (!PF) load_d((g + 1) & 3, 0, d);
             // ---- output phase: Y row oi of the lane's tile = A^T M A, + bias, + add, ReLU; 2 pixels x 4 channels ---------------
             {
                 f32x4 sv[4];
@@ -248,9 +271,9 @@ __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
                 const int oy = cur.oy0 + 2 * ty + oi, ox = cur.ox0 + 2 * tx;
                 if (oy < p.H && ox < p.W) {          // blocks at the right / bottom edge of a map that is no multiple of 16 (W even)
                     const long o = (((long)cur.n * p.H + oy) * p.W + ox) * p.Co + cur.co0 + 4 * t;
-                    if (p.add) {
-                        y0 += *(const f32x4*)(p.add + o);
-                        y1 += *(const f32x4*)(p.add + o + p.Co);
+                    if (PF) {
+                        y0 += pf[0];           // zeros without an `add`
+                        y1 += pf[1];
                     }
                     if (p.relu) {
                         y0 = __builtin_elementwise_max(y0, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -258,14 +281,14 @@ __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
                     }
                     *(f32x4*)(p.y + o) = y0;
                     *(f32x4*)(p.y + o + p.Co) = y1;
-                    if (p.bs_x) {
+                    if (PF && p.bs_x) {
                         const int cq = cur.co0 + 4 * t;
                         const f32x4 mu = *(const f32x4*)(p.bs_mean + cq), is = *(const f32x4*)(p.bs_invstd + cq);
-                        const f32x4 x0 = *(const f32x4*)(p.bs_x + o), x1 = *(const f32x4*)(p.bs_x + o + p.Co);
+                        const f32x4 x0 = pf[2], x1 = pf[3];
                         f32x4 g0 = y0, g1 = y1;
                         if (p.bs_relu) {
                             if (p.bs_y) {
-                                const f32x4 v0 = *(const f32x4*)(p.bs_y + o), v1 = *(const f32x4*)(p.bs_y + o + p.Co);
+                                const f32x4 v0 = pf[4], v1 = pf[5];
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) {
                                     g0[c] = v0[c] > 0.f ? g0[c] : 0.f;
@@ -289,6 +312,7 @@ __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
                     }
                 }
             }
+            if (PF) load_d((g + 1) & 3, 0, d);
         }
         if (p.stats) {
             // batch-norm column sums of this block: over the lanes of a wave that share the channels (kk), then over the waves
@@ -334,17 +358,18 @@ __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
     __builtin_amdgcn_s_waitcnt(0);
 }
 
+template <bool PF>
 __global__ __launch_bounds__(512, 2) void wino2f_ws_kernel(const W2Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
-        case 0: w2s_run<0, 0>(p, smem); break;
-        case 1: w2s_run<0, 2>(p, smem); break;
-        case 2: w2s_run<1, 0>(p, smem); break;
-        case 3: w2s_run<1, 2>(p, smem); break;
-        case 4: w2s_run<2, 0>(p, smem); break;
-        case 5: w2s_run<2, 2>(p, smem); break;
-        case 6: w2s_run<3, 0>(p, smem); break;
-        default: w2s_run<3, 2>(p, smem); break;
+        case 0: w2s_run<0, 0, PF>(p, smem); break;
+        case 1: w2s_run<0, 2, PF>(p, smem); break;
+        case 2: w2s_run<1, 0, PF>(p, smem); break;
+        case 3: w2s_run<1, 2, PF>(p, smem); break;
+        case 4: w2s_run<2, 0, PF>(p, smem); break;
+        case 5: w2s_run<2, 2, PF>(p, smem); break;
+        case 6: w2s_run<3, 0, PF>(p, smem); break;
+        default: w2s_run<3, 2, PF>(p, smem); break;
     }
 }
 
@@ -618,7 +643,7 @@ __global__ __launch_bounds__(256) void w2g_dfilter_kernel(const float* __restric
 // geometry this kernel covers
 extern "C" int denet_conv_wino2f_ok(int N, int H, int W, int Ci, int Co) {
     return (Ci == 64 && Co > 0 && Co % 64 == 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && N > 0 &&
-            (long)N * H * W * 64 * 4 < 0xF0000000L) ? 1 : 0;
+            (long)N * H * W * 64 * 4 < 0xF0000000L && (long)N * H * W * Co * 4 < 0x7FFFFFFFL) ? 1 : 0;
 }
 
 // y = conv3x3(x) stride 1 pad 1 (+ bias) (+ add) from the F(2x2) transformed filters u = [16][Co][64]
@@ -651,6 +676,7 @@ extern "C" int denet_conv_wino2f_sums(const float* x, const float* u, const floa
     p.nco = Co / 64;
     p.relu = relu;
     p.x_bytes = (unsigned)((size_t)N * H * W * 64 * 4);
+    p.y_bytes = (unsigned)((size_t)N * H * W * Co * 4);
     const long blocks = (long)N * p.by * p.bx;
     p.items = (int)(blocks * p.nco);
     // the LDS footprint allows one workgroup per CU: a persistent grid, work items strided over it
@@ -679,7 +705,9 @@ extern "C" int denet_conv_wino2f_sums(const float* x, const float* u, const floa
     }
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)wino2f_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)wino2f_ws_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)wino2f_ws_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
         if (e != hipSuccess) {
             denet_set_error("conv_wino2f: hipFuncSetAttribute(%d B LDS): %s", S_LDS_BYTES, hipGetErrorString(e));
             return -(int)e;
@@ -687,7 +715,9 @@ extern "C" int denet_conv_wino2f_sums(const float* x, const float* u, const floa
         attr_set = true;
     }
     const int prof = denet_prof_begin(10, 0, 0, 0, stream);
-    hipLaunchKernelGGL(wino2f_ws_kernel, dim3((unsigned)grid), dim3(512), S_LDS_BYTES, stream, p);
+    // the variant that prefetches the output phase's operands only where there are any (it costs the plain pass 4 %)
+    if (p.add || p.bs_x) hipLaunchKernelGGL(wino2f_ws_kernel<true>, dim3((unsigned)grid), dim3(512), S_LDS_BYTES, stream, p);
+    else hipLaunchKernelGGL(wino2f_ws_kernel<false>, dim3((unsigned)grid), dim3(512), S_LDS_BYTES, stream, p);
     denet_prof_end(prof, stream);
     DENET_CHECK_LAUNCH("conv_wino2f");
     return DENET_OK;
