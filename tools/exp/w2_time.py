@@ -39,7 +39,7 @@ def full():
     check(L.denet_conv_wino2f(ptr(x), ptr(u), None, ptr(add), ptr(y), 0, ptr(st), st.numel() * 8, ctypes.byref(rows), N, H, W, C, C, stream_ptr()))
 
 
-print("DENET_W2_EXP=%s  plain %.1f us  add+stats %.1f us" % (os.environ.get("DENET_W2_EXP", "0"), timed(plain), timed(full)))
+print("forward: plain %.1f us  add + statistics %.1f us" % (timed(plain), timed(full)))
 
 
 # the data-gradient form: accumulated add + the backward sums of a batch norm (input bx, output by, ReLU)
