@@ -351,6 +351,18 @@ def test_conv_stem_small_c(hip):
     assert float(dw[:, :, :, 3].abs().max()) == 0.0
 
 
+def test_generic_kernels_still_cover_the_first_layer(hip):
+    """DENET_STEM=0 (read once per process, hence a process of its own): the implicit-GEMM kernels on the padded 7 x 8 x 4 layout,
+    which the first layer ran on before csrc/stem.hip and every other small-channel geometry still does"""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "conv_stem_small_c"],
+                       env=dict(os.environ, DENET_STEM="0"), capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("case", [(3, 48, 272), (1, 18, 130), (2, 224, 224), (5, 512, 512)])
 def test_first_layer_kernels(hip, case):
     """the first layer's own kernels (csrc/stem.hip: 147 real taps instead of 7 x 8 x 4 padded ones; blocks of 8 x 64 output pixels,
