@@ -8,6 +8,7 @@
 // Per-channel reductions are accumulated in fp64 per thread, combined through LDS, written as
 // per-workgroup partials and finished by a second tiny kernel: deterministic, no atomics.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -417,6 +418,83 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// The pooled form of bn_bwd_apply_kernel for the stem's 3x3 / stride 2 / pad 1 max pool over an even map: a thread owns the
+// 2 x 2 input pixels (2 qy + {0, 1}, 2 qx + {0, 1}) of 4 channels. The windows that contain them are (qy, qx), (qy, qx + 1),
+// (qy + 1, qx), (qy + 1, qx + 1) - four (gradient, argmax) loads for four pixels instead of nine, no divisions; an even pixel is
+// in one window, an odd-even pair in two, the odd-odd pixel in all four. The gathered gradient adds the windows in
+// pool_gather's order (window row, then column), so the result is bit-identical to the general kernel.
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_quad_kernel(const float* __restrict__ x, const float* __restrict__ dyp,
+                                                                     const unsigned char* __restrict__ arg,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                     const float* __restrict__ coef, float* __restrict__ dx, int N,
+                                                                     int H, int W, int C, FastDiv fc, FastDiv fow, FastDiv foh) {
+    const int OH = H / 2, OW = W / 2, C4 = C / 4;
+    const long total = (long)N * OH * OW * C4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const uint32_t q = fc.div((uint32_t)i);
+        const int c = (int)((uint32_t)i - q * (uint32_t)C4) * 4;
+        const uint32_t t = fow.div(q);
+        const int qx = (int)(q - t * (uint32_t)OW);
+        const int n = (int)foh.div(t);
+        const int qy = (int)(t - (uint32_t)n * (uint32_t)OH);
+        float mu[4], is[4], sc[4], sh[4], mg[4], mgx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mu[k] = mean[c + k];
+            is[k] = invstd[c + k];
+            sc[k] = gamma[c + k] * is[k];
+            sh[k] = (beta ? beta[c + k] : 0.f) - mu[k] * sc[k];
+            mg[k] = coef[c + k];
+            mgx[k] = coef[C + c + k];
+        }
+        // the four windows: w[a][b] = window (qy + a, qx + b); outside the pooled map: no window (tap 255 matches nothing)
+        f32x4 wv[2][2];
+        uchar4 wa[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const bool in = qy + a < OH && qx + b < OW;
+                const long o = (((long)n * OH + (in ? qy + a : qy)) * OW + (in ? qx + b : qx)) * C + c;
+                wv[a][b] = *(const f32x4*)(dyp + o);
+                const uchar4 av = *(const uchar4*)(arg + o);
+                wa[a][b] = in ? av : make_uchar4(255, 255, 255, 255);
+            }
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                // window (qy + a, qx + b) holds pixel (2 qy + py, 2 qx + px) at tap (py + 1 - 2 a, px + 1 - 2 b) when that is in 0..2
+                f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int a = 0; a <= py; ++a)
+#pragma unroll
+                    for (int b = 0; b <= px; ++b) {
+                        const int tap = (py + 1 - 2 * a) * 3 + (px + 1 - 2 * b);
+                        const bool in = qy + a < OH && qx + b < OW;
+                        if (in) {                   // (pool_gather skips windows outside the map: no "+ 0" for them either)
+                            g[0] += (wa[a][b].x == tap) ? wv[a][b][0] : 0.f;
+                            g[1] += (wa[a][b].y == tap) ? wv[a][b][1] : 0.f;
+                            g[2] += (wa[a][b].z == tap) ? wv[a][b][2] : 0.f;
+                            g[3] += (wa[a][b].w == tap) ? wv[a][b][3] : 0.f;
+                        }
+                    }
+                const long o = (((long)n * H + 2 * qy + py) * W + 2 * qx + px) * C + c;
+                const f32x4 xv = *(const f32x4*)(x + o);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = fmaf(xv[k], sc[k], sh[k]) > 0.f ? g[k] : 0.f;
+                f32x4 d;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float xh = (xv[k] - mu[k]) * is[k];
+                    d[k] = sc[k] * (g[k] - mg[k] - xh * mgx[k]);
+                }
+                *(f32x4*)(dx + o) = d;
+            }
+    }
+}
+
 // inference transform: batch_norm.py:50-52 feeds var = (1/stdinv)^2 to cuDNN which adds eps again
 __global__ void bn_test_coef_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_stdinv, int C,
                                     float eps, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
@@ -643,6 +721,33 @@ extern "C" int denet_bn_relu_pool_fwd_train_xhat(const float* x, float* y_pool, 
     return DENET_OK;
 }
 
+// the pointwise pass of the fused layer's backward: the quad kernel where the pool is the stem's (3x3, stride 2, pad 1, even map;
+// DENET_POOL_QUAD=0: the general kernel), bit-identical either way
+static void launch_pool_apply(const float* x, const float* dy_pool, const unsigned char* argmax, const float* gamma, const float* beta,
+                              const float* save_mean, const float* save_invstd, const float* coef, float* dx, int N, int H, int W, int C,
+                              int OH, int OW, int k, int stride, int pad, hipStream_t stream) {
+    static int quad = -1;
+    if (quad < 0) {
+        const char* e = getenv("DENET_POOL_QUAD");
+        quad = e ? atoi(e) : 1;
+    }
+    if (quad && k == 3 && stride == 2 && pad == 1 && H % 2 == 0 && W % 2 == 0 && OH == H / 2 && OW == W / 2) {
+        FastDiv fc, fow, foh;
+        fc.init(C / 4); fow.init(OW); foh.init(OH);
+        const long total = (long)N * OH * OW * (C / 4);
+        long blocks = (total + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        hipLaunchKernelGGL(bn_bwd_apply_pool_quad_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, dy_pool, argmax, gamma, beta,
+                           save_mean, save_invstd, coef, dx, N, H, W, C, fc, fow, foh);
+        return;
+    }
+    const long M = (long)N * H * W;
+    BnMap m = bn_map(M, C);
+    const PoolGeom g = pool_geom(H, W, OH, OW, k, stride, pad, C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(m.gx, m.gy), dim3(256), 0, stream, x, (const float*)nullptr, dy_pool,
+                       gamma, beta, save_mean, save_invstd, coef, dx, (float*)nullptr, M, C, m.LC, 1, argmax, g);
+}
+
 // its gradient: dy_pool [N,OH,OW,C] + argmax -> dx [N,H,W,C], dgamma, dbeta (masked BN gradient of the gathered pool gradient)
 extern "C" int denet_bn_relu_pool_bwd(const float* x, const float* dy_pool, const unsigned char* argmax, const float* gamma,
                                       const float* beta, const float* save_mean, const float* save_invstd, float* dx,
@@ -661,8 +766,7 @@ extern "C" int denet_bn_relu_pool_bwd(const float* x, const float* dy_pool, cons
                        gamma, beta, save_mean, save_invstd, M, C, m.LC, 1, partial, argmax, g);
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FC - 1) / FC), dim3(FINAL_NT), 0, stream, partial, m.gy, M, C, dgamma,
                        dbeta, coef);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(m.gx, m.gy), dim3(256), 0, stream, x, (const float*)nullptr, dy_pool,
-                       gamma, beta, save_mean, save_invstd, coef, dx, (float*)nullptr, M, C, m.LC, 1, argmax, g);
+    launch_pool_apply(x, dy_pool, argmax, gamma, beta, save_mean, save_invstd, coef, dx, N, H, W, C, OH, OW, k, stride, pad, stream);
     DENET_CHECK_LAUNCH("bn_relu_pool_bwd");
     return DENET_OK;
 }
@@ -699,11 +803,7 @@ extern "C" int denet_bn_relu_pool_bwd_apply(const float* x, const float* dy_pool
     DENET_CHECK_ARG(x && dy_pool && argmax && gamma && beta && save_mean && save_invstd && coef && dx, "bn_relu_pool_bwd_apply: null pointer");
     DENET_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && k > 0 && stride > 0 && pad >= 0 && (long)N * H * W < (1L << 31),
                     "bn_relu_pool_bwd_apply: bad arguments");
-    const long M = (long)N * H * W;
-    BnMap m = bn_map(M, C);
-    const PoolGeom g = pool_geom(H, W, OH, OW, k, stride, pad, C);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(m.gx, m.gy), dim3(256), 0, stream, x, (const float*)nullptr, dy_pool,
-                       gamma, beta, save_mean, save_invstd, coef, dx, (float*)nullptr, M, C, m.LC, 1, argmax, g);
+    launch_pool_apply(x, dy_pool, argmax, gamma, beta, save_mean, save_invstd, coef, dx, N, H, W, C, OH, OW, k, stride, pad, stream);
     DENET_CHECK_LAUNCH("bn_relu_pool_bwd_apply");
     return DENET_OK;
 }

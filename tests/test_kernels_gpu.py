@@ -294,11 +294,13 @@ def test_fused_winograd_f2_kernels_under_memory_pressure(hip):
         ops._WINO.update(saved[1])
 
 
-@pytest.mark.parametrize("case", [(2, 32, 32, 64, 3, 2, 1), (3, 17, 23, 32, 3, 2, 1), (2, 16, 16, 128, 2, 2, 0), (1, 15, 15, 32, 3, 1, 1)])
+@pytest.mark.parametrize("case", [(2, 32, 32, 64, 3, 2, 1), (3, 17, 23, 32, 3, 2, 1), (2, 16, 16, 128, 2, 2, 0), (1, 15, 15, 32, 3, 1, 1),
+                                  (3, 20, 36, 96, 3, 2, 1), (1, 2, 2, 32, 3, 2, 1)])
 def test_bn_relu_pool_fused_equals_separate_passes(hip, case):
     """BN + ReLU + max pool in one pass (bn.hip: denet_bn_relu_pool_fwd_train / _bwd; batch_norm_relu.py:34-54 -> pool.py:38)
     against bn_fwd_train(relu) + maxpool_fwd and maxpool_bwd + bn_bwd: bit-identical output, argmax taps (ties between the
-    many zeros behind the ReLU included), statistics, dx, dgamma, dbeta"""
+    many zeros behind the ReLU included), statistics, dx, dgamma, dbeta. Even maps under the 3x3 / 2 / 1 pool take the 2 x 2-pixel
+    form of the backward pointwise pass (bn_bwd_apply_pool_quad_kernel), the others the general one"""
     from denet_amd import ops
     N, H, W, C, k, s, p = case
     g = torch.Generator().manual_seed(sum(case))
