@@ -370,7 +370,12 @@ __global__ __launch_bounds__(1024) void pair_finalize_kernel(const ImgState* __r
     const int ntie = min((int)st.ntie, tie_cap_for(sample_count));
     const Cand* in = cand + (long)b * (sample_count + TIE_CAP);
     const int n = nless + ntie;
-    for (int i = threadIdx.x; i < NP; i += 1024) {
+    // the network sorts the smallest power of two that holds the n candidates there are (a cold corner detector proposes none:
+    // nothing to sort, 5 us instead of 100), padded with keys that sort last
+    int np = 1;
+    while (np < n) np <<= 1;
+    if (np > NP) np = NP;
+    for (int i = threadIdx.x; i < np; i += 1024) {
         Cand e;
         if (i < nless) e = in[i];
         else if (i < n) e = in[sample_count + (i - nless)];
@@ -378,9 +383,9 @@ __global__ __launch_bounds__(1024) void pair_finalize_kernel(const ImgState* __r
         s[i] = e;
     }
     __syncthreads();
-    for (int k = 2; k <= NP; k <<= 1) {
+    for (int k = 2; k <= np; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < NP / 2; t += 1024) {
+            for (int t = threadIdx.x; t < np / 2; t += 1024) {
                 const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const int hi = lo | j;
                 const bool up = ((lo & k) == 0);
