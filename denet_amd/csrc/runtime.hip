@@ -245,6 +245,22 @@ extern "C" int denet_host_edit_samples_stream(const uint32_t* stream, long n_str
     return rc;
 }
 
+// The host's whole share of the RoI hand-off in ONE call, for the moment the device stands idle between its proposal and the
+// gather: denet_samples_finish_host (sample tuples from the packed proposal: det_out [B][S][5]) followed by
+// denet_host_edit_samples_stream on them. Same outputs as the two calls.
+extern "C" int denet_samples_finish_host(const int* box_host, const float* absd_host, const int* count_host, int B,
+                                         int sample_count, int H, int W, float* samples_host);
+extern "C" int denet_host_handoff_stream(const uint32_t* stream, long n_stream, long* cursor, int* exhausted, const int* box_host,
+                                         const float* absd_host, const int* count_host, int H, int W, int B, int S, int n_keep,
+                                         const double* gt, const int* gt_off, int sample_gt, int* ws, float* det_out, double* out_pr,
+                                         double* out_box, float* out_box_f32) {
+    DENET_CHECK_ARG(det_out, "handoff_stream: null pointer");
+    int rc = denet_samples_finish_host(box_host, absd_host, count_host, B, S, H, W, det_out);
+    if (rc != DENET_OK) return rc;
+    return denet_host_edit_samples_stream(stream, n_stream, cursor, exhausted, det_out, count_host, B, S, n_keep, gt, gt_off, sample_gt,
+                                          ws, out_pr, out_box, out_box_f32);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Detection targets of a batch (denet/layer/denet_detect.py:147-235), RoI-major: row m = b*S + index.
 // IoU matrix in float32 with the operation order of the compiled Theano function (common/theano_util.py:38-59);

@@ -528,6 +528,94 @@ extern "C" int denet_build_samples_stats(const void* workspace, size_t workspace
     return DENET_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The training-time RoI list editing (denet/layer/denet_sparse.py:184-201) ON THE DEVICE, for the batches that need no
+// random.sample: every image proposes at most n_keep RoIs (a detector early in training; the host checks the counts). Then the
+// edited list of image b is: its count[b] proposals, (S - count[b]) random boxes, the last n_gt of them replaced by the ground
+// truth - and the generator outputs a random box draws sit at a position that follows from the counts alone: 8 outputs per
+// box (four `random()` of two outputs each, in the order x0, y0, x1, y1), images in order. The outputs come from a stretch drawn
+// ahead on the host (denet_host_mt_prefetch) and uploaded at the start of the step; the host walks through the same stretch
+// later, off the critical path, for the Python-side list (denet_host_edit_samples_stream) - same values, bit for bit:
+//   proposal  -> denet_samples_finish_host's box arithmetic, (float)((double)x0 / W) ...
+//   random    -> x0 = 0.0 + (1.0 - 0.0) * r, x1 = x0 + (1.0 - x0) * r (random.uniform), r = (a >> 5) * 2^26 + (b >> 6)) / 2^53,
+//                doubles, no contraction (this file is compiled with -ffp-contract=off), rounded to fp32 on store
+//   truth     -> (float)gt
+// One workgroup per image, a thread per RoI slot. out_bbox [B][S][4] floats = what build_bbox_array would upload.
+static __global__ __launch_bounds__(256) void edit_samples_kernel(const int* __restrict__ box, const int* __restrict__ count, int H, int W,
+                                                           const uint32_t* __restrict__ mt_out, long n_out, long cursor0,
+                                                           const double* __restrict__ gt, const int* __restrict__ gt_off,
+                                                           int sample_gt, int S, int n_keep, float* __restrict__ out_bbox,
+                                                           int* __restrict__ status) {
+    const int b = blockIdx.x;
+    long first = cursor0;                    // outputs drawn by the images before this one
+    bool bad = false;
+    for (int i = 0; i < b; ++i) {
+        const int c = count[i];
+        bad |= c > n_keep;
+        first += 8L * (S - (c < S ? c : S));
+    }
+    const int n = count[b];
+    bad |= n > n_keep || n < 0 || first + 8L * (S - n) > n_out;
+    if (bad) {                               // not this kernel's case (or the stretch is too short): the host must not use the result
+        if (threadIdx.x == 0) atomicOr(status, 1);
+        return;
+    }
+    const int g0 = sample_gt ? gt_off[b] : 0, ng = sample_gt ? gt_off[b + 1] - g0 : 0;
+    for (int i = threadIdx.x; i < S; i += blockDim.x) {
+        float* o = out_bbox + ((long)b * S + i) * 4;
+        if (i >= S - ng) {
+            const double* g = gt + (long)(g0 + (S - 1 - i)) * 4;
+            o[0] = (float)g[0]; o[1] = (float)g[1]; o[2] = (float)g[2]; o[3] = (float)g[3];
+        } else if (i < n) {
+            const int* bx = box + ((long)b * S + i) * 4;
+            // through fp32 and back, as the host list holds the fp32 tuple of denet_samples_finish_host
+            o[0] = (float)((double)bx[0] / W);
+            o[1] = (float)((double)bx[1] / H);
+            o[2] = (float)((double)(bx[2] + 1) / W);
+            o[3] = (float)((double)(bx[3] + 1) / H);
+        } else {
+            const uint32_t* m = mt_out + first + 8L * (i - n);
+            double r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t a = m[2 * k] >> 5, c2 = m[2 * k + 1] >> 6;
+                r[k] = (a * 67108864.0 + c2) * (1.0 / 9007199254740992.0);
+            }
+            const double x0 = 0.0 + (1.0 - 0.0) * r[0];
+            const double y0 = 0.0 + (1.0 - 0.0) * r[1];
+            const double x1 = x0 + (1.0 - x0) * r[2];
+            const double y1 = y0 + (1.0 - y0) * r[3];
+            o[0] = (float)x0; o[1] = (float)y0; o[2] = (float)x1; o[3] = (float)y1;
+        }
+    }
+    if (b == (int)gridDim.x - 1 && threadIdx.x == 0) {
+        const long used = first + 8L * (S - n) - cursor0;
+        status[1] = (int)used;               // outputs consumed by the batch (the host arrives at the same number)
+    }
+}
+
+// box [B][S][4] int32 and count [B]: denet_build_samples' outputs as they lie on the device; H, W: the corner map; mt_out [n_out]:
+// the generator outputs drawn ahead, cursor0 = how many of them earlier draws of the step have used; gt [n][4] doubles + gt_off
+// [B + 1] (sample_gt != 0); status [2] int32, zeroed here: [0] != 0 afterwards = an image proposed more than n_keep RoIs or the
+// stretch is too short - out_bbox is then incomplete and the caller edits on the host as before; [1] = outputs consumed.
+extern "C" int denet_edit_samples_device(const int* box, const int* count, int H, int W, const uint32_t* mt_out, long n_out,
+                                         long cursor0, const double* gt, const int* gt_off, int sample_gt, int B, int S, int n_keep,
+                                         float* out_bbox, int* status, hipStream_t stream) {
+    DENET_CHECK_ARG(box && count && mt_out && out_bbox && status, "edit_samples_device: null pointer");
+    DENET_CHECK_ARG(!sample_gt || (gt && gt_off), "edit_samples_device: ground truth missing");
+    DENET_CHECK_ARG(B > 0 && S > 0 && n_keep >= 0 && n_keep <= S && H > 0 && W > 0 && n_out >= 0 && cursor0 >= 0,
+                    "edit_samples_device: bad sizes");
+    hipError_t e = hipMemsetAsync(status, 0, 2 * sizeof(int), stream);
+    if (e != hipSuccess) {
+        denet_set_error("edit_samples_device: memset: %s", hipGetErrorString(e));
+        return -(int)e;
+    }
+    hipLaunchKernelGGL(edit_samples_kernel, dim3(B), dim3(256), 0, stream, box, count, H, W, mt_out, n_out, cursor0, gt, gt_off,
+                       sample_gt, S, n_keep, out_bbox, status);
+    DENET_CHECK_LAUNCH("edit_samples_device");
+    return DENET_OK;
+}
+
 // Host epilogue: turns the integer boxes + |d| of denet_build_samples (copied to the host) into the
 // reference's sample tuples (pr, x0, y0, x1, y1) with the reference's exact host arithmetic
 // (denet_sparse.cc:306-307): pr = (float)(1.0 / (1.0 + std::exp(fabs(d)))) with the fp32 exp overload,

@@ -27,6 +27,11 @@ TAP_CUDA = 1     # denet_sparse_op.py:65-71
 SPECULATE_COLD = os.environ.get("DENET_SPECULATE_COLD", "1") != "0"
 # the generator outputs of a step's RoI editing are drawn while the device runs the backbone (DeNetSparseLayer._prefetch_random)
 PREFETCH_RANDOM = os.environ.get("DENET_PREFETCH_RANDOM", "1") != "0"
+# batches in which no image proposes more RoIs than the list keeps are edited ON THE DEVICE (DeNetSparseLayer._device_edit): the
+# gather does not wait for the host's editing, which runs beside it for the Python-side list; 0 switches it off
+DEVICE_EDIT = os.environ.get("DENET_DEVICE_EDIT", "1") != "0"
+# every other batch: the host's share of the hand-off cut down to one native call + the upload (DeNetSparseLayer._fast_handoff)
+FAST_HANDOFF = os.environ.get("DENET_FAST_HANDOFF", "1") != "0"
 
 
 class PyRandomMirror:
@@ -127,8 +132,9 @@ class DeNetSparseLayer(AbstractLayer):
             raise NotImplementedError("RoI clustering needs the %d best candidates per image; the device proposal ranks at "
                                       "most 7936 (sample_num <= 28)" % self.proposal_count)
 
-        self.sample_pr = []        # per image float64 [n]
+        self.sample_pr = []        # per image float64 [n]      (the three host-side views may be PENDING: _resolve_edit)
         self.sample_boxes = []     # per image float64 [n,4]
+        self.sample_bbox_f32 = None
         self.sample_bbox = None    # device [B*sn*sn, 4]
         self.output_feat = self.grid_size * self.grid_size * self.corner_layer.sample_shape[1] + 2
         self.output_shape = (self.batch_size, self.output_feat, self.sample_num, self.sample_num)
@@ -137,6 +143,26 @@ class DeNetSparseLayer(AbstractLayer):
         self._pinned = None
         self.coverage = (0, 0)
         self.phase_ms = {}         # host phases of the last RoI hand-off in ms, the reference's names (denet_sparse.py:127-161)
+
+    # the host-side views of the edited RoI list. After a device-side edit (_device_edit) they are produced by the first reader -
+    # the detection layer's get_target, a few layers on, while the device runs the gather and the head
+    def _resolve_edit(self):
+        job = self.__dict__.pop("_lazy_edit", None)
+        if job is not None:
+            job()
+
+    def _lazy_view(name):
+        def get(self):
+            self._resolve_edit()
+            return getattr(self, name)
+
+        def put(self, v):
+            self.__dict__.pop("_lazy_edit", None)        # an explicit list replaces whatever was pending
+            setattr(self, name, v)
+        return property(get, put)
+
+    sample_pr, sample_boxes, sample_bbox_f32 = _lazy_view("_sample_pr"), _lazy_view("_sample_boxes"), _lazy_view("_sample_bbox_f32")
+    del _lazy_view
 
     @staticmethod
     def parse_desc(layers, name, tags, params):
@@ -189,9 +215,26 @@ class DeNetSparseLayer(AbstractLayer):
         h = self._res_host
         hcount = h[B * S * 5:]
         self._raw_samples = None
+        self._deferred = None
+        if raw_only and (self._device_edit(hcount) or self._fast_handoff(hcount)):
+            # the bbox array is on its way (edited on the device, or by ONE native host call); everything else of the host's share
+            # - the Python-side list, the generator's state - waits for its first reader
+            self._deferred = timer
+            self._log_get_samples(timer)
+            return None, None
+        return self._finish_samples(timer, raw_only)
+
+    def _finish_samples(self, timer, raw_only, log=True):
+        """host epilogue of the proposal: sample tuples from the packed result in the pinned buffer"""
+        import torch
+        cl = self.corner_layer
+        B, S = self.batch_size, self.proposal_count
+        h = self._res_host
+        hcount = h[B * S * 5:]
         if int(hcount.sum()) == 0:        # cold detector: nothing proposed
             empty_pr, empty_bx = numpy.zeros((0,)), numpy.zeros((0, 4))
-            self._log_get_samples(timer)
+            if log:
+                self._log_get_samples(timer)
             return [empty_pr] * B, [empty_bx] * B
         hbox = h[:B * S * 4].view(B, S, 4)
         habsd = h[B * S * 4:B * S * 5].view(torch.float32).view(B, S)
@@ -205,7 +248,8 @@ class DeNetSparseLayer(AbstractLayer):
         if self.cluster:
             raw, hcount = ops.cluster_samples_host(raw, hcount, self.nms_threshold, self.sample_count)
         self._raw_samples = (raw, hcount)
-        self._log_get_samples(timer)
+        if log:
+            self._log_get_samples(timer)
         if raw_only:
             return None, None
         samples = raw.astype(numpy.float64)
@@ -328,6 +372,8 @@ class DeNetSparseLayer(AbstractLayer):
         while the GPU is busy with the backbone instead of inside the GPU-idle hand-off: ground-truth arrays and the
         snapshot of the stdlib generator (re-validated with PyRandomMirror.fresh() before use)"""
         B = self.batch_size
+        self._resolve_edit()              # (a list of the previous step nobody read)
+        self._check_device_edit_status()
         prep = {"metas": metas, "mirror": PyRandomMirror()}
         if self.sample_gt:
             gts = [numpy.asarray(m["bbox"], dtype=numpy.float64).reshape(-1, 4) for m in metas]
@@ -340,9 +386,12 @@ class DeNetSparseLayer(AbstractLayer):
         self._prep = prep
         self._spec = None
         self._prefetch = None
+        self._dev_edit = None
         if get_train() and self._native_edit_ok(metas):
             if PREFETCH_RANDOM:
                 self._prefetch_random()
+                if DEVICE_EDIT and self._on_device() and not self.cluster:
+                    self._upload_for_device_edit(metas, prep)
             if SPECULATE_COLD and self._on_device():
                 self._speculate_cold(metas, prep)
 
@@ -360,8 +409,17 @@ class DeNetSparseLayer(AbstractLayer):
         max_snaps = n // 624 + 3
         buf = getattr(self, "_pf_buf", None)
         if buf is None or buf[0].size != n:
-            buf = self._pf_buf = (numpy.empty(n, dtype=numpy.uint32), numpy.empty((max_snaps, 624), dtype=numpy.uint32),
-                                  numpy.empty(max_snaps, dtype=numpy.int64))
+            if self._on_device():
+                import torch
+                # pinned: the stretch is also uploaded for the device-side editing (_upload_for_device_edit)
+                self._pf_pinned = torch.empty(n, dtype=torch.int32).pin_memory()
+                out0 = self._pf_pinned.numpy().view(numpy.uint32)
+            else:
+                out0 = numpy.empty(n, dtype=numpy.uint32)
+            buf = self._pf_buf = (out0, numpy.empty((max_snaps, 624), dtype=numpy.uint32), numpy.empty(max_snaps, dtype=numpy.int64))
+        prev = self.__dict__.pop("_pf_upload", None)
+        if prev is not None:
+            prev.synchronize()            # the previous step's upload out of this buffer (a whole step old: done)
         out, snaps, first = buf
         mirror = PyRandomMirror()
         key, pos = mirror.key.copy(), mirror.pos.copy()
@@ -369,6 +427,168 @@ class DeNetSparseLayer(AbstractLayer):
         _lib.check(_lib.load().denet_host_mt_prefetch(key.ctypes.data, pos.ctypes.data, n, out.ctypes.data, snaps.ctypes.data,
                                                       first.ctypes.data, max_snaps, ctypes.byref(ns)), "mt_prefetch")
         self._prefetch = {"mirror": mirror, "n": n, "ns": ns.value, "pos0": int(mirror.pos[0])}
+
+    def _upload_for_device_edit(self, metas, prep):
+        """what the device-side editing reads, sent while the device runs the backbone: the generator outputs drawn ahead and the
+        ground-truth boxes"""
+        import torch
+        pf = self._prefetch
+        B, S = self.batch_size, self.sample_count
+        st = self.__dict__.get("_de_static")
+        if st is None:
+            st = self._de_static = {"gt": torch.empty((B * S + 1, 4), dtype=torch.float64).pin_memory(),
+                                    "off": torch.empty(B + 1, dtype=torch.int32).pin_memory(),
+                                    "status": torch.zeros(2, dtype=torch.int32, device="cuda"),
+                                    "status_host": torch.zeros(2, dtype=torch.int32).pin_memory()}
+        off, gt = prep["off"], prep["gt"]
+        ng = int(off[-1])
+        if ng > B * S:
+            return
+        st["off"].numpy()[:] = off
+        st["gt"].numpy()[:max(ng, 1)] = gt[:max(ng, 1)]
+        side = ops.side_stream(2)
+        with torch.cuda.stream(side):
+            mt = self._pf_pinned.cuda(non_blocking=True)
+            gtd = st["gt"][:max(ng, 1)].cuda(non_blocking=True)
+            offd = st["off"].cuda(non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._pf_upload = ev
+        self._dev_edit = {"metas": metas, "mt": mt, "gt": gtd, "off": offd, "ev": ev, "n": pf["n"]}
+
+    def _device_edit(self, hcount):
+        """The hand-off when no image proposes more RoIs than the list keeps (no random.sample: every step of a detector early in
+        training): denet_edit_samples_device writes the bbox array from the proposal as it lies on the device, the uploaded
+        generator outputs and the ground truth - the gather starts behind one small device-to-host copy. The host's own editing
+        (same stretch of outputs, same values: test_device_side_editing_equals_the_host_list) is left to the first reader of the
+        Python-side list. False: not this case, the ordinary path runs."""
+        import torch
+        de, pf = self.__dict__.get("_dev_edit"), self.__dict__.get("_prefetch")
+        prep = self.__dict__.get("_prep")
+        B, S = self.batch_size, self.sample_count
+        n_keep = S - math.floor(self.random_sample * S)
+        if not DEVICE_EDIT or de is None or pf is None or prep is None or de["metas"] is not prep["metas"] or self.proposal_count != S:
+            return False
+        hc = hcount.numpy()
+        if int(hc.sum()) == 0 or int(hc.max()) > n_keep or not pf["mirror"].fresh():
+            return False              # (nothing proposed: the prepared cold list is cheaper still)
+        from .. import lib as _lib
+        cl = self.corner_layer
+        cur = torch.cuda.current_stream()
+        cur.wait_event(de["ev"])
+        for t in (de["mt"], de["gt"], de["off"]):
+            t.record_stream(cur)
+        out = torch.empty((B * S, 4), dtype=torch.float32, device="cuda")
+        r, st = self._res_dev, self._de_static
+        _lib.check(_lib.load().denet_edit_samples_device(
+            _lib.ptr(r[:B * S * 4]), _lib.ptr(r[B * S * 5:]), cl.height, cl.width, _lib.ptr(de["mt"]), de["n"], 0, _lib.ptr(de["gt"]),
+            _lib.ptr(de["off"]), int(bool(self.sample_gt)), B, S, n_keep, _lib.ptr(out), _lib.ptr(st["status"]), _lib.stream_ptr()),
+            "edit_samples_device")
+        st["status_host"].copy_(st["status"], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._de_status_ev = (ev, int(8 * (B * S - int(hc.sum()))))
+        self.sample_bbox = out
+        self._dev_edit = None
+        self.device_edits = getattr(self, "device_edits", 0) + 1
+
+        def job():
+            # the host's share, beside the device's gather and head: sample tuples, then the editing on the SAME stretch of
+            # generator outputs (no other choice is consistent with what the device has used)
+            timer = common.Timer()
+            self._finish_samples(timer, True, log=False)
+            det, cnt = self._raw_samples
+            if self._pinned is None:
+                self._pinned = torch.empty((B * S, 4), dtype=torch.float32).pin_memory()
+            f32 = self._pinned.numpy()
+            if not pf["mirror"].fresh():
+                raise RuntimeError("the stdlib generator moved between the device-side RoI editing and the host's: the two lists "
+                                   "would differ")
+            self._prefetch = None
+            done = self._native_edit_stream(pf, numpy.ascontiguousarray(det, dtype=numpy.float32),
+                                            numpy.ascontiguousarray(cnt, dtype=numpy.int32), prep, f32)
+            assert done is not None, "the prefetched stretch ran dry without a random.sample"
+            out_pr, out_box, mirror = done
+            mirror.push()
+            self._prep = None
+            self._sample_pr, self._sample_boxes = list(out_pr), list(out_box)
+            self._sample_bbox_f32 = f32.reshape(B, S, 4)
+        self._lazy_edit = job
+        return True
+
+    def _fast_handoff(self, hcount):
+        """The hand-off with the device idle as short as the host can make it: sample tuples + editing on the prefetched generator
+        outputs in ONE native call (denet_host_handoff_stream), the upload of the bbox array, nothing else. What the rest of the
+        step wants from the host - the lists, the generator's state handed back to `random` - is left to the first reader
+        (_resolve_edit), who runs beside the device's gather and head. False: no prefetched stretch / it ran dry / nothing proposed:
+        the ordinary path."""
+        import ctypes
+        import torch
+        from .. import lib as _lib
+        pf, prep = self.__dict__.get("_prefetch"), self.__dict__.get("_prep")
+        B, S = self.batch_size, self.sample_count
+        if not FAST_HANDOFF or pf is None or prep is None or self.cluster or self.proposal_count != S or not self._on_device():
+            return False
+        hc = hcount.numpy()
+        if int(hc.sum()) == 0 or not pf["mirror"].fresh():
+            return False
+        cl = self.corner_layer
+        n_keep = S - math.floor(self.random_sample * S)
+        if self._pinned is None:
+            self._pinned = torch.empty((B * S, 4), dtype=torch.float32).pin_memory()
+        bufs = self.__dict__.get("_ho_bufs")
+        if bufs is None:
+            bufs = self._ho_bufs = {"ws": numpy.empty(2 * S, dtype=numpy.int32), "turn": 0,
+                                    "det": [numpy.empty((B, S, 5), dtype=numpy.float32) for _ in range(2)],
+                                    "cnt": [numpy.empty(B, dtype=numpy.int32) for _ in range(2)]}
+        bufs["turn"] ^= 1
+        det, cnt = bufs["det"][bufs["turn"]], bufs["cnt"][bufs["turn"]]
+        cnt[:] = hc
+        out_pr, out_box = self._edit_out()
+        out, snaps, first = self._pf_buf
+        h = self._res_host
+        hp = h.data_ptr()
+        cursor, dry = ctypes.c_long(0), ctypes.c_int(0)
+        off, gt = prep["off"], prep["gt"]
+        f32 = self._pinned.numpy()
+        _lib.check(_lib.load().denet_host_handoff_stream(
+            out.ctypes.data, pf["n"], ctypes.byref(cursor), ctypes.byref(dry), hp, hp + 4 * B * S * 4, cnt.ctypes.data, cl.height,
+            cl.width, B, S, n_keep, gt.ctypes.data, off.ctypes.data, int(bool(self.sample_gt)), bufs["ws"].ctypes.data,
+            det.ctypes.data, out_pr.ctypes.data, out_box.ctypes.data, f32.ctypes.data), "handoff_stream")
+        if dry.value:
+            return False
+        self.sample_bbox = self._pinned.cuda(non_blocking=True)
+        self._prefetch = None
+        c = cursor.value
+
+        def job():
+            # the state after c outputs: the snapshot they ended in, with CPython's lazy refill (a position of 624 stays 624)
+            if not pf["mirror"].fresh():
+                raise RuntimeError("the stdlib generator moved between the RoI hand-off and the bookkeeping of its draws")
+            j = max(0, int(numpy.searchsorted(first[:pf["ns"]], c, side="left")) - 1)
+            mirror = pf["mirror"]
+            mirror.key = snaps[j].copy()
+            mirror.pos[0] = (pf["pos0"] if j == 0 else 0) + (c - int(first[j]))
+            assert 0 <= int(mirror.pos[0]) <= 624
+            mirror.push()
+            self._prep = None
+            self._raw_samples = (det, cnt)
+            self._sample_pr, self._sample_boxes = list(out_pr), list(out_box)
+            self._sample_bbox_f32 = f32.reshape(B, S, 4)
+        self._lazy_edit = job
+        self.fast_handoffs = getattr(self, "fast_handoffs", 0) + 1
+        return True
+
+    def _check_device_edit_status(self):
+        """the status word of the previous step's device-side editing (copied back asynchronously; a step old by now)"""
+        pend = self.__dict__.pop("_de_status_ev", None)
+        if pend is None:
+            return
+        ev, used = pend
+        ev.synchronize()
+        flag, dev_used = [int(v) for v in self._de_static["status_host"].tolist()]
+        if flag != 0 or dev_used != used:
+            raise RuntimeError("device-side RoI editing: status %d, %d generator outputs used (host: %d)" % (flag, dev_used, used))
 
     def _native_edit_stream(self, pf, det, cnt, prep, out_f32):
         """the editing on the prefetched outputs; returns (out_pr, out_box, mirror holding the state after them) or None when the
@@ -519,9 +739,13 @@ class DeNetSparseLayer(AbstractLayer):
     def get_target(self, model, data_x, metas):
         timer = common.Timer()
         native = self._native_edit_ok(metas)
+        if self.__dict__.get("_prep") is None or self._prep["metas"] is not metas:
+            self._dev_edit = None            # prepared for another batch
         prs, boxes = self._device_samples(raw_only=native)
         timer.mark()
-        if native:
+        if native and self._deferred is not None:
+            self._deferred = None            # edited on the device (_device_edit): the gather is not waiting for anything
+        elif native:
             self._edit_and_upload_native(metas)
         else:
             self.sample_pr, self.sample_boxes = self.edit_samples(prs, boxes, metas)

@@ -26,6 +26,7 @@ SIGNATURES = {
     "denet_host_edit_samples": (I, [P, P, P, P, I, I, I, P, P, I, P, P, P, P]),
     "denet_host_mt_prefetch": (I, [P, P, L, P, P, P, I, P]),
     "denet_host_edit_samples_stream": (I, [P, L, P, P, P, P, I, I, I, P, P, I, P, P, P, P]),
+    "denet_host_handoff_stream": (I, [P, L, P, P, P, P, P, I, I, I, I, I, P, P, I, P, P, P, P, P]),
     "denet_host_detect_targets": (I, [P, P, P, P, I, I, I, I, I, I, ctypes.c_double, ctypes.c_double, P, P, P, P]),
     "denet_conv_fwd": (I, [P, P, P, P, P] + [I] * 12 + [P]),
     "denet_conv_fwd_act": (I, [P, P, P, P, P] + [I] * 13 + [P]),
@@ -132,6 +133,7 @@ SIGNATURES = {
     "denet_build_samples_workspace_bytes": (Z, [I] * 6),
     "denet_build_samples": (I, [P, P, P, P, P, Z] + [I] * 4 + [F, I, I, I, P]),
     "denet_build_samples_stats": (I, [P, Z] + [I] * 6 + [P, P, P]),
+    "denet_edit_samples_device": (I, [P, P, I, I, P, L, L, P, P] + [I] * 4 + [P, P, P]),
     "denet_host_cluster_samples": (I, [P, I, F, I, P, P]),
     "denet_samples_finish_host": (I, [P, P, P, I, I, I, I, P]),
 }

@@ -63,6 +63,12 @@ int denet_host_edit_samples_stream(const unsigned* stream_host, long n_stream, l
                                    const float* det_host, const int* count_host, int B, int S, int n_keep, const double* gt_host,
                                    const int* gt_off_host, int sample_gt, int* ws_host, double* out_pr_host, double* out_box_host,
                                    float* out_box_f32_host);
+/* the host's whole share of the hand-off in one call (the device stands idle meanwhile): denet_samples_finish_host into
+ * det_out_host [B][S][5], then denet_host_edit_samples_stream on it. Same outputs as the two calls. */
+int denet_host_handoff_stream(const unsigned* stream_host, long n_stream, long* cursor_host, int* exhausted_host,
+                              const int* box_host, const float* absd_host, const int* count_host, int H, int W, int B, int S,
+                              int n_keep, const double* gt_host, const int* gt_off_host, int sample_gt, int* ws_host,
+                              float* det_out_host, double* out_pr_host, double* out_box_host, float* out_box_f32_host);
 /* detection targets of a batch (denet/layer/denet_detect.py:147-235) in RoI-major layout: fp32 IoU matrix in the
  * operation order of common/theano_util.py:38-59, class / class x fitness-bin targets for IoU > t0, box-regression
  * target of the arg-max ground truth for IoU > t1, rows normalised and divided by S. gt: concatenated [n,4] doubles,
@@ -471,6 +477,18 @@ size_t denet_build_samples_workspace_bytes(int B, int Cn, int H, int W, int max_
 int denet_build_samples(const float* corner_pr, int* out_box, float* out_absd, int* out_count, void* workspace,
                         size_t workspace_bytes, int B, int Cn, int H, int W, float corner_threshold, int sample_count,
                         int max_corners, int local_max, hipStream_t stream);
+/* The training-time RoI list editing (DeNetSparseLayer.get_target, denet/layer/denet_sparse.py:184-201) on the device, for the
+ * batches in which no image proposes more than n_keep RoIs (no random.sample; the host checks the counts it has copied): proposals
+ * (denet_samples_finish_host's box arithmetic), random boxes from generator outputs drawn ahead on the host
+ * (denet_host_mt_prefetch; 8 per box, their position follows from the counts), ground truth in the last slots. box [B][S][4]
+ * int32 and count [B] are denet_build_samples' device outputs, H x W the corner map, mt_out [n_out] the uploaded outputs, cursor0
+ * the number already used, gt [n][4] doubles + gt_off [B+1]. out_bbox [B][S][4] floats = what build_bbox_array would upload, bit
+ * for bit what denet_host_edit_samples(_stream) writes to out_box_f32 - the host runs that later, beside the device's gather and
+ * head, for the Python-side list. status [2] (device, zeroed here): [0] != 0: not this call's case, out_bbox incomplete;
+ * [1]: outputs consumed. */
+int denet_edit_samples_device(const int* box, const int* count, int H, int W, const uint32_t* mt_out, long n_out, long cursor0,
+                              const double* gt, const int* gt_off, int sample_gt, int B, int S, int n_keep, float* out_bbox,
+                              int* status, hipStream_t stream);
 /* diagnostics of the LAST denet_build_samples call on `workspace` (same geometry): corners kept per (image, type) after the
  * max_corners truncation (denet_sparse.cc:526-530) -> ncorner_out [B*Cn] int32, candidate boxes generated per image by the
  * pair search (:337-373) -> candidates_out [B] uint32; device buffers, copies on `stream`. */

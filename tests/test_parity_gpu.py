@@ -771,6 +771,51 @@ def test_prepared_cold_roi_list_equals_the_hand_off_path(hip):
         assert torch.equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2], warm
 
 
+def test_device_side_editing_equals_the_host_list(hip):
+    """The two short forms of the RoI hand-off against the ordinary one. DeNetSparseLayer._device_edit: when no image proposes
+    more RoIs than the list keeps (no random.sample), the bbox array is written on the device (denet_edit_samples_device:
+    proposals, random boxes from generator outputs drawn ahead, ground truth) and the host's editing runs later for the
+    Python-side list. _fast_handoff: every other batch - one native call (sample tuples + editing on the prefetched outputs) and
+    the upload, the bookkeeping later. Reference loop: denet/layer/denet_sparse.py:184-201. The device array equals the host's
+    float32 array bit for bit; lists, parameters after three steps and the generator's position are identical in all three
+    modes; a detector that proposes more than the list keeps does not take the device path."""
+    from denet_amd.layer import denet_sparse as DS
+    res, took = {}, {}
+    saved = (DS.DEVICE_EDIT, DS.FAST_HANDOFF)
+    biases, modes = (5.6, 5.0, 4.0), ((True, True), (False, True), (False, False))
+    try:
+        for bias in biases:          # a few dozen ... more than 519 proposals per image
+            for mode in modes:
+                DS.DEVICE_EDIT, DS.FAST_HANDOFF = mode
+                random.seed(21)
+                model = zoo.warm_corner_head(zoo.denet34(2, "skip", 128, class_num=80, seed=1), bias, 0.3)
+                model.build_train_func("nesterov")
+                dns = [l for l in model.layers if l.type_name == "denet-sparse"][0]
+                x, metas = zoo.synthetic_batch(2, 128, seed=11)
+                lists, arrays = [], []
+                for it in range(3):
+                    model.train_step(x, metas, 0, it, 0.0, [0.9], 1e-4)      # lr 0: the detector stays as warm as it is
+                    dev_bbox = dns.sample_bbox.clone()
+                    lists.append(dns.sample_bbox_list)
+                    torch.cuda.synchronize()
+                    assert torch.equal(dev_bbox.cpu().view(-1), torch.from_numpy(dns.sample_bbox_f32.reshape(-1).copy()))
+                    arrays.append(dev_bbox.cpu())
+                took[(bias, mode)] = (getattr(dns, "device_edits", 0), getattr(dns, "fast_handoffs", 0))
+                res[(bias, mode)] = (model.P.clone(), lists, arrays, random.random())
+    finally:
+        DS.DEVICE_EDIT, DS.FAST_HANDOFF = saved
+    for bias in biases:
+        ref = res[(bias, (False, False))]
+        assert took[(bias, (False, False))] == (0, 0)
+        for mode in modes[:2]:
+            a = res[(bias, mode)]
+            assert torch.equal(a[0], ref[0]) and a[1] == ref[1] and a[3] == ref[3], (bias, mode)
+            assert all(torch.equal(u, v) for u, v in zip(a[2], ref[2])), (bias, mode)
+        assert took[(bias, (False, True))][0] == 0 and took[(bias, (False, True))][1] >= 2, took
+    assert any(took[(bias, (True, True))][0] >= 2 for bias in biases), took      # the device path ran
+    assert any(took[(bias, (True, True))][0] == 0 and took[(bias, (True, True))][1] >= 2 for bias in biases), took      # too warm for it
+
+
 def test_acc_mode_accumulates_and_averages(hip):
     """--use-acc-mode (model_cnn.py:374-392): train_begin / F x train_step / train_end = ONE update with the mean gradient and
     the mean of the would-be batch-norm running statistics, every sub-step starting from the same parameters"""
