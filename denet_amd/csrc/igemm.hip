@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
     float* out = p.out;
     if (MODE == MODE_WGRAD) out += (long)split_id * p.split_stride;
     if (MODE == MODE_FWD || MODE == MODE_WGRAD) out += by * p.batch_out;
-    if ((MODE == MODE_FWD || MODE == MODE_DGRAD) && p.stats) {      // (data gradient: stride 1 only, checked by the host)
+    if ((MODE == MODE_FWD || MODE == MODE_DGRAD) && p.stats) {
         // ---- store + batch-norm column sums. Lane (li, lh) holds row m and, per (j, g), 4 consecutive columns: the sums
         // over the rows of the tile are a reduction over li (shuffles inside each 32-lane half), then over the two waves
         // stacked along M (LDS), written as doubles: partial[tile_m][0][n] = sum, [1][n] = sum of squares.
@@ -652,7 +652,14 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
                     for (int i = 0; i < TM; ++i) {
                         const int m = m0 + (wm * TM + i) * 32 + li;
                         if (m < p.M) {
-                            const long row = (long)m * p.NC;
+                            long row = (long)m * p.NC;
+                            if (MODE == MODE_DGRAD && p.stride > 1) {      // pixel m of this parity class (see the plain epilogue)
+                                const uint32_t ni = p.div_row_hw.div(m);
+                                const uint32_t rem = m - ni * (p.Hc * p.Wc);
+                                const uint32_t ya = p.div_row_w.div(rem);
+                                const uint32_t xa = rem - ya * p.Wc;
+                                row = (((long)ni * p.H + (ya * p.stride + dg_py)) * p.W + (xa * p.stride + dg_px)) * p.NC;
+                            }
                             f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                             v += bias4;
                             if (p.add) v += *(const f32x4*)(p.add + row + n);
@@ -704,7 +711,8 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
                 a += (double)red[(w * 2 + 0) * BN + tid];
                 b += (double)red[(w * 2 + 1) * BN + tid];
             }
-            double* ps = p.stats + (long)tile_m * 2 * p.NC;
+            // one row per (parity class, row tile): every pixel of dx is in exactly one
+            double* ps = p.stats + ((MODE == MODE_DGRAD ? (long)blockIdx.y * p.tiles_m : 0L) + tile_m) * 2 * p.NC;
             ps[n0 + tid] = a;
             ps[p.NC + n0 + tid] = b;
         }
@@ -1408,17 +1416,19 @@ extern "C" int denet_conv_dgrad(const float* dy, const float* w, const float* ad
     return conv_dgrad_impl(dy, w, add, dx, nullptr, nullptr, N, H, W, C, K, R, S, S_real, stride, pad, OH, OW, stream);
 }
 
-// denet_conv_dgrad of a stride-1 layer whose dx is the gradient of the OUTPUT of the batch norm `sums_of` (see
-// denet_conv_wino_dgrad_sums): the epilogue also writes that layer's backward reductions, stats_partial
-// [ceil(N*H*W / 128)][2][C] doubles, *stats_rows rows (0 and no sums for strides > 1)
+// denet_conv_dgrad of a layer whose dx is the gradient of the OUTPUT of the batch norm `sums_of` (see
+// denet_conv_wino_dgrad_sums): the epilogue also writes that layer's backward reductions, stats_partial [rows][2][C] doubles
+// with rows = stride^2 * ceil(N*(H/stride)*(W/stride) / 128) (a row per parity class of input pixels and row tile; *stats_rows
+// receives it, 0 and no sums when the buffer is too small)
 extern "C" int denet_conv_dgrad_sums(const float* dy, const float* w, const float* add, float* dx, const denet_bn_link* sums_of,
                                      double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int C, int K,
                                      int R, int S, int S_real, int stride, int pad, int OH, int OW, hipStream_t stream) {
     DENET_CHECK_ARG(sums_of && stats_partial && stats_rows, "conv_dgrad_sums: null pointer");
     DENET_CHECK_ARG(sums_of->x && sums_of->mean && sums_of->invstd && (!sums_of->relu || sums_of->y || (sums_of->gamma && sums_of->beta)),
                     "conv_dgrad_sums: incomplete batch-norm description");
-    const long rows = ((long)N * H * W + 127) / 128;
-    const bool ok = stride == 1 && stats_bytes >= (size_t)rows * 2 * C * sizeof(double);
+    const bool geom = stride >= 1 && H % stride == 0 && W % stride == 0;
+    const long rows = geom ? (long)stride * stride * (((long)N * (H / stride) * (W / stride) + 127) / 128) : 0;
+    const bool ok = geom && stats_bytes >= (size_t)rows * 2 * C * sizeof(double);
     *stats_rows = ok ? (int)rows : 0;
     return conv_dgrad_impl(dy, w, add, dx, ok ? sums_of : nullptr, ok ? stats_partial : nullptr, N, H, W, C, K, R, S, S_real, stride,
                            pad, OH, OW, stream);

@@ -202,7 +202,8 @@ class ConvLayer(AbstractLayer):
         # gradient of that output, and a Winograd pass can leave that batch norm's two backward reductions behind (ops.BnSums)
         sums = None
         bn = self.input.bn_producer
-        if ops.BWD_SUMS and bn is not None and self._cache().get("train") and getattr(self.input, "requires_grad", True):
+        if (ops.BWD_SUMS and bn is not None and self._cache().get("train") and getattr(self.input, "requires_grad", True)
+                and not getattr(self, "not_last_writer", False)):
             sums = bn.sums_request(self.input)
         link = self.output.take_pending_grad()
         if link is not None:

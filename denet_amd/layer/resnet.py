@@ -190,6 +190,9 @@ class ResnetLayer(AbstractLayer):
         if sc:
             sc[-1].output.grad = dres
             for l in reversed(sc):
+                # the main branch's first convolution adds its data gradient to the block input's AFTER this branch: backward sums
+                # of the batch norm in front of the block left here would be thrown away (ConvLayer.backward)
+                l.not_last_writer = True
                 l.backward(ctx)
         else:
             self.input.add_grad(dres)

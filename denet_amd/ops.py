@@ -778,12 +778,13 @@ def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None,
         cache["dgrad_tile"] = 0
     if PROFILE is not None:
         PROFILE.add(_conv_flops(g, logical))
-    if sums is not None and g[8] == 1 and (int(BWD_SUMS) & 2):
-        # stride 1: the epilogue of the implicit-GEMM kernel leaves the batch norm's backward reductions behind as well
+    if sums is not None and (int(BWD_SUMS) & 2) and g[1] % g[8] == 0 and g[2] % g[8] == 0:
+        # the epilogue of the implicit-GEMM kernel leaves the batch norm's backward reductions behind as well (a row of sums per
+        # row tile, and per parity class of input pixels when the layer strides)
         import ctypes
         N, H, W, C = g[0], g[1], g[2], g[3]
         rows = ctypes.c_int(0)
-        sb = sums.buffer(cache, (N * H * W + 127) // 128, C)
+        sb = sums.buffer(cache, (N * H * W + 127) // 128 + g[8] * g[8], C)
         so = sums.c_struct()
         check(_L().denet_conv_dgrad_sums(ptr(dy), ptr(w), ptr(add), ptr(dx), ctypes.byref(so), ptr(sb), sb.numel() * 8,
                                          ctypes.byref(rows), *g, stream_ptr()), "conv_dgrad_sums")

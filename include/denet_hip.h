@@ -209,6 +209,8 @@ int denet_conv_wino_dgrad_sums(const float* dy, const float* w, const float* u_c
                                const denet_bn_link* sums_of, double* stats_partial, size_t stats_bytes, int* stats_rows,
                                float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
                                hipStream_t stream);
+/* denet_conv_dgrad_sums: the implicit-GEMM data gradient with the same request, any stride (rows = stride^2 *
+ * ceil(N*(H/stride)*(W/stride) / 128): one per parity class of input pixels and row tile). */
 int denet_conv_dgrad_sums(const float* dy, const float* w, const float* add, float* dx, const denet_bn_link* sums_of,
                           double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int C, int K, int R,
                           int S, int S_real, int stride, int pad, int OH, int OW, hipStream_t stream);

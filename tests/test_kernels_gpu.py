@@ -440,7 +440,7 @@ def test_conv_is_mfma_exact_order_free(hip):
     _close(y, ref, rtol=1e-5)
 
 
-@pytest.mark.parametrize("path", ["wino4", "wino2", "fused64", "direct1x1"])
+@pytest.mark.parametrize("path", ["wino4", "wino2", "fused64", "direct1x1", "direct3x3s2", "direct1x1s2"])
 @pytest.mark.parametrize("relu,with_y", [(False, False), (True, False), (True, True)])
 def test_data_gradient_pass_leaves_the_batch_norm_backward_sums(hip, path, relu, with_y):
     """denet_conv_wino_dgrad_sums / denet_conv_wino2f_sums / denet_conv_dgrad_sums + denet_bn_bwd_final: a data-gradient pass
@@ -451,9 +451,11 @@ def test_data_gradient_pass_leaves_the_batch_norm_backward_sums(hip, path, relu,
     from denet_amd import ops
     g = torch.Generator().manual_seed(5)
     N, H, W = 2, 16, 16
-    C, K, R = {"wino4": (128, 96, 3), "wino2": (64, 128, 3), "fused64": (64, 64, 3), "direct1x1": (256, 160, 1)}[path]
+    C, K, R = {"wino4": (128, 96, 3), "wino2": (64, 128, 3), "fused64": (64, 64, 3), "direct1x1": (256, 160, 1),
+               "direct3x3s2": (64, 128, 3), "direct1x1s2": (128, 256, 1)}[path]
     pad = 1 if R == 3 else 0
-    dy = torch.randn(N, H, W, K, generator=g).cuda()                   # gradient of the convolution's output
+    stride = 2 if path.endswith("s2") else 1          # strided layers: a row of sums per parity class of input pixels
+    dy = torch.randn(N, H // stride, W // stride, K, generator=g).cuda()   # gradient of the convolution's output
     w = (torch.randn(K, R, R, C, generator=g) * 0.05).cuda()
     addt = torch.randn(N, H, W, C, generator=g).cuda()                 # an earlier contribution to the same gradient
     x = (torch.randn(N, H, W, C, generator=g) * 1.5 + 0.3).cuda()      # the batch norm's input
@@ -461,16 +463,16 @@ def test_data_gradient_pass_leaves_the_batch_norm_backward_sums(hip, path, relu,
     rm, rs = torch.zeros(C).cuda(), torch.ones(C).cuda()
     res = torch.randn(N, H, W, C, generator=g).cuda() if with_y else None
     y, sm, si = ops.bn_fwd_train(x, gamma, beta, rm, rs, relu=relu, res=res)
-    geom = ops.conv_geom((N, H, W, C), w.shape, 1, pad, None)
+    geom = ops.conv_geom((N, H, W, C), w.shape, stride, pad, None)
     saved = (dict(ops._WINO), ops.BWD_SUMS)
     try:
         ops.BWD_SUMS = 3
-        ops._WINO[(1, geom)] = {"wino4": 4, "wino2": 2, "fused64": ops.FUSED2, "direct1x1": 0}[path]
+        ops._WINO[(1, geom)] = {"wino4": 4, "wino2": 2, "fused64": ops.FUSED2}.get(path, 0)
         sums = ops.BnSums(x, y if (relu and with_y) else None, gamma, beta, sm, si, relu)
         cache = {}
-        dz = ops.conv_dgrad(dy, w, (N, H, W, C), add=addt, stride=1, pad=pad, cache=cache, sums=sums)
+        dz = ops.conv_dgrad(dy, w, (N, H, W, C), add=addt, stride=stride, pad=pad, cache=cache, sums=sums)
         assert sums.partial is not None, "the pass did not leave the sums"
-        dz_plain = ops.conv_dgrad(dy, w, (N, H, W, C), add=addt, stride=1, pad=pad, cache={})
+        dz_plain = ops.conv_dgrad(dy, w, (N, H, W, C), add=addt, stride=stride, pad=pad, cache={})
         assert torch.equal(dz, dz_plain)                               # the gradient itself is untouched by the request
         yy = y if (relu and with_y) else None
         la, _ = ops.bn_bwd_link(x, yy, dz, gamma, sm, si, relu=relu, beta=beta, pre=sums.partial)
