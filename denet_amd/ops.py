@@ -908,7 +908,7 @@ SUMS_COUNT = [0]           # data-gradient passes that also produced a batch nor
 # gradient it produces (denet_conv_wino_dgrad_sums / denet_conv_wino2f_sums): that layer's backward then needs no pass of its own
 # over (gradient, input, output) for them. The sums are accumulated per block in fp32 before they are widened (as the forward
 # statistics from the convolution epilogues are), so they differ from bn_bwd_partial_kernel's in the last bits. 0: off
-BWD_SUMS = int(os.environ.get("DENET_BN_BWD_SUMS", "3"))      # bit 0: Winograd passes, bit 1: direct stride-1 passes (1x1 head)
+BWD_SUMS = int(os.environ.get("DENET_BN_BWD_SUMS", "3"))      # bit 0: Winograd passes, bit 1: direct passes (1x1 head, strided 3x3 layers)
 
 
 def _bn_link_struct(x, aux, y, gamma, beta, mean, invstd, coef, out, relu):
