@@ -30,6 +30,10 @@ PREFETCH_RANDOM = os.environ.get("DENET_PREFETCH_RANDOM", "1") != "0"
 # batches in which no image proposes more RoIs than the list keeps are edited ON THE DEVICE (DeNetSparseLayer._device_edit): the
 # gather does not wait for the host's editing, which runs beside it for the Python-side list; 0 switches it off
 DEVICE_EDIT = os.environ.get("DENET_DEVICE_EDIT", "1") != "0"
+# ... and, OPT-IN (DENET_DEVICE_SAMPLE=1), those with random.sample as well (denet_edit_samples_device_sampled: the rejection
+# sampling and the pool swaps replayed on the device, exact). Not the default: the scan over the generator outputs is ~450
+# dependent 64-candidate windows for a batch of 32 (156 us + 43 us for the swaps), no shorter than the fast host hand-off below
+DEVICE_SAMPLE = os.environ.get("DENET_DEVICE_SAMPLE", "0") == "1"
 # every other batch: the host's share of the hand-off cut down to one native call + the upload (DeNetSparseLayer._fast_handoff)
 FAST_HANDOFF = os.environ.get("DENET_FAST_HANDOFF", "1") != "0"
 
@@ -470,7 +474,8 @@ class DeNetSparseLayer(AbstractLayer):
         if not DEVICE_EDIT or de is None or pf is None or prep is None or de["metas"] is not prep["metas"] or self.proposal_count != S:
             return False
         hc = hcount.numpy()
-        if int(hc.sum()) == 0 or int(hc.max()) > n_keep or not pf["mirror"].fresh():
+        trim = int(hc.max()) > n_keep
+        if int(hc.sum()) == 0 or (trim and not DEVICE_SAMPLE) or not pf["mirror"].fresh():
             return False              # (nothing proposed: the prepared cold list is cheaper still)
         from .. import lib as _lib
         cl = self.corner_layer
@@ -480,14 +485,25 @@ class DeNetSparseLayer(AbstractLayer):
             t.record_stream(cur)
         out = torch.empty((B * S, 4), dtype=torch.float32, device="cuda")
         r, st = self._res_dev, self._de_static
-        _lib.check(_lib.load().denet_edit_samples_device(
-            _lib.ptr(r[:B * S * 4]), _lib.ptr(r[B * S * 5:]), cl.height, cl.width, _lib.ptr(de["mt"]), de["n"], 0, _lib.ptr(de["gt"]),
-            _lib.ptr(de["off"]), int(bool(self.sample_gt)), B, S, n_keep, _lib.ptr(out), _lib.ptr(st["status"]), _lib.stream_ptr()),
-            "edit_samples_device")
+        if trim:
+            ws = st.get("ws")
+            if ws is None:
+                ws = st["ws"] = torch.empty(_lib.load().denet_edit_samples_sampled_workspace_bytes(B, n_keep), dtype=torch.uint8,
+                                            device="cuda")
+            _lib.check(_lib.load().denet_edit_samples_device_sampled(
+                _lib.ptr(r[:B * S * 4]), _lib.ptr(r[B * S * 5:]), cl.height, cl.width, _lib.ptr(de["mt"]), de["n"], 0,
+                _lib.ptr(de["gt"]), _lib.ptr(de["off"]), int(bool(self.sample_gt)), B, S, n_keep, _lib.ptr(out), _lib.ptr(st["status"]),
+                _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "edit_samples_device_sampled")
+        else:
+            _lib.check(_lib.load().denet_edit_samples_device(
+                _lib.ptr(r[:B * S * 4]), _lib.ptr(r[B * S * 5:]), cl.height, cl.width, _lib.ptr(de["mt"]), de["n"], 0,
+                _lib.ptr(de["gt"]), _lib.ptr(de["off"]), int(bool(self.sample_gt)), B, S, n_keep, _lib.ptr(out), _lib.ptr(st["status"]),
+                _lib.stream_ptr()), "edit_samples_device")
         st["status_host"].copy_(st["status"], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self._de_status_ev = (ev, int(8 * (B * S - int(hc.sum()))))
+        self._de_status_ev = [ev, None]          # [1]: the outputs the HOST's editing of the same batch uses (the job below)
+        pend = self._de_status_ev
         self.sample_bbox = out
         self._dev_edit = None
         self.device_edits = getattr(self, "device_edits", 0) + 1
@@ -507,8 +523,10 @@ class DeNetSparseLayer(AbstractLayer):
             self._prefetch = None
             done = self._native_edit_stream(pf, numpy.ascontiguousarray(det, dtype=numpy.float32),
                                             numpy.ascontiguousarray(cnt, dtype=numpy.int32), prep, f32)
-            assert done is not None, "the prefetched stretch ran dry without a random.sample"
+            if done is None:
+                raise RuntimeError("the prefetched generator outputs ran dry in the host's editing of a batch the device has edited")
             out_pr, out_box, mirror = done
+            pend[1] = self._last_cursor
             mirror.push()
             self._prep = None
             self._sample_pr, self._sample_boxes = list(out_pr), list(out_box)
@@ -587,8 +605,8 @@ class DeNetSparseLayer(AbstractLayer):
         ev, used = pend
         ev.synchronize()
         flag, dev_used = [int(v) for v in self._de_static["status_host"].tolist()]
-        if flag != 0 or dev_used != used:
-            raise RuntimeError("device-side RoI editing: status %d, %d generator outputs used (host: %d)" % (flag, dev_used, used))
+        if flag != 0 or (used is not None and dev_used != used):
+            raise RuntimeError("device-side RoI editing: status %d, %d generator outputs used (host: %s)" % (flag, dev_used, used))
 
     def _native_edit_stream(self, pf, det, cnt, prep, out_f32):
         """the editing on the prefetched outputs; returns (out_pr, out_box, mirror holding the state after them) or None when the
@@ -609,7 +627,7 @@ class DeNetSparseLayer(AbstractLayer):
         if dry.value:
             return None
         # the state after c outputs: the snapshot they ended in, with CPython's lazy refill (a position of 624 stays 624)
-        c = cursor.value
+        c = self._last_cursor = cursor.value
         j = max(0, int(numpy.searchsorted(first[:pf["ns"]], c, side="left")) - 1)
         mirror = pf["mirror"]
         mirror.key = snaps[j].copy()

@@ -775,18 +775,20 @@ def test_device_side_editing_equals_the_host_list(hip):
     """The two short forms of the RoI hand-off against the ordinary one. DeNetSparseLayer._device_edit: when no image proposes
     more RoIs than the list keeps (no random.sample), the bbox array is written on the device (denet_edit_samples_device:
     proposals, random boxes from generator outputs drawn ahead, ground truth) and the host's editing runs later for the
-    Python-side list. _fast_handoff: every other batch - one native call (sample tuples + editing on the prefetched outputs) and
-    the upload, the bookkeeping later. Reference loop: denet/layer/denet_sparse.py:184-201. The device array equals the host's
+    Python-side list; with DEVICE_SAMPLE also the batches that need random.sample (denet_edit_samples_device_sampled: the rejection
+    sampling and the pool swaps of CPython's random.sample replayed on the device). _fast_handoff: every other batch - one native
+    call (sample tuples + editing on the prefetched outputs) and the upload, the bookkeeping later. Reference loop: denet/layer/denet_sparse.py:184-201. The device array equals the host's
     float32 array bit for bit; lists, parameters after three steps and the generator's position are identical in all three
     modes; a detector that proposes more than the list keeps does not take the device path."""
     from denet_amd.layer import denet_sparse as DS
     res, took = {}, {}
-    saved = (DS.DEVICE_EDIT, DS.FAST_HANDOFF)
-    biases, modes = (5.6, 5.0, 4.0), ((True, True), (False, True), (False, False))
+    saved = (DS.DEVICE_EDIT, DS.FAST_HANDOFF, DS.DEVICE_SAMPLE)
+    biases, modes = (5.6, 5.0, 4.0), ((True, True), (False, True), (False, False), ("sampled", True))
     try:
         for bias in biases:          # a few dozen ... more than 519 proposals per image
             for mode in modes:
-                DS.DEVICE_EDIT, DS.FAST_HANDOFF = mode
+                DS.DEVICE_EDIT, DS.FAST_HANDOFF = bool(mode[0]), mode[1]
+                DS.DEVICE_SAMPLE = mode[0] == "sampled"      # random.sample replayed on the device as well
                 random.seed(21)
                 model = zoo.warm_corner_head(zoo.denet34(2, "skip", 128, class_num=80, seed=1), bias, 0.3)
                 model.build_train_func("nesterov")
@@ -803,11 +805,12 @@ def test_device_side_editing_equals_the_host_list(hip):
                 took[(bias, mode)] = (getattr(dns, "device_edits", 0), getattr(dns, "fast_handoffs", 0))
                 res[(bias, mode)] = (model.P.clone(), lists, arrays, random.random())
     finally:
-        DS.DEVICE_EDIT, DS.FAST_HANDOFF = saved
+        DS.DEVICE_EDIT, DS.FAST_HANDOFF, DS.DEVICE_SAMPLE = saved
     for bias in biases:
         ref = res[(bias, (False, False))]
         assert took[(bias, (False, False))] == (0, 0)
-        for mode in modes[:2]:
+        assert took[(bias, ("sampled", True))][0] == 3, took          # every batch with proposals is edited on the device
+        for mode in (modes[0], modes[1], modes[3]):
             a = res[(bias, mode)]
             assert torch.equal(a[0], ref[0]) and a[1] == ref[1] and a[3] == ref[3], (bias, mode)
             assert all(torch.equal(u, v) for u, v in zip(a[2], ref[2])), (bias, mode)
