@@ -38,6 +38,9 @@ extern "C" int denet_conv_stem_ok(int pass, int N, int H, int W, int C, int K, i
                                   int OW);
 extern "C" int denet_conv_stem_fwd(const float* x, const float* w, const float* bias, float* y, double* stats_partial,
                                    size_t stats_bytes, int* stats_rows, int N, int H, int W, hipStream_t stream);
+extern "C" int denet_conv_stem_fwd_act(const float* x, int x_nchw, const float* w, const float* bias, float* y, int relu,
+                                       double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W,
+                                       hipStream_t stream);
 extern "C" size_t denet_conv_stem_wgrad_workspace_bytes(void);
 extern "C" int denet_conv_stem_wgrad(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes, int N,
                                      int H, int W, hipStream_t stream);

@@ -1371,8 +1371,8 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
     int rc = check_geom(N, H, W, C, K, R, S, S_real, stride, pad, OH, OW);
     if (rc) return rc;
     DENET_CHECK_ARG(x && w && y, "conv_fwd: null pointer");
-    if (!add && !relu && !stats && denet_conv_stem_ok(0, N, H, W, C, K, R, S, S_real, stride, pad, OH, OW))
-        return denet_conv_stem_fwd(x, w, bias, y, nullptr, 0, nullptr, N, H, W, stream);
+    if (!add && !stats && denet_conv_stem_ok(0, N, H, W, C, K, R, S, S_real, stride, pad, OH, OW))
+        return denet_conv_stem_fwd_act(x, 0, w, bias, y, relu, nullptr, 0, nullptr, N, H, W, stream);
     IgemmParams p = {};
     p.act = x; p.wgt = w; p.out = y; p.bias = bias; p.add = add; p.relu = relu ? 1 : 0; p.stats = stats;
     p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K;

@@ -53,7 +53,7 @@ struct StemParams {
     double* stats;       // [grid][2][64] or null
     const float* dy;     // [N][OH][OW][64] (filter gradient)
     float* part;         // [grid][PART]
-    int N, H, W, OH, OW, tiles_y, tiles_x, tiles, planar;
+    int N, H, W, OH, OW, tiles_y, tiles_x, tiles, planar, relu;
 };
 
 struct Block {
@@ -224,6 +224,7 @@ __global__ __launch_bounds__(NTH, 2) void stem_fwd_kernel(const StemParams p) {
                     const int px = 32 * i + 8 * r + (lane >> 3);
                     f32x4 v = *(const f32x4*)(stg + (8 * r + (lane >> 3)) * STG + 4 * (lane & 7));
                     v += bias4;
+                    if (p.relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});      // (the inference fold of BN + ReLU)
                     if (oy < p.OH && cur.ox0 + px < p.OW) {
                         *(f32x4*)(yrow + px * 64 + 32 * j) = v;
                         ssum[j] += v;
@@ -458,12 +459,22 @@ extern "C" int denet_conv_stem_fwd(const float* x, const float* w, const float* 
 
 // the same; x_nchw != 0: x is the image batch as the reference holds it, [N][3][H][W] (dataset/__init__.py:359, the layout
 // model_cnn.py feeds the first layer) - no NHWC copy of the input has to exist
+extern "C" int denet_conv_stem_fwd_act(const float* x, int x_nchw, const float* w, const float* bias, float* y, int relu,
+                                       double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W,
+                                       hipStream_t stream);
 extern "C" int denet_conv_stem_fwd_from(const float* x, int x_nchw, const float* w, const float* bias, float* y, double* stats_partial,
                                         size_t stats_bytes, int* stats_rows, int N, int H, int W, hipStream_t stream) {
+    return denet_conv_stem_fwd_act(x, x_nchw, w, bias, y, 0, stats_partial, stats_bytes, stats_rows, N, H, W, stream);
+}
+
+// the same with y = max(y, 0) when relu != 0 (inference: the batch norm behind the layer folded into w / bias, its ReLU here)
+extern "C" int denet_conv_stem_fwd_act(const float* x, int x_nchw, const float* w, const float* bias, float* y, int relu,
+                                       double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W,
+                                       hipStream_t stream) {
     DENET_CHECK_ARG(x && w && y, "conv_stem_fwd: null pointer");
     DENET_CHECK_ARG(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "conv_stem_fwd: needs even H and W");
     StemParams p = {};
-    p.x = x; p.w = w; p.bias = bias; p.y = y; p.planar = x_nchw ? 1 : 0;
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.planar = x_nchw ? 1 : 0; p.relu = relu ? 1 : 0;
     const int grid = fill(p, N, H, W);
     DENET_CHECK_ARG(grid > 0, "conv_stem_fwd: cannot query the device");
     if (stats_partial) {

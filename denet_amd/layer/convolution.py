@@ -187,6 +187,16 @@ class ConvLayer(AbstractLayer):
             w_f, b_f = ops.bn_fold(self._w(), self.beta.dev if self.use_bias else None, bn.omega.dev, bn.beta.dev,
                                    bn.mean.dev, bn.stdinv.dev, bn.eps)
             ent = cache["fold"] = (ops.WEIGHTS_VERSION, bn, w_f, b_f)
+        link = self.input.take_pending_data()
+        if isinstance(link, ops.NchwLink):
+            self.input.set_pending_data(link)          # (see forward: the first layer reads the planar batch)
+            if add is None and ops.conv_stem_ok(link.x, self.omega.dev_shape, self.stride[0], self.pad, self.filter_shape[3]):
+                y = ops.conv_stem_fwd(link.x, ent[2], ent[3], cache, False, logical=self._logical(), relu=relu)
+                self.output.data = y
+                (out_act if out_act is not None else bn.output).data = y
+                return y
+        elif link is not None:
+            self.input.data = link.materialise()
         y = ops.conv_fwd(self.input.data, ent[2], bias=ent[3], add=add, stride=self.stride[0], pad=self.pad,
                          s_real=self.filter_shape[3], logical=self._logical(), cache=cache, relu=relu)
         self.output.data = y

@@ -57,6 +57,7 @@ SIGNATURES = {
     "denet_conv_stem_fwd": (I, [P] * 5 + [Z, P] + [I] * 3 + [P]),
     "denet_conv_stem_fwd_from": (I, [P, I] + [P] * 4 + [Z, P] + [I] * 3 + [P]),
     "denet_conv_stem_wgrad_from": (I, [P, I] + [P] * 3 + [Z] + [I] * 3 + [P]),
+    "denet_conv_stem_fwd_act": (I, [P, I] + [P] * 3 + [I, P, Z, P] + [I] * 3 + [P]),
     "denet_conv_stem_wgrad_workspace_bytes": (Z, []),
     "denet_conv_stem_wgrad": (I, [P] * 4 + [Z] + [I] * 3 + [P]),
     "denet_conv_tune": (I, [I, P, P, P, P, P, P, Z] + [I] * 12 + [P]),

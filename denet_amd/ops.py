@@ -842,8 +842,9 @@ def conv_stem_ok(x_nchw, w_shape, stride, pad, s_real):
     return C == 3 and bool(_L().denet_conv_stem_ok(0, *a)) and bool(_L().denet_conv_stem_ok(1, *a))
 
 
-def conv_stem_fwd(x_nchw, w, bias, cache, bn_stats, logical=None):
-    """y = conv7x7/2(x) + bias from the planar image batch (+ the batch-norm column sums: cache["bn_stats"], see conv_fwd)"""
+def conv_stem_fwd(x_nchw, w, bias, cache, bn_stats, logical=None, relu=False):
+    """y = conv7x7/2(x) + bias from the planar image batch (+ the batch-norm column sums: cache["bn_stats"], see conv_fwd; or,
+    relu, the ReLU of the inference fold)"""
     import ctypes
     N, _, H, W = x_nchw.shape
     K = w.shape[0]
@@ -856,8 +857,8 @@ def conv_stem_fwd(x_nchw, w, bias, cache, bn_stats, logical=None):
             st = cache["bn_stats_buf"] = torch.empty(1024 * 2 * K, dtype=torch.float64, device="cuda")
     if PROFILE is not None:
         PROFILE.add(_conv_flops(g, logical))
-    check(_L().denet_conv_stem_fwd_from(ptr(x_nchw), 1, ptr(w), ptr(bias), ptr(y), ptr(st), st.numel() * 8 if st is not None else 0,
-                                        ctypes.byref(rows), N, H, W, stream_ptr()), "conv_stem_fwd")
+    check(_L().denet_conv_stem_fwd_act(ptr(x_nchw), 1, ptr(w), ptr(bias), ptr(y), int(bool(relu)), ptr(st),
+                                       st.numel() * 8 if st is not None else 0, ctypes.byref(rows), N, H, W, stream_ptr()), "conv_stem_fwd")
     cache["bn_stats"] = (st, rows.value) if st is not None else None
     return y
 

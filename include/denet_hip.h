@@ -162,6 +162,8 @@ int denet_conv_stem_fwd(const float* x, const float* w, const float* bias, float
  * training step then never makes an NHWC copy of its input */
 int denet_conv_stem_fwd_from(const float* x, int x_nchw, const float* w, const float* bias, float* y, double* stats_partial,
                              size_t stats_bytes, int* stats_rows, int N, int H, int W, hipStream_t stream);
+int denet_conv_stem_fwd_act(const float* x, int x_nchw, const float* w, const float* bias, float* y, int relu, double* stats_partial,
+                            size_t stats_bytes, int* stats_rows, int N, int H, int W, hipStream_t stream);   /* + y = max(y, 0) */
 int denet_conv_stem_wgrad_from(const float* x, int x_nchw, const float* dy, float* dw, float* workspace, size_t workspace_bytes,
                                int N, int H, int W, hipStream_t stream);
 size_t denet_conv_stem_wgrad_workspace_bytes(void);

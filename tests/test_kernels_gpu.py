@@ -401,9 +401,12 @@ def test_first_layer_kernels(hip, case):
     # (a lane adds 32 values in fp32 before the doubles take over)
     torch.testing.assert_close(part[0], yd.sum(0), rtol=1e-6, atol=1e-6 * float(yd.abs().sum(0).max()))
     torch.testing.assert_close(part[1], (yd * yd).sum(0), rtol=1e-6, atol=1e-6)
-    # through the generic entry point (which hands this geometry over), without bias / statistics
+    # through the generic entry point (which hands this geometry over), without bias / statistics; and with the ReLU of the
+    # inference fold in the epilogue
     y2 = ops.conv_fwd(xn, wn, stride=2, pad=3, s_real=7)
     assert torch.equal(y2 + bias, y) or float((y2 + bias - y).abs().max()) < 1e-6 * scale
+    y4 = ops.conv_fwd(xn, wn, bias=bias, stride=2, pad=3, s_real=7, relu=True)
+    assert torch.equal(y4, y.clamp_min(0))
     dyn = _nhwc(dy)
     ws = torch.empty(lib().denet_conv_stem_wgrad_workspace_bytes() // 4, device="cuda")
     dws = []
