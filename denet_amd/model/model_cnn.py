@@ -447,6 +447,13 @@ class ModelCNN:
             self.S.copy_(acc["S0"])            # every sub-step starts from the statistics at train_begin
         ctx = self.forward(data_x, data_m, train=True)
         self.backward(ctx)
+        # host work a layer has left for later (the RoI list's bookkeeping after a short hand-off, DeNetSparseLayer._resolve_edit) is
+        # done before the step returns at the latest: the caller's own draws from `random` must find the generator where the
+        # reference's step would have left it
+        for layer in walk_layers(self.layers):
+            fin = getattr(layer, "_resolve_edit", None)
+            if fin is not None:
+                fin()
         scale = 1.0 / self.dist.world_size if self.dist is not None else 1.0
         n_decay = self.n_trainable if self.bias_decay else self.n_weights
         if acc is not None:
