@@ -220,6 +220,8 @@ class DeNetSparseLayer(AbstractLayer):
         hcount = h[B * S * 5:]
         self._raw_samples = None
         self._deferred = None
+        self.proposed_total = getattr(self, "proposed_total", 0) + int(hcount.sum())      # (what regime a run was in: bench.py)
+        self.proposed_steps = getattr(self, "proposed_steps", 0) + 1
         if raw_only and (self._device_edit(hcount) or self._fast_handoff(hcount)):
             # the bbox array is on its way (edited on the device, or by ONE native host call); everything else of the host's share
             # - the Python-side list, the generator's state - waits for its first reader
