@@ -115,8 +115,7 @@ static int py_random_sample_from(Src& src, int n, int k, int* pool_ws, int* out)
     for (int i = 0; i < n; ++i) pool_ws[i] = i;
     for (int i = 0; i < k; ++i) {
         const uint32_t m = (uint32_t)(n - i);
-        int bits = 0;
-        while ((m >> bits) != 0) bits++;
+        const int bits = 32 - __builtin_clz(m);          // m.bit_length() (m >= 1)
         uint32_t r = src.next() >> (32 - bits);
         while (r >= m && src.ok()) r = src.next() >> (32 - bits);
         if (!src.ok()) return DENET_OK;          // the caller checks the source
@@ -259,6 +258,66 @@ extern "C" int denet_host_handoff_stream(const uint32_t* stream, long n_stream, 
     if (rc != DENET_OK) return rc;
     return denet_host_edit_samples_stream(stream, n_stream, cursor, exhausted, det_out, count_host, B, S, n_keep, gt, gt_off, sample_gt,
                                           ws, out_pr, out_box, out_box_f32);
+}
+
+// ... and the part of it the device is actually waiting for: the bbox array alone (out_box_f32 [B][S][4]), straight from the
+// packed proposal's integer boxes - the same selection (random.sample on the same outputs), the same random boxes, the same
+// float32 values as denet_host_handoff_stream writes, without the score arithmetic (expf) and the double-precision lists, which
+// the caller produces later with that call from the same cursor (nothing has been consumed for good: *cursor is its own copy).
+extern "C" int denet_host_handoff_boxes_stream(const uint32_t* stream, long n_stream, long* cursor, int* exhausted,
+                                               const int* box_host, const int* count_host, int H, int W, int B, int S, int n_keep,
+                                               const double* gt, const int* gt_off, int sample_gt, int* ws, float* out_box_f32) {
+#pragma clang fp contract(off)
+    DENET_CHECK_ARG(stream && cursor && exhausted && *cursor >= 0 && *cursor <= n_stream, "handoff_boxes_stream: bad stream arguments");
+    DENET_CHECK_ARG(box_host && count_host && ws && out_box_f32, "handoff_boxes_stream: null pointer");
+    DENET_CHECK_ARG(B > 0 && S > 0 && n_keep >= 0 && n_keep <= S && H > 0 && W > 0, "handoff_boxes_stream: bad sizes");
+    DENET_CHECK_ARG(!sample_gt || (gt_off && (gt || gt_off[B] == 0)), "handoff_boxes_stream: ground truth missing");
+    MtStream src{stream, n_stream, *cursor, true};
+    int* pool = ws;          // [S]
+    int* pick = ws + S;      // [S]
+    // (float)((double)v / W) for every cell coordinate 0 .. W (and H): 2 x 70 000 divisions per batch become table reads
+    float tw[258], th[258];
+    DENET_CHECK_ARG(H <= 256 && W <= 256, "handoff_boxes_stream: map %dx%d unsupported", H, W);
+    for (int v = 0; v <= W + 1; ++v) tw[v] = (float)((double)v / W);
+    for (int v = 0; v <= H + 1; ++v) th[v] = (float)((double)v / H);
+    for (int b = 0; b < B && src.ok(); ++b) {
+        const int* bx = box_host + (size_t)b * S * 4;
+        float* f = out_box_f32 + (size_t)b * S * 4;
+        int n = count_host[b];
+        DENET_CHECK_ARG(n >= 0 && n <= S, "handoff_boxes_stream: count[%d] = %d out of range", b, n);
+        const bool trim = n > n_keep;
+        if (trim) {
+            int rc = py_random_sample_from(src, n, n_keep, pool, pick);
+            if (rc != DENET_OK) return rc;
+            if (!src.ok()) break;
+            n = n_keep;
+        }
+        for (int i = 0; i < n; ++i) {
+            const int* r = bx + (size_t)(trim ? pick[i] : i) * 4;
+            DENET_CHECK_ARG((unsigned)r[0] <= (unsigned)W && (unsigned)r[2] <= (unsigned)W && (unsigned)r[1] <= (unsigned)H &&
+                            (unsigned)r[3] <= (unsigned)H, "handoff_boxes_stream: box outside the map");
+            f[i * 4 + 0] = tw[r[0]];
+            f[i * 4 + 1] = th[r[1]];
+            f[i * 4 + 2] = tw[r[2] + 1];
+            f[i * 4 + 3] = th[r[3] + 1];
+        }
+        for (int i = n; i < S; ++i) {
+            const double x0 = 0.0 + (1.0 - 0.0) * mt_random(src);
+            const double y0 = 0.0 + (1.0 - 0.0) * mt_random(src);
+            const double x1 = x0 + (1.0 - x0) * mt_random(src);
+            const double y1 = y0 + (1.0 - y0) * mt_random(src);
+            f[i * 4 + 0] = (float)x0; f[i * 4 + 1] = (float)y0; f[i * 4 + 2] = (float)x1; f[i * 4 + 3] = (float)y1;
+        }
+        if (sample_gt) {
+            const int g0 = gt_off[b], ng = gt_off[b + 1] - g0;
+            DENET_CHECK_ARG(ng >= 0 && ng <= S, "handoff_boxes_stream: image %d has %d ground-truth boxes (> %d RoIs)", b, ng, S);
+            for (int k = 0; k < ng; ++k)
+                for (int c = 0; c < 4; ++c) f[(S - 1 - k) * 4 + c] = (float)gt[(size_t)(g0 + k) * 4 + c];
+        }
+    }
+    *cursor = src.cursor;
+    *exhausted = src.good ? 0 : 1;
+    return DENET_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------

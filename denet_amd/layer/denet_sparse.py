@@ -215,14 +215,18 @@ class DeNetSparseLayer(AbstractLayer):
             cl.sample_shared = cl.conv.output.data
         self._res_host.copy_(r, non_blocking=True)
         ops.wait_stream()
+        # from here to the upload of the bbox array the device stands idle: numpy views of the pinned buffer made once, every
+        # property of the counts computed once
         timer.mark()
-        h = self._res_host
-        hcount = h[B * S * 5:]
+        hc = self.__dict__.get("_res_counts")
+        if hc is None or hc.size != B:
+            hc = self._res_counts = self._res_host.numpy()[B * S * 5:]
+        tot = int(hc.sum())
         self._raw_samples = None
         self._deferred = None
-        self.proposed_total = getattr(self, "proposed_total", 0) + int(hcount.sum())      # (what regime a run was in: bench.py)
+        self.proposed_total = getattr(self, "proposed_total", 0) + tot      # (what regime a run was in: bench.py)
         self.proposed_steps = getattr(self, "proposed_steps", 0) + 1
-        if raw_only and (self._device_edit(hcount) or self._fast_handoff(hcount)):
+        if raw_only and tot > 0 and self._short_handoff(hc, tot):
             # the bbox array is on its way (edited on the device, or by ONE native host call); everything else of the host's share
             # - the Python-side list, the generator's state - waits for its first reader
             self._deferred = timer
@@ -462,23 +466,30 @@ class DeNetSparseLayer(AbstractLayer):
         self._pf_upload = ev
         self._dev_edit = {"metas": metas, "mt": mt, "gt": gtd, "off": offd, "ev": ev, "n": pf["n"]}
 
-    def _device_edit(self, hcount):
+    def _short_handoff(self, hc, tot):
+        """the two short forms of the hand-off (what they share is checked once)"""
+        pf, prep = self.__dict__.get("_prefetch"), self.__dict__.get("_prep")
+        if pf is None or prep is None or self.cluster or self.proposal_count != self.sample_count or not self._on_device():
+            return False
+        if not (DEVICE_EDIT or FAST_HANDOFF) or not pf["mirror"].fresh():
+            return False
+        return self._device_edit(hc, tot, pf, prep) or self._fast_handoff(hc, pf, prep)
+
+    def _device_edit(self, hc, tot, pf, prep):
         """The hand-off when no image proposes more RoIs than the list keeps (no random.sample: every step of a detector early in
         training): denet_edit_samples_device writes the bbox array from the proposal as it lies on the device, the uploaded
         generator outputs and the ground truth - the gather starts behind one small device-to-host copy. The host's own editing
         (same stretch of outputs, same values: test_device_side_editing_equals_the_host_list) is left to the first reader of the
         Python-side list. False: not this case, the ordinary path runs."""
         import torch
-        de, pf = self.__dict__.get("_dev_edit"), self.__dict__.get("_prefetch")
-        prep = self.__dict__.get("_prep")
+        de = self.__dict__.get("_dev_edit")
         B, S = self.batch_size, self.sample_count
         n_keep = S - math.floor(self.random_sample * S)
-        if not DEVICE_EDIT or de is None or pf is None or prep is None or de["metas"] is not prep["metas"] or self.proposal_count != S:
+        if not DEVICE_EDIT or de is None or de["metas"] is not prep["metas"]:
             return False
-        hc = hcount.numpy()
         trim = int(hc.max()) > n_keep
-        if int(hc.sum()) == 0 or (trim and not DEVICE_SAMPLE) or not pf["mirror"].fresh():
-            return False              # (nothing proposed: the prepared cold list is cheaper still)
+        if trim and not DEVICE_SAMPLE:
+            return False
         from .. import lib as _lib
         cl = self.corner_layer
         cur = torch.cuda.current_stream()
@@ -536,55 +547,68 @@ class DeNetSparseLayer(AbstractLayer):
         self._lazy_edit = job
         return True
 
-    def _fast_handoff(self, hcount):
-        """The hand-off with the device idle as short as the host can make it: sample tuples + editing on the prefetched generator
-        outputs in ONE native call (denet_host_handoff_stream), the upload of the bbox array, nothing else. What the rest of the
-        step wants from the host - the lists, the generator's state handed back to `random` - is left to the first reader
-        (_resolve_edit), who runs beside the device's gather and head. False: no prefetched stretch / it ran dry / nothing proposed:
-        the ordinary path."""
+    def _fast_handoff(self, hc, pf, prep):
+        """The hand-off with the device idle as short as the host can make it: ONE native call that writes the bbox array alone
+        (denet_host_handoff_boxes_stream: the selection and the random boxes on the prefetched generator outputs, no score
+        arithmetic, no lists) and its upload into a device buffer that already exists. Everything else the rest of the step wants
+        from the host - the sample tuples, the lists (denet_host_handoff_stream over the same outputs), the generator's state
+        handed back to `random` - is left to the first reader (_resolve_edit), who runs beside the device's gather and head.
+        False: the stretch ran dry: the ordinary path."""
         import ctypes
         import torch
         from .. import lib as _lib
-        pf, prep = self.__dict__.get("_prefetch"), self.__dict__.get("_prep")
+        if not FAST_HANDOFF:
+            return False
         B, S = self.batch_size, self.sample_count
-        if not FAST_HANDOFF or pf is None or prep is None or self.cluster or self.proposal_count != S or not self._on_device():
-            return False
-        hc = hcount.numpy()
-        if int(hc.sum()) == 0 or not pf["mirror"].fresh():
-            return False
-        cl = self.corner_layer
-        n_keep = S - math.floor(self.random_sample * S)
-        if self._pinned is None:
-            self._pinned = torch.empty((B * S, 4), dtype=torch.float32).pin_memory()
         bufs = self.__dict__.get("_ho_bufs")
         if bufs is None:
-            bufs = self._ho_bufs = {"ws": numpy.empty(2 * S, dtype=numpy.int32), "turn": 0,
-                                    "det": [numpy.empty((B, S, 5), dtype=numpy.float32) for _ in range(2)],
-                                    "cnt": [numpy.empty(B, dtype=numpy.int32) for _ in range(2)]}
+            cl = self.corner_layer
+            if self._pinned is None:
+                self._pinned = torch.empty((B * S, 4), dtype=torch.float32).pin_memory()
+            bufs = self._ho_bufs = {
+                "ws": numpy.empty(2 * S, dtype=numpy.int32), "turn": 0, "scratch": numpy.empty(B * S * 4, dtype=numpy.float32),
+                "det": [numpy.empty((B, S, 5), dtype=numpy.float32) for _ in range(2)],
+                "cnt": [numpy.empty(B, dtype=numpy.int32) for _ in range(2)],
+                "dev": [torch.empty((B * S, 4), dtype=torch.float32, device="cuda") for _ in range(2)],
+                "cursor": ctypes.c_long(0), "dry": ctypes.c_int(0), "fn": _lib.load().denet_host_handoff_boxes_stream,
+                "hp": self._res_host.data_ptr(), "f32": self._pinned.numpy(), "hw": (cl.height, cl.width),
+                "n_keep": S - math.floor(self.random_sample * S)}
         bufs["turn"] ^= 1
-        det, cnt = bufs["det"][bufs["turn"]], bufs["cnt"][bufs["turn"]]
+        turn = bufs["turn"]
+        cnt = bufs["cnt"][turn]
         cnt[:] = hc
-        out_pr, out_box = self._edit_out()
         out, snaps, first = self._pf_buf
-        h = self._res_host
-        hp = h.data_ptr()
-        cursor, dry = ctypes.c_long(0), ctypes.c_int(0)
+        cursor, dry = bufs["cursor"], bufs["dry"]
+        cursor.value = 0
         off, gt = prep["off"], prep["gt"]
-        f32 = self._pinned.numpy()
-        _lib.check(_lib.load().denet_host_handoff_stream(
-            out.ctypes.data, pf["n"], ctypes.byref(cursor), ctypes.byref(dry), hp, hp + 4 * B * S * 4, cnt.ctypes.data, cl.height,
-            cl.width, B, S, n_keep, gt.ctypes.data, off.ctypes.data, int(bool(self.sample_gt)), bufs["ws"].ctypes.data,
-            det.ctypes.data, out_pr.ctypes.data, out_box.ctypes.data, f32.ctypes.data), "handoff_stream")
+        H, W = bufs["hw"]
+        _lib.check(bufs["fn"](out.ctypes.data, pf["n"], ctypes.byref(cursor), ctypes.byref(dry), bufs["hp"], cnt.ctypes.data, H, W, B, S,
+                              bufs["n_keep"], gt.ctypes.data, off.ctypes.data, int(bool(self.sample_gt)), bufs["ws"].ctypes.data,
+                              bufs["f32"].ctypes.data), "handoff_boxes_stream")
         if dry.value:
             return False
-        self.sample_bbox = self._pinned.cuda(non_blocking=True)
+        dev = bufs["dev"][turn]
+        dev.copy_(self._pinned, non_blocking=True)
+        self.sample_bbox = dev
         self._prefetch = None
         c = cursor.value
+        self.fast_handoffs = getattr(self, "fast_handoffs", 0) + 1
 
         def job():
-            # the state after c outputs: the snapshot they ended in, with CPython's lazy refill (a position of 624 stays 624)
+            # the lists: sample tuples + the editing once more, over the same outputs (float32 array into a scratch buffer: the
+            # pinned one may still be on its way to the device)
             if not pf["mirror"].fresh():
                 raise RuntimeError("the stdlib generator moved between the RoI hand-off and the bookkeeping of its draws")
+            det = bufs["det"][turn]
+            out_pr, out_box = self._edit_out()
+            c2, dry2 = ctypes.c_long(0), ctypes.c_int(0)
+            hp = bufs["hp"]
+            _lib.check(_lib.load().denet_host_handoff_stream(
+                out.ctypes.data, pf["n"], ctypes.byref(c2), ctypes.byref(dry2), hp, hp + 4 * B * S * 4, cnt.ctypes.data, H, W, B, S,
+                bufs["n_keep"], gt.ctypes.data, off.ctypes.data, int(bool(self.sample_gt)), bufs["ws"].ctypes.data, det.ctypes.data,
+                out_pr.ctypes.data, out_box.ctypes.data, bufs["scratch"].ctypes.data), "handoff_stream")
+            assert not dry2.value and c2.value == c, (c2.value, c)
+            # the state after c outputs: the snapshot they ended in, with CPython's lazy refill (a position of 624 stays 624)
             j = max(0, int(numpy.searchsorted(first[:pf["ns"]], c, side="left")) - 1)
             mirror = pf["mirror"]
             mirror.key = snaps[j].copy()
@@ -594,9 +618,8 @@ class DeNetSparseLayer(AbstractLayer):
             self._prep = None
             self._raw_samples = (det, cnt)
             self._sample_pr, self._sample_boxes = list(out_pr), list(out_box)
-            self._sample_bbox_f32 = f32.reshape(B, S, 4)
+            self._sample_bbox_f32 = bufs["f32"].reshape(B, S, 4)
         self._lazy_edit = job
-        self.fast_handoffs = getattr(self, "fast_handoffs", 0) + 1
         return True
 
     def _check_device_edit_status(self):

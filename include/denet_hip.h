@@ -69,6 +69,12 @@ int denet_host_handoff_stream(const unsigned* stream_host, long n_stream, long* 
                               const int* box_host, const float* absd_host, const int* count_host, int H, int W, int B, int S,
                               int n_keep, const double* gt_host, const int* gt_off_host, int sample_gt, int* ws_host,
                               float* det_out_host, double* out_pr_host, double* out_box_host, float* out_box_f32_host);
+/* ... and the part of it the device is waiting for - the bbox array alone, from the packed proposal's integer boxes: the same
+ * selection, random boxes and float32 values, without the score arithmetic and the double-precision lists (the caller produces
+ * those later with denet_host_handoff_stream from the same cursor). */
+int denet_host_handoff_boxes_stream(const unsigned* stream_host, long n_stream, long* cursor_host, int* exhausted_host,
+                                    const int* box_host, const int* count_host, int H, int W, int B, int S, int n_keep,
+                                    const double* gt_host, const int* gt_off_host, int sample_gt, int* ws_host, float* out_box_f32_host);
 /* detection targets of a batch (denet/layer/denet_detect.py:147-235) in RoI-major layout: fp32 IoU matrix in the
  * operation order of common/theano_util.py:38-59, class / class x fitness-bin targets for IoU > t0, box-regression
  * target of the arg-max ground truth for IoU > t1, rows normalised and divided by S. gt: concatenated [n,4] doubles,
