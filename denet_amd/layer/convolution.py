@@ -170,6 +170,21 @@ class ConvLayer(AbstractLayer):
                 return
             link = None
         x = self.input.data if link is None else None
+        skip = getattr(self, "skip_behind", None)
+        if skip is not None and add is None and get_train() and ctx is not None:
+            # the SKIP layer behind adds its tap to this layer's output: here, in the epilogue (ModelCNN.build_train_func links the
+            # two); the sum is the SKIP layer's output, and what a batch norm behind THAT wants to know about it is measured here
+            want_skip_stats = getattr(skip.output, "want_stats", False)
+            y = ops.conv_fwd(x, self._w(), bias=None, add=skip.y.data, stride=self.stride[0], pad=self.pad,
+                             s_real=self.filter_shape[3], logical=self._logical(), cache=cache, bn_stats=want_skip_stats, link=link)
+            if link is not None:
+                self.input.data = link.materialise()
+            self.output.data = None              # the convolution's own output is never written
+            self.output.stats = None
+            skip.output.data = y
+            skip.output.stats = cache.pop("bn_stats", None) if want_skip_stats else None
+            skip._fused_in = ctx
+            return
         self.output.data = ops.conv_fwd(x, self._w(), bias=self.beta.dev if self.use_bias else None, add=add,
                                         stride=self.stride[0], pad=self.pad, s_real=self.filter_shape[3],
                                         logical=self._logical(), cache=cache, bn_stats=want_stats, link=link)

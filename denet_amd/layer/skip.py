@@ -80,6 +80,9 @@ class SkipLayer(AbstractLayer):
         return True
 
     def forward(self, ctx):
+        if ctx is not None and getattr(self, "_fused_in", None) is ctx:
+            self._fused_in = None        # the convolution in front has written x + tap (ConvLayer.forward, skip_behind)
+            return
         if self.combine_mode == "concat":
             self.output.data = ops.concat_fwd(self.x.data, self.y.data, self.x_shape[1], self.y_shape[1], self.output.cp)
         elif len(self.layers) > 1:

@@ -14,6 +14,7 @@ import getpass
 import math
 import random
 
+import os
 import numpy
 
 from .. import common
@@ -297,6 +298,15 @@ class ModelCNN:
             if a.type_name == "batchnorm-relu" and b.type_name == "pool" and b.mode == "max" and b.input is a.output \
                     and self._consumers(a.output) == 1:
                 a.pool_behind = b
+        # a SKIP layer that adds its tap (same channel count: no projection) to the output of the convolution right in front of it
+        # (the up-sampling path of the skip models, skip.py:81-86): the addition goes into that convolution's epilogue, and with it the statistics of the batch
+        # norm behind the SKIP layer - no pass of its own over the sum (DENET_SKIP_FUSE=0: separate passes)
+        for a, b in zip(self.layers[:-1], self.layers[1:]):
+            a.skip_behind = None
+            if (os.environ.get("DENET_SKIP_FUSE", "1") != "0" and a.type_name == "conv" and b.type_name == "skip"
+                    and getattr(b, "combine_mode", None) == "proj-add" and len(getattr(b, "layers", [])) <= 1 and b.x is a.output
+                    and self._consumers(a.output) == 1 and not a.use_bias):
+                a.skip_behind = b
         if not skip_build:
             self.pack_device()
         self.func["train_step"] = self._device_step

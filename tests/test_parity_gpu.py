@@ -169,7 +169,9 @@ def _force_list(model):
     out = []
     for layer in model.layers[1:]:
         t = layer.type_name
-        if t in ("conv", "batchnorm", "batchnorm-relu", "pool", "pool-inv", "deconv", "border", "crop-mirror"):
+        if t == "conv" and getattr(layer, "skip_behind", None) is not None and layer.output.data is None:
+            out.append(None)              # the SKIP layer behind adds its tap in this convolution's epilogue: only the sum exists
+        elif t in ("conv", "batchnorm", "batchnorm-relu", "pool", "pool-inv", "deconv", "border", "crop-mirror"):
             out.append(nchw(layer.output))
         elif t == "dropout":
             out.append(nchw(layer.output))        # parity runs are training steps (the test path is an identity)
@@ -769,6 +771,40 @@ def test_prepared_cold_roi_list_equals_the_hand_off_path(hip):
     for warm in (False, True):
         a, b = res[(warm, True)], res[(warm, False)]
         assert torch.equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2], warm
+
+
+def test_skip_addition_in_the_convolution_epilogue(hip):
+    """ModelCNN.build_train_func links a SKIP layer that adds its tap without a projection (skip.py:81-86) to the convolution right in
+    front of it: the tap
+    is added in that convolution's epilogue, which also measures the statistics of the batch norm behind the SKIP layer. Against
+    the separate passes (DENET_SKIP_FUSE=0): the sum itself is the same two fp32 numbers added (bit-identical forward output),
+    the statistics come from the epilogue's fp32 partial sums instead of a double-precision pass: one training step, state
+    within 1e-5 max-norm relative"""
+    import os
+    res = []
+    saved = os.environ.get("DENET_SKIP_FUSE")
+    try:
+        for fuse in ("1", "0"):
+            os.environ["DENET_SKIP_FUSE"] = fuse
+            random.seed(7)
+            model = zoo.warm_corner_head(zoo.denet34(2, "skip", 128, class_num=80, seed=1), 4.0, 0.3)
+            model.build_train_func("nesterov")
+            linked = [l for l in model.layers if getattr(l, "skip_behind", None) is not None]
+            assert len(linked) == (2 if fuse == "1" else 0)
+            x, metas = zoo.synthetic_batch(2, 128, seed=11)
+            cost = model.train_step(x, metas, 0, 0, 0.02, [0.9], 1e-4)[0]
+            skips = [l for l in model.layers if l.type_name == "skip"]
+            torch.cuda.synchronize()
+            res.append((model.P.clone(), model.M.clone(), model.S.clone(), cost, [s.output.data.clone() for s in skips]))
+    finally:
+        if saved is None:
+            os.environ.pop("DENET_SKIP_FUSE", None)
+        else:
+            os.environ["DENET_SKIP_FUSE"] = saved
+    assert torch.equal(res[0][4][0], res[1][4][0])            # the first sum of the forward pass: the same bits
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    assert abs(res[0][3] - res[1][3]) <= 1e-5 * abs(res[1][3])
 
 
 def test_device_side_editing_equals_the_host_list(hip):
