@@ -84,10 +84,12 @@ __device__ __forceinline__ f32x4 wino_fma(float c, f32x4 v, f32x4 acc) {
         }                                                  \
     }
 
-// V[xi][t][c] = (B^T d B)[xi]: one thread per (tile, 4 channels); d = TS x TS input patch at (MO*ty-1, MO*tx-1)
+// V[xi][t][c] = (B^T d B)[xi]: one thread per (tile, 4 channels); d = TS x TS input patch at (MO*ty-1, MO*tx-1).
+// up = 1: x is [N][H/2][W/2][C] and the layer's input is its 2 x 2 nearest-neighbour up-sampling (the pool-inverse layer in front,
+// pool_inv.py:10-41, never written): pixel (iy, ix) reads (iy / 2, ix / 2)
 template <int MO>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H,
-                                                         int W, int C, int TH, int TW, long T) {
+                                                         int W, int C, int TH, int TW, long T, int up) {
     using WT = Wino<MO>;
     constexpr int TS = WT::TS;
     const int c4n = C / 4;
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         for (int i = 0; i < TS; ++i) {
             const int iy = MO * ty - 1 + i;
             const bool ok = ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
-            d[i] = ok ? ld4(x + (((long)n * H + iy) * W + ix) * C + c4 * 4) : z;
+            d[i] = ok ? ld4(x + (((long)n * (H >> up) + (iy >> up)) * (W >> up) + (ix >> up)) * C + c4 * 4) : z;
         }
 #pragma unroll
         for (int i = 0; i < TS; ++i) {
@@ -749,7 +751,7 @@ int wino_filter(int mo, bool dgrad, const float* w, float* U, int K, int C, hipS
 int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u_cached, float* v_keep, const float* bias,
              const float* add, float* out, float* ws, size_t ws_bytes, int N, int H, int W, int Cin, int Cout,
              hipStream_t stream, int relu = 0, double* stats = nullptr, const BnFoldDev* fold = nullptr, float* dm_out = nullptr,
-             hipEvent_t transform_done = nullptr, const BnFoldDev* out_sums = nullptr) {
+             hipEvent_t transform_done = nullptr, const BnFoldDev* out_sums = nullptr, int in_up = 0) {
     // in: [N,H,W,Cin]   out: [N,H,W,Cout]   w: KRSC with (K,C) = dgrad ? (Cin,Cout) : (Cout,Cin)
     // fold: the input is formed on the fly from a batch-norm layer (wino_prep_kernel; dgrad: backward form, dm_out receives dM)
     DENET_CHECK_ARG((in || fold) && w && out && ws, "conv_wino: null pointer");
@@ -788,7 +790,7 @@ int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u
             else hipLaunchKernelGGL((wino_prep_kernel<4, false>), dim3(blocks), dim3(256), 0, stream, *fold, V, (float*)nullptr, N, H, W, Cin, d.TH, d.TW, d.T);
         }
     } else {
-        WINO_LAUNCH(mo, wino_input_kernel, d.T * (Cin / 4), in, V, N, H, W, Cin, d.TH, d.TW, d.T);
+        WINO_LAUNCH(mo, wino_input_kernel, d.T * (Cin / 4), in, V, N, H, W, Cin, d.TH, d.TW, d.T, in_up);
     }
     DENET_CHECK_LAUNCH("conv_wino transforms");
     if (transform_done) {
@@ -826,7 +828,7 @@ static int wino_wgrad_run(const float* x, const float* dy, const float* dm_ready
     float* dM = dU + d.nU + d.nV;
     if (!V) {      // v_cached: the transformed input the forward pass of this layer kept (same tile)
         float* Vw = dU + d.nU;
-        WINO_LAUNCH(tile, wino_input_kernel, d.T * (C / 4), x, Vw, N, H, W, C, d.TH, d.TW, d.T);
+        WINO_LAUNCH(tile, wino_input_kernel, d.T * (C / 4), x, Vw, N, H, W, C, d.TH, d.TW, d.T, 0);
         V = Vw;
     }
     const float* dMr = dm_ready;       // already formed by the backward fold of the data-gradient call (wino_prep_kernel)
@@ -989,6 +991,26 @@ extern "C" int denet_conv_wino_fwd_act(const float* x, const float* w, const flo
 // denet_conv_wino_fwd whose output transform also emits the batch-norm column sums (see denet_conv_fwd_stats):
 // stats_partial [rows][2][K] doubles, rows = N*(H/tile)*(W/tile)*(K/4) / 256 written to *stats_rows; *stats_rows = 0 (and no
 // sums) when 256 is not a multiple of K/4 - the caller then lets the batch norm compute its own statistics
+// denet_conv_wino_fwd_stats on the 2 x 2 nearest-neighbour up-sampling of x_small [N][H/2][W/2][C] (H, W: the layer's input size):
+// the pool-inverse layer in front of the convolution (pool_inv.py:10-41) inside the input transform, its output never written
+extern "C" int denet_conv_wino_fwd_stats_up(const float* x_small, const float* w, const float* u_cached, float* v_keep,
+                                            const float* bias, const float* add, float* y, double* stats_partial,
+                                            size_t stats_bytes, int* stats_rows, float* workspace, size_t workspace_bytes,
+                                            int tile, int N, int H, int W, int C, int K, hipStream_t stream) {
+    DENET_CHECK_ARG((tile == 2 || tile == 4) && H % 2 == 0 && W % 2 == 0, "conv_wino_fwd_stats_up: bad arguments");
+    double* st = nullptr;
+    if (stats_partial) {
+        DENET_CHECK_ARG(stats_rows, "conv_wino_fwd_stats_up: null pointer");
+        const int k4n = K / 4;
+        const long rows = ((long)N * (H / tile) * (W / tile) * k4n + 255) / 256;
+        const bool ok = k4n > 0 && k4n <= 256 && 256 % k4n == 0 && stats_bytes >= (size_t)rows * 2 * K * sizeof(double);
+        *stats_rows = ok ? (int)rows : 0;
+        st = ok ? stats_partial : nullptr;
+    }
+    return wino_run(tile, false, x_small, w, u_cached, v_keep, bias, add, y, workspace, workspace_bytes, N, H, W, C, K, stream, 0, st,
+                    nullptr, nullptr, nullptr, nullptr, 1);
+}
+
 extern "C" int denet_conv_wino_fwd_stats(const float* x, const float* w, const float* u_cached, float* v_keep,
                                          const float* bias, const float* add, float* y, double* stats_partial,
                                          size_t stats_bytes, int* stats_rows, float* workspace, size_t workspace_bytes,

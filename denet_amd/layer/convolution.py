@@ -169,16 +169,21 @@ class ConvLayer(AbstractLayer):
                 self._planar_x = link.x
                 return
             link = None
-        x = self.input.data if link is None else None
+        up = None
+        if isinstance(link, ops.UpLink):
+            up, link = link, None                 # the pool-inverse layer in front has not written its output (ops.UpLink)
+        x = self.input.data if (link is None and up is None) else None
         skip = getattr(self, "skip_behind", None)
         if skip is not None and add is None and get_train() and ctx is not None:
             # the SKIP layer behind adds its tap to this layer's output: here, in the epilogue (ModelCNN.build_train_func links the
             # two); the sum is the SKIP layer's output, and what a batch norm behind THAT wants to know about it is measured here
             want_skip_stats = getattr(skip.output, "want_stats", False)
             y = ops.conv_fwd(x, self._w(), bias=None, add=skip.y.data, stride=self.stride[0], pad=self.pad,
-                             s_real=self.filter_shape[3], logical=self._logical(), cache=cache, bn_stats=want_skip_stats, link=link)
+                             s_real=self.filter_shape[3], logical=self._logical(), cache=cache, bn_stats=want_skip_stats, link=link,
+                             up=up)
             if link is not None:
                 self.input.data = link.materialise()
+            self._settle_up(up)
             self.output.data = None              # the convolution's own output is never written
             self.output.stats = None
             skip.output.data = y
@@ -187,10 +192,21 @@ class ConvLayer(AbstractLayer):
             return
         self.output.data = ops.conv_fwd(x, self._w(), bias=self.beta.dev if self.use_bias else None, add=add,
                                         stride=self.stride[0], pad=self.pad, s_real=self.filter_shape[3],
-                                        logical=self._logical(), cache=cache, bn_stats=want_stats, link=link)
+                                        logical=self._logical(), cache=cache, bn_stats=want_stats, link=link, up=up)
         if link is not None:
             self.input.data = link.materialise()
+        self._settle_up(up)
         self.output.stats = cache.pop("bn_stats", None) if want_stats else None
+
+    def _settle_up(self, up):
+        """after a forward pass on an un-written up-sampled input: the tensor if the pass had to make it, else still pending (the
+        filter gradient asks for it on its own stream, anybody else through Act.data)"""
+        if up is None:
+            return
+        if up.result is not None:
+            self.input.data = up.result
+        else:
+            self.input.set_pending_data(up)
 
     def forward_folded(self, ctx, bn, add=None, relu=False, out_act=None):
         """inference only: this convolution with the batch-norm layer behind it folded into its filters (recomputed
@@ -221,7 +237,13 @@ class ConvLayer(AbstractLayer):
     def backward(self, ctx):
         # (the first layer on the planar network input has no data gradient and reads the image as it is)
         planar = getattr(self, "_planar_x", None) if not getattr(self.input, "requires_grad", True) else None
-        x = self.input.data if planar is None else None
+        # an input that is the un-written output of a pool-inverse layer (ops.UpLink, see forward): the data gradient needs its shape
+        # only, the filter gradient makes the tensor on ITS stream (it has the time) unless the transformed input was kept
+        up = self.input._pending_data if isinstance(self.input._pending_data, ops.UpLink) and self.input._data is None else None
+        if up is not None and self.output._pending_grad is not None:
+            up = None                             # (a linked batch-norm gradient: the one-kernel form reads x itself)
+        x = self.input.data if (planar is None and up is None) else None
+        x_shape = tuple(up.shape) if up is not None else (tuple(x.shape) if x is not None else None)
         st, pad, sr = self.stride[0], self.pad, self.filter_shape[3]
         # the batch norm (of this training step) whose output is this layer's input: the data-gradient pass below writes the
         # gradient of that output, and a Winograd pass can leave that batch norm's two backward reductions behind (ops.BnSums)
@@ -250,9 +272,9 @@ class ConvLayer(AbstractLayer):
         # two MFMA-bound GEMMs of hundreds of GFLOP gain nothing from sharing the chip (measured: the 4736 -> 1536 head layer's
         # pair takes 4.9 ms side by side, 2.1 + 2.2 ms one after the other) and the data gradient is the one the backward sweep
         # waits for: it goes first, the filter gradient follows on the second stream beside the HBM-bound passes that come next
-        first = need_dx and sr == 1 and st == 1 and 2e-9 * dy.numel() * x.shape[-1] >= ops.DGRAD_FIRST_GFLOP
+        first = need_dx and sr == 1 and st == 1 and 2e-9 * dy.numel() * x_shape[-1] >= ops.DGRAD_FIRST_GFLOP
         if first:
-            self.input.grad = ops.conv_dgrad(dy, self._w(), tuple(x.shape), add=self.input.grad, stride=st, pad=pad,
+            self.input.grad = ops.conv_dgrad(dy, self._w(), x_shape, add=self.input.grad, stride=st, pad=pad,
                                              s_real=sr, logical=self._logical(), cache=self._cache(), sums=sums)
             self.input.grad_sums = sums
         if self.enabled and self.omega.grad is not None:
@@ -265,6 +287,8 @@ class ConvLayer(AbstractLayer):
                     ops.conv_stem_wgrad(planar, dy, self.omega.dev_shape, self.omega.grad.view(self.omega.dev_shape),
                                         logical=self._logical())
                 else:
+                    if up is not None:
+                        x = self.input.data          # (written here, on the filter-gradient stream)
                     ops.conv_wgrad(x, dy, self.omega.dev_shape, stride=st, pad=pad, s_real=sr,
                                    out=self.omega.grad.view(self.omega.dev_shape), logical=self._logical(),
                                    cache=self._cache())
@@ -273,6 +297,6 @@ class ConvLayer(AbstractLayer):
             if self.use_bias and tail:
                 ops.colsum(dy.view(-1, self.kp), out=self.beta.grad)
         if need_dx and not first:
-            self.input.grad = ops.conv_dgrad(dy, self._w(), tuple(x.shape), add=self.input.grad, stride=st, pad=pad,
+            self.input.grad = ops.conv_dgrad(dy, self._w(), x_shape, add=self.input.grad, stride=st, pad=pad,
                                              s_real=sr, logical=self._logical(), cache=self._cache(), sums=sums)
             self.input.grad_sums = sums

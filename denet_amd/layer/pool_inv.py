@@ -30,6 +30,12 @@ class PoolInvLayer(AbstractLayer):
         return json
 
     def forward(self, ctx):
+        from . import get_train
+        if ctx is not None and get_train() and self.size == (2, 2) and ops.UP_LINK:
+            # training: the up-sampled tensor is written by whoever asks for it - a Winograd convolution behind this layer reads
+            # the small one inside its input transform (ops.UpLink, ConvLayer.forward)
+            self.output.set_pending_data(ops.UpLink(self.input.data))
+            return
         self.output.data = ops.pool_inv_fwd(self.input.data, self.size[1], self.size[0])
 
     def backward(self, ctx):

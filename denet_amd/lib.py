@@ -45,6 +45,7 @@ SIGNATURES = {
     "denet_conv_wino_fwd": (I, [P] * 8 + [Z] + [I] * 6 + [P]),
     "denet_conv_wino_fwd_act": (I, [P] * 7 + [I, P, Z] + [I] * 6 + [P]),
     "denet_conv_wino_fwd_stats": (I, [P] * 8 + [Z, P, P, Z] + [I] * 6 + [P]),
+    "denet_conv_wino_fwd_stats_up": (I, [P] * 8 + [Z, P, P, Z] + [I] * 6 + [P]),
     "denet_conv_wino_dgrad": (I, [P] * 6 + [Z] + [I] * 6 + [P]),
     "denet_gemm_bf16x3_ok": (I, [I] * 3),
     "denet_gemm_bf16x3_nt": (I, [P] * 4 + [I] * 3 + [P]),

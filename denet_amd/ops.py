@@ -402,7 +402,7 @@ def _transpose(src, R, C):
 
 
 def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, logical=None, cache=None, relu=False,
-             bn_stats=False, link=None):
+             bn_stats=False, link=None, up=None):
     """bn_stats (training, the layer behind is a batch norm): the epilogue of the pass also writes the per-channel sums of y;
     cache["bn_stats"] = (partial sums tensor, rows) for bn_fwd_train(pre=...), or None when the chosen kernel cannot.
     link (BnLink, x = None): the input is the output of a batch norm whose pointwise pass has not run; a Winograd pass evaluates
@@ -417,7 +417,16 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
         if PROFILE is not None:
             PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])
         return _conv_wino_fwd_linked(link, g, tile, w, bias, add, out, cache, bn_stats)
-    g = conv_geom(x.shape, w.shape, stride, pad, s_real)
+    if up is not None:
+        # up (UpLink, x = None): the input is a pool-inverse layer's output that has not been written. A training pass on the
+        # un-fused Winograd kernels (already decided for this geometry) reads the small tensor in its input transform; every other
+        # case writes the up-sampled tensor first
+        gu = conv_geom(up.shape, w.shape, stride, pad, s_real)
+        if not (_WINO.get((0, gu)) in (2, 4) and ((0, gu) in _TUNED or not AUTOTUNE) and cache is not None and cache.get("train") and bn_stats
+                and not relu and not _bf16x3_geom(gu)):
+            x = up.materialise()
+            up = None
+    g = conv_geom(up.shape if up is not None else x.shape, w.shape, stride, pad, s_real)
     N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
     y = out if out is not None else empty(N, OH, OW, K)
     if add is None and not relu and _bf16x3_geom(g):
@@ -470,7 +479,11 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
                 if v_keep is None or v_keep.numel() != nv:
                     v_keep = cache["V"] = torch.empty(nv, dtype=torch.float32, device="cuda")
                 cache["V_tile"] = tile
-        return conv_wino_fwd(x, w, bias, add, out=y, tile=tile, u=u, v_keep=v_keep, relu=relu, stats=(st, cache) if st is not None else None)
+        if up is not None and st is None:
+            x, up = up.materialise(), None
+        return conv_wino_fwd(x, w, bias, add, out=y, tile=tile, u=u, v_keep=v_keep, relu=relu, stats=(st, cache) if st is not None else None,
+                             up=up)
+    assert up is None
     if cache is not None:
         cache["fwd_tile"] = 0
     if PROFILE is not None:
@@ -663,9 +676,10 @@ def _wino_ws(tile, N, H, W, C, K):
     return WS.get("wino_side" if _ON_WGRAD_STREAM else "wino", _L().denet_conv_wino_workspace_bytes(tile, N, H, W, C, K))
 
 
-def conv_wino_fwd(x, w, bias=None, add=None, out=None, tile=2, u=None, v_keep=None, relu=False, stats=None):
-    """stats = (float64 buffer, cache dict): the output transform also writes the batch-norm column sums (conv_fwd bn_stats)"""
-    N, H, W, C = x.shape
+def conv_wino_fwd(x, w, bias=None, add=None, out=None, tile=2, u=None, v_keep=None, relu=False, stats=None, up=None):
+    """stats = (float64 buffer, cache dict): the output transform also writes the batch-norm column sums (conv_fwd bn_stats);
+    up (UpLink, x = None; tiles 2 / 4 with stats only): the input is the 2 x 2 up-sampling of up.src, read in the input transform"""
+    N, H, W, C = up.shape if up is not None else x.shape
     K = w.shape[0]
     y = out if out is not None else empty(N, H, W, K)
     if tile == FUSED2:
@@ -684,11 +698,12 @@ def conv_wino_fwd(x, w, bias=None, add=None, out=None, tile=2, u=None, v_keep=No
         import ctypes
         st, cache = stats
         rows = ctypes.c_int(0)
-        check(_L().denet_conv_wino_fwd_stats(ptr(x), ptr(w), ptr(u), ptr(v_keep), ptr(bias), ptr(add), ptr(y), ptr(st),
-                                             st.numel() * 8, ctypes.byref(rows), ptr(ws), ws.numel(), tile, N, H, W, C, K,
-                                             stream_ptr()), "conv_wino_fwd_stats")
+        fn = _L().denet_conv_wino_fwd_stats_up if up is not None else _L().denet_conv_wino_fwd_stats
+        check(fn(ptr(up.src if up is not None else x), ptr(w), ptr(u), ptr(v_keep), ptr(bias), ptr(add), ptr(y), ptr(st),
+                 st.numel() * 8, ctypes.byref(rows), ptr(ws), ws.numel(), tile, N, H, W, C, K, stream_ptr()), "conv_wino_fwd_stats")
         cache["bn_stats"] = (st, rows.value) if rows.value > 0 else None
         return y
+    assert up is None, "an up-sampled input is only read by the statistics form"
     check(_L().denet_conv_wino_fwd_act(ptr(x), ptr(w), ptr(u), ptr(v_keep), ptr(bias), ptr(add), ptr(y), int(relu), ptr(ws),
                                        ws.numel(), tile, N, H, W, C, K, stream_ptr()), "conv_wino_fwd")
     return y
@@ -821,6 +836,26 @@ def conv_wgrad(x, dy, w_shape, stride=1, pad=0, s_real=None, out=None, logical=N
         PROFILE.add(_conv_flops(g, logical))
     direct()
     return dw
+
+
+UP_LINK = os.environ.get("DENET_UP_LINK", "1") != "0"
+
+
+class UpLink:
+    """the output of a pool-inverse layer (2 x 2 nearest-neighbour up-sampling, pool_inv.py:10-41) that has not been written: a
+    Winograd convolution behind it reads the small tensor inside its input transform (denet_conv_wino_fwd_stats_up), anybody else
+    calls materialise(); result = the up-sampled tensor once it exists"""
+
+    def __init__(self, src):
+        self.src = src
+        N, H, W, C = src.shape
+        self.shape = (N, 2 * H, 2 * W, C)
+        self.result = None
+
+    def materialise(self):
+        if self.result is None:
+            self.result = pool_inv_fwd(self.src, 2, 2)
+        return self.result
 
 
 class NchwLink:

@@ -131,6 +131,12 @@ int denet_conv_wino_fwd_stats(const float* x, const float* w, const float* u_cac
                               const float* add, float* y, double* stats_partial, size_t stats_bytes, int* stats_rows,
                               float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
                               hipStream_t stream);
+/* ..._up: the same on the 2 x 2 nearest-neighbour up-sampling of x_small [N][H/2][W/2][C] (H, W: the layer's input size) - the
+ * pool-inverse layer in front of the convolution (denet/layer/pool_inv.py:10-41) evaluated inside the input transform */
+int denet_conv_wino_fwd_stats_up(const float* x_small, const float* w, const float* u_cached, float* v_keep, const float* bias,
+                              const float* add, float* y, double* stats_partial, size_t stats_bytes, int* stats_rows,
+                              float* workspace, size_t workspace_bytes, int tile, int N, int H, int W, int C, int K,
+                              hipStream_t stream);
 /* OPT-IN, not the fp32 path: C[M][N] = A[M][K] B[N][K]^T (+ bias[N]) with every product as a 3-term bf16 split on the bf16
  * matrix cores (a_hi b_hi + a_hi b_lo + a_lo b_hi, fp32 accumulation): the forward pass of a 1x1 stride-1 convolution
  * (convolution.py:80-83; the detection head) at ~1e-6 relative error instead of the exact fp32 FMA chain of denet_conv_fwd. */

@@ -773,6 +773,44 @@ def test_prepared_cold_roi_list_equals_the_hand_off_path(hip):
         assert torch.equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2], warm
 
 
+def test_pool_inverse_inside_the_input_transform(hip):
+    """ops.UpLink: in training a pool-inverse layer (2 x 2 nearest-neighbour up-sampling, pool_inv.py:10-41 / pool_inv_op.py:38-63)
+    leaves its output unwritten; the Winograd convolution behind it reads the small tensor inside its input transform
+    (denet_conv_wino_fwd_stats_up), the filter gradient makes the up-sampled tensor on its own stream. Same values read, same
+    kernels otherwise: two training steps, parameters / momentum / running statistics bit for bit"""
+    res = []
+    saved = (ops.UP_LINK, dict(ops._WINO))
+    try:
+        for on in (True, False):
+            ops.UP_LINK = on
+            random.seed(7)
+            model = zoo.warm_corner_head(zoo.denet34(2, "skip", 256, class_num=80, seed=1), 4.0, 0.3)
+            model.build_train_func("nesterov")
+            x, metas = zoo.synthetic_batch(2, 256, seed=11)
+            if not res:
+                model.train_step(x, metas, 0, 0, 0.0, [0.9], 0.0)          # decides the launch configurations once
+                for (mode, g) in list(ops._WINO):
+                    if mode == 0 and g[5] == 3 and g[8] == 1 and ops.conv_wino_ok(g, 4) and g[3] in (256, 512):
+                        ops._WINO[(mode, g)] = 4                          # the two convolutions behind PI on the un-fused F(4x4) pass
+                random.seed(7)
+                model = zoo.warm_corner_head(zoo.denet34(2, "skip", 256, class_num=80, seed=1), 4.0, 0.3)
+                model.build_train_func("nesterov")
+            pis = [l for l in model.layers if l.type_name == "pool-inv"]
+            costs = []
+            for it in range(2):
+                costs.append(model.train_step(x, metas, 0, it, 0.02, [0.9], 1e-4)[0])
+            torch.cuda.synchronize()
+            res.append((model.P.clone(), model.M.clone(), model.S.clone(), costs, [p.output.data.clone() for p in pis]))
+    finally:
+        ops.UP_LINK = saved[0]
+        ops._WINO.clear()
+        ops._WINO.update(saved[1])
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(a, b)
+    assert res[0][3] == res[1][3]
+    assert all(torch.equal(u, v) for u, v in zip(res[0][4], res[1][4]))
+
+
 def test_skip_addition_in_the_convolution_epilogue(hip):
     """ModelCNN.build_train_func links a SKIP layer that adds its tap without a projection (skip.py:81-86) to the convolution right in
     front of it: the tap
