@@ -1341,7 +1341,7 @@ extern "C" int denet_conv_fwd(const float* x, const float* w, const float* bias,
 
 static int conv_fwd_impl(const float* x, const float* w, const float* bias, const float* add, float* y, int relu,
                          double* stats, int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad,
-                         int OH, int OW, hipStream_t stream);
+                         int OH, int OW, hipStream_t stream, const denet_bn_link* sums_of = nullptr);
 
 // forward convolution with an activation in the epilogue: y = act(conv(x, w) + bias + add), relu != 0: max(., 0)
 extern "C" int denet_conv_fwd_act(const float* x, const float* w, const float* bias, const float* add, float* y, int relu,
@@ -1367,7 +1367,7 @@ extern "C" int denet_conv_fwd_stats(const float* x, const float* w, const float*
 
 static int conv_fwd_impl(const float* x, const float* w, const float* bias, const float* add, float* y, int relu,
                          double* stats, int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad,
-                         int OH, int OW, hipStream_t stream) {
+                         int OH, int OW, hipStream_t stream, const denet_bn_link* sums_of) {
     int rc = check_geom(N, H, W, C, K, R, S, S_real, stride, pad, OH, OW);
     if (rc) return rc;
     DENET_CHECK_ARG(x && w && y, "conv_fwd: null pointer");
@@ -1375,6 +1375,10 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
         return denet_conv_stem_fwd_act(x, 0, w, bias, y, relu, nullptr, 0, nullptr, N, H, W, stream);
     IgemmParams p = {};
     p.act = x; p.wgt = w; p.out = y; p.bias = bias; p.add = add; p.relu = relu ? 1 : 0; p.stats = stats;
+    if (sums_of && stats) {          // the column sums of the epilogue become a batch norm's backward reductions (denet_conv_dgrad_1x1t)
+        p.bs_x = sums_of->x; p.bs_y = sums_of->relu ? sums_of->y : nullptr; p.bs_gamma = sums_of->gamma; p.bs_beta = sums_of->beta;
+        p.bs_mean = sums_of->mean; p.bs_invstd = sums_of->invstd; p.bs_relu = sums_of->relu;
+    }
     p.N = N; p.H = H; p.W = W; p.C = C; p.OH = OH; p.OW = OW; p.K = K;
     p.R = R; p.S = S; p.S_real = S_real; p.stride = stride; p.sshift = ilog2_exact(stride); p.pad = pad;
     p.act_bytes = (unsigned)((size_t)N * H * W * C * 4); p.wgt_bytes = (unsigned)((size_t)K * R * S * C * 4);
@@ -1432,6 +1436,28 @@ extern "C" int denet_conv_dgrad_sums(const float* dy, const float* w, const floa
     *stats_rows = ok ? (int)rows : 0;
     return conv_dgrad_impl(dy, w, add, dx, ok ? sums_of : nullptr, ok ? stats_partial : nullptr, N, H, W, C, K, R, S, S_real, stride,
                            pad, OH, OW, stream);
+}
+
+// the data gradient of a 1x1 stride-1 convolution as a FORWARD product over the transposed filter wt [C][K]
+// (dx[pix][c] = sum_k dy[pix][k] wt[c][k]): the forward loop reads both operands reduction-contiguous and runs the pipelined
+// 128 x 128 tile (the head layers: 118 -> 137, 100 -> 124 TFLOP/s against the k-major filter reads of the data-gradient mode),
+// same products in the same order - bit-identical to denet_conv_dgrad. sums_of / stats_partial as in denet_conv_dgrad_sums
+// (both null: no sums), rows = ceil(N*H*W / 128).
+extern "C" int denet_conv_dgrad_1x1t(const float* dy, const float* wt, const float* add, float* dx, const denet_bn_link* sums_of,
+                                     double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int C, int K,
+                                     hipStream_t stream) {
+    DENET_CHECK_ARG(dy && wt && dx, "conv_dgrad_1x1t: null pointer");
+    bool ok = false;
+    if (sums_of) {
+        DENET_CHECK_ARG(stats_partial && stats_rows, "conv_dgrad_1x1t: null pointer");
+        DENET_CHECK_ARG(sums_of->x && sums_of->mean && sums_of->invstd && (!sums_of->relu || sums_of->y || (sums_of->gamma && sums_of->beta)),
+                        "conv_dgrad_1x1t: incomplete batch-norm description");
+        const long rows = ((long)N * H * W + 127) / 128;
+        ok = stats_bytes >= (size_t)rows * 2 * C * sizeof(double);
+        *stats_rows = ok ? (int)rows : 0;
+    }
+    return conv_fwd_impl(dy, wt, nullptr, add, dx, 0, ok ? stats_partial : nullptr, N, H, W, K, C, 1, 1, 1, 1, 0, H, W, stream,
+                         ok ? sums_of : nullptr);
 }
 
 static int conv_dgrad_impl(const float* dy, const float* w, const float* add, float* dx, const denet_bn_link* sums_of,

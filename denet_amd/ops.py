@@ -395,8 +395,8 @@ def _gemm_bf16x3(a, b, bias, out, M, N, K):
     return out
 
 
-def _transpose(src, R, C):
-    dst = empty(C, R)
+def _transpose(src, R, C, out=None):
+    dst = out if out is not None else empty(C, R)
     check(_L().denet_transpose_f32(ptr(src), ptr(dst), R, C, stream_ptr()), "transpose_f32")
     return dst
 
@@ -588,12 +588,23 @@ def _cached_u(cache, dgrad, tile):
     return ent[1]
 
 
+def _cached_wt(cache):
+    """transposed filter of a large 1x1 layer prepared ahead by wino_prefetch_filters (None: the caller transposes)"""
+    ent = cache.get("wt") if cache is not None else None
+    if ent is None or not ent[1]:
+        return None
+    wait_upload(cache.get("wt_event"))
+    ent[1] = False                            # valid for one step: the solver changes the weights
+    return ent[0]
+
+
 def wino_prefetch_filters(caches_and_weights, after=None):
     """For every convolution layer that runs Winograd passes: transform its filters for the forward and the data-gradient
     pass on a side stream, right at the start of a training step (the ~60 small launches leave the critical path)."""
     global _SIDE_FILTER
     todo = [(c, w) for c, w in caches_and_weights if c.get("fwd_tile") or c.get("dgrad_tile")]
-    if not todo:
+    tr = [(c, w) for c, w in caches_and_weights if c.get("dgrad_1x1t")]
+    if not todo and not tr:
         return
     if _SIDE_FILTER is None:
         init_streams()
@@ -627,6 +638,19 @@ def wino_prefetch_filters(caches_and_weights, after=None):
         for i in range(0, len(todo), 8):
             run(todo[i:i + 8], 0, "fwd_tile")
         run(todo, 1, "dgrad_tile")
+        if tr:
+            # the transposed filters of the large 1x1 layers' data-gradient products (conv_dgrad)
+            for c, w in tr:
+                K, _, _, C = w.shape
+                ent = c.get("wt")
+                if ent is None or ent[0].numel() != K * C:
+                    ent = c["wt"] = [torch.empty(C, K, dtype=torch.float32, device="cuda"), False]
+                _transpose(w, K, C, out=ent[0])
+                ent[1] = True
+            ev = torch.cuda.Event()
+            ev.record(_SIDE_FILTER)
+            for c, _ in tr:
+                c["wt_event"] = ev
 
 
 _SIDE_FILTER = None
@@ -637,6 +661,9 @@ _ON_WGRAD_STREAM = False
 WGRAD_STREAM = os.environ.get("DENET_WGRAD_STREAM", "1") != "0"
 # a layer whose data-gradient GEMM is at least this large runs it BEFORE its filter gradient is queued (layer/convolution.py)
 DGRAD_FIRST_GFLOP = float(os.environ.get("DENET_DGRAD_FIRST_GFLOP", "100"))
+# a 1x1 stride-1 layer whose data-gradient GEMM is at least this large runs it as a forward product over the transposed filter
+# (conv_dgrad; 0 = never)
+DGRAD_1X1T_GFLOP = float(os.environ.get("DENET_DGRAD_1X1T_GFLOP", "100"))
 
 
 class wgrad_stream:
@@ -775,6 +802,32 @@ def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None,
         if cache is not None:
             cache["dgrad_tile"] = 0
         return _gemm_bf16x3(dy, _transpose(w, K, C), None, dx, N * H * W, C, K)       # dx[pix][c] = dy[pix][k] (w^T)[c][k]^T
+    if DGRAD_1X1T_GFLOP > 0 and g[5] == 1 and g[6] == 1 and g[8] == 1 and g[9] == 0 and g[3] % 32 == 0 and g[4] % 32 == 0 \
+            and 2e-9 * dy.numel() * g[3] >= DGRAD_1X1T_GFLOP:
+        # a large 1x1 layer (the head): the forward kernel over the transposed filter (denet_conv_dgrad_1x1t, bit-identical);
+        # the transposed copy comes from the side stream (wino_prefetch_filters) when a training step prepared it
+        import ctypes
+        N, H, W, C, K = g[0], g[1], g[2], g[3], g[4]
+        wt = _cached_wt(cache)
+        if wt is None:
+            wt = _transpose(w, K, C)
+        if cache is not None:
+            cache["dgrad_tile"] = 0
+            cache["dgrad_1x1t"] = True
+        gt = conv_geom((N, H, W, K), (C, 1, 1, K), 1, 0, None)
+        if not _tune_first(0, gt, dy, wt, None, add, dx, None) and PROFILE is not None:
+            PROFILE.add(_conv_flops(g, logical))
+        rows = ctypes.c_int(0)
+        sb = so = None
+        if sums is not None and (int(BWD_SUMS) & 2):
+            sb = sums.buffer(cache, (N * H * W + 127) // 128, C)
+            so = sums.c_struct()
+        check(_L().denet_conv_dgrad_1x1t(ptr(dy), ptr(wt), ptr(add), ptr(dx), ctypes.byref(so) if so is not None else None, ptr(sb),
+                                         sb.numel() * 8 if sb is not None else 0, ctypes.byref(rows), N, H, W, C, K, stream_ptr()),
+              "conv_dgrad_1x1t")
+        if sb is not None:
+            sums.done(sb, rows.value)
+        return dx
     _tune_first(1, g, dy, w, None, add, dx, None)
 
     def direct():

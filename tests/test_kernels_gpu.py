@@ -491,6 +491,58 @@ def test_data_gradient_pass_leaves_the_batch_norm_backward_sums(hip, path, relu,
         ops.BWD_SUMS = saved[1]
 
 
+@pytest.mark.parametrize("case", [(2, 12, 12, 448, 160, False, False), (2, 12, 12, 256, 96, True, False), (3, 8, 8, 160, 256, True, True),
+                                  (1, 5, 7, 96, 64, False, True)])
+def test_data_gradient_of_a_1x1_layer_over_the_transposed_filter(hip, case):
+    """denet_conv_dgrad_1x1t (the head layers: forward kernel over w^T, ops.DGRAD_1X1T_GFLOP) against denet_conv_dgrad /
+    denet_conv_dgrad_sums on the same tensors: the gradient bit for bit (with and without an earlier contribution), the batch
+    norm's backward sums bit for bit as well (the same epilogue over the same 128-row tiles); from a prepared transposed copy
+    (ops.wino_prefetch_filters) and from the call's own"""
+    from denet_amd import ops
+    N, H, W, C, K, with_add, with_sums = case
+    g = torch.Generator().manual_seed(9)
+    dy = torch.randn(N, H, W, K, generator=g).cuda()
+    w = (torch.randn(K, 1, 1, C, generator=g) * 0.05).cuda()
+    addt = torch.randn(N, H, W, C, generator=g).cuda() if with_add else None
+    x = (torch.randn(N, H, W, C, generator=g) * 1.5 + 0.3).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    y, sm, si = ops.bn_fwd_train(x, gamma, beta, torch.zeros(C).cuda(), torch.ones(C).cuda(), relu=True)
+    saved = (ops.DGRAD_1X1T_GFLOP, ops.BWD_SUMS, dict(ops._WINO))
+    out = {}
+    try:
+        ops.BWD_SUMS = 3
+        for mode in ("plain", "transposed", "prepared"):
+            ops.DGRAD_1X1T_GFLOP = 0.0 if mode == "plain" else 1e-9
+            sums = ops.BnSums(x, None, gamma, beta, sm, si, True) if with_sums else None
+            cache = {"train": True}
+            if mode == "prepared":
+                cache["dgrad_1x1t"] = True
+                ops.wino_prefetch_filters([(cache, w)])
+                assert cache["wt"][1]
+            dx = ops.conv_dgrad(dy, w, (N, H, W, C), add=addt, stride=1, pad=0, cache=cache, sums=sums)
+            if mode != "plain":
+                assert cache.get("dgrad_1x1t")
+            if mode == "prepared":
+                assert not cache["wt"][1]                  # consumed: valid for one step
+            if with_sums:
+                assert sums.partial is not None
+                la, _ = ops.bn_bwd_link(x, None, dx, gamma, sm, si, relu=True, beta=beta, pre=sums.partial)
+                out[mode] = (dx.clone(), la.coef.clone())
+            else:
+                out[mode] = (dx.clone(),)
+    finally:
+        ops.DGRAD_1X1T_GFLOP, ops.BWD_SUMS = saved[:2]
+        ops._WINO.clear()
+        ops._WINO.update(saved[2])
+    ref = torch.einsum("nhwk,kc->nhwc", dy.double(), w[:, 0, 0, :].double())
+    if with_add:
+        ref = ref + addt.double()
+    _close(out["plain"][0], ref.float(), rtol=1e-5)
+    for mode in ("transposed", "prepared"):
+        for a, b in zip(out[mode], out["plain"]):
+            assert torch.equal(a, b), mode
+
+
 @pytest.mark.parametrize("shape", [(4, 16, 16, 64), (2, 8, 8, 1536), (3, 5, 7, 768), (2, 32, 32, 128)])
 @pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
 def test_bn_fwd_bwd(hip, shape, relu, res):
