@@ -280,12 +280,29 @@ __global__ __launch_bounds__(256) void sparse_bwd_kernel(const float* __restrict
     const int* cs = cell_start + (long)b * (HW + 1);
     const int start = cs[cell], end = cs[cell + 1];
     const int* ord = order + (long)b * n;
-    if (e < epi) {
-        // entry j of the cell belongs to lane group j % epi: a fixed left-to-right chain per group
-        for (int i = start + e; i < end; i += epi) {
-            const int slot = ord[i];
-            const int roi = slot / ntap, tap = slot - roi * ntap;
-            acc += *(const f32x4*)(dy + ((long)b * rois_per_image + roi) * KP + (long)tap * F + f4 * 4);
+    // entry j of the cell belongs to lane group j % epi: a fixed left-to-right chain per group. The slots of up to CH entries come
+    // in with ONE coalesced load and are handed out by shuffles, and a group has the rows of four entries in flight before it
+    // adds them (in order): slot -> address -> row was two dependent loads per entry, 3-4 times in a row per wave - the kernel
+    // ran at the latency of that chain (281 us alone, 0.84 ms beside the first head layer's filter gradient)
+    const int CH = (64 / epi) * epi;
+    const bool grp = e < epi;
+    const float* dyb = dy + (long)b * rois_per_image * KP + f4 * 4;
+    for (int base = start; base < end; base += CH) {
+        const int cnt = min(CH, end - base);
+        const int mine = (lane < cnt) ? ord[base + lane] : 0;
+        for (int j0 = 0; j0 < cnt; j0 += 4 * epi) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * epi + e;
+                const int slot = __shfl(mine, j & 63, 64);
+                const int roi = slot / ntap, tap = slot - roi * ntap;
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (grp && j < cnt) v[u] = *(const f32x4*)(dyb + (long)roi * KP + (long)tap * F);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (grp && j0 + u * epi + e < cnt) acc += v[u];
         }
     }
     f32x4 tot = acc;

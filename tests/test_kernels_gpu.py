@@ -852,6 +852,46 @@ def test_sparse_fwd_bwd(hip, rule):
     assert torch.equal(dfmap2[..., coff:], dfmap[..., coff:])
 
 
+@pytest.mark.parametrize("Fc", [96, 80, 32, 256])
+def test_sparse_bwd_summation_order(hip, Fc):
+    """the gather gradient's result is DEFINED bit for bit (the deterministic replacement of the reference's atomicAdd scatter,
+    denet_sparse_op.py:171-212): the (roi, tap) entries of a cell in ascending slot order, entry j in chain j % epi with
+    epi = 64 // (F / 4), every chain summed left to right from +0, the chains added in order - emulated here in numpy float32.
+    Clustered boxes put hundreds of entries on a cell (the kernel takes the slots of a cell in chunks of (64 // epi) * epi)"""
+    from denet_amd import ops
+    rng = np.random.RandomState(4)
+    B, H, W, rois, gs = 2, 12, 12, 150, 5
+    CP = ((Fc + 31) // 32) * 32
+    M = B * rois
+    cx, cy = rng.normal(0.5, 0.06, M), rng.normal(0.5, 0.06, M)
+    w, h = rng.uniform(0.02, 0.15, M), rng.uniform(0.02, 0.15, M)
+    bbox = np.clip(np.stack([cx - w, cy - h, cx + w, cy + h], 1), 0, 1).astype(np.float32)
+    fmap = torch.zeros(B, H, W, CP).cuda()
+    KP = ((gs * gs * Fc + 2 + 31) // 32) * 32
+    _, taps = ops.sparse_fwd(fmap, torch.from_numpy(bbox).cuda(), 0, Fc, rois, gs, KP, 0)
+    dy = rng.uniform(-1, 1, (M, KP)).astype(np.float32)
+    dfmap = torch.zeros(B, H, W, CP).cuda()
+    ops.sparse_bwd(torch.from_numpy(dy).cuda(), taps, dfmap, 0, Fc, rois, gs, Fc)
+    got = dfmap.cpu().numpy().reshape(B, H * W, CP)
+    tp = taps.cpu().numpy().reshape(B, rois * gs * gs)
+    epi = 64 // (Fc // 4)
+    ntap = gs * gs
+    most = 0
+    for b in range(B):
+        for cell in range(H * W):
+            slots = np.nonzero(tp[b] == cell)[0]                      # ascending slot = roi * ntap + tap
+            most = max(most, len(slots))
+            chains = [np.zeros(Fc, np.float32) for _ in range(epi)]
+            for j, sl in enumerate(slots):
+                roi, tap = divmod(int(sl), ntap)
+                chains[j % epi] = chains[j % epi] + dy[b * rois + roi, tap * Fc:(tap + 1) * Fc]
+            tot = chains[0]
+            for k in range(1, epi):
+                tot = tot + chains[k]
+            assert np.array_equal(got[b, cell, :Fc], tot), (b, cell, len(slots))
+    assert most > 128                                                  # more than two chunks of slots on one cell
+
+
 @pytest.mark.parametrize("case", [(32, 64, 64, 576, 7), (3, 20, 36, 100, 5), (2, 128, 128, 2304, 7), (1, 9, 7, 3000, 2)])
 def test_sparse_tap_counting_sort(hip, case):
     """the grouping of the (roi, tap) slots by cell that the gather gradient sums over (replaces the reference's atomicAdd
