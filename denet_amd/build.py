@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libdenet_hip.so")
 
-SOURCES = ["runtime.hip", "igemm.hip", "bn.hip", "pool.hip", "elementwise.hip", "dss.hip", "samples.hip", "detect.hip", "winograd.hip", "wino2f.hip", "stem.hip", "gemm3b.hip",
+SOURCES = ["runtime.hip", "igemm.hip", "bn.hip", "pool.hip", "elementwise.hip", "dss.hip", "samples.hip", "detect.hip", "winograd.hip", "wino2f.hip", "wino4f.hip", "stem.hip", "gemm3b.hip",
            "augment.hip", "image.hip"]
 # files whose integer results must not depend on FMA contraction
 NO_CONTRACT = {"dss.hip", "samples.hip", "detect.hip", "augment.hip", "image.hip"}
@@ -58,7 +58,7 @@ def build(force=False, verbose=False):
         hipcc = "hipcc"
     version = _hipcc_version(hipcc)
     objs = []
-    headers = [os.path.join(CSRC, "common.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "denet_hip.h")]
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))

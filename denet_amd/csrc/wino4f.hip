@@ -1,0 +1,433 @@
+// Winograd F(4x4,3x3): the 36 component products AND the output transform in one kernel - M never reaches HBM.
+// Reference op: the `C[k,3]` layer, denet/layer/convolution.py:80-83 (forward) and its data gradient, model_cnn.py:318 (the
+// same pipeline on dy with the rotated, channel-swapped filters). The un-fused path of winograd.hip runs the products as 36
+// batched GEMMs that write M[36][T][K] and a transform kernel that reads it back: for a 128-channel layer on a 64x64 map that
+// is 2 x 151 MB of the pass's 740 MB, and the K = 128 products need the HBM stream and the matrix pipe at the same time.
+//
+// Here a workgroup owns TB tiles x 64 output channels and walks the 36 components ITSELF:
+//     for xi = (l, m):   M = V[xi][tiles][:] . U[xi][channels][:]^T        (v_mfma_f32_16x16x4_f32, 4 registers per lane)
+//                        Y[i][j] += AT[i][l] * AT[j][m] * M                 (<= 16 fused multiply-adds per value, VALU)
+// so only the 16 output positions of a (tile, channel) live in registers (64 per lane) - 16 waves of one 16 x 16 block each,
+// i.e. the whole register file of a CU holds the outputs of 64 tiles x 64 channels (TB = 32: 8 waves, two workgroups per CU).
+// Operands: V / U rows of 64 reduction channels (256 B) arrive by LDS-DMA (buffer_load ... lds, 16 B per lane), four chunks
+// of (TB + 64) rows in flight; the 16-byte slots of a row are XOR-swizzled with the row index at the SOURCE address (the DMA
+// writes LDS linearly), which makes the ds_read_b128 fragment reads conflict-free. One barrier per chunk, in the MIDDLE of the
+// chunk's products: it publishes chunk s+1 (every wave has waited for its own pieces) and frees the buffer of chunk s-1 for
+// the pieces of chunk s+3 - the matrix pipe never waits for it, the fragments of the next 16 channels are in registers.
+// The epilogue is the output transform's (winograd.hip wino_output_kernel): bias / add / ReLU, the batch-norm column sums of
+// what is stored, or the backward sums of the batch norm whose output gradient is written.
+// Association: Y is accumulated component by component instead of A^T (M A) column by column: same sums, other rounding
+// (measured against fp64 in tests/test_conv_fullsize_gpu.py like every other pass).
+#include "common.h"
+#include "../../include/denet_hip.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+struct W4Params {
+    const float* V;      // [36][T][C]
+    const float* U;      // [36][K][C]
+    const float* bias;   // [K] or null
+    const float* add;    // [N,H,W,K] or null
+    float* y;            // [N,H,W,K]
+    double* stats;       // [tile blocks][2][K] or null
+    const float* bs_x;   // backward sums (see winograd.hip BnFoldDev / wino_output_kernel)
+    const float* bs_y;
+    const float* bs_gamma;
+    const float* bs_beta;
+    const float* bs_mean;
+    const float* bs_invstd;
+    int bs_relu;
+    int N, H, W, C, K, TH, TW;
+    int T;
+    int relu;
+    int tiles_k;         // 64-channel blocks
+    int chunks;          // C / 64
+    unsigned v_bytes, u_bytes, y_bytes;
+    unsigned long long* dbg;   // -DW4_TRACE builds: s_memtime stamps of workgroup 0 (tools/exp/w4_trace.py)
+};
+
+constexpr int W4_NBUF = 4;
+constexpr int W4_OOB = (int)0xF0000000u;
+constexpr float W4_AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+
+// s_waitcnt vmcnt(vm) only (lgkmcnt / expcnt left alone) and the compiler kept from moving memory operations across
+#define W4_WAIT_VM(vm) __builtin_amdgcn_s_waitcnt(((vm) & 15) | ((((vm) >> 4) & 3) << 14) | (7 << 4) | (15 << 8))
+#ifdef W4_TRACE
+#define W4_STAMP() if (p.dbg && blockIdx.x == 0 && lane == 0 && dbg_n < 600) p.dbg[wave * 640 + dbg_n++] = __builtin_amdgcn_s_memtime()
+#else
+#define W4_STAMP()
+#endif
+#define W4_BARRIER()                       \
+    {                                      \
+        asm volatile("" ::: "memory");     \
+        __builtin_amdgcn_s_barrier();      \
+        asm volatile("" ::: "memory");     \
+    }
+
+// TB tiles x 64 channels per workgroup, TB / 16 x 4 waves of one 16 x 16 block.
+// EP: 0 = store only, 1 = + batch-norm column sums of what is stored, 2 = + backward sums of the batch norm in front
+constexpr int W4_SLOT = 32768;                    // LDS bytes per chunk buffer (V rows, then U rows)
+template <int TB, int EP>
+__device__ __forceinline__ void wino4f_body(const W4Params& p) {
+    constexpr int NW = TB / 4;                    // waves
+    constexpr int V_BYTES = TB * 256;             // a chunk of V rows
+    constexpr int VP = TB / 4;                    // 1 KB pieces of the V chunk (4 rows each)
+    constexpr int PIECES = VP + 16;
+    constexpr int PPW = PIECES / NW;              // pieces per wave and chunk
+    static_assert(PIECES % NW == 0, "pieces divide over the waves");
+    static_assert(W4_NBUF == 4 && V_BYTES + 16384 <= W4_SLOT, "two pairs of buffers, 64 KB apart");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tw = wave % (TB / 16), kw = wave / (TB / 16);
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int kblk = (int)(bid % (uint32_t)p.tiles_k), tblk = (int)(bid / (uint32_t)p.tiles_k);
+    const int t0 = tblk * TB, k0 = kblk * 64;
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)p.V, 0, p.v_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, p.u_bytes, 0x00020000);
+
+    // ---- DMA pieces of this wave: piece q = wave + NW * j; q < VP: rows 4q..4q+3 of the V chunk, else of the U chunk ----
+    int pv_off[PPW];          // byte offset of this lane's 16 bytes inside component 0, chunk 0
+    const int prow = lane >> 4, pslot = lane & 15;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int q = wave + NW * j;
+        const bool isv = q < VP;
+        const int row = 4 * (isv ? q : q - VP) + prow;
+        const int chunk16 = pslot ^ (row & 15);
+        pv_off[j] = ((isv ? t0 : k0) + row) * p.C * 4 + chunk16 * 16;
+    }
+    const int compV = p.T * p.C * 4, compU = p.K * p.C * 4;     // bytes per component
+    int d_cc = 0, d_sV = 0, d_sU = 0, d_left = 36 * p.chunks, d_buf = 0;
+    auto issue = [&]() {
+        const bool live = d_left > 0;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int q = wave + NW * j;
+            const bool isv = q < VP;
+            char* dst = smem + d_buf * W4_SLOT + (isv ? q * 1024 : V_BYTES + (q - VP) * 1024);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(isv ? rV : rU, (lds_ptr_t)dst, 16, live ? pv_off[j] : W4_OOB, isv ? d_sV : d_sU,
+                                                     0, 0);
+        }
+        d_left -= 1;
+        d_buf = (d_buf + 1) & (W4_NBUF - 1);
+        d_cc += 1;
+        if (d_cc == p.chunks) {
+            d_cc = 0;
+            d_sV += compV - (p.chunks - 1) * 256;
+            d_sU += compU - (p.chunks - 1) * 256;
+        } else {
+            d_sV += 256;
+            d_sU += 256;
+        }
+    };
+
+    // ---- fragment addresses: lane (r = lane % 16, g = lane / 16) reads row 16 grp + r, 16-byte slot (4 kb + g) ^ r of the
+    // chunk; one register per 16-channel block and operand, the chunk's buffer is the instruction's immediate offset (0 or one
+    // slot) and the PAIR of buffers a flip of bit 16 in the registers every second chunk
+    const int r15 = lane & 15, g = lane >> 4;
+    const int lo = ((g ^ (r15 & 3)) << 4), h2 = (r15 >> 2) & 3;
+    int aV[4], aU[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        aV[kb] = (16 * tw + r15) * 256 + lo + ((kb ^ h2) << 6);
+        aU[kb] = V_BYTES + (16 * kw + r15) * 256 + lo + ((kb ^ h2) << 6);
+    }
+
+    f32x4 Y[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Y[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 fu[2], fv[2];
+    auto frags = [&](int par, int kb, int slot) {
+        fu[slot] = *(const f32x4*)(smem + aU[kb] + par * W4_SLOT);
+        fv[slot] = *(const f32x4*)(smem + aV[kb] + par * W4_SLOT);
+    };
+    // four accumulator chains (one per product of a 16-channel block): a product never waits for the one issued before it
+    f32x4 Mc[4];
+    auto mm = [&](int slot) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Mc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fu[slot][t], fv[slot][t], Mc[t], 0, 0, 0);
+    };
+    // issue order of a 16-channel block: the two fragment reads of the NEXT block go out behind the first two products of this
+    // one (left to the compiler they are sunk below the products that free their registers: the LDS latency fully exposed)
+    auto order = [&]() {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int dbg_n = 0;
+    (void)dbg_n;
+    issue();
+    issue();
+    issue();
+    W4_WAIT_VM(2 * PPW);
+    W4_BARRIER();
+    frags(0, 0, 0);
+    // one chunk of 64 reduction channels out of buffer `par` of the current pair; the first fragments are in slot 0
+    auto chunk = [&](auto PAR) {
+        constexpr int par = decltype(PAR)::value;
+        frags(par, 1, 1);
+        mm(0);
+        order();
+        frags(par, 2, 0);
+        mm(1);
+        order();
+        // chunk s+1 published, the buffer of chunk s-1 free: its pieces (chunk s+3) leave now
+        W4_STAMP();
+        W4_WAIT_VM(PPW);
+        W4_STAMP();
+        W4_BARRIER();
+        W4_STAMP();
+        issue();
+        frags(par, 3, 1);
+        mm(0);
+        order();
+        if (par == 1) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                aV[kb] ^= 2 * W4_SLOT;
+                aU[kb] ^= 2 * W4_SLOT;
+            }
+        }
+        frags(par ^ 1, 0, 0);
+        mm(1);
+        order();
+    };
+    auto component = [&](auto LI, auto MI) {
+        constexpr int l = decltype(LI)::value, m = decltype(MI)::value;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Mc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int cc = 0; cc < p.chunks; cc += 2) {
+            chunk(std::integral_constant<int, 0>{});
+            chunk(std::integral_constant<int, 1>{});
+        }
+        const f32x4 M = (Mc[0] + Mc[1]) + (Mc[2] + Mc[3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float c = W4_AT[i][l] * W4_AT[j][m];
+                if (c != 0.f) {
+                    if (c == 1.f) Y[4 * i + j] += M;
+                    else if (c == -1.f) Y[4 * i + j] -= M;
+                    else {
+                        Y[4 * i + j][0] = __builtin_fmaf(c, M[0], Y[4 * i + j][0]);
+                        Y[4 * i + j][1] = __builtin_fmaf(c, M[1], Y[4 * i + j][1]);
+                        Y[4 * i + j][2] = __builtin_fmaf(c, M[2], Y[4 * i + j][2]);
+                        Y[4 * i + j][3] = __builtin_fmaf(c, M[3], Y[4 * i + j][3]);
+                    }
+                    // opaque: the update stays HERE (left alone, the compiler sinks the 36 updates to the epilogue and
+                    // keeps every component's M alive until then - 144 registers, spilled)
+                    asm volatile("" : "+v"(Y[4 * i + j]));
+                }
+            }
+    };
+    auto row = [&](auto LI) {
+        component(LI, std::integral_constant<int, 0>{});
+        component(LI, std::integral_constant<int, 1>{});
+        component(LI, std::integral_constant<int, 2>{});
+        component(LI, std::integral_constant<int, 3>{});
+        component(LI, std::integral_constant<int, 4>{});
+        component(LI, std::integral_constant<int, 5>{});
+    };
+    row(std::integral_constant<int, 0>{});
+    row(std::integral_constant<int, 1>{});
+    row(std::integral_constant<int, 2>{});
+    row(std::integral_constant<int, 3>{});
+    row(std::integral_constant<int, 4>{});
+    row(std::integral_constant<int, 5>{});
+    W4_STAMP();
+    __builtin_amdgcn_s_waitcnt(0);       // the trailing (out-of-range) pieces have landed before the buffers are reused
+
+    // ---- epilogue: lane = (tile t0 + 16 tw + r15, channels k0 + 16 kw + 4 g .. + 3) ----
+    // every tensor of the output's shape goes through a buffer descriptor: one 32-bit lane offset (out of range for a lane
+    // without a tile / channels: its stores are dropped, its loads return 0; an absent tensor is a descriptor of 0 bytes) +
+    // a wave-uniform offset per output position. The operands of the four positions of an output row are loaded together.
+    const int t = t0 + 16 * tw + r15;
+    const int kc = k0 + 16 * kw + 4 * g;
+    const bool valid = t < p.T && kc < p.K;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ssum = z, ssq = z;
+    {
+        const int tx = t % p.TW;
+        const int ty = (t / p.TW) % p.TH;
+        const int n = t / (p.TW * p.TH);
+        const int voff = valid ? (((n * p.H + 4 * ty) * p.W + 4 * tx) * p.K + kc) * 4 : W4_OOB;
+        const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.add, 0, p.add ? p.y_bytes : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_x, 0, p.bs_x ? p.y_bytes : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_y, 0, p.bs_y ? p.y_bytes : 0u, 0x00020000);
+        const int kcs = valid ? kc : 0;
+        f32x4 b = z;
+        if (p.bias) b = *(const f32x4*)(p.bias + kcs);
+        const float floor_ = p.relu ? 0.f : -__builtin_inff();
+        f32x4 bmu = z, bis = z, bsc = z, bsh = z;
+        if (EP == 2) {
+            bmu = *(const f32x4*)(p.bs_mean + kcs);
+            bis = *(const f32x4*)(p.bs_invstd + kcs);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bsc[c] = (p.bs_gamma ? p.bs_gamma[kcs + c] : 1.f) * bis[c];
+                bsh[c] = (p.bs_beta ? p.bs_beta[kcs + c] : 0.f) - bmu[c] * bsc[c];
+            }
+        }
+        // the ReLU mask of the backward sums: from the forward output (bs_y), recomputed from x, or none
+        const bool mask_y = p.bs_relu && p.bs_y, mask_x = p.bs_relu && !p.bs_y;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 av[4], xv[4], yv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int soff = (i * p.W + j) * p.K * 4;
+                av[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, soff, 0));
+                if (EP == 2) {
+                    xv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, voff, soff, 0));
+                    yv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, voff, soff, 0));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int soff = (i * p.W + j) * p.K * 4;
+                f32x4 acc = (Y[4 * i + j] + b) + av[j];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = fmaxf(acc[c], floor_);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc), rY, voff, soff, 0);
+                if (EP == 2) {
+                    f32x4 gq;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float mk = mask_y ? yv[j][c] : (mask_x ? fmaf(xv[j][c], bsc[c], bsh[c]) : 1.f);
+                        gq[c] = mk > 0.f ? acc[c] : 0.f;
+                        ssq[c] += gq[c] * ((xv[j][c] - bmu[c]) * bis[c]);
+                    }
+                    ssum += gq;
+                } else if (EP == 1) {
+                    ssum += acc;
+                    ssq += acc * acc;
+                }
+            }
+        }
+        if (!valid) {
+            ssum = z;
+            ssq = z;
+        }
+    }
+    W4_STAMP();
+    if (EP == 0) return;
+    // the 16 values of a lane were added in fp32; from here on doubles: over the 16 tiles of the wave (shuffles inside each
+    // group of 16 lanes), then over the tile waves through LDS in wave order
+    double ds[8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        ds[c] = (double)ssum[c];
+        ds[4 + c] = (double)ssq[c];
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) ds[c] += __shfl_xor(ds[c], off, 64);
+    __syncthreads();
+    double* red = (double*)smem;                  // [tile wave][2][64 channels]
+    if (r15 == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            red[(tw * 2 + 0) * 64 + 16 * kw + 4 * g + c] = ds[c];
+            red[(tw * 2 + 1) * 64 + 16 * kw + 4 * g + c] = ds[4 + c];
+        }
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int which = tid >> 6, ch = tid & 63;
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < TB / 16; ++w) a += red[(w * 2 + which) * 64 + ch];
+        if (k0 + ch < p.K) p.stats[((long)tblk * 2 + which) * p.K + k0 + ch] = a;
+    }
+}
+
+template <int EP>
+__global__ __launch_bounds__(1024) void wino4f_kernel_64(const W4Params p) {
+    wino4f_body<64, EP>(p);
+}
+template <int EP>
+__global__ __launch_bounds__(512, 2) void wino4f_kernel_32(const W4Params p) {
+    wino4f_body<32, EP>(p);
+}
+
+int g_w4_mode = -1;
+unsigned long long* g_w4_dbg = nullptr;       // -1: DENET_WINO4F / DENET_WINO4F_TB from the environment; 0: off; 32 / 64: that tile block wherever it fits
+
+}  // namespace
+
+// tests / experiments: overrides the environment's choice of the fused F(4x4) kernel (-1 restores it); returns the old value
+extern "C" int denet_conv_wino4f_debug(unsigned long long* buf) { g_w4_dbg = buf; return 0; }
+extern "C" int denet_conv_wino4f_mode(int mode) {
+    const int old = g_w4_mode;
+    g_w4_mode = (mode == 0 || mode == 32 || mode == 64) ? mode : -1;
+    return old;
+}
+
+// the tile-block size the fused kernel would use for this problem (0: the un-fused path runs): a launch has to fill the chip
+// with ONE round of workgroups, each of which walks all 36 components
+int denet_wino4f_block(int tile, long T, int C, int K) {
+    if (tile != 4 || C % 128 != 0 || K % 64 != 0 || T <= 0 || T * 64 * K >= (1L << 31)) return 0;
+    static const int env_on = [] { const char* e = getenv("DENET_WINO4F"); return e ? atoi(e) : 1; }();
+    static const int env_tb = [] { const char* e = getenv("DENET_WINO4F_TB"); return e ? atoi(e) : 0; }();
+    const int mode = g_w4_mode >= 0 ? g_w4_mode : (env_on ? env_tb : 0);
+    if (g_w4_mode < 0 && !env_on) return 0;
+    if (g_w4_mode == 0) return 0;
+    if (mode == 32 || mode == 64) return mode;
+    const long kb = K / 64;
+    if (((T + 63) / 64) * kb >= 224) return 64;
+    return 0;
+}
+
+// rows of partial statistics the fused kernel writes for this problem
+int denet_wino4f_stats_rows(int tb, long T) { return (int)((T + tb - 1) / tb); }
+
+int denet_wino4f_run(int tb, const float* V, const float* U, const float* bias, const float* add, float* y, double* stats,
+                     const float* bs_x, const float* bs_y, const float* bs_gamma, const float* bs_beta, const float* bs_mean,
+                     const float* bs_invstd, int bs_relu, int N, int H, int W, int C, int K, int relu, hipStream_t stream) {
+    DENET_CHECK_ARG(V && U && y && (tb == 32 || tb == 64), "conv_wino4f: bad arguments");
+    DENET_CHECK_ARG(H % 4 == 0 && W % 4 == 0 && C % 128 == 0 && K % 64 == 0, "conv_wino4f: unsupported geometry");
+    W4Params p = {};
+    p.V = V; p.U = U; p.bias = bias; p.add = add; p.y = y; p.stats = stats;
+    p.bs_x = bs_x; p.bs_y = bs_y; p.bs_gamma = bs_gamma; p.bs_beta = bs_beta; p.bs_mean = bs_mean; p.bs_invstd = bs_invstd;
+    p.bs_relu = bs_relu;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.TH = H / 4; p.TW = W / 4;
+    const long T = (long)N * p.TH * p.TW;
+    const size_t vb = (size_t)36 * T * C * 4, ub = (size_t)36 * K * C * 4;
+    DENET_CHECK_ARG(vb < 0xE0000000ul && ub < 0xE0000000ul, "conv_wino4f: operand too large for a buffer descriptor");
+    p.T = (int)T; p.relu = relu; p.tiles_k = K / 64; p.chunks = C / 64;
+    p.dbg = g_w4_dbg;
+    p.v_bytes = (unsigned)vb; p.u_bytes = (unsigned)ub; p.y_bytes = (unsigned)((size_t)T * 16 * K * 4);
+    const int tiles_t = (int)((T + tb - 1) / tb);
+    const int lds = W4_NBUF * W4_SLOT;
+    const int ep = !stats ? 0 : (bs_x ? 2 : 1);
+    typedef void (*kern_t)(const W4Params);
+    static const kern_t kerns[2][3] = {{wino4f_kernel_32<0>, wino4f_kernel_32<1>, wino4f_kernel_32<2>},
+                                       {wino4f_kernel_64<0>, wino4f_kernel_64<1>, wino4f_kernel_64<2>}};
+    static bool attr_done[2][3] = {};
+    const kern_t fn = kerns[tb == 64][ep];
+    if (!attr_done[tb == 64][ep]) {
+        const hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            denet_set_error("conv_wino4f: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+            return -(int)e;
+        }
+        attr_done[tb == 64][ep] = true;
+    }
+    const int prof = denet_prof_begin(12, tb, 64, W4_NBUF, stream);
+    hipLaunchKernelGGL(fn, dim3((unsigned)(tiles_t * p.tiles_k)), dim3(tb * 16), lds, stream, p);
+    denet_prof_end(prof, stream);
+    DENET_CHECK_LAUNCH("conv_wino4f");
+    return DENET_OK;
+}

@@ -26,6 +26,13 @@ int denet_wgrad_batched(const float* x, const float* dy, float* dw, float* works
 int denet_wgrad_batched_tune(const float* x, const float* dy, float* dw, float* workspace, size_t workspace_bytes, int batch,
                              int T, int Cc, int Kr, hipStream_t stream);
 
+// wino4f.hip: F(4x4) products + output transform in one kernel
+int denet_wino4f_block(int tile, long T, int C, int K);
+int denet_wino4f_stats_rows(int tb, long T);
+int denet_wino4f_run(int tb, const float* V, const float* U, const float* bias, const float* add, float* y, double* stats,
+                     const float* bs_x, const float* bs_y, const float* bs_gamma, const float* bs_beta, const float* bs_mean,
+                     const float* bs_invstd, int bs_relu, int N, int H, int W, int C, int K, int relu, hipStream_t stream);
+
 namespace {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
@@ -801,14 +808,31 @@ int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u
             return -(int)e;
         }
     }
-    rc = denet_gemm_batched_nt(V, U, Mx, d.NX, (int)d.T, Cout, Cin, d.T * Cin, kc, d.T * Cout, stream);
-    if (rc) return rc;
     // out_sums (with stats): the sums written are the backward reductions of the batch norm whose output gradient `out` is
     BnFoldDev bs = {};
     if (out_sums && stats) bs = *out_sums;
+    if (const int tb4 = denet_wino4f_block(mo, d.T, Cin, Cout))      // products + output transform in one kernel: no M
+        return denet_wino4f_run(tb4, V, U, bias, add, out, stats, bs.x, bs.y, bs.gamma, bs.beta, bs.mean, bs.invstd, bs.relu, N, H, W,
+                                Cin, Cout, relu, stream);
+    rc = denet_gemm_batched_nt(V, U, Mx, d.NX, (int)d.T, Cout, Cin, d.T * Cin, kc, d.T * Cout, stream);
+    if (rc) return rc;
     WINO_LAUNCH(mo, wino_output_kernel, d.T * (Cout / 4), Mx, bias, add, out, N, H, W, Cout, d.TH, d.TW, d.T, relu, stats, bs);
     DENET_CHECK_LAUNCH("conv_wino output");
     return DENET_OK;
+}
+
+// rows of partial column sums the output side of a pass writes ([rows][2][Kout] doubles), 0 = this pass cannot: the fused
+// F(4x4) kernel leaves one row per tile block, the output transform one per 256 threads (needs 256 % (Kout / 4) == 0)
+int wino_stats_rows(int tile, int N, int H, int W, int Cin, int Kout, size_t stats_bytes) {
+    const long T = (long)N * (H / tile) * (W / tile);
+    long rows;
+    if (const int tb4 = denet_wino4f_block(tile, T, Cin, Kout)) rows = denet_wino4f_stats_rows(tb4, T);
+    else {
+        const int k4n = Kout / 4;
+        if (!(k4n > 0 && k4n <= 256 && 256 % k4n == 0)) return 0;
+        rows = (T * k4n + 255) / 256;
+    }
+    return stats_bytes >= (size_t)rows * 2 * Kout * sizeof(double) ? (int)rows : 0;
 }
 
 }  // namespace
@@ -883,11 +907,8 @@ extern "C" int denet_conv_wino_fwd_fold(const denet_bn_link* bn, const float* w,
     double* st = nullptr;
     if (stats_partial) {
         DENET_CHECK_ARG(stats_rows && !relu, "conv_wino_fwd_fold: bad statistics arguments");
-        const int k4n = K / 4;
-        const long rows = ((long)N * (H / tile) * (W / tile) * k4n + 255) / 256;
-        const bool ok = k4n > 0 && k4n <= 256 && 256 % k4n == 0 && stats_bytes >= (size_t)rows * 2 * K * sizeof(double);
-        *stats_rows = ok ? (int)rows : 0;
-        st = ok ? stats_partial : nullptr;
+        *stats_rows = wino_stats_rows(tile, N, H, W, C, K, stats_bytes);
+        st = *stats_rows ? stats_partial : nullptr;
     }
     return wino_run(tile, false, nullptr, w, u_cached, v_keep, bias, add, y, workspace, workspace_bytes, N, H, W, C, K, stream,
                     relu ? 1 : 0, st, &f);
@@ -901,17 +922,14 @@ extern "C" int denet_conv_wino_fwd_fold(const denet_bn_link* bn, const float* w,
 // y = its forward output or NULL, gamma / beta / mean / invstd, relu); the output transform then also writes that layer's two
 // backward reductions, stats_partial [rows][2][C] doubles (*stats_rows = 0: this channel count is not supported, no sums)
 static int sums_request(const denet_bn_link* sums_of, double* stats_partial, size_t stats_bytes, int* stats_rows, int tile, int N,
-                        int H, int W, int C, BnFoldDev* bs, double** st) {
+                        int H, int W, int C, int K, BnFoldDev* bs, double** st) {
     *st = nullptr;
     if (!sums_of) return DENET_OK;
     DENET_CHECK_ARG(stats_partial && stats_rows, "conv_wino dgrad: the backward sums need a buffer");
     DENET_CHECK_ARG(sums_of->x && sums_of->mean && sums_of->invstd && (!sums_of->relu || sums_of->y || (sums_of->gamma && sums_of->beta)),
                     "conv_wino dgrad: incomplete batch-norm description for the backward sums");
-    const int k4n = C / 4;
-    const long rows = ((long)N * (H / tile) * (W / tile) * k4n + 255) / 256;
-    const bool ok = k4n > 0 && k4n <= 256 && 256 % k4n == 0 && stats_bytes >= (size_t)rows * 2 * C * sizeof(double);
-    *stats_rows = ok ? (int)rows : 0;
-    if (ok) {
+    *stats_rows = wino_stats_rows(tile, N, H, W, K, C, stats_bytes);
+    if (*stats_rows) {
         *bs = BnFoldDev{};
         bs->x = sums_of->x; bs->y = sums_of->relu ? sums_of->y : nullptr; bs->gamma = sums_of->gamma; bs->beta = sums_of->beta;
         bs->mean = sums_of->mean; bs->invstd = sums_of->invstd; bs->relu = sums_of->relu;
@@ -928,7 +946,7 @@ extern "C" int denet_conv_wino_dgrad_fold(const denet_bn_link* bn, float* dm_out
     double* st;
     int rc = fold_from(bn, true, &f);
     if (rc) return rc;
-    rc = sums_request(sums_of, stats_partial, stats_bytes, stats_rows, tile, N, H, W, C, &bs, &st);
+    rc = sums_request(sums_of, stats_partial, stats_bytes, stats_rows, tile, N, H, W, C, K, &bs, &st);
     if (rc) return rc;
     return wino_run(tile, true, nullptr, w, u_cached, nullptr, nullptr, add, dx, workspace, workspace_bytes, N, H, W, K, C, stream,
                     0, st, &f, dm_out, (hipEvent_t)transform_done_event, st ? &bs : nullptr);
@@ -941,7 +959,7 @@ extern "C" int denet_conv_wino_dgrad_sums(const float* dy, const float* w, const
                                           hipStream_t stream) {
     BnFoldDev bs;
     double* st;
-    int rc = sums_request(sums_of, stats_partial, stats_bytes, stats_rows, tile, N, H, W, C, &bs, &st);
+    int rc = sums_request(sums_of, stats_partial, stats_bytes, stats_rows, tile, N, H, W, C, K, &bs, &st);
     if (rc) return rc;
     return wino_run(tile, true, dy, w, u_cached, nullptr, nullptr, add, dx, workspace, workspace_bytes, N, H, W, K, C, stream, 0, st,
                     nullptr, nullptr, nullptr, st ? &bs : nullptr);
@@ -1001,11 +1019,8 @@ extern "C" int denet_conv_wino_fwd_stats_up(const float* x_small, const float* w
     double* st = nullptr;
     if (stats_partial) {
         DENET_CHECK_ARG(stats_rows, "conv_wino_fwd_stats_up: null pointer");
-        const int k4n = K / 4;
-        const long rows = ((long)N * (H / tile) * (W / tile) * k4n + 255) / 256;
-        const bool ok = k4n > 0 && k4n <= 256 && 256 % k4n == 0 && stats_bytes >= (size_t)rows * 2 * K * sizeof(double);
-        *stats_rows = ok ? (int)rows : 0;
-        st = ok ? stats_partial : nullptr;
+        *stats_rows = wino_stats_rows(tile, N, H, W, C, K, stats_bytes);
+        st = *stats_rows ? stats_partial : nullptr;
     }
     return wino_run(tile, false, x_small, w, u_cached, v_keep, bias, add, y, workspace, workspace_bytes, N, H, W, C, K, stream, 0, st,
                     nullptr, nullptr, nullptr, nullptr, 1);
@@ -1016,13 +1031,9 @@ extern "C" int denet_conv_wino_fwd_stats(const float* x, const float* w, const f
                                          size_t stats_bytes, int* stats_rows, float* workspace, size_t workspace_bytes,
                                          int tile, int N, int H, int W, int C, int K, hipStream_t stream) {
     DENET_CHECK_ARG(stats_partial && stats_rows && (tile == 2 || tile == 4), "conv_wino_fwd_stats: bad arguments");
-    const int k4n = K / 4;
-    const long threads = (long)N * (H / tile) * (W / tile) * k4n;
-    const long rows = (threads + 255) / 256;
-    const bool ok = k4n > 0 && k4n <= 256 && 256 % k4n == 0 && stats_bytes >= (size_t)rows * 2 * K * sizeof(double);
-    *stats_rows = ok ? (int)rows : 0;
+    *stats_rows = wino_stats_rows(tile, N, H, W, C, K, stats_bytes);
     return wino_run(tile, false, x, w, u_cached, v_keep, bias, add, y, workspace, workspace_bytes, N, H, W, C, K, stream, 0,
-                    ok ? stats_partial : nullptr);
+                    *stats_rows ? stats_partial : nullptr);
 }
 
 // transformed filters of a layer, prepared ahead of its passes (e.g. for all layers on a side stream right after the

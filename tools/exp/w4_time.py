@@ -1,0 +1,58 @@
+"""Fused F(4x4) product + output-transform kernel (csrc/wino4f.hip) against the un-fused passes: same inputs, difference and
+time per pass (every kernel alone on the chip). usage: python tools/exp/w4_time.py [B]"""
+import os, sys, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from denet_amd import ops
+from denet_amd.lib import load
+
+L = load()
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+GEOMS = [("l2_3x3", 64, 64, 128, 128), ("up2_3x3", 64, 64, 256, 128), ("l3_3x3", 32, 32, 256, 256), ("up1_3x3", 32, 32, 512, 256),
+         ("l4_3x3", 16, 16, 512, 512)]
+if os.environ.get("W4_GEOMS"):
+    GEOMS = [g for g in GEOMS if g[0] in os.environ["W4_GEOMS"].split(",")]
+
+
+def timeit(fn, iters=10):
+    fn(); fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+
+
+for name, H, W, C, K in GEOMS:
+    torch.manual_seed(1)
+    x = torch.randn(B, H, W, C, device="cuda")
+    w = torch.randn(K, 3, 3, C, device="cuda") * 0.05
+    bias = torch.randn(K, device="cuda")
+    add = torch.randn(B, H, W, K, device="cuda")
+    dy = torch.randn(B, H, W, K, device="cuda")
+    u = ops.conv_wino_filter(w, 4, dgrad=False)
+    ud = ops.conv_wino_filter(w, 4, dgrad=True)
+    res = {}
+    for mode in (0, 64, 32):
+        L.denet_conv_wino4f_mode(mode)
+        cache = {}
+        st = torch.zeros(1 << 22, dtype=torch.float64, device="cuda")
+        y = ops.conv_wino_fwd(x, w, bias, add, tile=4, u=u, stats=(st, cache))
+        stt, rows = cache["bn_stats"]
+        sums = stt[: rows * 2 * K].view(rows, 2, K).sum(0).clone()
+        dx = ops.conv_wino_dgrad(dy, w, tile=4, u=ud)
+        tf = timeit(lambda: ops.conv_wino_fwd(x, w, bias, add, tile=4, u=u, stats=(st, cache)))
+        td = timeit(lambda: ops.conv_wino_dgrad(dy, w, tile=4, u=ud))
+        res[mode] = (y.clone(), dx.clone(), sums, tf, td, rows)
+    L.denet_conv_wino4f_mode(-1)
+    y0, dx0, s0, tf0, td0, r0 = res[0]
+    flop = 2.0 * B * H * W * C * K * 9 / 4
+    line = "%-8s B=%d  unfused fwd %6.1f us dgrad %6.1f us |" % (name, B, tf0, td0)
+    for mode in (64, 32):
+        y1, dx1, s1, tf1, td1, r1 = res[mode]
+        ey = float((y1 - y0).abs().max() / y0.abs().max())
+        ed = float((dx1 - dx0).abs().max() / dx0.abs().max())
+        es = float(((s1 - s0).abs() / (s0.abs() + 1e-3 * s0.abs().max())).max())
+        line += " TB%d fwd %6.1f us (%.0f TF) dgrad %6.1f us err y %.1e dx %.1e sums %.1e rows %d |" % (mode, tf1, flop / tf1 / 1e6, td1, ey, ed, es, r1)
+    print(line, flush=True)
