@@ -20,8 +20,13 @@ Extra legs (rank 0, N=1 only; outside the timed region):
                 the threshold; the second takes the max_corners truncation branch): RoI proposal on the GPU, host hand-off
                 phases under the reference's names.
   split_bf16    OPT-IN variant, never the headline: the head GEMMs as 3-term bf16 splits (own key, own number).
-  cpu_baseline  the numpy/C++ oracle (oracle/, a CPU restatement of the reference path, kind "port") runs ONE
-                training step of the same model at batch 1 on the host cores.
+  config2 / config5
+                BASELINE.json's secondary configurations as legs of this line (a few seconds each): ResNet-34 224x224 batch
+                64 (examples/resnet34-imagenet.sh:7) and DeNet-101 wide 512x512 batch 16 with joint fitness + bounded-IoU
+                loss, `DND.JB` (papers/dss/denet101.sh:19): images/sec of full training steps and the executed-FLOP matrix
+                utilisation.
+  cpu_baseline  the numpy/C++ oracle (oracle/, a CPU restatement of the reference path, kind "port") runs full training
+                steps of the same model at batch 4 on the host cores (CPU model and core count stated).
 """
 import argparse
 import json
@@ -64,6 +69,48 @@ def host_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def config_leg(name, model, x, metas, steps, warm):
+    """images/sec of full training steps of a secondary configuration + the FLOPs its matrix kernels execute (KernelProfile:
+    every implicit-GEMM / fused Winograd launch of one extra step, Winograd layers with their reduced products)"""
+    import torch
+    from denet_amd import ops
+    model.build_train_func("nesterov")
+    xd = torch.from_numpy(x).cuda()
+    random.seed(1)
+    it = 0
+    for _ in range(warm):
+        model.train_step(xd, metas, 0, it, 0.05, [0.9], 1e-4)
+        it += 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cost, _ = model.train_step(xd, metas, 0, it, 0.05, [0.9], 1e-4)
+        it += 1
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    prof = ops.KernelProfile()
+    ops.PROFILE = prof
+    model.train_step(xd, metas, 0, it, 0.05, [0.9], 1e-4)
+    ops.PROFILE = None
+    executed = sum(a["flops"] for a in prof.summary().values())
+    B = x.shape[0]
+    return {"workload": name, "batch": B, "value": round(B / dt, 1), "unit": "images/sec", "ms_per_step": round(1e3 * dt, 2),
+            "steps": steps, "warmup": warm, "dtype": "f32", "step_gflop_executed_per_image": round(executed / B / 1e9, 2),
+            "step_mfma_util_executed": round(executed / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "final_cost": round(float(cost), 5)}
 
 
 def self_launch(n):
@@ -207,6 +254,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-warm", action="store_true", help="skip the warm / stress corner-regime legs (rank 0, N=1)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the config2 / config5 legs (rank 0, N=1)")
     ap.add_argument("--no-split-bf16", action="store_true",
                     help="skip the leg of the OPT-IN variant (head GEMMs as 3-term bf16 splits; own key, never the headline)")
     ap.add_argument("--regime", default="cold", choices=["cold", "warm"],
@@ -273,6 +321,7 @@ def main():
         dp.start_timing()
     dns_layer = [l for l in model.layers if l.type_name == "denet-sparse"][0]
     dns_layer.proposed_total = dns_layer.proposed_steps = 0
+    dns_layer.handoff_modes = {k: 0 for k in dns_layer.handoff_modes}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         cost, _ = model.train_step(xd, metas, 0, it, lr, mom, decay)
@@ -323,6 +372,8 @@ def main():
                                    if args.regime == "cold" else "warm"),
                    "global_batch": BATCH_PER_GPU * world, "batch_per_gpu": BATCH_PER_GPU, "classes": 80,
                    "rois_per_image": 576, "detector_rois_per_image_in_the_timed_steps": round(det_rois, 1),
+                   # which form of the RoI hand-off each timed step took (denet_amd/layer/roi_handoff.py)
+                   "handoff_modes": dict(dns_layer.handoff_modes),
                    "parallelism": "dp%d" % world, "solver": "nesterov",
                    "conv_algorithms": "fp32 throughout; per layer and pass the fastest of the direct implicit GEMM, "
                                       "Winograd F(2x2,3x3)/F(4x4,3x3) and (64 input channels) F(2x2,3x3) fused into one "
@@ -374,11 +425,38 @@ def main():
         # exercises the RoI proposal for real: "warm" = a few hundred corners per type and image (pair search of
         # denet_sparse.cc:337-373, top-576 selection, random.sample trim), "stress" = more than max_corners = 1024 cells per
         # type above the threshold (the truncation branch, denet_sparse.cc:526-530, then up to 2 x 1024^2 pairs per image)
-        del model
+        try:
+            del model
+        except NameError:
+            pass
         torch.cuda.empty_cache()
         for key, target in (("warm_regime", 40.0), ("stress_regime", 1400.0)):
             try:
                 out[key] = regime_leg(args, xd, metas, target, lr, mom, decay)
+            except Exception as exc:          # an extra leg must never cost the headline line
+                out[key] = {"error": repr(exc)[:300]}
+            torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_configs:
+        # BASELINE.json configs 2 and 5 (parity-test cases; their throughput rides along so that a driver-run record carries it)
+        try:
+            del model
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        for key in ("config2", "config5"):
+            try:
+                if key == "config2":
+                    mc = zoo.resnet34(64, 224, 1000)
+                    xc, mtc = zoo.synthetic_batch(64, 224, 1000, seed=1, image_class=True)
+                    out[key] = config_leg("ResNet-34 backbone + classifier 224x224 (examples/resnet34-imagenet.sh:7), full train step, "
+                                          "algorithmic 22.0 GFLOP per image and step", mc, xc, mtc, 8, 3)
+                else:
+                    mc = zoo.denet101(16, "wide", 512, 80, head_desc=zoo.DENET101_WIDE_DESC.replace("DND[0.5,1,1]", "DND.JB[0.5,1,1]"))
+                    xc, mtc = zoo.synthetic_batch(16, 512, 80, seed=1)
+                    out[key] = config_leg("DeNet-101 wide 512x512, 2304 RoIs per image, joint fitness + bounded-IoU loss DND.JB "
+                                          "(papers/dss/denet101.sh:19), full train step", mc, xc, mtc, 5, 2)
+                del mc
             except Exception as exc:          # an extra leg must never cost the headline line
                 out[key] = {"error": repr(exc)[:300]}
             torch.cuda.empty_cache()
@@ -428,21 +506,24 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import model as OM
         cores = host_cores()
-        m1 = zoo.denet34(1, "skip", 512, class_num=80, seed=1)
-        om = OM.OracleModel(m1.export_json(), 1)
-        x1, metas1 = zoo.synthetic_batch(1, 512, 80, seed=1)
+        CB = 4                                      # the CPU leg runs batch 4, scaled to images/sec
+        m1 = zoo.denet34(CB, "skip", 512, class_num=80, seed=1)
+        om = OM.OracleModel(m1.export_json(), CB)
+        x1, metas1 = zoo.synthetic_batch(CB, 512, 80, seed=1)
         random.seed(1)
         from threadpoolctl import threadpool_limits
         with threadpool_limits(limits=cores):      # BLAS threads = the cores this process may really use
             t0 = time.perf_counter()
             nsteps = 0
-            while nsteps < 8 and (nsteps == 0 or time.perf_counter() - t0 < 12.0):
+            while nsteps < 4 and (nsteps == 0 or time.perf_counter() - t0 < 14.0):
                 om.train_step(x1, metas1, nsteps, lr, mom[0], decay, "nesterov")
                 nsteps += 1
             cdt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": round(nsteps / cdt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-                               "sample": "%d full train steps at batch 1 of the same model (numpy im2col+BLAS conv, "
-                                         "C++ RoI proposal), %.1f s" % (nsteps, cdt)}
+        out["cpu_baseline"] = {"value": round(CB * nsteps / cdt, 4), "unit": "images/sec", "cores": cores, "cpu": cpu_model(),
+                               "kind": "port",
+                               "sample": "%d full train steps at batch %d of the same model (numpy im2col+BLAS conv, "
+                                         "C++ RoI proposal), %.1f s; a proxy for the reference's Theano CPU path, which "
+                                         "cannot run here (Theano is not installed)" % (nsteps, CB, cdt)}
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -594,183 +594,6 @@ static __global__ __launch_bounds__(256) void edit_samples_kernel(const int* __r
     }
 }
 
-// ---- the same with random.sample (an image proposes more than n_keep RoIs: the list keeps what random.sample(list, n_keep)
-// picks - CPython's pool branch: for i in range(k): j = _randbelow(n - i); result[i] = pool[j]; pool[j] = pool[n - i - 1], with
-// _randbelow(m) = getrandbits(m.bit_length()) until < m), in two kernels:
-//   edit_scan_kernel   one wave walks the images IN ORDER - how many generator outputs an image uses depends on the rejections of
-//                      its _randbelow calls, so an image's position in the stretch follows from the images before it. A window of
-//                      64 outputs is judged at once: lane l holds candidate r_l and is accepted iff r_l < m - (accepted before
-//                      l) - a triangular system solved by iterating the ballot to its fixed point (exact: lane l is final once the
-//                      lanes before it are; in practice 2-4 rounds); a window ends early where the k-th draw is made or m drops
-//                      below a power of two (the next candidate then has fewer bits). It writes the accepted values j_i and
-//                      where the image's random boxes start in the stretch;
-//   edit_apply_kernel  one workgroup per image replays the pool swaps on the j_i (one lane, LDS), then writes the bbox array
-//                      as edit_samples_kernel does, proposals through the picks.
-static __global__ __launch_bounds__(64) void edit_scan_kernel(const int* __restrict__ count, const uint32_t* __restrict__ mt_out, long n_out,
-                                                              long cursor0, int B, int S, int n_keep, int* __restrict__ sel,
-                                                              long* __restrict__ box_start, int* __restrict__ status) {
-    // the stretch is walked through an LDS window of 8192 outputs (a global load per 64-candidate window would cost its whole
-    // latency every time: the next window's position is only known when this one is judged)
-    constexpr int WIN = 8192;
-    __shared__ uint32_t win[WIN];
-    const int lane = threadIdx.x;
-    const unsigned long long below = (1ULL << lane) - 1ULL;
-    long pos = cursor0;
-    long base = -(long)WIN - 1;                  // stream index of win[0]: nothing loaded yet
-    bool bad = false;
-    for (int b = 0; b < B && !bad; ++b) {
-        const int n = count[b];
-        if (n < 0 || n > S) {
-            bad = true;
-            break;
-        }
-        int n_eff = n;
-        if (n > n_keep) {
-            const int k = n_keep;
-            int i = 0;
-            while (i < k) {
-                const int m = n - i;
-                const int bits = 32 - __clz(m);                               // m.bit_length()
-                const int cap_bits = m - (1 << (bits - 1)) + 1;               // draws that still see this bit length
-                const int cap = (k - i) < cap_bits ? (k - i) : cap_bits;
-                if (pos + 64 > n_out) {
-                    bad = true;
-                    break;
-                }
-                if (pos < base || pos + 64 > base + WIN) {               // refill from here on (128 loads per lane in flight)
-                    base = pos;
-                    for (int q0 = 0; q0 < WIN; q0 += 64 * 16) {          // 16 loads per lane in flight at a time
-                        uint32_t v[16];
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) {
-                            const long q = base + q0 + 64 * u + lane;
-                            v[u] = mt_out[q < n_out ? q : n_out - 1];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) win[q0 + 64 * u + lane] = v[u];
-                    }
-                    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): my LDS writes are done (one wave: no barrier)
-                }
-                const int r = (int)(win[pos - base + lane] >> (32 - bits));
-                unsigned long long acc = __ballot(r < m - lane);             // everybody before me accepted: a lower bound
-                for (int round = 0; round < 64; ++round) {
-                    const int before = __popcll(acc & below);
-                    const unsigned long long nxt = __ballot(r < m - before);
-                    if (nxt == acc) break;
-                    acc = nxt;
-                }
-                const int before = __popcll(acc & below);
-                const bool mine = (acc >> lane) & 1ULL;
-                const int total = __popcll(acc);
-                int consumed = 64, taken = total;
-                if (total >= cap) {                                           // the cap-th accepted candidate ends the window
-                    const unsigned long long hit = __ballot(mine && before == cap - 1);
-                    consumed = __ffsll((long long)hit);
-                    taken = cap;
-                }
-                if (mine && before < taken) sel[(long)b * n_keep + i + before] = r;
-                i += taken;
-                pos += consumed;
-            }
-            n_eff = k;
-        }
-        if (lane == 0) box_start[b] = pos;
-        pos += 8L * (S - n_eff);
-        if (pos > n_out) bad = true;
-    }
-    if (lane == 0) {
-        if (bad) atomicOr(status, 1);
-        status[1] = (int)(pos - cursor0);
-    }
-}
-
-static __global__ __launch_bounds__(256) void edit_apply_kernel(const int* __restrict__ box, const int* __restrict__ count, int H, int W,
-                                                                const uint32_t* __restrict__ mt_out, const int* __restrict__ sel,
-                                                                const long* __restrict__ box_start, const double* __restrict__ gt,
-                                                                const int* __restrict__ gt_off, int sample_gt, int S, int n_keep,
-                                                                float* __restrict__ out_bbox, const int* __restrict__ status) {
-    extern __shared__ int lds[];            // pool [S] | pick [S]
-    int* pool = lds;
-    int* pick = lds + S;
-    const int b = blockIdx.x;
-    if (status[0] != 0) return;             // the scan gave up: the host must not use the result
-    int n = count[b];
-    if (n > n_keep) {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) pool[i] = i;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int* js = sel + (long)b * n_keep;
-            for (int i = 0; i < n_keep; ++i) {
-                const int j = js[i];
-                pick[i] = pool[j];
-                pool[j] = pool[n - i - 1];
-            }
-        }
-        __syncthreads();
-        n = n_keep;
-    } else {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) pick[i] = i;
-        __syncthreads();
-    }
-    const long first = box_start[b];
-    const int g0 = sample_gt ? gt_off[b] : 0, ng = sample_gt ? gt_off[b + 1] - g0 : 0;
-    for (int i = threadIdx.x; i < S; i += blockDim.x) {
-        float* o = out_bbox + ((long)b * S + i) * 4;
-        if (i >= S - ng) {
-            const double* g = gt + (long)(g0 + (S - 1 - i)) * 4;
-            o[0] = (float)g[0]; o[1] = (float)g[1]; o[2] = (float)g[2]; o[3] = (float)g[3];
-        } else if (i < n) {
-            const int* bx = box + ((long)b * S + pick[i]) * 4;
-            o[0] = (float)((double)bx[0] / W);
-            o[1] = (float)((double)bx[1] / H);
-            o[2] = (float)((double)(bx[2] + 1) / W);
-            o[3] = (float)((double)(bx[3] + 1) / H);
-        } else {
-            const uint32_t* m = mt_out + first + 8L * (i - n);
-            double r[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t a = m[2 * k] >> 5, c2 = m[2 * k + 1] >> 6;
-                r[k] = (a * 67108864.0 + c2) * (1.0 / 9007199254740992.0);
-            }
-            const double x0 = 0.0 + (1.0 - 0.0) * r[0];
-            const double y0 = 0.0 + (1.0 - 0.0) * r[1];
-            const double x1 = x0 + (1.0 - x0) * r[2];
-            const double y1 = y0 + (1.0 - y0) * r[3];
-            o[0] = (float)x0; o[1] = (float)y0; o[2] = (float)x1; o[3] = (float)y1;
-        }
-    }
-}
-
-// denet_edit_samples_device for ANY batch: images that propose more than n_keep RoIs are trimmed as random.sample would
-// (workspace: denet_edit_samples_sampled_workspace_bytes(B, n_keep) device bytes). status as there ([0] != 0: the stretch of
-// generator outputs was too short or a count out of range: out_bbox is not to be used).
-extern "C" size_t denet_edit_samples_sampled_workspace_bytes(int B, int n_keep) {
-    return (B > 0 && n_keep >= 0) ? (size_t)B * n_keep * sizeof(int) + (size_t)B * sizeof(long) + 64 : 0;
-}
-extern "C" int denet_edit_samples_device_sampled(const int* box, const int* count, int H, int W, const uint32_t* mt_out, long n_out,
-                                                 long cursor0, const double* gt, const int* gt_off, int sample_gt, int B, int S,
-                                                 int n_keep, float* out_bbox, int* status, void* workspace, size_t workspace_bytes,
-                                                 hipStream_t stream) {
-    DENET_CHECK_ARG(box && count && mt_out && out_bbox && status && workspace, "edit_samples_device_sampled: null pointer");
-    DENET_CHECK_ARG(!sample_gt || (gt && gt_off), "edit_samples_device_sampled: ground truth missing");
-    DENET_CHECK_ARG(B > 0 && S > 0 && S <= 8192 && n_keep >= 0 && n_keep <= S && H > 0 && W > 0 && n_out >= 0 && cursor0 >= 0,
-                    "edit_samples_device_sampled: bad sizes");
-    DENET_CHECK_ARG(workspace_bytes >= denet_edit_samples_sampled_workspace_bytes(B, n_keep), "edit_samples_device_sampled: workspace too small");
-    long* box_start = (long*)workspace;                                     // 8-byte aligned first
-    int* sel = (int*)((char*)workspace + (((size_t)B * sizeof(long) + 63) & ~(size_t)63));
-    hipError_t e = hipMemsetAsync(status, 0, 2 * sizeof(int), stream);
-    if (e != hipSuccess) {
-        denet_set_error("edit_samples_device_sampled: memset: %s", hipGetErrorString(e));
-        return -(int)e;
-    }
-    hipLaunchKernelGGL(edit_scan_kernel, dim3(1), dim3(64), 0, stream, count, mt_out, n_out, cursor0, B, S, n_keep, sel, box_start, status);
-    hipLaunchKernelGGL(edit_apply_kernel, dim3(B), dim3(256), (size_t)2 * S * sizeof(int), stream, box, count, H, W, mt_out, sel, box_start,
-                       gt, gt_off, sample_gt, S, n_keep, out_bbox, status);
-    DENET_CHECK_LAUNCH("edit_samples_device_sampled");
-    return DENET_OK;
-}
-
 // box [B][S][4] int32 and count [B]: denet_build_samples' outputs as they lie on the device; H, W: the corner map; mt_out [n_out]:
 // the generator outputs drawn ahead, cursor0 = how many of them earlier draws of the step have used; gt [n][4] doubles + gt_off
 // [B + 1] (sample_gt != 0); status [2] int32, zeroed here: [0] != 0 afterwards = an image proposed more than n_keep RoIs or the

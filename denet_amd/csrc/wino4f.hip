@@ -27,6 +27,7 @@ namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct W4Params {
     const float* V;      // [36][T][C]
@@ -57,6 +58,10 @@ constexpr float W4_AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 
 
 // s_waitcnt vmcnt(vm) only (lgkmcnt / expcnt left alone) and the compiler kept from moving memory operations across
 #define W4_WAIT_VM(vm) __builtin_amdgcn_s_waitcnt(((vm) & 15) | ((((vm) >> 4) & 3) << 14) | (7 << 4) | (15 << 8))
+#ifndef W4_EXP
+#define W4_EXP 0      // experiment builds (tools/exp/w4_trace_build.sh -DW4_EXP=bits): 1 no fragment reads, 2 no updates (one chain over all
+                      // components), 4 no barrier, 8 no DMA, 16 no products (the fragments are still read)
+#endif
 #ifdef W4_TRACE
 #define W4_STAMP() if (p.dbg && blockIdx.x == 0 && lane == 0 && dbg_n < 600) p.dbg[wave * 640 + dbg_n++] = __builtin_amdgcn_s_memtime()
 #else
@@ -140,18 +145,81 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
     }
 
     f32x4 Y[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) Y[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 fu[2], fv[2];
+    if (W4_EXP & 1) asm volatile("" : "=v"(fu[0]), "=v"(fu[1]), "=v"(fv[0]), "=v"(fv[1]));
     auto frags = [&](int par, int kb, int slot) {
+        if (W4_EXP & 1) return;
         fu[slot] = *(const f32x4*)(smem + aU[kb] + par * W4_SLOT);
         fv[slot] = *(const f32x4*)(smem + aV[kb] + par * W4_SLOT);
     };
-    // four accumulator chains (one per product of a 16-channel block): a product never waits for the one issued before it
-    f32x4 Mc[4];
-    auto mm = [&](int slot) {
+    // two accumulator chains (even / odd products of a 16-channel block): a product never waits for the one issued before
+    // it. ZC: the block starts a component (the chains start from zero: no clearing pass)
+    f32x4 Mc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    auto mm = [&](int slot, auto ZC) {
+        constexpr bool zc = decltype(ZC)::value && !(W4_EXP & 2);
+        if (W4_EXP & 16) {
+            asm volatile("" ::"v"(fu[slot]), "v"(fv[slot]));
+            return;
+        }
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) Mc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fu[slot][t], fv[slot][t], Mc[t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t)
+            Mc[t & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fu[slot][t], fv[slot][t], (zc && t < 2) ? z4 : Mc[t & 1], 0, 0, 0);
+    };
+    // The output transform in two stages, every multiply-add packed (v_pk_fma_f32): fp32 MFMA and fp32 vector instructions
+    // share the SIMD's multiply-add lanes on this chip - vector work is NOT hidden behind the products, every instruction of it
+    // is matrix time lost (measured: the one-stage update, <= 16 multiply-adds per value and component, doubled the kernel's
+    // run time). Row stage, per component (l, m):  Z[j] += AT[j][m] M          (<= 4 per value)
+    // column stage, per finished row l:           Y[i][j] += AT[i][l] Z[j]    (<= 16 per value, six times)
+    // = 180 multiply-adds per value instead of 324. Z / Y pass through an opaque asm after every update: left alone, the
+    // compiler sinks the updates to the epilogue and keeps every component's M alive until then (spilled).
+    f32x4 Z[4];
+    auto fma4 = [&](f32x4& acc, float c, const f32x4& v, bool first) {
+        f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+        f32x2 alo = {acc[0], acc[1]}, ahi = {acc[2], acc[3]};
+        const f32x2 cc = {c, c};
+        if (first) {
+            if (c != 1.f) { lo = lo * cc; hi = hi * cc; }
+            alo = lo; ahi = hi;
+        } else if (c == 1.f) { alo += lo; ahi += hi; }
+        else { alo = __builtin_elementwise_fma(lo, cc, alo); ahi = __builtin_elementwise_fma(hi, cc, ahi); }
+        acc = f32x4{alo[0], alo[1], ahi[0], ahi[1]};
+    };
+    auto update = [&](auto LI, auto MI) {
+        constexpr int l = decltype(LI)::value, m = decltype(MI)::value;
+        if (W4_EXP & 2) {
+            if (l == 5 && m == 5) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) Y[i] = Mc[0] + Mc[1];
+            }
+            return;
+        }
+        const f32x4 M = Mc[0] + Mc[1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float c = W4_AT[j][m];
+            // the first contribution to Z[j] of a row: m = 0 for j = 0, m = 1 for the others (AT[j][0] = 0)
+            const bool first = (j == 0) ? m == 0 : m == 1;
+            if (c != 0.f) {
+                fma4(Z[j], c, M, first);
+                asm volatile("" : "+v"(Z[j]));
+            }
+        }
+        if (m == 5) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float c = W4_AT[i][l];
+                // the first contribution to Y[i][.]: row 0 for i = 0, row 1 for the others
+                const bool first = (i == 0) ? l == 0 : l == 1;
+                if (c != 0.f) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        fma4(Y[4 * i + j], c, Z[j], first);
+                        asm volatile("" : "+v"(Y[4 * i + j]));
+                    }
+                }
+            }
+        }
     };
     // issue order of a 16-channel block: the two fragment reads of the NEXT block go out behind the first two products of this
     // one (left to the compiler they are sunk below the products that free their registers: the LDS latency fully exposed)
@@ -171,24 +239,27 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
     W4_WAIT_VM(2 * PPW);
     W4_BARRIER();
     frags(0, 0, 0);
-    // one chunk of 64 reduction channels out of buffer `par` of the current pair; the first fragments are in slot 0
-    auto chunk = [&](auto PAR) {
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    // one chunk of 64 reduction channels out of buffer `par` of the current pair; the first fragments are in slot 0.
+    // FIRST: the chunk starts a component
+    auto chunk = [&](auto PAR, auto FIRST) {
         constexpr int par = decltype(PAR)::value;
         frags(par, 1, 1);
-        mm(0);
+        mm(0, FIRST);
         order();
         frags(par, 2, 0);
-        mm(1);
+        mm(1, F_{});
         order();
         // chunk s+1 published, the buffer of chunk s-1 free: its pieces (chunk s+3) leave now
         W4_STAMP();
         W4_WAIT_VM(PPW);
         W4_STAMP();
-        W4_BARRIER();
+        if (!(W4_EXP & 4)) W4_BARRIER();
         W4_STAMP();
-        issue();
+        if (!(W4_EXP & 8)) issue();
         frags(par, 3, 1);
-        mm(0);
+        mm(0, F_{});
         order();
         if (par == 1) {
 #pragma unroll
@@ -198,37 +269,17 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
             }
         }
         frags(par ^ 1, 0, 0);
-        mm(1);
+        mm(1, F_{});
         order();
     };
     auto component = [&](auto LI, auto MI) {
-        constexpr int l = decltype(LI)::value, m = decltype(MI)::value;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) Mc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int cc = 0; cc < p.chunks; cc += 2) {
-            chunk(std::integral_constant<int, 0>{});
-            chunk(std::integral_constant<int, 1>{});
+        chunk(std::integral_constant<int, 0>{}, T_{});
+        chunk(std::integral_constant<int, 1>{}, F_{});
+        for (int cc = 2; cc < p.chunks; cc += 2) {
+            chunk(std::integral_constant<int, 0>{}, F_{});
+            chunk(std::integral_constant<int, 1>{}, F_{});
         }
-        const f32x4 M = (Mc[0] + Mc[1]) + (Mc[2] + Mc[3]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float c = W4_AT[i][l] * W4_AT[j][m];
-                if (c != 0.f) {
-                    if (c == 1.f) Y[4 * i + j] += M;
-                    else if (c == -1.f) Y[4 * i + j] -= M;
-                    else {
-                        Y[4 * i + j][0] = __builtin_fmaf(c, M[0], Y[4 * i + j][0]);
-                        Y[4 * i + j][1] = __builtin_fmaf(c, M[1], Y[4 * i + j][1]);
-                        Y[4 * i + j][2] = __builtin_fmaf(c, M[2], Y[4 * i + j][2]);
-                        Y[4 * i + j][3] = __builtin_fmaf(c, M[3], Y[4 * i + j][3]);
-                    }
-                    // opaque: the update stays HERE (left alone, the compiler sinks the 36 updates to the epilogue and
-                    // keeps every component's M alive until then - 144 registers, spilled)
-                    asm volatile("" : "+v"(Y[4 * i + j]));
-                }
-            }
+        update(LI, MI);
     };
     auto row = [&](auto LI) {
         component(LI, std::integral_constant<int, 0>{});
@@ -385,8 +436,11 @@ int denet_wino4f_block(int tile, long T, int C, int K) {
     if (g_w4_mode < 0 && !env_on) return 0;
     if (g_w4_mode == 0) return 0;
     if (mode == 32 || mode == 64) return mode;
+    // one round of workgroups has to fill the 256 CUs: 64-tile blocks if they do (the 64x64 maps of DeNet-34: 128 x 2), else
+    // 32-tile blocks (the 32x32 maps: 64 x 4); a 16x16 map (T = 512) has too few tiles either way
     const long kb = K / 64;
     if (((T + 63) / 64) * kb >= 224) return 64;
+    if (((T + 31) / 32) * kb >= 224) return 32;
     return 0;
 }
 
@@ -425,7 +479,7 @@ int denet_wino4f_run(int tb, const float* V, const float* U, const float* bias, 
         }
         attr_done[tb == 64][ep] = true;
     }
-    const int prof = denet_prof_begin(12, tb, 64, W4_NBUF, stream);
+    const int prof = denet_prof_begin(14, tb, 64, W4_NBUF, stream);
     hipLaunchKernelGGL(fn, dim3((unsigned)(tiles_t * p.tiles_k)), dim3(tb * 16), lds, stream, p);
     denet_prof_end(prof, stream);
     DENET_CHECK_LAUNCH("conv_wino4f");

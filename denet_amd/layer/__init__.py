@@ -74,14 +74,27 @@ class Act:
     @property
     def data(self):
         if self._data is None and self._pending_data is not None:
+            import torch
             link, self._pending_data = self._pending_data, None
             self._data = link.materialise()
+            # written on whatever stream the first reader runs on (a filter-gradient pass materialises an up-sampled tensor on the
+            # second stream): a later reader on another stream is ordered behind that write
+            self._data_stream = torch.cuda.current_stream()
+            self._data_event = torch.cuda.Event()
+            self._data_event.record(self._data_stream)
+        elif getattr(self, "_data_event", None) is not None:
+            import torch
+            cur = torch.cuda.current_stream()
+            if cur != self._data_stream:
+                cur.wait_event(self._data_event)
+                self._data.record_stream(cur)
         return self._data
 
     @data.setter
     def data(self, v):
         self._data = v
         self._pending_data = None
+        self._data_event = None
 
     @property
     def grad(self):
@@ -105,6 +118,7 @@ class Act:
     def set_pending_data(self, link):
         self._data = None
         self._pending_data = link
+        self._data_event = None
 
     def take_pending_data(self):
         """the pending batch-norm link, or None; the taker must store the tensor it materialises into .data"""

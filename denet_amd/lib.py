@@ -139,8 +139,6 @@ SIGNATURES = {
     "denet_build_samples": (I, [P, P, P, P, P, Z] + [I] * 4 + [F, I, I, I, P]),
     "denet_build_samples_stats": (I, [P, Z] + [I] * 6 + [P, P, P]),
     "denet_edit_samples_device": (I, [P, P, I, I, P, L, L, P, P] + [I] * 4 + [P, P, P]),
-    "denet_edit_samples_sampled_workspace_bytes": (Z, [I, I]),
-    "denet_edit_samples_device_sampled": (I, [P, P, I, I, P, L, L, P, P] + [I] * 4 + [P, P, P, Z, P]),
     "denet_host_cluster_samples": (I, [P, I, F, I, P, P]),
     "denet_samples_finish_host": (I, [P, P, P, I, I, I, I, P]),
 }

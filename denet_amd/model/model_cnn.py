@@ -322,11 +322,19 @@ class ModelCNN:
             return
         if isinstance(data_x, torch.Tensor):
             x = data_x if data_x.is_cuda else data_x.cuda(non_blocking=True)
+            if x.dtype != torch.float32:
+                x = x.float()                      # the first layer's kernels take raw float pointers
         else:
             x = torch.from_numpy(numpy.ascontiguousarray(data_x, dtype=numpy.float32)).cuda(non_blocking=True)
         assert tuple(x.shape) == self.get_input_shape(), (tuple(x.shape), self.get_input_shape())
         # the NHWC copy is made when a layer asks for it: the first convolution's own kernels read the planar batch (ops.NchwLink)
-        self.input.set_pending_data(ops.NchwLink(x.contiguous(), self.input.cp))
+        # A caller's device tensor is read IN PLACE, and last of all by the first layer's filter gradient on the second stream at
+        # the very end of the backward sweep, after train_step has returned: the buffer must stay untouched until
+        # `self.input_consumed` (an event recorded behind the solver, which waits for that stream) has completed.
+        x = x.contiguous()
+        if ops._WGRAD_STREAM is not None:
+            x.record_stream(ops._WGRAD_STREAM)     # the caching allocator must not hand the block out while that stream reads it
+        self.input.set_pending_data(ops.NchwLink(x, self.input.cp))
 
     def _consumers(self, act):
         """number of layers (nested ones included) that read `act` as their input or as a skip tap"""
@@ -484,6 +492,10 @@ class ModelCNN:
                             float(learn_rate), float(momentum[0]), it, float(decay), SOLVER_MODES[self.solver_mode],
                             scale)
         ops.bump_weights_version()       # parameters and BN running statistics moved: inference caches are stale
+        import torch
+        if getattr(self, "input_consumed", None) is None:
+            self.input_consumed = torch.cuda.Event()
+        self.input_consumed.record()     # behind the solver: every reader of this step's input batch (both streams) is done
         if not fetch_cost:
             return None
         self._cost_ready.synchronize()

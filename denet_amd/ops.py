@@ -60,7 +60,7 @@ class KernelProfile:
         ms, v = ctypes.c_float(), [ctypes.c_int() for _ in range(4)]
         for i, flops in enumerate(self.flops):
             check(L.denet_conv_profile_read(i, ctypes.byref(ms), *[ctypes.byref(x) for x in v]), "conv_profile_read")
-            name = {10: "wino2f_ws_kernel", 11: "wino2f_wgrad_kernel", 12: "stem_fwd_kernel", 13: "stem_wgrad_kernel"}.get(v[0].value) or \
+            name = {10: "wino2f_ws_kernel", 11: "wino2f_wgrad_kernel", 12: "stem_fwd_kernel", 13: "stem_wgrad_kernel", 14: "wino4f_kernel"}.get(v[0].value) or \
                 "igemm_kernel<%d, %d, %d, 2, 2, %d>" % tuple(x.value for x in v)
             a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
             a["launches"] += 1
@@ -323,6 +323,8 @@ def conv_backward_linked(link, x, w, w_shape, add, dw_out, cache, stride=1, pad=
     Returns dx, or None when this layer's passes are not both Winograd passes of one tile (the caller materialises the gradient
     and takes the ordinary path)."""
     import ctypes
+    if not (int(BWD_SUMS) & 1):
+        sums = None                  # DENET_BN_BWD_SUMS bit 0: the Winograd passes leave the backward reductions to the batch norm
     g = conv_geom(x.shape, w_shape, stride, pad, s_real)
     N, H, W, C, K = g[0], g[1], g[2], g[3], g[4]
     tile = _WINO.get((1, g))
@@ -841,7 +843,7 @@ def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None,
         if cache is not None:
             cache["dgrad_tile"] = tile
             u = _cached_u(cache, 1, tile)
-        return conv_wino_dgrad(dy, w, add, out=dx, tile=tile, u=u, sums=sums, cache=cache)
+        return conv_wino_dgrad(dy, w, add, out=dx, tile=tile, u=u, sums=sums if (int(BWD_SUMS) & 1) else None, cache=cache)
     if cache is not None:
         cache["dgrad_tile"] = 0
     if PROFILE is not None:

@@ -513,13 +513,6 @@ int denet_build_samples(const float* corner_pr, int* out_box, float* out_absd, i
  * for bit what denet_host_edit_samples(_stream) writes to out_box_f32 - the host runs that later, beside the device's gather and
  * head, for the Python-side list. status [2] (device, zeroed here): [0] != 0: not this call's case, out_bbox incomplete;
  * [1]: outputs consumed. */
-/* ..._device_sampled: any batch - images that propose more than n_keep RoIs keep what random.sample(list, n_keep) would pick
- * (CPython's pool branch: _randbelow rejection sampling + pool swaps, replayed exactly: one wave walks the images in order and
- * judges 64 generator outputs at a time, one workgroup per image replays the swaps). workspace: ..._sampled_workspace_bytes. */
-size_t denet_edit_samples_sampled_workspace_bytes(int B, int n_keep);
-int denet_edit_samples_device_sampled(const int* box, const int* count, int H, int W, const uint32_t* mt_out, long n_out,
-                                      long cursor0, const double* gt, const int* gt_off, int sample_gt, int B, int S, int n_keep,
-                                      float* out_bbox, int* status, void* workspace, size_t workspace_bytes, hipStream_t stream);
 int denet_edit_samples_device(const int* box, const int* count, int H, int W, const uint32_t* mt_out, long n_out, long cursor0,
                               const double* gt, const int* gt_off, int sample_gt, int B, int S, int n_keep, float* out_bbox,
                               int* status, hipStream_t stream);

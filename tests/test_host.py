@@ -621,7 +621,7 @@ def test_prefetched_generator_outputs_give_the_same_editing():
     (denet_host_mt_prefetch / denet_host_edit_samples_stream) against the editing on the live generator: same lists, same
     upload array and the stdlib generator in the identical state afterwards (trim / no trim / empty / full lists, several
     steps in a row so that refills of the 624-word state fall at every kind of position)"""
-    from denet_amd.layer import denet_sparse as DS
+    from denet_amd.layer import roi_handoff as DS
     saved = DS.PREFETCH_RANDOM
     try:
         for rs in (0.1, 0.5):

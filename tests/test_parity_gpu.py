@@ -737,18 +737,19 @@ def test_batch_norm_backward_sums_from_the_data_gradient_pass(hip, img, tile):
     assert worst < 3e-5 and worst_b < 3e-5, (worst, worst_b)
 
 
-def test_prepared_cold_roi_list_equals_the_hand_off_path(hip):
-    """DeNetSparseLayer._speculate_cold: with a cold corner detector (no proposals: weights as initialised) the edited RoI list
-    is prepared at the start of the step on a copy of the stdlib generator and adopted at the hand-off; a warm detector must
-    discard it. Three steps either way: the same RoI lists (reference loop: denet/layer/denet_sparse.py:184-201), the same
-    parameters bit for bit, the generator at the same position afterwards"""
-    from denet_amd.layer import denet_sparse as DS
+def test_cold_detector_hand_off_equals_the_host_path(hip):
+    """With a cold corner detector (no proposals: weights as initialised, the regime of the first training steps)
+    the edited RoI list is all random boxes + ground truth. The device-side editing takes such a batch too (no image proposes
+    more than the list keeps); a warm detector that proposes more than that takes the fast host hand-off. Three steps with the
+    short forms on and off: the same RoI lists (reference loop: denet/layer/denet_sparse.py:184-201), the same parameters bit
+    for bit, the generator at the same position afterwards"""
+    from denet_amd.layer import roi_handoff as RH
     res = {}
-    saved = DS.SPECULATE_COLD
+    saved = (RH.DEVICE_EDIT, RH.FAST_HANDOFF)
     try:
         for warm in (False, True):
-            for spec in (True, False):
-                DS.SPECULATE_COLD = spec
+            for short in (True, False):
+                RH.DEVICE_EDIT = RH.FAST_HANDOFF = short
                 random.seed(21)
                 model = zoo.denet34(2, "skip", 128, class_num=80, seed=1)
                 if warm:
@@ -761,108 +762,41 @@ def test_prepared_cold_roi_list_equals_the_hand_off_path(hip):
                     model.train_step(x, metas, 0, it, 0.0 if warm else 0.02, [0.9], 1e-4)      # lr 0: the warm head stays warm
                     lists.append(dns.sample_bbox_list)
                 torch.cuda.synchronize()
-                hits = getattr(dns, "cold_hits", 0)
+                modes = dict(dns.handoff_modes)
+                assert sum(modes.values()) == 3, modes
                 # (the first step may draw from the generator between the preparation and the hand-off - a layer seed - and
-                # then falls back to the ordinary path, which is the point of the freshness check)
-                assert (hits >= 2) if (spec and not warm) else (hits == 0), (warm, spec, hits)
-                res[(warm, spec)] = (model.P.clone(), lists, random.random())
+                # then takes the ordinary path, which is the point of the freshness check)
+                if not short:
+                    assert modes == {"device_edit": 0, "fast": 0, "host": 3}, modes
+                elif not warm:
+                    assert modes["device_edit"] >= 2 and modes["fast"] == 0, modes
+                res[(warm, short)] = (model.P.clone(), lists, random.random())
     finally:
-        DS.SPECULATE_COLD = saved
+        RH.DEVICE_EDIT, RH.FAST_HANDOFF = saved
     for warm in (False, True):
         a, b = res[(warm, True)], res[(warm, False)]
         assert torch.equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2], warm
 
 
-def test_pool_inverse_inside_the_input_transform(hip):
-    """ops.UpLink: in training a pool-inverse layer (2 x 2 nearest-neighbour up-sampling, pool_inv.py:10-41 / pool_inv_op.py:38-63)
-    leaves its output unwritten; the Winograd convolution behind it reads the small tensor inside its input transform
-    (denet_conv_wino_fwd_stats_up), the filter gradient makes the up-sampled tensor on its own stream. Same values read, same
-    kernels otherwise: two training steps, parameters / momentum / running statistics bit for bit"""
-    res = []
-    saved = (ops.UP_LINK, dict(ops._WINO))
-    try:
-        for on in (True, False):
-            ops.UP_LINK = on
-            random.seed(7)
-            model = zoo.warm_corner_head(zoo.denet34(2, "skip", 256, class_num=80, seed=1), 4.0, 0.3)
-            model.build_train_func("nesterov")
-            x, metas = zoo.synthetic_batch(2, 256, seed=11)
-            if not res:
-                model.train_step(x, metas, 0, 0, 0.0, [0.9], 0.0)          # decides the launch configurations once
-                for (mode, g) in list(ops._WINO):
-                    if mode == 0 and g[5] == 3 and g[8] == 1 and ops.conv_wino_ok(g, 4) and g[3] in (256, 512):
-                        ops._WINO[(mode, g)] = 4                          # the two convolutions behind PI on the un-fused F(4x4) pass
-                random.seed(7)
-                model = zoo.warm_corner_head(zoo.denet34(2, "skip", 256, class_num=80, seed=1), 4.0, 0.3)
-                model.build_train_func("nesterov")
-            pis = [l for l in model.layers if l.type_name == "pool-inv"]
-            costs = []
-            for it in range(2):
-                costs.append(model.train_step(x, metas, 0, it, 0.02, [0.9], 1e-4)[0])
-            torch.cuda.synchronize()
-            res.append((model.P.clone(), model.M.clone(), model.S.clone(), costs, [p.output.data.clone() for p in pis]))
-    finally:
-        ops.UP_LINK = saved[0]
-        ops._WINO.clear()
-        ops._WINO.update(saved[1])
-    for a, b in zip(res[0][:3], res[1][:3]):
-        assert torch.equal(a, b)
-    assert res[0][3] == res[1][3]
-    assert all(torch.equal(u, v) for u, v in zip(res[0][4], res[1][4]))
-
-
-def test_skip_addition_in_the_convolution_epilogue(hip):
-    """ModelCNN.build_train_func links a SKIP layer that adds its tap without a projection (skip.py:81-86) to the convolution right in
-    front of it: the tap
-    is added in that convolution's epilogue, which also measures the statistics of the batch norm behind the SKIP layer. Against
-    the separate passes (DENET_SKIP_FUSE=0): the sum itself is the same two fp32 numbers added (bit-identical forward output),
-    the statistics come from the epilogue's fp32 partial sums instead of a double-precision pass: one training step, state
-    within 1e-5 max-norm relative"""
-    import os
-    res = []
-    saved = os.environ.get("DENET_SKIP_FUSE")
-    try:
-        for fuse in ("1", "0"):
-            os.environ["DENET_SKIP_FUSE"] = fuse
-            random.seed(7)
-            model = zoo.warm_corner_head(zoo.denet34(2, "skip", 128, class_num=80, seed=1), 4.0, 0.3)
-            model.build_train_func("nesterov")
-            linked = [l for l in model.layers if getattr(l, "skip_behind", None) is not None]
-            assert len(linked) == (2 if fuse == "1" else 0)
-            x, metas = zoo.synthetic_batch(2, 128, seed=11)
-            cost = model.train_step(x, metas, 0, 0, 0.02, [0.9], 1e-4)[0]
-            skips = [l for l in model.layers if l.type_name == "skip"]
-            torch.cuda.synchronize()
-            res.append((model.P.clone(), model.M.clone(), model.S.clone(), cost, [s.output.data.clone() for s in skips]))
-    finally:
-        if saved is None:
-            os.environ.pop("DENET_SKIP_FUSE", None)
-        else:
-            os.environ["DENET_SKIP_FUSE"] = saved
-    assert torch.equal(res[0][4][0], res[1][4][0])            # the first sum of the forward pass: the same bits
-    for a, b in zip(res[0][:3], res[1][:3]):
-        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
-    assert abs(res[0][3] - res[1][3]) <= 1e-5 * abs(res[1][3])
 
 
 def test_device_side_editing_equals_the_host_list(hip):
-    """The two short forms of the RoI hand-off against the ordinary one. DeNetSparseLayer._device_edit: when no image proposes
+    """The two short forms of the RoI hand-off against the ordinary one. RoiHandoff._device_edit: when no image proposes
     more RoIs than the list keeps (no random.sample), the bbox array is written on the device (denet_edit_samples_device:
     proposals, random boxes from generator outputs drawn ahead, ground truth) and the host's editing runs later for the
-    Python-side list; with DEVICE_SAMPLE also the batches that need random.sample (denet_edit_samples_device_sampled: the rejection
-    sampling and the pool swaps of CPython's random.sample replayed on the device). _fast_handoff: every other batch - one native
-    call (sample tuples + editing on the prefetched outputs) and the upload, the bookkeeping later. Reference loop: denet/layer/denet_sparse.py:184-201. The device array equals the host's
+    Python-side list. _fast_handoff: every other batch - one native call (sample tuples + editing on the prefetched outputs) and
+    the upload, the bookkeeping later. Reference loop: denet/layer/denet_sparse.py:184-201. The device array equals the host's
     float32 array bit for bit; lists, parameters after three steps and the generator's position are identical in all three
-    modes; a detector that proposes more than the list keeps does not take the device path."""
-    from denet_amd.layer import denet_sparse as DS
+    modes; a detector that proposes more than the list keeps does not take the device path; `handoff_modes` says which form
+    every step took."""
+    from denet_amd.layer import roi_handoff as RH
     res, took = {}, {}
-    saved = (DS.DEVICE_EDIT, DS.FAST_HANDOFF, DS.DEVICE_SAMPLE)
-    biases, modes = (5.6, 5.0, 4.0), ((True, True), (False, True), (False, False), ("sampled", True))
+    saved = (RH.DEVICE_EDIT, RH.FAST_HANDOFF)
+    biases, modes = (5.6, 5.0, 4.0), ((True, True), (False, True), (False, False))
     try:
         for bias in biases:          # a few dozen ... more than 519 proposals per image
             for mode in modes:
-                DS.DEVICE_EDIT, DS.FAST_HANDOFF = bool(mode[0]), mode[1]
-                DS.DEVICE_SAMPLE = mode[0] == "sampled"      # random.sample replayed on the device as well
+                RH.DEVICE_EDIT, RH.FAST_HANDOFF = mode
                 random.seed(21)
                 model = zoo.warm_corner_head(zoo.denet34(2, "skip", 128, class_num=80, seed=1), bias, 0.3)
                 model.build_train_func("nesterov")
@@ -876,15 +810,15 @@ def test_device_side_editing_equals_the_host_list(hip):
                     torch.cuda.synchronize()
                     assert torch.equal(dev_bbox.cpu().view(-1), torch.from_numpy(dns.sample_bbox_f32.reshape(-1).copy()))
                     arrays.append(dev_bbox.cpu())
-                took[(bias, mode)] = (getattr(dns, "device_edits", 0), getattr(dns, "fast_handoffs", 0))
+                assert sum(dns.handoff_modes.values()) == 3, dns.handoff_modes
+                took[(bias, mode)] = (dns.handoff_modes["device_edit"], dns.handoff_modes["fast"])
                 res[(bias, mode)] = (model.P.clone(), lists, arrays, random.random())
     finally:
-        DS.DEVICE_EDIT, DS.FAST_HANDOFF, DS.DEVICE_SAMPLE = saved
+        RH.DEVICE_EDIT, RH.FAST_HANDOFF = saved
     for bias in biases:
         ref = res[(bias, (False, False))]
         assert took[(bias, (False, False))] == (0, 0)
-        assert took[(bias, ("sampled", True))][0] == 3, took          # every batch with proposals is edited on the device
-        for mode in (modes[0], modes[1], modes[3]):
+        for mode in modes[:2]:
             a = res[(bias, mode)]
             assert torch.equal(a[0], ref[0]) and a[1] == ref[1] and a[3] == ref[3], (bias, mode)
             assert all(torch.equal(u, v) for u, v in zip(a[2], ref[2])), (bias, mode)

@@ -44,15 +44,38 @@ for name, H, W, C, K in GEOMS:
         dx = ops.conv_wino_dgrad(dy, w, tile=4, u=ud)
         tf = timeit(lambda: ops.conv_wino_fwd(x, w, bias, add, tile=4, u=u, stats=(st, cache)))
         td = timeit(lambda: ops.conv_wino_dgrad(dy, w, tile=4, u=ud))
-        res[mode] = (y.clone(), dx.clone(), sums, tf, td, rows)
+        # the fused kernel alone (event pair around its launch)
+        kf = kd = 0.0
+        if mode:
+            ms, v = ctypes.c_float(), [ctypes.c_int() for _ in range(4)]
+            for which in (0, 1):
+                L.denet_conv_profile(1)
+                for _ in range(5):
+                    if which == 0:
+                        ops.conv_wino_fwd(x, w, bias, add, tile=4, u=u, stats=(st, cache))
+                    else:
+                        ops.conv_wino_dgrad(dy, w, tile=4, u=ud)
+                torch.cuda.synchronize()
+                tot = 0.0
+                for i in range(L.denet_conv_profile_count()):
+                    L.denet_conv_profile_read(i, ctypes.byref(ms), *[ctypes.byref(a) for a in v])
+                    if v[0].value == 14:
+                        tot += ms.value
+                L.denet_conv_profile(0)
+                if which == 0:
+                    kf = tot / 5 * 1e3
+                else:
+                    kd = tot / 5 * 1e3
+        res[mode] = (y.clone(), dx.clone(), sums, tf, td, rows, kf, kd)
     L.denet_conv_wino4f_mode(-1)
-    y0, dx0, s0, tf0, td0, r0 = res[0]
+    y0, dx0, s0, tf0, td0, r0 = res[0][:6]
     flop = 2.0 * B * H * W * C * K * 9 / 4
     line = "%-8s B=%d  unfused fwd %6.1f us dgrad %6.1f us |" % (name, B, tf0, td0)
     for mode in (64, 32):
-        y1, dx1, s1, tf1, td1, r1 = res[mode]
+        y1, dx1, s1, tf1, td1, r1, kf, kd = res[mode]
         ey = float((y1 - y0).abs().max() / y0.abs().max())
         ed = float((dx1 - dx0).abs().max() / dx0.abs().max())
         es = float(((s1 - s0).abs() / (s0.abs() + 1e-3 * s0.abs().max())).max())
-        line += " TB%d fwd %6.1f us (%.0f TF) dgrad %6.1f us err y %.1e dx %.1e sums %.1e rows %d |" % (mode, tf1, flop / tf1 / 1e6, td1, ey, ed, es, r1)
+        line += " TB%d fwd %6.1f (kernel %5.1f = %3.0f TF) dgrad %6.1f (kernel %5.1f = %3.0f TF) err y %.1e dx %.1e sums %.1e |" % (
+            mode, tf1, kf, flop / max(kf, 1e-3) / 1e6, td1, kd, flop / max(kd, 1e-3) / 1e6, ey, ed, es)
     print(line, flush=True)
