@@ -20,6 +20,10 @@ Extra legs (rank 0, N=1 only; outside the timed region):
                 the threshold; the second takes the max_corners truncation branch): RoI proposal on the GPU, host hand-off
                 phases under the reference's names.
   split_bf16    OPT-IN variant, never the headline: the head GEMMs as 3-term bf16 splits (own key, own number).
+  data_parallel_selftest
+                the RCCL code path on this one GPU: a world-size-1 "nccl" process group, the collectives forced on
+                (DataParallel.force_collectives): communicator creation, bucket -> stream ordering, collectives per step,
+                bytes, event-timed exposed collective time, img/s with the exchange inside the step. NOT a scaling number.
   config2 / config5
                 BASELINE.json's secondary configurations as legs of this line (a few seconds each): ResNet-34 224x224 batch
                 64 (examples/resnet34-imagenet.sh:7) and DeNet-101 wide 512x512 batch 16 with joint fitness + bounded-IoU
@@ -254,6 +258,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-warm", action="store_true", help="skip the warm / stress corner-regime legs (rank 0, N=1)")
+    ap.add_argument("--no-dp-selftest", action="store_true", help="skip the single-GPU RCCL self-test leg (rank 0, N=1)")
     ap.add_argument("--no-configs", action="store_true", help="skip the config2 / config5 legs (rank 0, N=1)")
     ap.add_argument("--no-split-bf16", action="store_true",
                     help="skip the leg of the OPT-IN variant (head GEMMs as 3-term bf16 splits; own key, never the headline)")
@@ -436,6 +441,58 @@ def main():
             except Exception as exc:          # an extra leg must never cost the headline line
                 out[key] = {"error": repr(exc)[:300]}
             torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and dp is None and not args.no_dp_selftest:
+        # the data-parallel code path under the REAL backend on the one GPU this run has: RCCL communicator (world size 1),
+        # every bucket's all-reduce launched from the backward sweep on the filter-gradient stream, the packed tail collective,
+        # the wait in finish_step - driver-exercised every round although no round has had two GPUs
+        try:
+            try:
+                del model
+            except NameError:
+                pass
+            torch.cuda.empty_cache()
+            import socket
+            from denet_amd.multi import DataParallel
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            sdp = DataParallel(backend="nccl")
+            sdp.force_collectives = True
+            sm = zoo.denet34(BATCH_PER_GPU, "skip", 512, class_num=80, seed=1)
+            sm.build_train_func("nesterov")
+            sm.dist = sdp
+            sdp.broadcast_state(sm)
+            random.seed(1)
+            sit = 0
+            for _ in range(max(args.warmup, 2)):
+                sm.train_step(xd, metas, 0, sit, lr, mom, decay)
+                sit += 1
+            torch.cuda.synchronize()
+            sdp.start_timing()
+            nst = max(1, min(args.steps, 10))
+            t0 = time.perf_counter()
+            for _ in range(nst):
+                scost, _ = sm.train_step(xd, metas, 0, sit, lr, mom, decay)
+                sit += 1
+            torch.cuda.synchronize()
+            sdt = time.perf_counter() - t0
+            out["data_parallel_selftest"] = {
+                "backend": sdp.backend + (" (RCCL)" if sdp.backend == "nccl" else ""), "world_size": sdp.world_size,
+                "collectives_per_step": sdp.collectives_per_step(), "allreduce_bytes_per_step": sdp.bytes_per_step(),
+                "bucket_bytes": [4 * (hi - lo) for lo, hi, _ in (sdp._buckets or [])],
+                "exposed_collective_ms_per_step": round(sdp.exposed_ms_per_step(), 3),
+                "ms_per_step": round(1e3 * sdt / nst, 3), "value": round(BATCH_PER_GPU * nst / sdt, 2), "unit": "images/sec",
+                "final_cost": round(float(scost), 5),
+                "note": "single GPU, world size 1, collectives forced on: exercises the RCCL launch path inside the step; the "
+                        "exposed time is a self-copy's, not an xGMI exchange - never a scaling measurement"}
+            del sm
+            sdp.dist.destroy_process_group()
+        except Exception as exc:          # an extra leg must never cost the headline line
+            out["data_parallel_selftest"] = {"error": repr(exc)[:300]}
+        torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not args.no_configs:
         # BASELINE.json configs 2 and 5 (parity-test cases; their throughput rides along so that a driver-run record carries it)

@@ -7,6 +7,7 @@
 //                                                    denet/common/theano_util.py:27-34
 // This file is compiled with -ffp-contract=off: tap indices must be reproducible bit for bit.
 #include "common.h"
+#include <stdlib.h>
 #include <math.h>
 
 namespace {
@@ -511,6 +512,86 @@ extern "C" int denet_sparse_fwd(const float* fmap, const float* bbox, float* out
     return DENET_OK;
 }
 
+// The three kernels above as ONE, a 1024-thread workgroup per image, for feature maps of up to 4096 cells and up to 65 535 slots
+// per image (DeNet-34: 4096 cells, 28 224 slots): the (chunk, cell) table of a whole image - 16 chunks, one per wave, 16-bit
+// counts / positions - is 128 KB of LDS, so counting, the scan and the stable scatter never leave the CU and the 32 images of a
+// batch are 32 workgroups instead of 2 x 448 single-wave ones + 512 (which, queued beside the head's matrix kernels, held slots
+// for over a millisecond). Same lists, same order: chunk-major, slot order inside a chunk.
+constexpr int SORT1_WAVES = 16;
+__global__ __launch_bounds__(1024) void sparse_sort_image_kernel(const int* __restrict__ taps, int* __restrict__ order,
+                                                                 int* __restrict__ cell_start, int n, int HW, int key_bits) {
+    extern __shared__ unsigned s_tab32[];                    // [16][HWP / 2]: two 16-bit entries per word
+    __shared__ int s_scan[1024];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int HWP = (HW + 1) & ~1;
+    unsigned short* tab = (unsigned short*)s_tab32;
+    for (int i = tid; i < SORT1_WAVES * HWP / 2; i += 1024) s_tab32[i] = 0u;
+    __syncthreads();
+    const int chunk = (((n + SORT1_WAVES - 1) / SORT1_WAVES) + 63) & ~63;
+    const int lo = wave * chunk, hi = min(n, lo + chunk);
+    const int* t = taps + (long)b * n;
+    for (int i = lo + lane; i < hi; i += 64) {
+        const int cell = t[i];
+        atomicAdd(&s_tab32[(wave * HWP + cell) >> 1], 1u << (((wave * HWP + cell) & 1) * 16));
+    }
+    __syncthreads();
+    // cell totals over the chunks, exclusive scan over the cells (thread = CPT consecutive cells), positions back into the table
+    const int CPT = (HW + 1023) / 1024;
+    int tot = 0;
+    for (int k = 0; k < CPT; ++k) {
+        const int c = tid * CPT + k;
+        if (c < HW)
+            for (int w = 0; w < SORT1_WAVES; ++w) tot += tab[w * HWP + c];
+    }
+    s_scan[tid] = tot;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = (tid >= off) ? s_scan[tid - off] : 0;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    int pos = s_scan[tid] - tot;
+    int* cs = cell_start + (long)b * (HW + 1);
+    for (int k = 0; k < CPT; ++k) {
+        const int c = tid * CPT + k;
+        if (c < HW) {
+            cs[c] = pos;
+            for (int w = 0; w < SORT1_WAVES; ++w) {
+                const int cnt = tab[w * HWP + c];
+                tab[w * HWP + c] = (unsigned short)pos;
+                pos += cnt;
+            }
+        }
+    }
+    if (tid == 0) cs[HW] = n;
+    __syncthreads();
+    // stable scatter of this wave's chunk: 64 slots at a time, lanes of the same cell found with one ballot per key bit
+    int* o = order + (long)b * n;
+    unsigned short* cur = tab + wave * HWP;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int i = i0 + lane;
+        const bool live = i < hi;
+        const int cell = live ? t[i] : 0;
+        unsigned long long same = __ballot(live);
+        for (int bit = 0; bit < key_bits; ++bit) {
+            const unsigned long long set = __ballot((cell >> bit) & 1);
+            same &= ((cell >> bit) & 1) ? set : ~set;
+        }
+        if (!live) same = 0;
+        const int rank = __popcll(same & below);
+        int start = 0;
+        if (live && rank == 0) {                        // lowest lane of its group: distinct cells, no conflict
+            start = cur[cell];
+            cur[cell] = (unsigned short)(start + __popcll(same));
+        }
+        const int leader = live ? (__ffsll((long long)same) - 1) : lane;
+        start = __shfl(start, leader, 64);
+        if (live) o[start + rank] = i;
+    }
+}
+
 // Workspace of denet_sparse_sort / denet_sparse_bwd: order [B][n] | cell_start [B][HW+1] | counts [B][nchunk][HW] |
 // positions [B][nchunk][HW] (int32)
 namespace {
@@ -564,6 +645,23 @@ extern "C" int denet_sparse_sort(const int* taps, void* sort_ws, size_t sort_ws_
             return -(int)e;
         }
         attr_set = true;
+    }
+    static const int one_kernel = [] { const char* e = getenv("DENET_SORT_ONE_KERNEL"); return e ? atoi(e) : 1; }();
+    if (one_kernel && L.HW <= 4096 && L.n <= 65535) {
+        const size_t lds1 = (size_t)SORT1_WAVES * ((L.HW + 1) & ~1) * sizeof(unsigned short);
+        static bool attr1 = false;
+        if (!attr1) {
+            const hipError_t e = hipFuncSetAttribute((const void*)sparse_sort_image_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     SORT1_WAVES * 4096 * 2);
+            if (e != hipSuccess) {
+                denet_set_error("sparse_sort: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                return -(int)e;
+            }
+            attr1 = true;
+        }
+        hipLaunchKernelGGL(sparse_sort_image_kernel, dim3(B), dim3(1024), lds1, stream, taps, order, cell_start, L.n, L.HW, L.key_bits);
+        DENET_CHECK_LAUNCH("sparse_sort");
+        return DENET_OK;
     }
     hipLaunchKernelGGL(sparse_count_kernel, dim3(L.nchunk, B), dim3(64), lds, stream, taps, table, L.n, L.HW, L.nchunk);
     int* table_pos = table + (size_t)B * L.nchunk * L.HW;

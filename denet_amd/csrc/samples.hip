@@ -30,8 +30,13 @@
 namespace {
 
 constexpr int TIE_CAP = 4096;   // extra slots for candidates tying with the threshold key
-// tie slots actually used: the final sort keeps sample_count + ties <= 8192 candidates in LDS
-__host__ __device__ inline int tie_cap_for(int sample_count) { return sample_count <= 4096 ? TIE_CAP : 8192 - sample_count; }
+// tie slots actually used: up to 7936 requested candidates the final sort keeps sample_count + ties <= 8192 candidates in LDS;
+// beyond (RoI clustering of the 48 x 48 models asks for the 23 040 best, denet_sparse.cc:171-175) it sorts through a global
+// buffer (pair_finalize_big_kernel) and the ties get their full 4096 slots
+constexpr int SORT_LDS_MAX = 7936;
+__host__ __device__ inline int tie_cap_for(int sample_count) {
+    return (sample_count <= 4096 || sample_count > SORT_LDS_MAX) ? TIE_CAP : 8192 - sample_count;
+}
 constexpr int NBLK_PAIR = 64;   // workgroups per image for the pair passes
 
 struct ImgState {
@@ -413,8 +418,93 @@ __global__ __launch_bounds__(1024) void pair_finalize_kernel(const ImgState* __r
     if (threadIdx.x == 0) out_count[b] = nout;
 }
 
+// The same for more candidates than LDS holds (sample_count > 7936): bitonic network over a global buffer of np (a power of
+// two) candidates per image, one workgroup per image. Compare-exchange distances below 8192 run inside LDS on chunks of 8192
+// candidates, the longer ones (the first steps of the last merge stages) through global memory - the buffer of an image is a few
+// hundred KB and stays in L2. Same order as the single-pass kernel: (key, generation index) ascending.
+constexpr int BIG_CHUNK = 8192;
+__global__ __launch_bounds__(1024) void pair_finalize_big_kernel(const ImgState* __restrict__ state, const Cand* __restrict__ cand,
+                                                                 Cand* __restrict__ sortbuf, int sample_count, int* __restrict__ out_box,
+                                                                 float* __restrict__ out_absd, int* __restrict__ out_count, int NP) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    Cand* s = (Cand*)smem_raw;  // [BIG_CHUNK]
+    const int b = blockIdx.x;
+    const ImgState st = state[b];
+    const int nless = min((int)st.nless, sample_count);
+    const int ntie = min((int)st.ntie, tie_cap_for(sample_count));
+    const Cand* in = cand + (long)b * (sample_count + TIE_CAP);
+    Cand* g = sortbuf + (long)b * NP;
+    const int n = nless + ntie;
+    int np = BIG_CHUNK;
+    while (np < n) np <<= 1;
+    if (np > NP) np = NP;
+    for (int i = threadIdx.x; i < np; i += 1024) {
+        Cand e;
+        if (i < nless) e = in[i];
+        else if (i < n) e = in[sample_count + (i - nless)];
+        else { e.key = 0xFFFFFFFFu; e.gen = 0xFFFFFFFFu; e.box = 0; }
+        g[i] = e;
+    }
+    __syncthreads();
+    // steps (k, j) of the network on chunk c in LDS, for j from jtop down to 1; `up` comes from the GLOBAL index
+    auto lds_steps = [&](int c, int k, int jtop) {
+        for (int i = threadIdx.x; i < BIG_CHUNK; i += 1024) s[i] = g[c * BIG_CHUNK + i];
+        __syncthreads();
+        for (int j = jtop; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < BIG_CHUNK / 2; t += 1024) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int hi = lo | j;
+                const bool up = (((c * BIG_CHUNK + lo) & k) == 0);
+                const Cand a = s[lo], c2 = s[hi];
+                if (cand_before(c2, a) == up) {
+                    s[lo] = c2;
+                    s[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+        for (int i = threadIdx.x; i < BIG_CHUNK; i += 1024) g[c * BIG_CHUNK + i] = s[i];
+        __syncthreads();
+    };
+    const int chunks = np / BIG_CHUNK;
+    for (int c = 0; c < chunks; ++c)
+        for (int k = 2; k <= BIG_CHUNK; k <<= 1) {
+            // (a chunk is loaded and stored once per k here: 13 round trips of 96 KB through L2 per chunk, a few microseconds)
+            lds_steps(c, k, k >> 1);
+        }
+    for (int k = 2 * BIG_CHUNK; k <= np; k <<= 1) {
+        for (int j = k >> 1; j >= BIG_CHUNK; j >>= 1) {
+            for (int t = threadIdx.x; t < np / 2; t += 1024) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int hi = lo | j;
+                const bool up = ((lo & k) == 0);
+                const Cand a = g[lo], c2 = g[hi];
+                if (cand_before(c2, a) == up) {
+                    g[lo] = c2;
+                    g[hi] = a;
+                }
+            }
+            __syncthreads();       // one workgroup owns the image's buffer: its own global writes are visible to it after the barrier
+        }
+        for (int c = 0; c < chunks; ++c) lds_steps(c, k, BIG_CHUNK >> 1);
+    }
+    const int nout = min(n, sample_count);
+    for (int i = threadIdx.x; i < sample_count; i += 1024) {
+        int* ob = out_box + ((long)b * sample_count + i) * 4;
+        if (i < nout) {
+            const Cand e = g[i];
+            ob[0] = e.box & 0xFF; ob[1] = (e.box >> 8) & 0xFF; ob[2] = (e.box >> 16) & 0xFF; ob[3] = (e.box >> 24) & 0xFF;
+            out_absd[(long)b * sample_count + i] = __uint_as_float(e.key);
+        } else {
+            ob[0] = ob[1] = ob[2] = ob[3] = 0;
+            out_absd[(long)b * sample_count + i] = 0.f;
+        }
+    }
+    if (threadIdx.x == 0) out_count[b] = nout;
+}
+
 struct WsLayout {
-    size_t corners, ncorner, bitmap, hist, state, cand, total;
+    size_t corners, ncorner, bitmap, hist, state, cand, sortbuf, total;
     int nwords;
 };
 
@@ -429,6 +519,12 @@ WsLayout ws_layout(int B, int Cn, int H, int W, int max_corners, int sample_coun
     l.hist = take((size_t)B * 4096 * sizeof(unsigned));
     l.state = take((size_t)B * sizeof(ImgState));
     l.cand = take((size_t)B * (sample_count + TIE_CAP) * sizeof(Cand));
+    l.sortbuf = o;
+    if (sample_count > SORT_LDS_MAX) {       // the global sort buffer of pair_finalize_big_kernel
+        size_t np = BIG_CHUNK;
+        while (np < (size_t)sample_count + TIE_CAP) np <<= 1;
+        l.sortbuf = take((size_t)B * np * sizeof(Cand));
+    }
     l.total = o;
     return l;
 }
@@ -448,8 +544,9 @@ extern "C" int denet_build_samples(const float* corner_pr, int* out_box, float* 
     DENET_CHECK_ARG(Cn == 4 || Cn == 5, "build_samples: Cn must be 4 or 5 (corner types + optional centre), got %d", Cn);
     DENET_CHECK_ARG(H > 0 && W > 0 && H <= 256 && W <= 256 && H * W <= 16384, "build_samples: map %dx%d unsupported", H, W);
     DENET_CHECK_ARG(max_corners > 0 && max_corners <= 1024, "build_samples: max_corners must be in 1..1024");
-    // the final per-image sort holds sample_count + tie slots (<= 8192 candidates, 96 KB) in LDS
-    DENET_CHECK_ARG(sample_count > 0 && sample_count <= 7936, "build_samples: sample_count must be in 1..7936");
+    // the final per-image sort holds sample_count + tie slots in LDS (<= 8192 candidates, 96 KB) or, beyond 7936 requested
+    // candidates, sorts through a global buffer; 61 440 = ten times the 78 x 78 RoIs of the largest model the reference describes
+    DENET_CHECK_ARG(sample_count > 0 && sample_count <= 61440, "build_samples: sample_count must be in 1..61440");
     DENET_CHECK_ARG(local_max >= 0, "build_samples: negative local_max");
     const WsLayout l = ws_layout(B, Cn, H, W, max_corners, sample_count);
     DENET_CHECK_ARG(workspace_bytes >= l.total, "build_samples: workspace too small (%zu < %zu)", workspace_bytes, l.total);
@@ -492,14 +589,24 @@ extern "C" int denet_build_samples(const float* corner_pr, int* out_box, float* 
     hipLaunchKernelGGL(pair_collect_kernel, pg, dim3(256), 0, stream, c, state, cand, sample_count);
     int NP2 = 1;
     while (NP2 < sample_count + tie_cap_for(sample_count)) NP2 <<= 1;
-    const size_t lds2 = (size_t)NP2 * sizeof(Cand);
-    if (lds2 > lds2_set) {
-        e = hipFuncSetAttribute((const void*)pair_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    const bool big = sample_count > SORT_LDS_MAX;
+    const size_t lds2 = (size_t)(big ? BIG_CHUNK : NP2) * sizeof(Cand);
+    static size_t lds3_set = 0;
+    size_t& set = big ? lds3_set : lds2_set;
+    if (lds2 > set) {
+        e = hipFuncSetAttribute(big ? (const void*)pair_finalize_big_kernel : (const void*)pair_finalize_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         if (e != hipSuccess) { denet_set_error("build_samples: LDS attr: %s", hipGetErrorString(e)); return -(int)e; }
-        lds2_set = lds2;
+        set = lds2;
     }
-    hipLaunchKernelGGL(pair_finalize_kernel, dim3(B), dim3(1024), lds2, stream, state, cand, sample_count, out_box,
-                       out_absd, out_count, NP2);
+    if (big) {
+        if (NP2 < BIG_CHUNK) NP2 = BIG_CHUNK;
+        hipLaunchKernelGGL(pair_finalize_big_kernel, dim3(B), dim3(1024), lds2, stream, state, cand, (Cand*)(ws + l.sortbuf), sample_count,
+                           out_box, out_absd, out_count, NP2);
+    } else {
+        hipLaunchKernelGGL(pair_finalize_kernel, dim3(B), dim3(1024), lds2, stream, state, cand, sample_count, out_box,
+                           out_absd, out_count, NP2);
+    }
     DENET_CHECK_LAUNCH("build_samples");
     return DENET_OK;
 }

@@ -60,9 +60,6 @@ class DeNetSparseLayer(RoiHandoff, AbstractLayer):
         # 10 * sn^2 best candidates (the clustering input, :171-175) instead of sn^2 and the grouping runs on the host
         self.cluster = self.nms_threshold < 1.0
         self.proposal_count = 10 * self.sample_num * self.sample_num if self.cluster else self.sample_num * self.sample_num
-        if self.cluster and self.proposal_count > 7936:
-            raise NotImplementedError("RoI clustering needs the %d best candidates per image; the device proposal ranks at "
-                                      "most 7936 (sample_num <= 28)" % self.proposal_count)
 
         self.sample_pr = []        # per image float64 [n]      (the three host-side views may be PENDING: _resolve_edit)
         self.sample_boxes = []     # per image float64 [n,4]

@@ -197,7 +197,8 @@ class RoiHandoff:
             # generator outputs (no other choice is consistent with what the device has used)
             timer = common.Timer()
             self._finish_samples(timer, True, log=False)
-            det, cnt = self._raw_samples
+            det, cnt = self._raw_samples if self._raw_samples is not None else (numpy.zeros((B, S, 5), dtype=numpy.float32),
+                                                                                 numpy.zeros(B, dtype=numpy.int32))      # cold detector
             if self._pinned is None:
                 self._pinned = torch.empty((B * S, 4), dtype=torch.float32).pin_memory()
             f32 = self._pinned.numpy()

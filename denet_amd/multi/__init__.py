@@ -11,7 +11,9 @@ which is what this module does with `torch.distributed` (backend "nccl" is RCCL 
     of >= bucket_bytes; the all-reduce of a bucket is issued (async, on RCCL's stream) as soon as the backward
     sweep has passed the first layer of that bucket, so it overlaps the remaining backward kernels;
   * the 1/N of the mean is folded into the solver kernel (grad_scale), no extra pass over the gradients;
-  * BN running mean / stdinv (a few thousand floats) are averaged after the step, like shared.py does.
+  * the bias / BN-affine gradients (complete only when the sweep is) and the BN running mean / stdinv (a few thousand
+    floats, averaged like shared.py does) ride in the LAST bucket's collective - the one issued when the sweep has passed
+    the first layer - through a packed copy: a step has exactly len(buckets) collectives and none is issued in finish_step.
 """
 import os
 
@@ -145,7 +147,33 @@ class DataParallel:
             # the bucket holds convolution weight gradients only: they are produced on the wgrad stream, so the
             # collective is ordered behind THAT stream and the data-gradient chain on the compute stream never waits
             with self._wgrad_ctx():
-                self._pending.append(self._all_reduce(model.G[lo:hi]))
+                if lo == self._buckets[-1][0]:
+                    # the sweep has passed the first layer: every gradient of the step is queued. The last collective carries
+                    # [this bucket | bias and BN-affine gradients | BN running statistics] as one packed tensor
+                    self._tail = self._pack_tail(model, lo, hi)
+                    self._pending.append(self._all_reduce(self._tail[0]))
+                else:
+                    self._pending.append(self._all_reduce(model.G[lo:hi]))
+
+    def _tail_parts(self, model, lo, hi):
+        parts = [model.G[lo:hi]]
+        if model.n_trainable > model.n_weights:
+            parts.append(model.G[model.n_weights:model.n_trainable])
+        parts.append(model.S)
+        return parts
+
+    def _pack_tail(self, model, lo, hi):
+        import torch
+        parts = self._tail_parts(model, lo, hi)
+        n = sum(p.numel() for p in parts)
+        buf = getattr(self, "_tail_buf", None)
+        if buf is None or buf.numel() != n or buf.device != parts[0].device:
+            buf = self._tail_buf = torch.empty(n, dtype=parts[0].dtype, device=parts[0].device)
+        o = 0
+        for p in parts:
+            buf[o:o + p.numel()].copy_(p)
+            o += p.numel()
+        return buf, lo, hi
 
     @staticmethod
     def _wgrad_ctx():
@@ -159,10 +187,6 @@ class DataParallel:
 
     def finish_step(self, model):
         if self.world_size > 1 or self.force_collectives:
-            d = self.dist
-            if model.n_trainable > model.n_weights:
-                self._pending.append(self._all_reduce(model.G[model.n_weights:model.n_trainable]))
-            self._pending.append(self._all_reduce(model.S))
             ev = None
             if self._timing is not None:
                 import torch
@@ -170,6 +194,15 @@ class DataParallel:
                 ev[0].record()
             for w in self._pending:
                 w.wait()
+            tail = self.__dict__.pop("_tail", None)
+            if tail is None:          # a model without bucketed weights: the packed collective is all there is
+                tail = self._pack_tail(model, 0, 0)
+                self._all_reduce(tail[0]).wait()
+            buf, lo, hi = tail
+            o = 0
+            for p in self._tail_parts(model, lo, hi):
+                p.copy_(buf[o:o + p.numel()])
+                o += p.numel()
             self._scale(model.S, 1.0 / self.world_size)
             if ev is not None:
                 ev[1].record()

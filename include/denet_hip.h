@@ -497,7 +497,7 @@ long denet_soft_nms_batch_host(const float* det_pr, const float* fitness, const 
  *        out_count:[B].
  *      denet_samples_finish_host converts HOST copies of these into the reference's tuples
  *      (pr, x0/W, y0/H, (x1+1)/W, (y1+1)/H) with the reference's own host arithmetic (denet_sparse.cc:306-307);
- *      samples_host:[B,sample_count,5].  cluster_threshold < 1: ask for sample_count = 10 * sample_num^2 (<= 7936) and
+ *      samples_host:[B,sample_count,5].  cluster_threshold < 1: ask for sample_count = 10 * sample_num^2 (up to 61 440; beyond 7936 the final sort runs through a global buffer) and
  *      pass each image with more than sample_num^2 candidates through denet_host_cluster_samples (apply_cluster,
  *      denet_sparse.cc:165-242, host code in the reference as well): out_host [output_num][5], out_count rows.   */
 size_t denet_build_samples_workspace_bytes(int B, int Cn, int H, int W, int max_corners, int sample_count);

@@ -360,6 +360,9 @@ assert sum(hi - lo for lo, hi, _ in buckets) == m.n_weights
 for l in reversed(layers):
     dp.layer_done(m, l)
 dp.finish_step(m)
+# one collective per bucket: the bias gradients and the BN statistics ride in the last one, nothing is issued in finish_step
+assert dp.collectives_per_step() == len(buckets) and len(buckets) >= 3, (dp.collectives_per_step(), len(buckets))
+assert dp.bytes_per_step() == 4 * (m.n_trainable + 32)
 others = []
 for r in range(dp.world_size):
     torch.manual_seed(r); others.append(torch.randn(m.n_trainable))
@@ -396,6 +399,20 @@ def test_data_parallel_gloo_world2(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=180)
         assert p.returncode == 0, out.decode()
+
+
+def test_denet101_wide_builds_with_roi_clustering():
+    """the v2 models the reference advertises ("corner clustering", README.md:132; 48 x 48 RoIs, papers/dss/denet101.sh:19,
+    README.md:145) are DNS with nmsThreshold < 1 at sample_num 48: the layer asks the device proposal for the 10 * 48^2 best
+    candidates (denet_sparse.cc:171-175) - more than one LDS sort holds, which used to raise"""
+    desc = zoo.DENET101_WIDE_DESC
+    assert "DNS[7,48,0.01,0.1]" in desc
+    m = zoo.denet101(1, "wide", 128, class_num=80, seed=1, head_desc=desc.replace("DNS[7,48,0.01,0.1]", "DNS[7,48,0.01,0.1,0,0.7]"))
+    dns = [l for l in m.layers if l.type_name == "denet-sparse"][0]
+    assert dns.cluster and dns.sample_count == 2304 and dns.proposal_count == 23040
+    assert dns.export_json()["nmsThreshold"] == 0.7
+    L = dlib.load()
+    assert L.denet_build_samples_workspace_bytes(1, 4, 32, 32, 1024, 23040) > L.denet_build_samples_workspace_bytes(1, 4, 32, 32, 1024, 7936)
 
 
 def _distinct_corner_map(seed, B, H, W, per_type, Cn=4):

@@ -21,11 +21,30 @@ from oracle import model as OM
 from oracle import layers as OL
 
 
+ELEMENTWISE = {}      # what -> (max-norm relative error, p99.99 of the element-wise statistic): tests print the worst at the end
+
+
 def rel_close(a, b, rtol=1e-3, what="", atol=0.0):
+    """two clauses, both asserted:
+      max-norm      max|a - b| <= rtol * max|b| (+ atol)
+      element-wise  |a - b| <= rtol * (|b| + rms(b)) (+ atol) for 99.99 % of the elements (the 99.99th percentile of
+                    |a - b| / (|b| + rms(b)); tensors of fewer than 10^4 elements: every element). The rms floor keeps sums that
+                    cancel to ~0 from dominating; a max-norm bound alone lets small activations be 100 % wrong."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     scale = np.abs(b).max() + 1e-12
-    err = np.abs(a - b).max()
+    d = np.abs(a - b)
+    err = d.max() if d.size else 0.0
     assert err <= rtol * scale + atol, "%s: max abs err %.3e vs scale %.3e (rel %.2e)" % (what, err, scale, err / scale)
+    if d.size == 0:
+        return
+    rms = float(np.sqrt(np.mean(b * b)))
+    stat = (np.maximum(d - atol, 0.0) / (np.abs(b) + rms + 1e-30)).reshape(-1)
+    q = float(np.quantile(stat, 0.9999)) if stat.size >= 10000 else float(stat.max())
+    if what:
+        prev = ELEMENTWISE.get(what.split(" ")[0], (0.0, 0.0))
+        ELEMENTWISE[what.split(" ")[0]] = (max(prev[0], err / scale), max(prev[1], q))
+    assert q <= rtol, "%s: element-wise p99.99 of |a-b| / (|b| + rms) = %.3e > %.1e (max-norm rel %.2e, rms %.3e)" % (
+        what, q, rtol, err / scale, rms)
 
 
 def random_corner_map(rng, B, H, W, frac, Cn=4):
@@ -285,9 +304,9 @@ def _warm_corner_head(model, bias, std, seed=3):
     conv.beta.set_value(b)
 
 
-@pytest.mark.parametrize("regime", ["cold", "warm"])
-def test_denet34_skip_train_step_vs_oracle(hip, regime):
-    B, IMG = 2, 128
+def _denet34_skip_steps_vs_oracle(regime, B, IMG, steps):
+    """free-running forward + teacher-forced forward / backward / solver of `steps` training steps against oracle/model.py
+    (reference: ModelCNN.train_step, model_cnn.py:407-445, on papers/dss/denet34.sh:13-15)"""
     model = zoo.denet34(B, "skip", IMG, class_num=80, seed=1)
     # break the all-zero detect head so that its gradients are exercised
     rng = np.random.RandomState(5)
@@ -300,7 +319,7 @@ def test_denet34_skip_train_step_vs_oracle(hip, regime):
     om = OM.OracleModel(model.export_json(), B)           # teacher forced, op by op
     model.build_train_func("nesterov")
     lr, mu, decay = 0.05, 0.9, 1e-4
-    for it in range(2):
+    for it in range(steps):
         random.seed(100 + it)
         cost, costs = model.train_step(x, metas, 0, it, lr, [mu], decay)
         dns = model.layers[31]
@@ -334,6 +353,21 @@ def test_denet34_skip_train_step_vs_oracle(hip, regime):
         ys, xs = om.taps
         taps_ref = (ys[:, :, None] * (IMG // 8) + xs[:, None, :]).reshape(ys.shape[0], -1)
         assert np.array_equal(dns._taps.cpu().numpy(), taps_ref)
+
+
+@pytest.mark.parametrize("regime", ["cold", "warm"])
+def test_denet34_skip_train_step_vs_oracle(hip, regime):
+    _denet34_skip_steps_vs_oracle(regime, 2, 128, 2)
+
+
+@pytest.mark.parametrize("regime", ["cold", "warm"])
+def test_denet34_skip_512_train_step_vs_oracle(hip, regime):
+    """the same at the resolution bench.py times (papers/dss/denet34.sh:13-15,42-43: 512x512, 64x64 corner maps, 576 RoIs per
+    image; F(4x4) on 64x64 / 32x32 / 16x16 maps incl. the fused product + output-transform kernel, the fused 64-channel
+    kernels, the first layer's kernels on 256-pixel rows): B = 2, one step, element-wise and max-norm"""
+    _denet34_skip_steps_vs_oracle(regime, 2, 512, 1)
+    worst = sorted(ELEMENTWISE.items(), key=lambda kv: -kv[1][1])[:5]
+    print("element-wise p99.99 / max-norm, worst five:", [(k, "%.2e" % v[1], "%.2e" % v[0]) for k, v in worst])
 
 
 def test_denet34_edge_case_ground_truth_vs_oracle(hip):
@@ -769,7 +803,7 @@ def test_cold_detector_hand_off_equals_the_host_path(hip):
                 if not short:
                     assert modes == {"device_edit": 0, "fast": 0, "host": 3}, modes
                 elif not warm:
-                    assert modes["device_edit"] >= 2 and modes["fast"] == 0, modes
+                    assert modes["device_edit"] >= 1 and modes["host"] <= 1, modes      # (the corner cost warms the head within the three steps)
                 res[(warm, short)] = (model.P.clone(), lists, random.random())
     finally:
         RH.DEVICE_EDIT, RH.FAST_HANDOFF = saved
@@ -1008,31 +1042,56 @@ def test_denet_center_corner_variant_vs_oracle(hip):
     assert abs(cost - ocost) <= 1e-4 * abs(ocost), (cost, ocost)
 
 
-def test_roi_clustering_device_path_vs_oracle(hip):
+@pytest.mark.parametrize("sn_model", [24, 48])
+def test_roi_clustering_device_path_vs_oracle(hip, sn_model):
     """DNS nmsThreshold < 1 (apply_cluster, denet_sparse.cc:165-242, 541-542): (1) the device proposal asked for the
     10 * sn^2 best candidates + the native host clustering against the C++ oracle on maps without score ties - exact;
-    (2) a DeNet-34 skip training step with `DNS[7,24,0.01,0.1,0,0.5]`: the layer's RoI lists equal the oracle's
-    clustered proposal on the product's own corner map, and the step stays in op-by-op parity"""
+    (2) a DeNet-34 skip training step with `DNS[7,sn,0.01,0.1,0,0.5]`: the layer's RoI lists equal the oracle's
+    clustered proposal on the product's own corner map, and the step stays in op-by-op parity. sn = 48 is the RoI grid of the
+    v2 models the reference advertises (README.md:132,145; papers/dss/denet101.sh:19): 10 x 2304 = 23 040 candidates per image,
+    more than one LDS sort holds - the two-level final sort of csrc/samples.hip (pair_finalize_big_kernel)"""
     from tests.test_host import _distinct_corner_map
-    sn, S = 6, 36
-    pr = _distinct_corner_map(11, 4, 64, 64, 90)
+    sn, per_type = (6, 90) if sn_model == 24 else (48, 420)
+    S = sn * sn
+    pr = _distinct_corner_map(11, 4 if sn_model == 24 else 2, 64, 64, per_type)
     d = torch.from_numpy(pr).cuda()
     box, absd, cnt = ops.build_samples(d, 0.01, 10 * S, 1024, 0)
     raw = ops.samples_finish_host(box.cpu(), absd.cpu(), cnt.cpu(), 64, 64).numpy()
     assert int(cnt.min()) == 10 * S
-    for thr in (0.3, 0.6):
-        got, gcnt = ops.cluster_samples_host(raw, cnt.cpu().numpy(), thr, S)
-        ref, _, _, rcnt = OM.oracle_build_samples_raw(pr, 0.01, sn, 1024, 0, thr)
-        assert np.array_equal(gcnt, rcnt)
+    if sn_model == 48:
+        # 23 040 of ~10^5 candidates: some |pr_f - pr_t| collide in fp32 at this density, and inside a group of equal keys the
+        # reference's order is unspecified (DESIGN.md section 4) - which the grouping is sensitive to, and the pure-Python second
+        # implementation that shares the product's tie order needs minutes at this size. What is NEW at sn = 48 is the ranking of
+        # more candidates than one LDS sort holds, so that is what is compared here, group by group (keys identical, boxes
+        # identical as sets inside a tie group); the grouping itself is the same host routine as at sn = 6 / 24
+        big = int(np.ceil((10 * S) ** 0.5))
+        _, rbox, rabsd, rcnt0 = OM.oracle_build_samples_raw(pr, 0.01, big, 1024, 0)
+        bx, ad = box.cpu().numpy(), absd.cpu().numpy()
         for b in range(pr.shape[0]):
-            assert np.array_equal(got[b, :gcnt[b]], ref[b, :rcnt[b]]), (thr, b)
+            n = 10 * S
+            assert rcnt0[b] >= n and np.array_equal(ad[b, :n], rabsd[b, :n]) and np.all(np.diff(ad[b, :n]) >= 0)
+            i = 0
+            while i < n:
+                j = i
+                while j + 1 < n and ad[b, j + 1] == ad[b, i]:
+                    j += 1
+                if j + 1 < n:              # (a group cut by the end of the list may keep other members)
+                    assert sorted(map(tuple, bx[b, i:j + 1].tolist())) == sorted(map(tuple, rbox[b, i:j + 1].tolist())), (b, i, j)
+                i = j + 1
+    else:
+        for thr in (0.3, 0.6):
+            got, gcnt = ops.cluster_samples_host(raw, cnt.cpu().numpy(), thr, S)
+            ref, _, _, rcnt = OM.oracle_build_samples_raw(pr, 0.01, sn, 1024, 0, thr)
+            assert np.array_equal(gcnt, rcnt)
+            for b in range(pr.shape[0]):
+                assert np.array_equal(got[b, :gcnt[b]], ref[b, :rcnt[b]]), (thr, b)
 
     B, IMG = 2, 128
-    desc = zoo.DENET34_SKIP_DESC.replace("DNS[7,24,0.01,0.1]", "DNS[7,24,0.01,0.1,0,0.5]")
+    desc = zoo.DENET34_SKIP_DESC.replace("DNS[7,24,0.01,0.1]", "DNS[7,%d,0.01,0.1,0,0.5]" % sn_model)
     model = zoo.denet34(B, "skip", IMG, class_num=80, seed=1, head_desc=desc)
     dnc = [l for l in model.layers if l.type_name == "denet-corner"][0]
     dns = [l for l in model.layers if l.type_name == "denet-sparse"][0]
-    assert dns.cluster and dns.proposal_count == 5760 and dns.export_json()["nmsThreshold"] == 0.5
+    assert dns.cluster and dns.proposal_count == 10 * sn_model * sn_model and dns.export_json()["nmsThreshold"] == 0.5
     rng = np.random.RandomState(5)
     dconv = model.layers[-1].layers[0]
     dconv.omega.set_value(rng.normal(0, 0.05, dconv.omega.value.shape))
@@ -1060,10 +1119,11 @@ def test_roi_clustering_device_path_vs_oracle(hip):
     assert abs(cost - ocost) <= 1e-4 * abs(ocost), (cost, ocost)
 
 
-def test_denet101_wide_train_step_vs_oracle(hip):
+@pytest.mark.parametrize("IMG", [128, 512])
+def test_denet101_wide_train_step_vs_oracle(hip, IMG):
     """BASELINE config 5 at reduced size: ResNet-101 bottleneck backbone, three skip scales (one through a plain
     SKIPSRC), SPLIT points, 48x48 = 2304 RoIs per image, joint-fitness + bounded-IoU head (papers/dss/denet101.sh)"""
-    B, IMG = 1, 128
+    B = 1           # IMG = 512: the resolution of papers/dss/denet101.sh:19 (BASELINE config 5), 128x128 corner map
     model = zoo.denet101(B, "wide", IMG, class_num=80, seed=1,
                          head_desc=zoo.DENET101_WIDE_DESC.replace("DND[0.5,1,1]", "DND.JB[0.5,1,1]"))
     by_type = lambda t: [l for l in model.layers if l.type_name == t][0]
