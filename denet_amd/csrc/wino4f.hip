@@ -74,12 +74,14 @@ constexpr float W4_AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 
         asm volatile("" ::: "memory");     \
     }
 
-// TB tiles x 64 channels per workgroup, TB / 16 x 4 waves of one 16 x 16 block.
+// TB tiles x 64 channels per workgroup; a wave owns 16 tiles x NB blocks of 16 channels (NB = 2: one tile fragment serves two
+// products, three fragment reads per eight products instead of four, and a 16-channel block of the wave's own products
+// covers 256 cycles of LDS latency), (TB / 16) x (4 / NB) waves.
 // EP: 0 = store only, 1 = + batch-norm column sums of what is stored, 2 = + backward sums of the batch norm in front
 constexpr int W4_SLOT = 32768;                    // LDS bytes per chunk buffer (V rows, then U rows)
-template <int TB, int EP>
+template <int TB, int NB, int EP>
 __device__ __forceinline__ void wino4f_body(const W4Params& p) {
-    constexpr int NW = TB / 4;                    // waves
+    constexpr int NW = (TB / 16) * (4 / NB);      // waves
     constexpr int V_BYTES = TB * 256;             // a chunk of V rows
     constexpr int VP = TB / 4;                    // 1 KB pieces of the V chunk (4 rows each)
     constexpr int PIECES = VP + 16;
@@ -141,39 +143,42 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
         aV[kb] = (16 * tw + r15) * 256 + lo + ((kb ^ h2) << 6);
-        aU[kb] = V_BYTES + (16 * kw + r15) * 256 + lo + ((kb ^ h2) << 6);
+        aU[kb] = V_BYTES + (16 * NB * kw + r15) * 256 + lo + ((kb ^ h2) << 6);
     }
 
-    f32x4 Y[16];
-    f32x4 fu[2], fv[2];
-    if (W4_EXP & 1) asm volatile("" : "=v"(fu[0]), "=v"(fu[1]), "=v"(fv[0]), "=v"(fv[1]));
+    f32x4 Y[NB][16];
+    f32x4 fu[2][NB], fv[2];
+    if (W4_EXP & 1) asm volatile("" : "=v"(fu[0][0]), "=v"(fu[1][0]), "=v"(fu[0][NB - 1]), "=v"(fu[1][NB - 1]), "=v"(fv[0]), "=v"(fv[1]));
     auto frags = [&](int par, int kb, int slot) {
         if (W4_EXP & 1) return;
-        fu[slot] = *(const f32x4*)(smem + aU[kb] + par * W4_SLOT);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) fu[slot][nb] = *(const f32x4*)(smem + aU[kb] + nb * 4096 + par * W4_SLOT);
         fv[slot] = *(const f32x4*)(smem + aV[kb] + par * W4_SLOT);
     };
-    // two accumulator chains (even / odd products of a 16-channel block): a product never waits for the one issued before
-    // it. ZC: the block starts a component (the chains start from zero: no clearing pass)
-    f32x4 Mc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    // two accumulator chains per block (even / odd products of a 16-channel block): a product never waits for the one issued
+    // before it. ZC: the block starts a component (the chains start from zero: no clearing pass)
+    f32x4 Mc[NB][2];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) Mc[nb][0] = Mc[nb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto mm = [&](int slot, auto ZC) {
         constexpr bool zc = decltype(ZC)::value && !(W4_EXP & 2);
         if (W4_EXP & 16) {
-            asm volatile("" ::"v"(fu[slot]), "v"(fv[slot]));
+            asm volatile("" ::"v"(fu[slot][0]), "v"(fv[slot]));
             return;
         }
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-            Mc[t & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fu[slot][t], fv[slot][t], (zc && t < 2) ? z4 : Mc[t & 1], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                Mc[nb][t & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fu[slot][nb][t], fv[slot][t], (zc && t < 2) ? z4 : Mc[nb][t & 1], 0, 0, 0);
     };
-    // The output transform in two stages, every multiply-add packed (v_pk_fma_f32): fp32 MFMA and fp32 vector instructions
-    // share the SIMD's multiply-add lanes on this chip - vector work is NOT hidden behind the products, every instruction of it
-    // is matrix time lost (measured: the one-stage update, <= 16 multiply-adds per value and component, doubled the kernel's
-    // run time). Row stage, per component (l, m):  Z[j] += AT[j][m] M          (<= 4 per value)
-    // column stage, per finished row l:           Y[i][j] += AT[i][l] Z[j]    (<= 16 per value, six times)
-    // = 180 multiply-adds per value instead of 324. Z / Y pass through an opaque asm after every update: left alone, the
-    // compiler sinks the updates to the epilogue and keeps every component's M alive until then (spilled).
-    f32x4 Z[4];
+    // The output transform in two stages, every multiply-add packed (v_pk_fma_f32).
+    // Row stage, per component (l, m):  Z[j] += AT[j][m] M          (<= 4 per value)
+    // column stage, per finished row l: Y[i][j] += AT[i][l] Z[j]    (<= 16 per value, six times)
+    // = 180 multiply-adds per value instead of the 324 of a one-stage update. Z / Y pass through an opaque asm after every
+    // update: left alone, the compiler sinks the updates to the epilogue and keeps every component's M alive until then (spilled).
+    f32x4 Z[NB][4];
     auto fma4 = [&](f32x4& acc, float c, const f32x4& v, bool first) {
         f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
         f32x2 alo = {acc[0], acc[1]}, ahi = {acc[2], acc[3]};
@@ -187,35 +192,38 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
     };
     auto update = [&](auto LI, auto MI) {
         constexpr int l = decltype(LI)::value, m = decltype(MI)::value;
-        if (W4_EXP & 2) {
-            if (l == 5 && m == 5) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) Y[i] = Mc[0] + Mc[1];
+        for (int nb = 0; nb < NB; ++nb) {
+            if (W4_EXP & 2) {
+                if (l == 5 && m == 5) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) Y[nb][i] = Mc[nb][0] + Mc[nb][1];
+                }
+                continue;
             }
-            return;
-        }
-        const f32x4 M = Mc[0] + Mc[1];
+            const f32x4 M = Mc[nb][0] + Mc[nb][1];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float c = W4_AT[j][m];
-            // the first contribution to Z[j] of a row: m = 0 for j = 0, m = 1 for the others (AT[j][0] = 0)
-            const bool first = (j == 0) ? m == 0 : m == 1;
-            if (c != 0.f) {
-                fma4(Z[j], c, M, first);
-                asm volatile("" : "+v"(Z[j]));
-            }
-        }
-        if (m == 5) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float c = W4_AT[i][l];
-                // the first contribution to Y[i][.]: row 0 for i = 0, row 1 for the others
-                const bool first = (i == 0) ? l == 0 : l == 1;
+            for (int j = 0; j < 4; ++j) {
+                const float c = W4_AT[j][m];
+                // the first contribution to Z[j] of a row: m = 0 for j = 0, m = 1 for the others (AT[j][0] = 0)
+                const bool first = (j == 0) ? m == 0 : m == 1;
                 if (c != 0.f) {
+                    fma4(Z[nb][j], c, M, first);
+                    asm volatile("" : "+v"(Z[nb][j]));
+                }
+            }
+            if (m == 5) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        fma4(Y[4 * i + j], c, Z[j], first);
-                        asm volatile("" : "+v"(Y[4 * i + j]));
+                for (int i = 0; i < 4; ++i) {
+                    const float c = W4_AT[i][l];
+                    // the first contribution to Y[i][.]: row 0 for i = 0, row 1 for the others
+                    const bool first = (i == 0) ? l == 0 : l == 1;
+                    if (c != 0.f) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            fma4(Y[nb][4 * i + j], c, Z[nb][j], first);
+                            asm volatile("" : "+v"(Y[nb][4 * i + j]));
+                        }
                     }
                 }
             }
@@ -224,11 +232,13 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
     // issue order of a 16-channel block: the two fragment reads of the NEXT block go out behind the first two products of this
     // one (left to the compiler they are sunk below the products that free their registers: the LDS latency fully exposed)
     auto order = [&]() {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        // fragment reads of the NEXT block behind the first products of this one, one read per product
+#pragma unroll
+        for (int r = 0; r < NB + 1; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NB - (NB + 1), 0);
         __builtin_amdgcn_sched_barrier(0);
     };
     int dbg_n = 0;
@@ -298,28 +308,32 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
     W4_STAMP();
     __builtin_amdgcn_s_waitcnt(0);       // the trailing (out-of-range) pieces have landed before the buffers are reused
 
-    // ---- epilogue: lane = (tile t0 + 16 tw + r15, channels k0 + 16 kw + 4 g .. + 3) ----
+    // ---- epilogue: lane = (tile t0 + 16 tw + r15, channels k0 + 16 (NB kw + nb) + 4 g .. + 3, nb = 0 .. NB-1) ----
     // every tensor of the output's shape goes through a buffer descriptor: one 32-bit lane offset (out of range for a lane
     // without a tile / channels: its stores are dropped, its loads return 0; an absent tensor is a descriptor of 0 bytes) +
     // a wave-uniform offset per output position. The operands of the four positions of an output row are loaded together.
     const int t = t0 + 16 * tw + r15;
-    const int kc = k0 + 16 * kw + 4 * g;
-    const bool valid = t < p.T && kc < p.K;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f32x4 ssum = z, ssq = z;
-    {
-        const int tx = t % p.TW;
-        const int ty = (t / p.TW) % p.TH;
-        const int n = t / (p.TW * p.TH);
+    const int tx = t % p.TW;
+    const int ty = (t / p.TW) % p.TH;
+    const int n = t / (p.TW * p.TH);
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.add, 0, p.add ? p.y_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_x, 0, p.bs_x ? p.y_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_y, 0, p.bs_y ? p.y_bytes : 0u, 0x00020000);
+    const float floor_ = p.relu ? 0.f : -__builtin_inff();
+    // the ReLU mask of the backward sums: from the forward output (bs_y), recomputed from x, or none
+    const bool mask_y = p.bs_relu && p.bs_y, mask_x = p.bs_relu && !p.bs_y;
+    double ds[NB][8];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int kc = k0 + 16 * (NB * kw + nb) + 4 * g;
+        const bool valid = t < p.T && kc < p.K;
+        f32x4 ssum = z, ssq = z;
         const int voff = valid ? (((n * p.H + 4 * ty) * p.W + 4 * tx) * p.K + kc) * 4 : W4_OOB;
-        const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.add, 0, p.add ? p.y_bytes : 0u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_x, 0, p.bs_x ? p.y_bytes : 0u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_y, 0, p.bs_y ? p.y_bytes : 0u, 0x00020000);
         const int kcs = valid ? kc : 0;
         f32x4 b = z;
         if (p.bias) b = *(const f32x4*)(p.bias + kcs);
-        const float floor_ = p.relu ? 0.f : -__builtin_inff();
         f32x4 bmu = z, bis = z, bsc = z, bsh = z;
         if (EP == 2) {
             bmu = *(const f32x4*)(p.bs_mean + kcs);
@@ -330,8 +344,6 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
                 bsh[c] = (p.bs_beta ? p.bs_beta[kcs + c] : 0.f) - bmu[c] * bsc[c];
             }
         }
-        // the ReLU mask of the backward sums: from the forward output (bs_y), recomputed from x, or none
-        const bool mask_y = p.bs_relu && p.bs_y, mask_x = p.bs_relu && !p.bs_y;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f32x4 av[4], xv[4], yv[4];
@@ -347,7 +359,7 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int soff = (i * p.W + j) * p.K * 4;
-                f32x4 acc = (Y[4 * i + j] + b) + av[j];
+                f32x4 acc = (Y[nb][4 * i + j] + b) + av[j];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = fmaxf(acc[c], floor_);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc), rY, voff, soff, 0);
@@ -370,29 +382,32 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
             ssum = z;
             ssq = z;
         }
+        // the 16 values of a lane were added in fp32; from here on doubles
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            ds[nb][c] = (double)ssum[c];
+            ds[nb][4 + c] = (double)ssq[c];
+        }
     }
     W4_STAMP();
     if (EP == 0) return;
-    // the 16 values of a lane were added in fp32; from here on doubles: over the 16 tiles of the wave (shuffles inside each
-    // group of 16 lanes), then over the tile waves through LDS in wave order
-    double ds[8];
+    // over the 16 tiles of the wave (shuffles inside each group of 16 lanes), then over the tile waves through LDS in wave order
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        ds[c] = (double)ssum[c];
-        ds[4 + c] = (double)ssq[c];
-    }
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1)
+        for (int off = 8; off > 0; off >>= 1)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) ds[c] += __shfl_xor(ds[c], off, 64);
+            for (int c = 0; c < 8; ++c) ds[nb][c] += __shfl_xor(ds[nb][c], off, 64);
     __syncthreads();
     double* red = (double*)smem;                  // [tile wave][2][64 channels]
     if (r15 == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            red[(tw * 2 + 0) * 64 + 16 * kw + 4 * g + c] = ds[c];
-            red[(tw * 2 + 1) * 64 + 16 * kw + 4 * g + c] = ds[4 + c];
-        }
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                red[(tw * 2 + 0) * 64 + 16 * (NB * kw + nb) + 4 * g + c] = ds[nb][c];
+                red[(tw * 2 + 1) * 64 + 16 * (NB * kw + nb) + 4 * g + c] = ds[nb][4 + c];
+            }
     }
     __syncthreads();
     if (tid < 128) {
@@ -404,13 +419,14 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
     }
 }
 
+// both shapes: 8 waves, up to 256 registers each (two waves per SIMD)
 template <int EP>
-__global__ __launch_bounds__(1024) void wino4f_kernel_64(const W4Params p) {
-    wino4f_body<64, EP>(p);
+__global__ __launch_bounds__(512, 2) void wino4f_kernel_64(const W4Params p) {
+    wino4f_body<64, 2, EP>(p);
 }
 template <int EP>
 __global__ __launch_bounds__(512, 2) void wino4f_kernel_32(const W4Params p) {
-    wino4f_body<32, EP>(p);
+    wino4f_body<32, 1, EP>(p);
 }
 
 int g_w4_mode = -1;
@@ -480,7 +496,7 @@ int denet_wino4f_run(int tb, const float* V, const float* U, const float* bias, 
         attr_done[tb == 64][ep] = true;
     }
     const int prof = denet_prof_begin(14, tb, 64, W4_NBUF, stream);
-    hipLaunchKernelGGL(fn, dim3((unsigned)(tiles_t * p.tiles_k)), dim3(tb * 16), lds, stream, p);
+    hipLaunchKernelGGL(fn, dim3((unsigned)(tiles_t * p.tiles_k)), dim3(512), lds, stream, p);
     denet_prof_end(prof, stream);
     DENET_CHECK_LAUNCH("conv_wino4f");
     return DENET_OK;
