@@ -628,7 +628,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
         // over the rows of the tile are a reduction over li (shuffles inside each 32-lane half), then over the two waves
         // stacked along M (LDS), written as doubles: partial[tile_m][0][n] = sum, [1][n] = sum of squares.
         __syncthreads();                       // the operand buffers are reused below: every wave is out of the main loop
-        float* red = smem;                     // [WM][2][BN]
+        double* redd = (double*)smem;          // [WM][2][BN] (the operand buffers hold at least 2 x 128 x 36 floats)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -689,17 +689,36 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
                         }
                     }
                 }
+                // fp32 while a partial holds at most 2 TM values (one shuffle step), doubles from there on: a sum of squares of
+                // 128-256 values kept in fp32 costs var = E[x^2] - mean^2 three digits at |mean| / std = 30
 #pragma unroll
-                for (int off = 16; off > 0; off >>= 1) {
+                for (int off = 16; off > 8; off >>= 1) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         sv[c] += __shfl_xor(sv[c], off, 64);
                         sq[c] += __shfl_xor(sq[c], off, 64);
                     }
                 }
+                double dv[4], dq[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    dv[c] = (double)sv[c];
+                    dq[c] = (double)sq[c];
+                }
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        dv[c] += __shfl_xor(dv[c], off, 64);
+                        dq[c] += __shfl_xor(dq[c], off, 64);
+                    }
+                }
                 if (li == 0) {
-                    *(f32x4*)(red + (wm * 2 + 0) * BN + nl) = sv;
-                    *(f32x4*)(red + (wm * 2 + 1) * BN + nl) = sq;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        redd[(wm * 2 + 0) * BN + nl + c] = dv[c];
+                        redd[(wm * 2 + 1) * BN + nl + c] = dq[c];
+                    }
                 }
             }
         }
@@ -708,8 +727,8 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
             double a = 0.0, b = 0.0;
 #pragma unroll
             for (int w = 0; w < WM; ++w) {
-                a += (double)red[(w * 2 + 0) * BN + tid];
-                b += (double)red[(w * 2 + 1) * BN + tid];
+                a += redd[(w * 2 + 0) * BN + tid];
+                b += redd[(w * 2 + 1) * BN + tid];
             }
             // one row per (parity class, row tile): every pixel of dx is in exactly one
             double* ps = p.stats + ((MODE == MODE_DGRAD ? (long)blockIdx.y * p.tiles_m : 0L) + tile_m) * 2 * p.NC;

@@ -329,7 +329,8 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
     for (int nb = 0; nb < NB; ++nb) {
         const int kc = k0 + 16 * (NB * kw + nb) + 4 * g;
         const bool valid = t < p.T && kc < p.K;
-        f32x4 ssum = z, ssq = z;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) ds[nb][c] = 0.0;
         const int voff = valid ? (((n * p.H + 4 * ty) * p.W + 4 * tx) * p.K + kc) * 4 : W4_OOB;
         const int kcs = valid ? kc : 0;
         f32x4 b = z;
@@ -346,6 +347,7 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            f32x4 ssum = z, ssq = z;          // the four values of an output row in fp32, doubles from there
             f32x4 av[4], xv[4], yv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -377,16 +379,13 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
                     ssq += acc * acc;
                 }
             }
-        }
-        if (!valid) {
-            ssum = z;
-            ssq = z;
-        }
-        // the 16 values of a lane were added in fp32; from here on doubles
+            if (EP != 0 && valid) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            ds[nb][c] = (double)ssum[c];
-            ds[nb][4 + c] = (double)ssq[c];
+                for (int c = 0; c < 4; ++c) {
+                    ds[nb][c] += (double)ssum[c];
+                    ds[nb][4 + c] += (double)ssq[c];
+                }
+            }
         }
     }
     W4_STAMP();
@@ -435,7 +434,9 @@ unsigned long long* g_w4_dbg = nullptr;       // -1: DENET_WINO4F / DENET_WINO4F
 }  // namespace
 
 // tests / experiments: overrides the environment's choice of the fused F(4x4) kernel (-1 restores it); returns the old value
-extern "C" int denet_conv_wino4f_debug(unsigned long long* buf) { g_w4_dbg = buf; return 0; }
+#ifdef W4_TRACE
+extern "C" int denet_conv_wino4f_debug(unsigned long long* buf) { g_w4_dbg = buf; return 0; }       // tools/exp/w4_trace.py
+#endif
 extern "C" int denet_conv_wino4f_mode(int mode) {
     const int old = g_w4_mode;
     g_w4_mode = (mode == 0 || mode == 32 || mode == 64) ? mode : -1;

@@ -537,12 +537,12 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                                                           double* __restrict__ stats, BnFoldDev bs) {
     using WT = Wino<MO>;
     constexpr int TS = WT::TS;
-    __shared__ f32x4 red[2][256];
+    __shared__ double red[2][256][4];
     const int k4n = K / 4;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const bool valid = idx < T * k4n;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f32x4 ssum = z, ssq = z;
+    double dsum[4] = {0.0, 0.0, 0.0, 0.0}, dsq[4] = {0.0, 0.0, 0.0, 0.0};      // per output row in fp32, doubles from there
     if (valid) {
         const int k4 = (int)(idx % k4n);
         const long t = idx / k4n;
@@ -575,7 +575,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
             }
         }
 #pragma unroll
-        for (int i = 0; i < MO; ++i)
+        for (int i = 0; i < MO; ++i) {
+            f32x4 ssum = z, ssq = z;
 #pragma unroll
             for (int j = 0; j < MO; ++j) {
                 f32x4 acc = z;
@@ -613,16 +614,32 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                     ssq += acc * acc;
                 }
             }
+            if (stats) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    dsum[c] += (double)ssum[c];
+                    dsq[c] += (double)ssq[c];
+                }
+            }
+        }
     }
     if (!stats) return;
-    // threads tid, tid + k4n, tid + 2 k4n, ... hold the same channels of different tiles
-    red[0][threadIdx.x] = ssum;
-    red[1][threadIdx.x] = ssq;
+    // threads tid, tid + k4n, tid + 2 k4n, ... hold the same channels of different tiles. The MO values of an output row were added
+    // in fp32; from there on the sums run in doubles (a sum of squares of 128-256 values kept in fp32 costs
+    // var = E[x^2] - mean^2 three digits at |mean| / std = 30)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        red[0][threadIdx.x][c] = dsum[c];
+        red[1][threadIdx.x][c] = dsq[c];
+    }
     __syncthreads();
     for (int st = 128; st >= k4n; st >>= 1) {
         if ((int)threadIdx.x < st) {
-            red[0][threadIdx.x] += red[0][threadIdx.x + st];
-            red[1][threadIdx.x] += red[1][threadIdx.x + st];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                red[0][threadIdx.x][c] += red[0][threadIdx.x + st][c];
+                red[1][threadIdx.x][c] += red[1][threadIdx.x + st][c];
+            }
         }
         __syncthreads();
     }
@@ -630,8 +647,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         double* ps = stats + (long)blockIdx.x * 2 * K + threadIdx.x * 4;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            ps[c] = (double)red[0][threadIdx.x][c];
-            ps[K + c] = (double)red[1][threadIdx.x][c];
+            ps[c] = red[0][threadIdx.x][c];
+            ps[K + c] = red[1][threadIdx.x][c];
         }
     }
 }

@@ -1434,6 +1434,14 @@ def sparse_sort_async(taps, B, H, W, rois_per_image, gs):
     if _SORT_STREAM is None:
         init_streams()
     ws = WS.get("sparse_sort", _L().denet_sparse_sort_workspace_bytes(B, H, W, rois_per_image, gs))
+    if H * W <= 4096 and rois_per_image * gs * gs <= 65535:
+        # the one-kernel sort (one 1024-thread workgroup per image, 128 KB of LDS): on a side stream its workgroups starve for
+        # LDS beside the head's matrix kernels until those drain (1.5-1.9 ms in the trace); alone it takes ~50 us, so it runs
+        # here, on the compute stream, right behind the gather
+        check(_L().denet_sparse_sort(ptr(taps), ptr(ws), ws.numel(), B, H, W, rois_per_image, gs, stream_ptr()), "sparse_sort")
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
     _SORT_STREAM.wait_stream(torch.cuda.current_stream())          # taps are written by sparse_fwd on this stream
     with torch.cuda.stream(_SORT_STREAM):
         check(_L().denet_sparse_sort(ptr(taps), ptr(ws), ws.numel(), B, H, W, rois_per_image, gs, stream_ptr()), "sparse_sort")

