@@ -254,6 +254,125 @@ def test_opt_in_bf16_split_head_gemms(hip, case):
         ops.HEAD_BF16X3 = saved
 
 
+@pytest.mark.parametrize("case", [(3, 20, 20, 128, 64), (2, 24, 36, 128, 192), (5, 16, 28, 256, 128), (1, 64, 64, 128, 128), (9, 32, 32, 256, 64), (3, 20, 28, 64, 256)])
+@pytest.mark.parametrize("tb", [64, 32])
+def test_fused_winograd_f4_kernel(hip, case, tb):
+    """csrc/wino4f.hip (F(4x4,3x3) component products + output transform in one kernel; convolution.py:80-83 and its data
+    gradient, model_cnn.py:318) forced on through denet_conv_wino4f_mode, both tile-block sizes, against an fp64 convolution and
+    against the un-fused passes: tile counts that are no multiple of the block (75, 108, 140 tiles: workgroups with rows beyond
+    the tensor), 64 / 128 / 192 output channels, 2 and 4 reduction chunks per component; all three epilogues - plain, bias + add +
+    the batch-norm column sums of what is stored, ReLU, and the backward sums of the batch norm whose output gradient the data
+    gradient writes (mask from y, mask recomputed from x, no mask). The reduction width must be a multiple of 128: cases with 64
+    (or 192) channels on one side run that pass un-fused, the other fused."""
+    import torch.nn.functional as Fn
+    from denet_amd import ops
+    N, H, W, C, K = case
+    L = ops._L()
+    gen = torch.Generator().manual_seed(sum(case) + tb)
+    x = torch.randn(N, H, W, C, generator=gen).cuda()
+    w = (torch.randn(K, 3, 3, C, generator=gen) * (2.0 / (9 * C)) ** 0.5).cuda()
+    bias = torch.randn(K, generator=gen).cuda()
+    addt = torch.randn(N, H, W, K, generator=gen).cuda()
+    dy = torch.randn(N, H, W, K, generator=gen).cuda()
+    acc0 = torch.randn(N, H, W, C, generator=gen).cuda()
+    xd, wd = x.double().permute(0, 3, 1, 2).contiguous().requires_grad_(True), w.double().permute(0, 3, 1, 2)
+    ref = Fn.conv2d(xd, wd, None, padding=1)
+    r = ref.detach().permute(0, 2, 3, 1)
+    rdx = torch.autograd.grad(ref, xd, dy.double().permute(0, 3, 1, 2))[0].permute(0, 2, 3, 1)
+    u, ud = ops.conv_wino_filter(w, 4, dgrad=False), ops.conv_wino_filter(w, 4, dgrad=True)
+    T = N * (H // 4) * (W // 4)
+
+    def rel(a, b):
+        return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+
+    def sums_of(sums):
+        buf, rows = sums.partial
+        return buf[:rows * 2 * C].view(rows, 2, C).sum(0).clone()
+
+    # backward sums: dx is the gradient of the output of a batch norm with input xb (and output yb)
+    xb = torch.randn(N, H, W, C, generator=gen).cuda()
+    gamma, beta = torch.rand(C, generator=gen).cuda() + 0.5, torch.randn(C, generator=gen).cuda() * 0.3
+    mean, invstd = xb.reshape(-1, C).mean(0), 1.0 / xb.reshape(-1, C).std(0)
+    yb = torch.relu((xb - mean) * invstd * gamma + beta)
+    res = {}
+    try:
+        for mode in (0, tb):
+            L.denet_conv_wino4f_mode(mode)
+            cache = {}
+            st = torch.zeros(1 << 20, dtype=torch.float64, device="cuda")
+            y = ops.conv_wino_fwd(x, w, bias, addt, tile=4, u=u, stats=(st, cache))
+            if cache["bn_stats"] is None:
+                assert mode == 0 and 256 % (K // 4) != 0              # the un-fused output transform cannot at this channel count
+                part = None
+            else:
+                stt, rows = cache["bn_stats"]
+                if mode and C % 128 == 0:
+                    assert rows == (T + tb - 1) // tb                  # one row of partial sums per tile block
+                part = stt[:rows * 2 * K].view(rows, 2, K).sum(0).clone()
+            y_plain = ops.conv_wino_fwd(x, w, tile=4, u=u)
+            y_relu = ops.conv_wino_fwd(x, w, bias, tile=4, u=u, relu=True)
+            dx = ops.conv_wino_dgrad(dy, w, add=acc0, tile=4, u=ud)
+            bs = []
+            for relu_, use_y in ((True, True), (True, False), (False, False)):
+                sums = ops.BnSums(xb, yb if use_y else None, gamma, beta, mean, invstd, relu_)
+                dxs = ops.conv_wino_dgrad(dy, w, tile=4, u=ud, sums=sums, cache={})
+                assert sums.partial is not None
+                bs.append((dxs.clone(), sums_of(sums)))
+            res[mode] = (y.clone(), part, y_plain.clone(), y_relu.clone(), dx.clone(), bs)
+    finally:
+        L.denet_conv_wino4f_mode(-1)
+    y0, part0, yp0, yr0, dx0, bs0 = res[0]
+    y1, part1, yp1, yr1, dx1, bs1 = res[tb]
+    r2 = r + bias.double() + addt.double()
+    assert rel(yp1, r) <= 3e-5 and rel(y1, r2) <= 3e-5 and rel(yr1, (r + bias.double()).clamp_min(0)) <= 3e-5
+    assert rel(dx1, rdx + acc0.double()) <= 3e-5
+    assert rel(y1, y0) <= 3e-5 and rel(dx1, dx0) <= 3e-5            # (the un-fused passes: another association of the same sums)
+    rr = r2.reshape(-1, K)
+    assert float((part1[0] - rr.sum(0)).abs().max() / rr.abs().sum(0).max()) <= 2e-5
+    assert float((part1[1] - (rr * rr).sum(0)).abs().max() / (rr * rr).sum(0).max()) <= 2e-5
+    for (dxa, sa), (dxb, sb), (relu_, use_y) in zip(bs0, bs1, ((True, True), (True, False), (False, False))):
+        assert rel(dxb, rdx) <= 3e-5 and rel(dxb, dxa) <= 3e-5
+        g = rdx if not relu_ else torch.where(yb.double() > 0, rdx, torch.zeros_like(rdx))
+        xhat = ((xb - mean) * invstd).double()
+        want = torch.stack([g.reshape(-1, C).sum(0), (g * xhat).reshape(-1, C).sum(0)])
+        scale = float(g.abs().reshape(-1, C).sum(0).max())
+        assert float((sb - want).abs().max()) / scale <= 5e-5, (relu_, use_y)
+        assert float((sb - sa).abs().max()) / scale <= 5e-5, (relu_, use_y)
+
+
+def test_fused_winograd_f4_kernel_under_memory_pressure(hip):
+    """the chunk pipeline of csrc/wino4f.hip (LDS-DMA four chunks deep, one barrier per chunk that publishes chunk s+1 and frees
+    the buffer of chunk s-1) against stretched memory latencies: a second stream saturates HBM while the fused kernel runs; same
+    results as alone, run to run bit-identical"""
+    from denet_amd import ops
+    ops.init_streams()
+    L = ops._L()
+    side = torch.cuda.Stream()
+    big_a = torch.empty(1 << 27, device="cuda")
+    big_b = torch.empty(1 << 27, device="cuda")
+    gen = torch.Generator().manual_seed(11)
+    try:
+        for it, (N, H, W, C, K, tb) in enumerate([(16, 64, 64, 128, 128, 64), (16, 32, 32, 256, 256, 32), (8, 64, 64, 256, 128, 64), (7, 36, 52, 128, 64, 32)]):
+            x = torch.randn(N, H, W, C, generator=gen).cuda()
+            w = (torch.randn(K, 3, 3, C, generator=gen) * 0.03).cuda()
+            u = ops.conv_wino_filter(w, 4, dgrad=False)
+            L.denet_conv_wino4f_mode(tb)
+            alone = ops.conv_wino_fwd(x, w, tile=4, u=u).clone()
+            torch.cuda.synchronize()
+            for rep in range(3):
+                with torch.cuda.stream(side):
+                    for _ in range(8):
+                        big_b.copy_(big_a, non_blocking=True)
+                y = ops.conv_wino_fwd(x, w, tile=4, u=u)
+                torch.cuda.synchronize()
+                assert torch.equal(y, alone), (it, rep)
+            L.denet_conv_wino4f_mode(0)
+            ref = ops.conv_wino_fwd(x, w, tile=4, u=u)
+            assert float((alone - ref).abs().max() / ref.abs().max()) < 3e-5
+    finally:
+        L.denet_conv_wino4f_mode(-1)
+
+
 def test_fused_winograd_f2_kernels_under_memory_pressure(hip):
     """the LDS refill protocol of csrc/wino2f.hip (row bands streamed in by LDS-DMA while the previous item is multiplied, waits
     that leave younger pieces in flight) against stretched memory latencies: random batch / image sizes with several work items
