@@ -52,7 +52,6 @@ struct W4Params {
     unsigned long long* dbg;   // -DW4_TRACE builds: s_memtime stamps of workgroup 0 (tools/exp/w4_trace.py)
 };
 
-constexpr int W4_NBUF = 4;
 constexpr int W4_OOB = (int)0xF0000000u;
 constexpr float W4_AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
 
@@ -78,16 +77,18 @@ constexpr float W4_AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 
 // products, three fragment reads per eight products instead of four, and a 16-channel block of the wave's own products
 // covers 256 cycles of LDS latency), (TB / 16) x (4 / NB) waves.
 // EP: 0 = store only, 1 = + batch-norm column sums of what is stored, 2 = + backward sums of the batch norm in front
-constexpr int W4_SLOT = 32768;                    // LDS bytes per chunk buffer (V rows, then U rows)
-template <int TB, int NB, int EP>
+// NBUF = 4: four 32 KB chunk buffers, the whole LDS of a CU minus the epilogue's scratch - one workgroup per CU. NBUF = 3 (32-tile
+// blocks, 24 KB per chunk): 72 KB, TWO workgroups per CU whose barriers and DMA waits cover each other.
+template <int TB, int NB, int EP, int NBUF>
 __device__ __forceinline__ void wino4f_body(const W4Params& p) {
+    constexpr int W4_SLOT = NBUF == 4 ? 32768 : TB * 256 + 16384;      // LDS bytes per chunk buffer (V rows, then U rows)
     constexpr int NW = (TB / 16) * (4 / NB);      // waves
     constexpr int V_BYTES = TB * 256;             // a chunk of V rows
     constexpr int VP = TB / 4;                    // 1 KB pieces of the V chunk (4 rows each)
     constexpr int PIECES = VP + 16;
     constexpr int PPW = PIECES / NW;              // pieces per wave and chunk
     static_assert(PIECES % NW == 0, "pieces divide over the waves");
-    static_assert(W4_NBUF == 4 && V_BYTES + 16384 <= W4_SLOT, "two pairs of buffers, 64 KB apart");
+    static_assert((NBUF == 4 || NBUF == 3) && V_BYTES + 16384 <= W4_SLOT, "chunk buffer holds the V and the U rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,7 +123,7 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
                                                      0, 0);
         }
         d_left -= 1;
-        d_buf = (d_buf + 1) & (W4_NBUF - 1);
+        d_buf = (d_buf + 1 == NBUF) ? 0 : d_buf + 1;
         d_cc += 1;
         if (d_cc == p.chunks) {
             d_cc = 0;
@@ -149,11 +150,15 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
     f32x4 Y[NB][16];
     f32x4 fu[2][NB], fv[2];
     if (W4_EXP & 1) asm volatile("" : "=v"(fu[0][0]), "=v"(fu[1][0]), "=v"(fu[0][NB - 1]), "=v"(fu[1][NB - 1]), "=v"(fv[0]), "=v"(fv[1]));
+    // NBUF = 4: `par` selects the buffer of the current pair (an immediate offset), the pair is a flip of bit 16 in the address
+    // registers; NBUF = 3: par = 0 reads the current chunk's buffer (byte offset boff), 1 the next chunk's
+    int boff = 0;
     auto frags = [&](int par, int kb, int slot) {
         if (W4_EXP & 1) return;
+        const int off = NBUF == 4 ? par * W4_SLOT : (par == 0 ? boff : (boff + W4_SLOT == NBUF * W4_SLOT ? 0 : boff + W4_SLOT));
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) fu[slot][nb] = *(const f32x4*)(smem + aU[kb] + nb * 4096 + par * W4_SLOT);
-        fv[slot] = *(const f32x4*)(smem + aV[kb] + par * W4_SLOT);
+        for (int nb = 0; nb < NB; ++nb) fu[slot][nb] = *(const f32x4*)(smem + aU[kb] + nb * 4096 + off);
+        fv[slot] = *(const f32x4*)(smem + aV[kb] + off);
     };
     // two accumulator chains per block (even / odd products of a 16-channel block): a product never waits for the one issued
     // before it. ZC: the block starts a component (the chains start from zero: no clearing pass)
@@ -243,10 +248,11 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
     };
     int dbg_n = 0;
     (void)dbg_n;
+    // NBUF - 1 chunks in flight
     issue();
     issue();
-    issue();
-    W4_WAIT_VM(2 * PPW);
+    if (NBUF == 4) issue();
+    W4_WAIT_VM((NBUF - 2) * PPW);
     W4_BARRIER();
     frags(0, 0, 0);
     using T_ = std::true_type;
@@ -255,32 +261,33 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
     // FIRST: the chunk starts a component
     auto chunk = [&](auto PAR, auto FIRST) {
         constexpr int par = decltype(PAR)::value;
-        frags(par, 1, 1);
+        frags(NBUF == 4 ? par : 0, 1, 1);
         mm(0, FIRST);
         order();
-        frags(par, 2, 0);
+        frags(NBUF == 4 ? par : 0, 2, 0);
         mm(1, F_{});
         order();
         // chunk s+1 published, the buffer of chunk s-1 free: its pieces (chunk s+3) leave now
         W4_STAMP();
-        W4_WAIT_VM(PPW);
+        W4_WAIT_VM((NBUF - 3) * PPW);
         W4_STAMP();
         if (!(W4_EXP & 4)) W4_BARRIER();
         W4_STAMP();
         if (!(W4_EXP & 8)) issue();
-        frags(par, 3, 1);
+        frags(NBUF == 4 ? par : 0, 3, 1);
         mm(0, F_{});
         order();
-        if (par == 1) {
+        if (NBUF == 4 && par == 1) {
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
                 aV[kb] ^= 2 * W4_SLOT;
                 aU[kb] ^= 2 * W4_SLOT;
             }
         }
-        frags(par ^ 1, 0, 0);
+        frags(NBUF == 4 ? (par ^ 1) : 1, 0, 0);
         mm(1, F_{});
         order();
+        if (NBUF != 4) boff = (boff + W4_SLOT == NBUF * W4_SLOT) ? 0 : boff + W4_SLOT;
     };
     auto component = [&](auto LI, auto MI) {
         chunk(std::integral_constant<int, 0>{}, T_{});
@@ -418,14 +425,19 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
     }
 }
 
-// both shapes: 8 waves, up to 256 registers each (two waves per SIMD)
+// 8 waves, up to 256 registers each (two waves per SIMD), one workgroup per CU ...
 template <int EP>
 __global__ __launch_bounds__(512, 2) void wino4f_kernel_64(const W4Params p) {
-    wino4f_body<64, 2, EP>(p);
+    wino4f_body<64, 2, EP, 4>(p);
 }
 template <int EP>
 __global__ __launch_bounds__(512, 2) void wino4f_kernel_32(const W4Params p) {
-    wino4f_body<32, 1, EP>(p);
+    wino4f_body<32, 1, EP, 4>(p);
+}
+// ... or 4 waves on 32 tiles x 64 channels (a wave: 16 tiles x 32 channels), three chunk buffers: two workgroups per CU
+template <int EP>
+__global__ __launch_bounds__(256, 2) void wino4f_kernel_32x2(const W4Params p) {
+    wino4f_body<32, 2, EP, 3>(p);
 }
 
 int g_w4_mode = -1;
@@ -439,7 +451,7 @@ extern "C" int denet_conv_wino4f_debug(unsigned long long* buf) { g_w4_dbg = buf
 #endif
 extern "C" int denet_conv_wino4f_mode(int mode) {
     const int old = g_w4_mode;
-    g_w4_mode = (mode == 0 || mode == 32 || mode == 64) ? mode : -1;
+    g_w4_mode = (mode == 0 || mode == 32 || mode == 33 || mode == 64) ? mode : -1;
     return old;
 }
 
@@ -452,22 +464,28 @@ int denet_wino4f_block(int tile, long T, int C, int K) {
     const int mode = g_w4_mode >= 0 ? g_w4_mode : (env_on ? env_tb : 0);
     if (g_w4_mode < 0 && !env_on) return 0;
     if (g_w4_mode == 0) return 0;
-    if (mode == 32 || mode == 64) return mode;
-    // one round of workgroups has to fill the 256 CUs: 64-tile blocks if they do (the 64x64 maps of DeNet-34: 128 x 2), else
-    // 32-tile blocks (the 32x32 maps: 64 x 4); a 16x16 map (T = 512) has too few tiles either way
+    if (mode == 32 || mode == 33 || mode == 64) return mode;
+    // one round of workgroups has to fill the 256 CUs. Best: 32-tile blocks as TWO 4-wave workgroups per CU (their barriers and DMA
+    // waits cover each other: the 64x64 maps of DeNet-34, 256 x 2 workgroups; l2 data gradient 116 -> 103 us against one 8-wave
+    // workgroup of 64 tiles); else 64-tile blocks if those fill the chip; else 32-tile blocks as one 8-wave workgroup per CU (the
+    // 32x32 maps: 64 x 4); a 16x16 map (T = 512) has too few tiles either way
     const long kb = K / 64;
+    if (((T + 31) / 32) * kb >= 448) return 33;
     if (((T + 63) / 64) * kb >= 224) return 64;
     if (((T + 31) / 32) * kb >= 224) return 32;
     return 0;
 }
 
 // rows of partial statistics the fused kernel writes for this problem
-int denet_wino4f_stats_rows(int tb, long T) { return (int)((T + tb - 1) / tb); }
+int denet_wino4f_stats_rows(int tb, long T) {
+    const int tiles = tb == 33 ? 32 : tb;       // 33: 32-tile blocks, two workgroups per CU
+    return (int)((T + tiles - 1) / tiles);
+}
 
 int denet_wino4f_run(int tb, const float* V, const float* U, const float* bias, const float* add, float* y, double* stats,
                      const float* bs_x, const float* bs_y, const float* bs_gamma, const float* bs_beta, const float* bs_mean,
                      const float* bs_invstd, int bs_relu, int N, int H, int W, int C, int K, int relu, hipStream_t stream) {
-    DENET_CHECK_ARG(V && U && y && (tb == 32 || tb == 64), "conv_wino4f: bad arguments");
+    DENET_CHECK_ARG(V && U && y && (tb == 32 || tb == 33 || tb == 64), "conv_wino4f: bad arguments");
     DENET_CHECK_ARG(H % 4 == 0 && W % 4 == 0 && C % 128 == 0 && K % 64 == 0, "conv_wino4f: unsupported geometry");
     W4Params p = {};
     p.V = V; p.U = U; p.bias = bias; p.add = add; p.y = y; p.stats = stats;
@@ -480,24 +498,27 @@ int denet_wino4f_run(int tb, const float* V, const float* U, const float* bias, 
     p.T = (int)T; p.relu = relu; p.tiles_k = K / 64; p.chunks = C / 64;
     p.dbg = g_w4_dbg;
     p.v_bytes = (unsigned)vb; p.u_bytes = (unsigned)ub; p.y_bytes = (unsigned)((size_t)T * 16 * K * 4);
-    const int tiles_t = (int)((T + tb - 1) / tb);
-    const int lds = W4_NBUF * W4_SLOT;
+    const int which = tb == 64 ? 1 : (tb == 33 ? 2 : 0);
+    const int tiles = tb == 64 ? 64 : 32;
+    const int tiles_t = (int)((T + tiles - 1) / tiles);
+    const int lds = which == 2 ? 3 * (32 * 256 + 16384) : 4 * 32768;
     const int ep = !stats ? 0 : (bs_x ? 2 : 1);
     typedef void (*kern_t)(const W4Params);
-    static const kern_t kerns[2][3] = {{wino4f_kernel_32<0>, wino4f_kernel_32<1>, wino4f_kernel_32<2>},
-                                       {wino4f_kernel_64<0>, wino4f_kernel_64<1>, wino4f_kernel_64<2>}};
-    static bool attr_done[2][3] = {};
-    const kern_t fn = kerns[tb == 64][ep];
-    if (!attr_done[tb == 64][ep]) {
+    static const kern_t kerns[3][3] = {{wino4f_kernel_32<0>, wino4f_kernel_32<1>, wino4f_kernel_32<2>},
+                                       {wino4f_kernel_64<0>, wino4f_kernel_64<1>, wino4f_kernel_64<2>},
+                                       {wino4f_kernel_32x2<0>, wino4f_kernel_32x2<1>, wino4f_kernel_32x2<2>}};
+    static bool attr_done[3][3] = {};
+    const kern_t fn = kerns[which][ep];
+    if (!attr_done[which][ep]) {
         const hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             denet_set_error("conv_wino4f: hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
             return -(int)e;
         }
-        attr_done[tb == 64][ep] = true;
+        attr_done[which][ep] = true;
     }
-    const int prof = denet_prof_begin(14, tb, 64, W4_NBUF, stream);
-    hipLaunchKernelGGL(fn, dim3((unsigned)(tiles_t * p.tiles_k)), dim3(512), lds, stream, p);
+    const int prof = denet_prof_begin(14, tb, 64, which == 2 ? 3 : 4, stream);
+    hipLaunchKernelGGL(fn, dim3((unsigned)(tiles_t * p.tiles_k)), dim3(which == 2 ? 256 : 512), lds, stream, p);
     denet_prof_end(prof, stream);
     DENET_CHECK_LAUNCH("conv_wino4f");
     return DENET_OK;

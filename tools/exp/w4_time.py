@@ -34,7 +34,7 @@ for name, H, W, C, K in GEOMS:
     u = ops.conv_wino_filter(w, 4, dgrad=False)
     ud = ops.conv_wino_filter(w, 4, dgrad=True)
     res = {}
-    for mode in (0, 64, 32):
+    for mode in (0, 64, 32, 33):
         L.denet_conv_wino4f_mode(mode)
         cache = {}
         st = torch.zeros(1 << 22, dtype=torch.float64, device="cuda")
@@ -71,7 +71,7 @@ for name, H, W, C, K in GEOMS:
     y0, dx0, s0, tf0, td0, r0 = res[0][:6]
     flop = 2.0 * B * H * W * C * K * 9 / 4
     line = "%-8s B=%d  unfused fwd %6.1f us dgrad %6.1f us |" % (name, B, tf0, td0)
-    for mode in (64, 32):
+    for mode in (64, 32, 33):
         y1, dx1, s1, tf1, td1, r1, kf, kd = res[mode]
         ey = float((y1 - y0).abs().max() / y0.abs().max())
         ed = float((dx1 - dx0).abs().max() / dx0.abs().max())
