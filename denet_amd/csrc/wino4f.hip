@@ -46,7 +46,7 @@ struct W4Params {
     int N, H, W, C, K, TH, TW;
     int T;
     int relu;
-    int tiles_k;         // 64-channel blocks
+    int tiles_k;         // channel blocks (64 or 32 channels per workgroup)
     int chunks;          // C / 64
     unsigned v_bytes, u_bytes, y_bytes;
     unsigned long long* dbg;   // -DW4_TRACE builds: s_memtime stamps of workgroup 0 (tools/exp/w4_trace.py)
@@ -79,23 +79,23 @@ constexpr float W4_AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 
 // EP: 0 = store only, 1 = + batch-norm column sums of what is stored, 2 = + backward sums of the batch norm in front
 // NBUF = 4: four 32 KB chunk buffers, the whole LDS of a CU minus the epilogue's scratch - one workgroup per CU. NBUF = 3 (32-tile
 // blocks, 24 KB per chunk): 72 KB, TWO workgroups per CU whose barriers and DMA waits cover each other.
-template <int TB, int NB, int EP, int NBUF>
+template <int TB, int KB, int NB, int EP, int NBUF>
 __device__ __forceinline__ void wino4f_body(const W4Params& p) {
-    constexpr int W4_SLOT = NBUF == 4 ? 32768 : TB * 256 + 16384;      // LDS bytes per chunk buffer (V rows, then U rows)
-    constexpr int NW = (TB / 16) * (4 / NB);      // waves
+    constexpr int W4_SLOT = NBUF == 4 ? 32768 : TB * 256 + KB * 256;      // LDS bytes per chunk buffer (V rows, then U rows)
+    constexpr int NW = (TB / 16) * (KB / 16 / NB);      // waves
     constexpr int V_BYTES = TB * 256;             // a chunk of V rows
     constexpr int VP = TB / 4;                    // 1 KB pieces of the V chunk (4 rows each)
-    constexpr int PIECES = VP + 16;
+    constexpr int PIECES = VP + KB / 4;
     constexpr int PPW = PIECES / NW;              // pieces per wave and chunk
     static_assert(PIECES % NW == 0, "pieces divide over the waves");
-    static_assert((NBUF == 4 || NBUF == 3) && V_BYTES + 16384 <= W4_SLOT, "chunk buffer holds the V and the U rows");
+    static_assert((NBUF == 4 || NBUF == 3) && V_BYTES + KB * 256 <= W4_SLOT, "chunk buffer holds the V and the U rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tw = wave % (TB / 16), kw = wave / (TB / 16);
     const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
     const int kblk = (int)(bid % (uint32_t)p.tiles_k), tblk = (int)(bid / (uint32_t)p.tiles_k);
-    const int t0 = tblk * TB, k0 = kblk * 64;
+    const int t0 = tblk * TB, k0 = kblk * KB;
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)p.V, 0, p.v_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, p.u_bytes, 0x00020000);
 
@@ -405,22 +405,22 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) ds[nb][c] += __shfl_xor(ds[nb][c], off, 64);
     __syncthreads();
-    double* red = (double*)smem;                  // [tile wave][2][64 channels]
+    double* red = (double*)smem;                  // [tile wave][2][KB channels]
     if (r15 == 0) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                red[(tw * 2 + 0) * 64 + 16 * (NB * kw + nb) + 4 * g + c] = ds[nb][c];
-                red[(tw * 2 + 1) * 64 + 16 * (NB * kw + nb) + 4 * g + c] = ds[nb][4 + c];
+                red[(tw * 2 + 0) * KB + 16 * (NB * kw + nb) + 4 * g + c] = ds[nb][c];
+                red[(tw * 2 + 1) * KB + 16 * (NB * kw + nb) + 4 * g + c] = ds[nb][4 + c];
             }
     }
     __syncthreads();
-    if (tid < 128) {
-        const int which = tid >> 6, ch = tid & 63;
+    if (tid < 2 * KB) {
+        const int which = tid / KB, ch = tid % KB;
         double a = 0.0;
 #pragma unroll
-        for (int w = 0; w < TB / 16; ++w) a += red[(w * 2 + which) * 64 + ch];
+        for (int w = 0; w < TB / 16; ++w) a += red[(w * 2 + which) * KB + ch];
         if (k0 + ch < p.K) p.stats[((long)tblk * 2 + which) * p.K + k0 + ch] = a;
     }
 }
@@ -428,16 +428,22 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
 // 8 waves, up to 256 registers each (two waves per SIMD), one workgroup per CU ...
 template <int EP>
 __global__ __launch_bounds__(512, 2) void wino4f_kernel_64(const W4Params p) {
-    wino4f_body<64, 2, EP, 4>(p);
+    wino4f_body<64, 64, 2, EP, 4>(p);
 }
 template <int EP>
 __global__ __launch_bounds__(512, 2) void wino4f_kernel_32(const W4Params p) {
-    wino4f_body<32, 1, EP, 4>(p);
+    wino4f_body<32, 64, 1, EP, 4>(p);
 }
 // ... or 4 waves on 32 tiles x 64 channels (a wave: 16 tiles x 32 channels), three chunk buffers: two workgroups per CU
 template <int EP>
 __global__ __launch_bounds__(256, 2) void wino4f_kernel_32x2(const W4Params p) {
-    wino4f_body<32, 2, EP, 3>(p);
+    wino4f_body<32, 64, 2, EP, 3>(p);
+}
+// ... or 4 waves on 32 tiles x 32 channels (a wave: 16 tiles x 16 channels), 16 KB chunk buffers: two to three workgroups per CU where
+// 32 x 64 blocks would leave one 4-wave workgroup per CU (the 32x32 maps: 64 x 8 workgroups)
+template <int EP>
+__global__ __launch_bounds__(256, 2) void wino4f_kernel_32k(const W4Params p) {
+    wino4f_body<32, 32, 1, EP, 3>(p);
 }
 
 int g_w4_mode = -1;
@@ -451,7 +457,7 @@ extern "C" int denet_conv_wino4f_debug(unsigned long long* buf) { g_w4_dbg = buf
 #endif
 extern "C" int denet_conv_wino4f_mode(int mode) {
     const int old = g_w4_mode;
-    g_w4_mode = (mode == 0 || mode == 32 || mode == 33 || mode == 64) ? mode : -1;
+    g_w4_mode = (mode == 0 || mode == 32 || mode == 33 || mode == 34 || mode == 64) ? mode : -1;
     return old;
 }
 
@@ -464,11 +470,19 @@ int denet_wino4f_block(int tile, long T, int C, int K) {
     const int mode = g_w4_mode >= 0 ? g_w4_mode : (env_on ? env_tb : 0);
     if (g_w4_mode < 0 && !env_on) return 0;
     if (g_w4_mode == 0) return 0;
-    if (mode == 32 || mode == 33 || mode == 64) return mode;
-    // one round of workgroups has to fill the 256 CUs. Best: 32-tile blocks as TWO 4-wave workgroups per CU (their barriers and DMA
-    // waits cover each other: the 64x64 maps of DeNet-34, 256 x 2 workgroups; l2 data gradient 116 -> 103 us against one 8-wave
-    // workgroup of 64 tiles); else 64-tile blocks if those fill the chip; else 32-tile blocks as one 8-wave workgroup per CU (the
-    // 32x32 maps: 64 x 4); a 16x16 map (T = 512) has too few tiles either way
+    if (mode == 32 || mode == 33 || mode == 34 || mode == 64) return mode;
+    // The workgroups of a launch have to fill the 256 CUs in ONE round, and two small workgroups per CU beat one large one: their
+    // barriers and DMA waits cover each other. Kernel alone, epilogues as a training step runs them (statistics / backward sums +
+    // add), l2 = 64x64 map 128 -> 128, l3 = 32x32 map 256 -> 256 (tools/exp/w4_time.py, W4_STEP_LIKE=1):
+    //   shape (mode)                            workgroups l2 / l3    l2 fwd  l2 dgrad   l3 fwd  l3 dgrad  [us]
+    //   64 tiles x 64 ch, 8 waves (64)              256 / 128           118     186       170     200
+    //   32 x 64, 8 waves (32)                       512 / 256           122     170       105     119
+    //   32 x 64, 4 waves, two per CU (33)           512 / 256           103     163       110     141
+    //   32 x 32, 4 waves, up to three per CU (34)  1024 / 512           118     161       101     119
+    // -> 32 x 64 as two 4-wave workgroups per CU where that gives >= 448 workgroups, the 8-wave shapes for smaller grids. The
+    // 32 x 32 shape (mode 34, forced only) wins the table on the 32x32 maps but LOSES inside the training step (same box, A / B:
+    // 1 030-1 044 against 1 054-1 056 img/s, this kernel 5.20 against 5.00 ms per step): more operand traffic per product, and its
+    // third workgroup per CU takes slots from the other stream's kernels. A 16x16 map (T = 512) has too few tiles either way.
     const long kb = K / 64;
     if (((T + 31) / 32) * kb >= 448) return 33;
     if (((T + 63) / 64) * kb >= 224) return 64;
@@ -478,14 +492,14 @@ int denet_wino4f_block(int tile, long T, int C, int K) {
 
 // rows of partial statistics the fused kernel writes for this problem
 int denet_wino4f_stats_rows(int tb, long T) {
-    const int tiles = tb == 33 ? 32 : tb;       // 33: 32-tile blocks, two workgroups per CU
+    const int tiles = tb == 64 ? 64 : 32;       // 32, 33, 34: 32-tile blocks
     return (int)((T + tiles - 1) / tiles);
 }
 
 int denet_wino4f_run(int tb, const float* V, const float* U, const float* bias, const float* add, float* y, double* stats,
                      const float* bs_x, const float* bs_y, const float* bs_gamma, const float* bs_beta, const float* bs_mean,
                      const float* bs_invstd, int bs_relu, int N, int H, int W, int C, int K, int relu, hipStream_t stream) {
-    DENET_CHECK_ARG(V && U && y && (tb == 32 || tb == 33 || tb == 64), "conv_wino4f: bad arguments");
+    DENET_CHECK_ARG(V && U && y && (tb == 32 || tb == 33 || tb == 34 || tb == 64), "conv_wino4f: bad arguments");
     DENET_CHECK_ARG(H % 4 == 0 && W % 4 == 0 && C % 128 == 0 && K % 64 == 0, "conv_wino4f: unsupported geometry");
     W4Params p = {};
     p.V = V; p.U = U; p.bias = bias; p.add = add; p.y = y; p.stats = stats;
@@ -495,19 +509,21 @@ int denet_wino4f_run(int tb, const float* V, const float* U, const float* bias, 
     const long T = (long)N * p.TH * p.TW;
     const size_t vb = (size_t)36 * T * C * 4, ub = (size_t)36 * K * C * 4;
     DENET_CHECK_ARG(vb < 0xE0000000ul && ub < 0xE0000000ul, "conv_wino4f: operand too large for a buffer descriptor");
-    p.T = (int)T; p.relu = relu; p.tiles_k = K / 64; p.chunks = C / 64;
+    const int kbw = tb == 34 ? 32 : 64;           // output channels per workgroup
+    p.T = (int)T; p.relu = relu; p.tiles_k = K / kbw; p.chunks = C / 64;
     p.dbg = g_w4_dbg;
     p.v_bytes = (unsigned)vb; p.u_bytes = (unsigned)ub; p.y_bytes = (unsigned)((size_t)T * 16 * K * 4);
-    const int which = tb == 64 ? 1 : (tb == 33 ? 2 : 0);
+    const int which = tb == 64 ? 1 : (tb == 33 ? 2 : (tb == 34 ? 3 : 0));
     const int tiles = tb == 64 ? 64 : 32;
     const int tiles_t = (int)((T + tiles - 1) / tiles);
-    const int lds = which == 2 ? 3 * (32 * 256 + 16384) : 4 * 32768;
+    const int lds = which == 2 ? 3 * (32 * 256 + 16384) : (which == 3 ? 3 * (32 * 256 + 32 * 256) : 4 * 32768);
     const int ep = !stats ? 0 : (bs_x ? 2 : 1);
     typedef void (*kern_t)(const W4Params);
-    static const kern_t kerns[3][3] = {{wino4f_kernel_32<0>, wino4f_kernel_32<1>, wino4f_kernel_32<2>},
+    static const kern_t kerns[4][3] = {{wino4f_kernel_32<0>, wino4f_kernel_32<1>, wino4f_kernel_32<2>},
                                        {wino4f_kernel_64<0>, wino4f_kernel_64<1>, wino4f_kernel_64<2>},
-                                       {wino4f_kernel_32x2<0>, wino4f_kernel_32x2<1>, wino4f_kernel_32x2<2>}};
-    static bool attr_done[3][3] = {};
+                                       {wino4f_kernel_32x2<0>, wino4f_kernel_32x2<1>, wino4f_kernel_32x2<2>},
+                                       {wino4f_kernel_32k<0>, wino4f_kernel_32k<1>, wino4f_kernel_32k<2>}};
+    static bool attr_done[4][3] = {};
     const kern_t fn = kerns[which][ep];
     if (!attr_done[which][ep]) {
         const hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -517,8 +533,8 @@ int denet_wino4f_run(int tb, const float* V, const float* U, const float* bias, 
         }
         attr_done[which][ep] = true;
     }
-    const int prof = denet_prof_begin(14, tb, 64, which == 2 ? 3 : 4, stream);
-    hipLaunchKernelGGL(fn, dim3((unsigned)(tiles_t * p.tiles_k)), dim3(which == 2 ? 256 : 512), lds, stream, p);
+    const int prof = denet_prof_begin(14, tb, kbw, which >= 2 ? 3 : 4, stream);
+    hipLaunchKernelGGL(fn, dim3((unsigned)(tiles_t * p.tiles_k)), dim3(which >= 2 ? 256 : 512), lds, stream, p);
     denet_prof_end(prof, stream);
     DENET_CHECK_LAUNCH("conv_wino4f");
     return DENET_OK;

@@ -269,7 +269,7 @@ int denet_conv_last_config(int* mode, int* bm, int* bn, int* nbuf, int* grid_y);
  * pair per convolution launch on the launch stream, (0) stops and frees; _read returns the duration of launch i and the
  * instantiation <mode,BM,BN,2,2,NBUF> it used (the name rocprofv3 --kernel-trace shows).                       */
 /* the fused F(4x4,3x3) product + output-transform kernel (csrc/wino4f.hip) inside the denet_conv_wino_* passes: 0 = never,
- * 32 / 64 = that tile block wherever the geometry allows (33: 32-tile blocks as two 4-wave workgroups per CU), -1 = the default
+ * 32 / 64 = that tile block wherever the geometry allows (33 / 34: 32-tile blocks as 4-wave workgroups on 64 / 32 output channels, several per CU), -1 = the default
  * policy (DENET_WINO4F, DENET_WINO4F_TB); returns the previous setting. Same operator as the un-fused passes (convolution.py:80-83), other rounding.                       */
 int denet_conv_wino4f_mode(int mode);
 int denet_conv_profile(int enable);

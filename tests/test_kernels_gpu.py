@@ -255,11 +255,11 @@ def test_opt_in_bf16_split_head_gemms(hip, case):
 
 
 @pytest.mark.parametrize("case", [(3, 20, 20, 128, 64), (2, 24, 36, 128, 192), (5, 16, 28, 256, 128), (1, 64, 64, 128, 128), (9, 32, 32, 256, 64), (3, 20, 28, 64, 256)])
-@pytest.mark.parametrize("tb", [64, 32, 33])
+@pytest.mark.parametrize("tb", [64, 32, 33, 34])
 def test_fused_winograd_f4_kernel(hip, case, tb):
     """csrc/wino4f.hip (F(4x4,3x3) component products + output transform in one kernel; convolution.py:80-83 and its data
-    gradient, model_cnn.py:318) forced on through denet_conv_wino4f_mode, all three shapes (64-tile blocks, 32-tile blocks as one
-    8-wave or - mode 33 - two 4-wave workgroups per CU), against an fp64 convolution and
+    gradient, model_cnn.py:318) forced on through denet_conv_wino4f_mode, all four shapes (64-tile blocks; 32-tile blocks as one 8-wave workgroup,
+    as 4-wave workgroups on 64 channels - mode 33 - or on 32 channels - mode 34), against an fp64 convolution and
     against the un-fused passes: tile counts that are no multiple of the block (75, 108, 140 tiles: workgroups with rows beyond
     the tensor), 64 / 128 / 192 output channels, 2 and 4 reduction chunks per component; all three epilogues - plain, bias + add +
     the batch-norm column sums of what is stored, ReLU, and the backward sums of the batch norm whose output gradient the data
@@ -353,7 +353,7 @@ def test_fused_winograd_f4_kernel_under_memory_pressure(hip):
     big_b = torch.empty(1 << 27, device="cuda")
     gen = torch.Generator().manual_seed(11)
     try:
-        for it, (N, H, W, C, K, tb) in enumerate([(16, 64, 64, 128, 128, 64), (16, 32, 32, 256, 256, 32), (8, 64, 64, 256, 128, 33), (7, 36, 52, 128, 64, 32), (16, 64, 64, 128, 128, 33)]):
+        for it, (N, H, W, C, K, tb) in enumerate([(16, 64, 64, 128, 128, 64), (16, 32, 32, 256, 256, 32), (8, 64, 64, 256, 128, 33), (7, 36, 52, 128, 64, 32), (16, 64, 64, 128, 128, 33), (16, 32, 32, 256, 256, 34), (9, 64, 64, 128, 192, 34)]):
             x = torch.randn(N, H, W, C, generator=gen).cuda()
             w = (torch.randn(K, 3, 3, C, generator=gen) * 0.03).cuda()
             u = ops.conv_wino_filter(w, 4, dgrad=False)

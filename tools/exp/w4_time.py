@@ -32,9 +32,12 @@ for name, H, W, C, K in GEOMS:
     add = torch.randn(B, H, W, K, device="cuda")
     dy = torch.randn(B, H, W, K, device="cuda")
     u = ops.conv_wino_filter(w, 4, dgrad=False)
+    xb = torch.randn(B, H, W, C, device="cuda"); gam = torch.rand(C, device="cuda") + 0.5; bet = torch.randn(C, device="cuda")
+    mu = xb.reshape(-1, C).mean(0); isd = 1.0 / xb.reshape(-1, C).std(0); yb = torch.relu((xb - mu) * isd * gam + bet)
+    accd = torch.randn(B, H, W, C, device="cuda")
     ud = ops.conv_wino_filter(w, 4, dgrad=True)
     res = {}
-    for mode in (0, 64, 32, 33):
+    for mode in (0, 64, 32, 33, 34):
         L.denet_conv_wino4f_mode(mode)
         cache = {}
         st = torch.zeros(1 << 22, dtype=torch.float64, device="cuda")
@@ -52,7 +55,13 @@ for name, H, W, C, K in GEOMS:
                 L.denet_conv_profile(1)
                 for _ in range(5):
                     if which == 0:
-                        ops.conv_wino_fwd(x, w, bias, add, tile=4, u=u, stats=(st, cache))
+                        if os.environ.get("W4_STEP_LIKE"):      # what a training step runs: statistics, no bias / add
+                            ops.conv_wino_fwd(x, w, None, None, tile=4, u=u, stats=(st, cache))
+                        else:
+                            ops.conv_wino_fwd(x, w, bias, add, tile=4, u=u, stats=(st, cache))
+                    elif os.environ.get("W4_STEP_LIKE"):        # ... the backward sums of the batch norm in front + the accumulated add
+                        bsum = ops.BnSums(xb, yb, gam, bet, mu, isd, True)
+                        ops.conv_wino_dgrad(dy, w, add=accd, tile=4, u=ud, sums=bsum, cache={})
                     else:
                         ops.conv_wino_dgrad(dy, w, tile=4, u=ud)
                 torch.cuda.synchronize()
@@ -71,7 +80,7 @@ for name, H, W, C, K in GEOMS:
     y0, dx0, s0, tf0, td0, r0 = res[0][:6]
     flop = 2.0 * B * H * W * C * K * 9 / 4
     line = "%-8s B=%d  unfused fwd %6.1f us dgrad %6.1f us |" % (name, B, tf0, td0)
-    for mode in (64, 32, 33):
+    for mode in (64, 32, 33, 34):
         y1, dx1, s1, tf1, td1, r1, kf, kd = res[mode]
         ey = float((y1 - y0).abs().max() / y0.abs().max())
         ed = float((dx1 - dx0).abs().max() / dx0.abs().max())
