@@ -1,6 +1,6 @@
 """host time of the RoI hand-off = the time the device stands idle: from the moment the host sees the proposal (ops.wait_stream
 returns) to the launch of the gather (ops.sparse_fwd), per step, in the regime of the first steps of the synthetic run (every
-list trimmed by random.sample). DENET_FAST_HANDOFF=0 / DENET_DEVICE_EDIT=0 / DENET_DEVICE_SAMPLE=1 select the form."""
+list trimmed by random.sample). DENET_SHORT_HANDOFF=0 selects the ordinary host path (round 4: one switch; the test hooks are roi_handoff.DEVICE_EDIT / FAST_HANDOFF)."""
 import os
 import sys
 import random

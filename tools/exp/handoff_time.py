@@ -24,26 +24,6 @@ for it in range(4, 24):
     for k, v in dns.phase_ms.items():
         acc[k] = acc.get(k, 0.0) + v
 torch.cuda.synchronize()
-print("ms/step %.3f" % ((time.perf_counter() - t0) / 20 * 1e3), {k: round(v / 20, 3) for k, v in sorted(acc.items())}, "cold hits", getattr(dns, "cold_hits", None))
+print("ms/step %.3f" % ((time.perf_counter() - t0) / 20 * 1e3), {k: round(v / 20, 3) for k, v in sorted(acc.items())}, "hand-off modes", dns.handoff_modes)
 
 print("device-side edits", getattr(dns, "device_edits", 0))
-
-import denet_amd.layer.denet_sparse as ds
-import math
-orig = ds.DeNetSparseLayer._device_edit
-
-
-def probe(self, hcount):
-    de, pf, prep = self.__dict__.get("_dev_edit"), self.__dict__.get("_prefetch"), self.__dict__.get("_prep")
-    hc = hcount.numpy()
-    why = ("no upload" if de is None else "no prefetch" if pf is None else "no prep" if prep is None else
-           "sum 0" if int(hc.sum()) == 0 else "max %d" % int(hc.max()) if int(hc.max()) > 519 else "moved" if not pf["mirror"].fresh() else "ok")
-    probe.log.append((why, int(hc.sum())))
-    return orig(self, hcount)
-
-
-probe.log = []
-ds.DeNetSparseLayer._device_edit = probe
-for it in range(24, 34):
-    model.train_step(xd, metas, 0, it, 0.1, [0.9], 1e-4)
-print(probe.log)
