@@ -57,6 +57,20 @@ def random_corner_map(rng, B, H, W, frac, Cn=4):
     return np.ascontiguousarray(np.stack([neg, pos], axis=1).astype(np.float32))
 
 
+def _box_key(pr_map, b, box):
+    """|pr_f - pr_t| of a candidate box as the reference evaluates it (denet_sparse.cc:276-303): sequential fp32 sums over the
+    four corner cells in the order TL, TR, BL, BR (+ the centre cell of the 5-map variant)"""
+    x0, y0, x1, y1 = box
+    cells = [(0, y0, x0), (1, y0, x1), (2, y1, x0), (3, y1, x1)]
+    if pr_map.shape[2] == 5:
+        cells.append((4, (y0 + y1) // 2, (x0 + x1) // 2))
+    sf = st = np.float32(0.0)
+    for c, y, x in cells:
+        sf = np.float32(sf + pr_map[b, 0, c, y, x])
+        st = np.float32(st + pr_map[b, 1, c, y, x])
+    return np.float32(abs(np.float32(sf - st)))
+
+
 def check_samples(pr_map, thr, sn, maxc, lm):
     d = torch.from_numpy(pr_map).cuda()
     box, absd, cnt = ops.build_samples(d, thr, sn * sn, maxc, lm)
@@ -80,7 +94,10 @@ def check_samples(pr_map, thr, sn, maxc, lm):
             ga = sorted(map(tuple, box[b, i:j + 1].tolist()))
             gb = sorted(map(tuple, rbox[b, i:j + 1].tolist()))
             if j + 1 == n and n == sn * sn and ga != gb:
-                pass     # a tie group cut by the top-K boundary may keep different members
+                # a tie group cut by the top-K boundary may keep different members - but only members that really HAVE the
+                # boundary score: the key of every box one side kept and the other did not is recomputed from the map
+                for bx in set(ga) ^ set(gb):
+                    assert _box_key(pr_map, b, bx) == absd[b, i], ("a box without the boundary score at the cut", b, bx)
             else:
                 assert ga == gb, "boxes differ at rank %d..%d" % (i, j)
             if j == i:
