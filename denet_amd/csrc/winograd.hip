@@ -33,6 +33,12 @@ int denet_wino4f_run(int tb, const float* V, const float* U, const float* bias, 
                      const float* bs_x, const float* bs_y, const float* bs_gamma, const float* bs_beta, const float* bs_mean,
                      const float* bs_invstd, int bs_relu, int N, int H, int W, int C, int K, int relu, hipStream_t stream);
 
+// wino4g.hip: F(4x4) filter-gradient component products + adjoint filter transform
+int denet_wino4g_splits(int tile, long T, int C, int K);
+size_t denet_wino4g_workspace_bytes(int splits, int C, int K);
+int denet_wino4g_run(int splits, const float* dM, const float* V, float* dU, float* part, size_t part_bytes, long T, int C, int K,
+                     hipStream_t stream);
+
 namespace {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
@@ -878,7 +884,11 @@ static int wino_wgrad_run(const float* x, const float* dy, const float* dm_ready
         dMr = dM;
     }
     DENET_CHECK_LAUNCH("conv_wino_wgrad transforms");
-    rc = denet_wgrad_batched(V, dMr, dU, split_ws, split_ws_bytes, d.NX, (int)d.T, C, K, stream);
+    const int sp = denet_wino4g_splits(tile, d.T, C, K);
+    if (sp && (sp == 1 || (split_ws && split_ws_bytes >= denet_wino4g_workspace_bytes(sp, C, K))))
+        rc = denet_wino4g_run(sp, dMr, V, dU, split_ws, split_ws_bytes, d.T, C, K, stream);     // the operands' rows as they lie
+    else
+        rc = denet_wgrad_batched(V, dMr, dU, split_ws, split_ws_bytes, d.NX, (int)d.T, C, K, stream);
     if (rc) return rc;
     WINO_LAUNCH(tile, wino_dfilter_kernel, (long)K * C, dU, dw, K, C);
     DENET_CHECK_LAUNCH("conv_wino_wgrad filter");

@@ -66,6 +66,7 @@ SIGNATURES = {
     "denet_conv_tuned": (I, [I] * 11 + [P, P, P]),
     "denet_conv_last_config": (I, [P] * 5),
     "denet_conv_wino4f_mode": (I, [I]),
+    "denet_conv_wino4g_mode": (I, [I]),
     "denet_conv_profile": (I, [I]),
     "denet_conv_profile_count": (I, []),
     "denet_conv_profile_read": (I, [I] + [P] * 5),

@@ -60,7 +60,7 @@ class KernelProfile:
         ms, v = ctypes.c_float(), [ctypes.c_int() for _ in range(4)]
         for i, flops in enumerate(self.flops):
             check(L.denet_conv_profile_read(i, ctypes.byref(ms), *[ctypes.byref(x) for x in v]), "conv_profile_read")
-            name = {10: "wino2f_ws_kernel", 11: "wino2f_wgrad_kernel", 12: "stem_fwd_kernel", 13: "stem_wgrad_kernel", 14: "wino4f_kernel"}.get(v[0].value) or \
+            name = {10: "wino2f_ws_kernel", 11: "wino2f_wgrad_kernel", 12: "stem_fwd_kernel", 13: "stem_wgrad_kernel", 14: "wino4f_kernel", 15: "wino4g_kernel"}.get(v[0].value) or \
                 "igemm_kernel<%d, %d, %d, 2, 2, %d>" % tuple(x.value for x in v)
             a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
             a["launches"] += 1

@@ -272,6 +272,10 @@ int denet_conv_last_config(int* mode, int* bm, int* bn, int* nbuf, int* grid_y);
  * 32 / 64 = that tile block wherever the geometry allows (33 / 34: 32-tile blocks as 4-wave workgroups on 64 / 32 output channels, several per CU), -1 = the default
  * policy (DENET_WINO4F, DENET_WINO4F_TB); returns the previous setting. Same operator as the un-fused passes (convolution.py:80-83), other rounding.                       */
 int denet_conv_wino4f_mode(int mode);
+/* the same for the F(4x4) FILTER-gradient products inside denet_conv_wino_wgrad / _wgrad_dm (csrc/wino4g.hip: component products
+ * on the contraction-major operands + the adjoint filter transform, model_cnn.py:318): 0 = never, 1 = wherever the geometry
+ * allows, -1 = default (DENET_WINO4G); returns the previous setting.                                                     */
+int denet_conv_wino4g_mode(int mode);
 int denet_conv_profile(int enable);
 int denet_conv_profile_count(void);
 int denet_conv_profile_read(int i, float* ms, int* mode, int* bm, int* bn, int* nbuf);

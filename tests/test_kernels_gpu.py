@@ -374,6 +374,43 @@ def test_fused_winograd_f4_kernel_under_memory_pressure(hip):
         L.denet_conv_wino4f_mode(-1)
 
 
+@pytest.mark.parametrize("case", [(3, 20, 20, 128, 128), (2, 24, 36, 128, 256), (5, 16, 28, 256, 128), (8, 64, 64, 128, 128), (16, 32, 32, 256, 256),
+                                  (1, 8, 8, 128, 128), (7, 16, 16, 512, 256), (4, 12, 20, 64, 128)])
+def test_winograd_f4_filter_gradient_kernel(hip, case):
+    """csrc/wino4g.hip (F(4x4,3x3) filter-gradient component products on the contraction-major operands; tensor.grad of
+    convolution.py:80-83 with respect to the filters, model_cnn.py:318) against an fp64 filter gradient and against the generic
+    batched split-K path: tile counts that are no multiple of the 16-tile chunk or of the slice (75, 108, 140 tiles), one to
+    sixteen slices, 128 x 128 ... 512 x 256 blocks, a 4-tile problem that stays on the generic path, 64 channels (generic path);
+    run to run bit-identical (the slices are added in slice order)."""
+    import torch.nn.functional as Fn
+    from denet_amd import ops
+    N, H, W, C, K = case
+    L = ops._L()
+    gen = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, H, W, C, generator=gen).cuda()
+    dy = torch.randn(N, H, W, K, generator=gen).cuda()
+    xd = x.double().permute(0, 3, 1, 2).contiguous()
+    wd = torch.zeros(K, C, 3, 3, dtype=torch.float64, device="cuda", requires_grad=True)
+    ref = torch.autograd.grad(Fn.conv2d(xd, wd, None, padding=1), wd, dy.double().permute(0, 3, 1, 2))[0].permute(0, 2, 3, 1)
+    res = {}
+    try:
+        for mode in (0, 1):
+            L.denet_conv_wino4g_mode(mode)
+            a = ops.conv_wino_wgrad(x, dy, tile=4).clone()
+            b = ops.conv_wino_wgrad(x, dy, tile=4).clone()
+            assert torch.equal(a, b), "not reproducible run to run"
+            res[mode] = a
+    finally:
+        L.denet_conv_wino4g_mode(-1)
+    s = float(ref.abs().max())
+    for mode in (0, 1):
+        assert float((res[mode].double() - ref).abs().max()) / s <= 5e-5, mode
+    assert float((res[1] - res[0]).abs().max()) / s <= 5e-5
+    T = N * (H // 4) * (W // 4)
+    if C % 128 or K % 128 or T < 64:
+        assert torch.equal(res[0], res[1])                # the generic path either way
+
+
 def test_fused_winograd_f2_kernels_under_memory_pressure(hip):
     """the LDS refill protocol of csrc/wino2f.hip (row bands streamed in by LDS-DMA while the previous item is multiplied, waits
     that leave younger pieces in flight) against stretched memory latencies: random batch / image sizes with several work items
