@@ -56,8 +56,17 @@ def pmc_traffic(kernel):
     if not files:
         return None
     with open(files[-1]) as f:
-        k = json.load(f)["kernels"].get(kernel)
-    if not k or k.get("write_bytes_per_launch") is None:
+        kernels = json.load(f)["kernels"]
+    k = kernels.get(kernel)
+    if k is None:
+        # a profile id that covers several instantiations (wino4f_kernel -> wino4f_kernel_32<1>, _32x2<2>, ...): launch-weighted
+        fam = [v for n, v in kernels.items() if n.startswith(kernel + "_") or n.startswith(kernel + "<")]
+        fam = [v for v in fam if v.get("write_bytes_per_launch") is not None and v.get("launches")]
+        if not fam:
+            return None
+        n = sum(v["launches"] for v in fam)
+        return round(sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in fam) / n)
+    if k.get("write_bytes_per_launch") is None:
         return None
     return round(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"])
 
