@@ -224,9 +224,13 @@ int denet_wino4g_run(int splits, const float* dM, const float* V, float* dU, flo
     G4Params p = {};
     p.dM = dM; p.V = V; p.part = splits == 1 ? dU : part;
     p.T = (int)T; p.K = K; p.C = C;
-    p.kblocks = K / 128; p.cblocks = C / 128; p.splits = splits;
+    p.kblocks = K / 128; p.cblocks = C / 128;
     const long per = (T + splits - 1) / splits;
     p.tiles_per_split = (int)((per + G4_CHUNK - 1) / G4_CHUNK * G4_CHUNK);
+    // rounding the slice up to whole chunks can leave the last slices without tiles: they are not launched
+    splits = (int)((T + p.tiles_per_split - 1) / p.tiles_per_split);
+    if (splits == 1) p.part = dU;
+    p.splits = splits;
     p.dm_bytes = (unsigned)((size_t)36 * T * K * 4);
     p.v_bytes = (unsigned)((size_t)36 * T * C * 4);
     const int nbuf = g4_nbuf(C, K);
