@@ -11,7 +11,7 @@
 //     go from LDS straight into v_mfma_f32_32x32x2_f32 (one ds_read_b32 per fragment);
 //   * forward: D^T[filter][pixel] += w[tap][filter] * patch[pixel][tap], the 160 x 64 filter matrix resident in LDS; epilogue
 //     bias + whole-line stores (each 32 x 32 block transposed through a per-wave LDS staging area) + the batch-norm column
-//     sums of y (a lane's fp32 sums cover 8 values, doubles from there: one row per WORKGROUP);
+//     sums of y (every value enters as a double: one row per WORKGROUP);
 //   * filter gradient: D[filter][tap] += dy[pixel][filter] * patch[pixel][tap]; here a wave owns 32 filters x all 160 taps over
 //     TWO rows of the block, its 80 accumulator registers live over ALL its blocks; the waves add theirs in a fixed order
 //     through LDS, one partial per workgroup goes to the workspace and stem_wgrad_reduce_kernel adds the partials in workgroup
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(NTH, 2) void stem_fwd_kernel(const StemParams p) {
     __syncthreads();
 
     // batch-norm sums of the filters the lane STORES (32 j + 4 (lane & 7) + {0..3}, see the epilogue) over all its pixels
-    // (fp32 over the 8 values of a block, doubles over the blocks)
+    // (doubles throughout)
     double dsum[2][4], dsq[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -207,9 +207,6 @@ __global__ __launch_bounds__(NTH, 2) void stem_fwd_kernel(const StemParams p) {
         // as [pixel][32 filters]: lane L writes filters 4 (L & 7).. of pixel 8 r + (L >> 3), 8 whole 128-byte rows per store
         const int oy = cur.oy0 + wave;
         float* const yrow = p.y + (((long)cur.n * p.OH + oy) * p.OW + cur.ox0) * 64 + 4 * (lane & 7);
-        f32x4 ssum[2], ssq[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) ssum[j] = ssq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -227,17 +224,16 @@ __global__ __launch_bounds__(NTH, 2) void stem_fwd_kernel(const StemParams p) {
                     if (p.relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});      // (the inference fold of BN + ReLU)
                     if (oy < p.OH && cur.ox0 + px < p.OW) {
                         *(f32x4*)(yrow + px * 64 + 32 * j) = v;
-                        ssum[j] += v;
-                        ssq[j] += v * v;
+                        // the one biased convolution in front of a batch norm (C.B[64,7,2] BN): every value and its square
+                        // enter the sums as doubles (128 double FMAs per lane and tile: nothing beside the 160-deep products)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const double dv = (double)v[q];
+                            dsum[j][q] += dv;
+                            dsq[j][q] = __builtin_fma(dv, dv, dsq[j][q]);
+                        }
                     }
                 }
-            }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                dsum[j][q] += (double)ssum[j][q];
-                dsq[j][q] += (double)ssq[j][q];
             }
         if (!has_next) break;
         tile = next;

@@ -83,8 +83,7 @@ __device__ __forceinline__ W2Item w2_item(int bx, int by, int nco, int item) {
 //     A^T . A, bias / add / ReLU, stores 16 bytes (a wave instruction covers whole 256-byte pixel rows of the output);
 //   * the input patch is refilled by LDS-DMA in three row bands, each one tile group after its last reader (below).
 constexpr int S_MB_SLOTS = 16 * 16 * 16;                     // M of a tile group: [xi][tile][co quad ^ tile] float4
-constexpr int S_RED_BYTES = 8 * 2 * 64 * 4;                  // batch-norm sums of the 8 waves
-constexpr int S_LDS_BYTES = P_BYTES + S_MB_SLOTS * 16 + S_RED_BYTES;     // 163 840: all of it
+constexpr int S_LDS_BYTES = P_BYTES + S_MB_SLOTS * 16;       // 159 744
 // The patch is refilled for the next item in three row bands, each as soon as no tile group reads it any more and at least one
 // whole tile group before it is read again (tile group g reads patch rows 4 g .. 4 g + 5):
 //   band A = rows 0..7   (slots   0..159: pieces at 0, 64, 96)    last read by group 1, refilled during group 2
@@ -98,7 +97,7 @@ template <int I, int J0, bool PF>
 __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
     f32x4* P = (f32x4*)smem;
     f32x4* MB = (f32x4*)(smem + P_BYTES);
-    float* red = (float*)(smem + P_BYTES + S_MB_SLOTS * 16);
+    double* red = (double*)MB;                   // the batch-norm sums of the 8 waves meet in the M buffer (between two items)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t = lane & 15, kk = lane >> 4;
@@ -315,25 +314,37 @@ __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
             if (PF) load_d((g + 1) & 3, 0, d);
         }
         if (p.stats) {
-            // batch-norm column sums of this block: over the lanes of a wave that share the channels (kk), then over the waves
+            // batch-norm column sums of this block. A lane's fp32 sums cover the 8 values of its four tile groups; from there
+            // doubles: over the lanes of a wave that share the channels (kk), then over the waves through the M buffer, which
+            // every wave has finished reading once the barrier below is passed
+            double ds[4], dq[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                ds[c] = (double)ssum[c];
+                dq[c] = (double)ssq[c];
+            }
 #pragma unroll
             for (int off = 16; off < 64; off <<= 1)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    ssum[c] += __shfl_xor(ssum[c], off, 64);
-                    ssq[c] += __shfl_xor(ssq[c], off, 64);
+                    ds[c] += __shfl_xor(ds[c], off, 64);
+                    dq[c] += __shfl_xor(dq[c], off, 64);
                 }
+            W2_BARRIER(63);
             if (kk == 0) {
-                *(f32x4*)(red + (wave * 2 + 0) * 64 + 4 * t) = ssum;
-                *(f32x4*)(red + (wave * 2 + 1) * 64 + 4 * t) = ssq;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    red[(wave * 2 + 0) * 64 + 4 * t + c] = ds[c];
+                    red[(wave * 2 + 1) * 64 + 4 * t + c] = dq[c];
+                }
             }
             W2_BARRIER(63);
             if (tid < 64) {
                 double a = 0.0, bq = 0.0;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) {
-                    a += (double)red[(w * 2 + 0) * 64 + tid];
-                    bq += (double)red[(w * 2 + 1) * 64 + tid];
+                    a += red[(w * 2 + 0) * 64 + tid];
+                    bq += red[(w * 2 + 1) * 64 + tid];
                 }
                 if (p.nco == 1) {
                     // one row per WORKGROUP (zeroed before the first item): lane tid owns its channel's two sums
