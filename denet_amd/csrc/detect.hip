@@ -171,6 +171,149 @@ __global__ __launch_bounds__(256) void detect_nms_kernel(const float* __restrict
     }
 }
 
+
+// Gaussian soft-NMS (denet_detect.cc:35-71) of one (class, image) per WAVE. The method is sequential in its selections (every
+// selected instance rescales the scores the next selection is made from), but the 80 x 32 (class, image) pairs of a batch are
+// independent, and inside a pair both steps of an iteration are parallel over the candidates: the arg-max over the live
+// scores (ties: the earliest list position - the reference's strict `>` scan over a std::list that keeps the scan order) and
+// the rescoring s -= iou^2 / threshold, discard below -6.9. The candidates of the pair sit in LDS ([S] x score, box, RoI);
+// a lane owns positions lane, lane + 64, ...; no barriers (one wave), the arg-max is a butterfly over (score, position).
+// Output, dense per pair: sel_roi / sel_score [pair][S] in selection order, sel_n[pair]; pair = b * class_num + cls.
+__global__ __launch_bounds__(64) void soft_nms_pair_kernel(const float* __restrict__ det_pr, const float* __restrict__ fitness,
+                                                           const float* __restrict__ bbox, const int* __restrict__ count,
+                                                           int* __restrict__ sel_roi, float* __restrict__ sel_score,
+                                                           int* __restrict__ sel_n, int S, int C1, float log_thr, float nms_thr,
+                                                           int do_nms) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* s_score = sm;              // [S]; a dead candidate holds -inf ... (its `alive` bit is what counts)
+    float* s_box = sm + S;            // [S][4]
+    int* s_idx = (int*)(sm + 5 * S);  // [S]
+    unsigned char* s_alive = (unsigned char*)(sm + 6 * S);   // [S]
+    const int cls = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int pair = b * (C1 - 1) + cls;
+    const int nb = min(count[b], S);
+    // candidates in RoI order (the reference's j, i scan)
+    int n = 0;
+    for (int chunk = 0; chunk < nb; chunk += 64) {
+        const int i = chunk + lane;
+        const long m = (long)b * S + i;
+        const bool pred = (i < nb) && (det_pr[m * C1 + cls] >= log_thr);
+        const unsigned long long mask = __ballot(pred);
+        if (pred) {
+            const int k = n + __popcll(mask & ((1ull << lane) - 1ull));
+            s_score[k] = fitness[m * C1 + cls];
+            s_idx[k] = i;
+            s_box[k * 4 + 0] = bbox[m * 4 + 0];
+            s_box[k * 4 + 1] = bbox[m * 4 + 1];
+            s_box[k * 4 + 2] = bbox[m * 4 + 2];
+            s_box[k * 4 + 3] = bbox[m * 4 + 3];
+            s_alive[k] = 1;
+        }
+        n += __popcll(mask);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    int* o_roi = sel_roi + (long)pair * S;
+    float* o_sc = sel_score + (long)pair * S;
+    if (!do_nms) {                    // denet_detect.cc:76: the threshold outside (0, 1) keeps every candidate, in list order
+        for (int k = lane; k < n; k += 64) {
+            o_roi[k] = s_idx[k];
+            o_sc[k] = s_score[k];
+        }
+        if (lane == 0) sel_n[pair] = n;
+        return;
+    }
+    const float discard = -6.9f;
+    int kept = 0;
+    while (true) {
+        // the live candidate with the largest score, the earliest position among equals. NaN scores never win a `>`:
+        // like the reference, a list whose head is NaN selects the head (position order decides) - the comparison below
+        // treats "no candidate yet" (pos = INT_MAX) as beaten by any live one
+        float best = 0.f;
+        int pos = 0x7fffffff;
+        for (int k = lane; k < n; k += 64) {
+            if (!s_alive[k]) continue;
+            const float v = s_score[k];
+            if (pos == 0x7fffffff || v > best) {
+                best = v;
+                pos = k;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ob = __shfl_xor(best, off, 64);
+            const int op = __shfl_xor(pos, off, 64);
+            // the reference's scan keeps the EARLIER element unless a later one is strictly greater
+            const bool take = (op != 0x7fffffff) && (pos == 0x7fffffff || (op < pos ? !(best > ob) : (ob > best)));
+            if (take) {
+                best = ob;
+                pos = op;
+            }
+        }
+        if (pos == 0x7fffffff) break;
+        const float mx0 = s_box[pos * 4], my0 = s_box[pos * 4 + 1], mx1 = s_box[pos * 4 + 2], my1 = s_box[pos * 4 + 3];
+        if (lane == 0) {
+            o_roi[kept] = s_idx[pos];
+            o_sc[kept] = best;
+            s_alive[pos] = 0;
+        }
+        ++kept;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < n; k += 64) {
+            if (!s_alive[k]) continue;
+            const float iou = box_iou(mx0, my0, mx1, my1, s_box[k * 4], s_box[k * 4 + 1], s_box[k * 4 + 2], s_box[k * 4 + 3]);
+            const float v = s_score[k] - iou * iou / nms_thr;
+            s_score[k] = v;
+            if (v < discard) s_alive[k] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) sel_n[pair] = kept;
+}
+
+// offsets of the pairs' selections in the flat output (image, class, selection order), the per-image totals and the total
+__global__ __launch_bounds__(1024) void soft_nms_scan_kernel(const int* __restrict__ sel_n, int* __restrict__ pair_off,
+                                                             int* __restrict__ per_image, int* __restrict__ total, int B, int CN) {
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x, P = B * CN;
+    int carry = 0;
+    for (int base = 0; base < P; base += 1024) {
+        const int v = base + tid < P ? sel_n[base + tid] : 0;
+        s_part[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int a = tid >= off ? s_part[tid - off] : 0;
+            __syncthreads();
+            s_part[tid] += a;
+            __syncthreads();
+        }
+        if (base + tid < P) pair_off[base + tid] = carry + s_part[tid] - v;
+        carry += s_part[1023];
+        __syncthreads();
+    }
+    if (tid == 0) *total = carry;
+    for (int b = tid; b < B; b += 1024) {
+        int a = 0;
+        for (int c = 0; c < CN; ++c) a += sel_n[b * CN + c];
+        per_image[b] = a;
+    }
+}
+
+__global__ __launch_bounds__(64) void soft_nms_gather_kernel(const int* __restrict__ sel_roi, const float* __restrict__ sel_score,
+                                                             const int* __restrict__ sel_n, const int* __restrict__ pair_off,
+                                                             float* __restrict__ out_score, int* __restrict__ out_cls,
+                                                             int* __restrict__ out_row, int S, int CN) {
+    const int cls = blockIdx.x, b = blockIdx.y, pair = b * CN + cls;
+    const int n = sel_n[pair], o = pair_off[pair];
+    for (int k = threadIdx.x; k < n; k += 64) {
+        out_score[o + k] = sel_score[(long)pair * S + k];
+        out_cls[o + k] = cls;
+        out_row[o + k] = b * S + sel_roi[(long)pair * S + k];
+    }
+}
+
 }  // namespace
 
 extern "C" int denet_detect_decode(const float* logits, const float* roi_bbox, float* det_pr, float* fitness,
@@ -292,4 +435,46 @@ extern "C" long denet_soft_nms_batch_host(const float* det_pr, const float* fitn
         out_count[b] = nb;
     }
     return total;
+}
+
+// The soft-NMS tail of a batch on the DEVICE (denet_detect.cc:99-173 with use_soft_nms): the same result as
+// denet_soft_nms_batch_host, bit for bit - out_score[k] (final log-domain score), out_cls[k], out_row[k] = b*S + RoI index in
+// the reference's output order (image, class ascending, selection order), out_count[b], *out_total. All pointers are device
+// memory; out_* hold B*class_num*S entries at most (the caller reads *out_total first); workspace: denet_soft_nms_workspace_bytes.
+extern "C" size_t denet_soft_nms_workspace_bytes(int B, int S, int class_num) {
+    const size_t P = (size_t)B * class_num;
+    return P * S * (sizeof(int) + sizeof(float)) + 2 * P * sizeof(int);
+}
+
+extern "C" int denet_soft_nms_batch(const float* det_pr, const float* fitness, const float* bbox, const int* count, int B, int S,
+                                    int class_num, float pr_threshold, float nms_threshold, float* out_score, int* out_cls,
+                                    int* out_row, int* out_count, int* out_total, void* workspace, size_t workspace_bytes,
+                                    hipStream_t stream) {
+    DENET_CHECK_ARG(det_pr && fitness && bbox && count && out_score && out_cls && out_row && out_count && out_total && workspace,
+                    "soft_nms_batch: null pointer");
+    DENET_CHECK_ARG(B > 0 && S > 0 && S <= 4096 && class_num > 0, "soft_nms_batch: bad sizes");
+    DENET_CHECK_ARG(workspace_bytes >= denet_soft_nms_workspace_bytes(B, S, class_num), "soft_nms_batch: workspace too small");
+    const size_t P = (size_t)B * class_num;
+    int* sel_roi = (int*)workspace;
+    float* sel_score = (float*)(sel_roi + P * S);
+    int* sel_n = (int*)(sel_score + P * S);
+    int* pair_off = sel_n + P;
+    const int do_nms = (nms_threshold > 0.0f && nms_threshold < 1.0f) ? 1 : 0;   // denet_detect.cc:76
+    const size_t lds = (size_t)S * 6 * sizeof(float) + (size_t)((S + 3) & ~3);
+    static size_t lds_set = 0;
+    if (lds > 65536 && lds > lds_set) {
+        const hipError_t e = hipFuncSetAttribute((const void*)soft_nms_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            denet_set_error("soft_nms_batch: hipFuncSetAttribute(%zu B LDS): %s", lds, hipGetErrorString(e));
+            return -(int)e;
+        }
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(soft_nms_pair_kernel, dim3(class_num, B), dim3(64), lds, stream, det_pr, fitness, bbox, count, sel_roi,
+                       sel_score, sel_n, S, class_num + 1, logf(pr_threshold), nms_threshold, do_nms);
+    hipLaunchKernelGGL(soft_nms_scan_kernel, dim3(1), dim3(1024), 0, stream, sel_n, pair_off, out_count, out_total, B, class_num);
+    hipLaunchKernelGGL(soft_nms_gather_kernel, dim3(class_num, B), dim3(64), 0, stream, sel_roi, sel_score, sel_n, pair_off,
+                       out_score, out_cls, out_row, S, class_num);
+    DENET_CHECK_LAUNCH("soft_nms_batch");
+    return DENET_OK;
 }

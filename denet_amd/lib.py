@@ -136,6 +136,8 @@ SIGNATURES = {
     "denet_detect_nms": (I, [P] * 5 + [I, I, I, F, F, P]),
     "denet_soft_nms_batch_host": (L, [P, P, P, P, I, I, I, F, F, P, P, P, P, L]),
     "denet_soft_nms_host": (I, [P, P, I, F, P, P, P]),
+    "denet_soft_nms_workspace_bytes": (Z, [I, I, I]),
+    "denet_soft_nms_batch": (I, [P, P, P, P, I, I, I, F, F, P, P, P, P, P, P, Z, P]),
     "denet_build_samples_workspace_bytes": (Z, [I] * 6),
     "denet_build_samples": (I, [P, P, P, P, P, Z] + [I] * 4 + [F, I, I, I, P]),
     "denet_build_samples_stats": (I, [P, Z] + [I] * 6 + [P, P, P]),

@@ -1565,6 +1565,26 @@ def soft_nms_batch_host(det_h, fit_h, box_h, counts, B, S, class_num, pr_thresho
     return score[:n], cls[:n], row[:n], per
 
 
+def soft_nms_batch(det_pr, fitness, bbox, count, B, S, class_num, pr_threshold, nms_threshold):
+    """the soft-NMS tail of a whole batch on the DEVICE (one wave per (class, image)) -> numpy (log-domain scores fp32, classes,
+    rows = b*S + RoI, per-image counts): what soft_nms_batch_host returns, bit for bit. Two device-to-host copies: the total
+    (with the per-image counts), then the `total` entries."""
+    import numpy
+    P = B * class_num
+    ws_bytes = int(_L().denet_soft_nms_workspace_bytes(B, S, class_num))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
+    score = torch.empty(P * S, dtype=torch.float32, device="cuda")
+    cr = torch.empty((2, P * S), dtype=torch.int32, device="cuda")
+    head = torch.empty(B + 1, dtype=torch.int32, device="cuda")          # per-image counts, then the total
+    check(_L().denet_soft_nms_batch(ptr(det_pr), ptr(fitness), ptr(bbox), ptr(count), B, S, class_num, float(pr_threshold),
+                                    float(nms_threshold), ptr(score), ptr(cr[0]), ptr(cr[1]), ptr(head),
+                                    ptr(head) + 4 * B, ptr(ws), ws_bytes, stream_ptr()), "soft_nms_batch")
+    head_h = head.cpu().numpy()
+    n = int(head_h[B])
+    cr_h = cr[:, :n].cpu().numpy()
+    return score[:n].cpu().numpy(), cr_h[0], cr_h[1], head_h[:B].copy()
+
+
 def soft_nms_host(score, box, nms_threshold):
     """numpy in / numpy out: (order, final scores) of one class' candidates (Gaussian soft-NMS)"""
     import ctypes

@@ -479,7 +479,8 @@ int denet_detect_loss(const float* logits, const float* det_target, const float*
  *      joint-fitness marginalisation; denet/layer/denet_detect.cc:99-173 build_detections_nms, :73-97 hard NMS,
  *      :35-71 Gaussian soft-NMS).  logits:[M,CP]; det_pr/fitness:[M,class_num+1] log domain; bbox:[M,4];
  *      count:[B] valid RoIs per image; keep:[B,class_num,S] bytes (1 = surviving detection). The soft-NMS variant is
- *      sequential by construction and runs on the host over one class' candidates.                           */
+ *      sequential in its selections: denet_soft_nms_batch runs one wave per (class, image) on the device, the *_host
+ *      entries are the same method on host copies (tests, single classes).                                    */
 int denet_detect_decode(const float* logits, const float* roi_bbox, float* det_pr, float* fitness, float* bbox, int M,
                         int CP, int class_num, int jointfit, int nreg, int nfit /* independent-fitness logits, :396-401 */,
                         float overlap_threshold, hipStream_t stream);
@@ -491,6 +492,13 @@ int denet_soft_nms_host(const float* score_host, const float* box_host, int n, f
 long denet_soft_nms_batch_host(const float* det_pr, const float* fitness, const float* bbox, const int* counts, int B, int S,
                                int class_num, float pr_threshold, float nms_threshold, float* out_score, int* out_cls,
                                int* out_row, int* out_count, long capacity);
+/* the same tail on the device, bit-identical to denet_soft_nms_batch_host: a wave per (class, image) runs the sequential
+ * selection (arg-max and rescoring parallel over the candidates); all pointers device memory, out_* sized B*class_num*S,
+ * *out_total = number of detections, out_count[b] per image; output order = (image, class, selection order), :153-160 */
+size_t denet_soft_nms_workspace_bytes(int B, int S, int class_num);
+int denet_soft_nms_batch(const float* det_pr, const float* fitness, const float* bbox, const int* count, int B, int S,
+                         int class_num, float pr_threshold, float nms_threshold, float* out_score, int* out_cls, int* out_row,
+                         int* out_count, int* out_total, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 /* ---- corner selection + RoI proposal  (denet/layer/denet_sparse.cc:489-557 run_build_samples, :321-471
  *      search_corners, :271-308 get_sample; Python-facing wrapper build_samples :559-668, which the reference

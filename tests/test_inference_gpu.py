@@ -124,6 +124,43 @@ def test_soft_nms_host_vs_oracle(hip):
         np.testing.assert_allclose(np.exp(score), ref[:, 0], rtol=2e-6)
 
 
+@pytest.mark.parametrize("B,sn,C,nms_thr", [(3, 12, 5, 0.4), (2, 24, 80, 0.5), (1, 48, 3, 0.6), (2, 12, 4, 1.5), (2, 12, 4, 0.3)])
+def test_soft_nms_device_vs_host_and_oracle(hip, B, sn, C, nms_thr):
+    """denet_soft_nms_batch (one wave per (class, image)) against the host call and the C++ oracle: the same detections in the
+    same order with the same scores, bit for bit - incl. exact score ties (duplicated candidates), images without candidates,
+    a threshold outside (0, 1) (no suppression: list order) and 48x48 RoIs (36 candidates per lane)"""
+    rng = np.random.RandomState(11 + sn + C)
+    S = sn * sn
+    box = _clustered_boxes(rng, B, S).reshape(B * S, 4)
+    fit = np.log(rng.uniform(0.005, 1.0, (B * S, C + 1))).astype(np.float32)
+    det = (fit + rng.normal(0, 0.3, fit.shape)).astype(np.float32)
+    # exact ties: copies of a candidate's score (and of a whole candidate) later in the list
+    fit[7::13, 0] = fit[5, 0]
+    box[9] = box[5]
+    fit[9, :] = fit[5, :]
+    det[9, :] = det[5, :]
+    counts = np.array([S - 3 * b for b in range(B)], np.int32)
+    if B > 1:
+        det[S:S + counts[1], C - 1] = -50.0          # an (image, class) pair without candidates
+    if nms_thr == 0.3:
+        counts[0] = 0                                  # an image without RoIs
+    pr_thr = 0.05
+    t = lambda a: torch.from_numpy(a).cuda()
+    sc_d, cls_d, row_d, per_d = ops.soft_nms_batch(t(det), t(fit), t(box), t(counts), B, S, C, pr_thr, nms_thr)
+    sc_h, cls_h, row_h, per_h = ops.soft_nms_batch_host(det, fit, box, counts, B, S, C, pr_thr, nms_thr)
+    assert np.array_equal(per_d, per_h) and per_h.sum() > 0
+    assert np.array_equal(cls_d, cls_h) and np.array_equal(row_d, row_h)
+    assert np.array_equal(sc_d.view(np.uint32), sc_h.view(np.uint32))
+    ref = _oracle_nms(det, fit, box, counts, B, sn, C + 1, pr_thr, nms_thr, True)
+    lo = 0
+    for b in range(B):
+        hi = lo + int(per_d[b])
+        assert hi - lo == len(ref[b])
+        assert np.array_equal(box[row_d[lo:hi]], ref[b][:, 2:]) and np.array_equal(cls_d[lo:hi], ref[b][:, 1].astype(np.int32))
+        np.testing.assert_allclose(np.exp(sc_d[lo:hi]), ref[b][:, 0], rtol=2e-6)
+        lo = hi
+
+
 @pytest.mark.parametrize("soft", [0, 1])
 def test_denet34_get_detections_vs_oracle(hip, soft):
     """whole inference path on DeNet-34 skip (128x128): test-mode forward -> corner detector RoIs -> head -> NMS"""
