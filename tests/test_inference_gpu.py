@@ -161,9 +161,13 @@ def test_soft_nms_device_vs_host_and_oracle(hip, B, sn, C, nms_thr):
         lo = hi
 
 
-@pytest.mark.parametrize("soft", [0, 1])
-def test_denet34_get_detections_vs_oracle(hip, soft):
-    """whole inference path on DeNet-34 skip (128x128): test-mode forward -> corner detector RoIs -> head -> NMS"""
+@pytest.mark.parametrize("soft", [0, 1, 2])
+def test_denet34_get_detections_vs_oracle(hip, soft, monkeypatch):
+    """whole inference path on DeNet-34 skip (128x128): test-mode forward -> corner detector RoIs -> head -> NMS
+    (soft = 1: Gaussian soft-NMS as a batch of 2 runs it, on host copies; 2: forced onto the device kernel)"""
+    if soft == 2:
+        monkeypatch.setenv("DENET_SOFT_NMS_HOST", "0")
+        soft = 1
     from tests.test_parity_gpu import _warm_corner_head, rel_close
     B, IMG = 2, 128
     model = zoo.denet34(B, "skip", IMG, class_num=20, seed=1)
