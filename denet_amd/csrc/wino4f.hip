@@ -26,8 +26,21 @@
 namespace {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+// buffer_store_dwordx4 through inline assembly, with two wait states behind it. A store of more than 64 bits reads its data
+// registers over several cycles; a vector instruction that overwrites them in the next cycle changes what is stored. The
+// compiler's hazard table inserts the wait state for global / flat stores and for buffer stores with an IMMEDIATE offset,
+// but exempts buffer stores whose soffset is a register - and on gfx950 that combination does corrupt the store: with the
+// intrinsic, an epilogue in which `v_or_b32 v80, ...` directly followed `buffer_store_dwordx4 v[80:83], .., s11 offen` wrote wrong
+// first dwords in lanes 12-15 of every row of 16 as soon as a second stream kept the memory system busy (found with a
+// re-ordered epilogue, tools/exp/w4_repro.py; the order below happened to keep a few instructions between the two).
+// tests/test_kernels_gpu.py::test_fused_winograd_f4_kernel_under_memory_pressure is the test that sees it.
+__device__ __forceinline__ void store_b128(const f32x4& v, const i32x4_t& rsrc, int voff, int soff) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
 
 struct W4Params {
     const float* V;      // [36][T][C]
@@ -324,7 +337,7 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
     const int tx = t % p.TW;
     const int ty = (t / p.TW) % p.TH;
     const int n = t / (p.TW * p.TH);
-    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y_bytes, 0x00020000);
+    const i32x4_t rsY = {(int)(unsigned)(unsigned long long)p.y, (int)(((unsigned long long)p.y >> 32) & 0xffffu), (int)p.y_bytes, 0x00020000};
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.add, 0, p.add ? p.y_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_x, 0, p.bs_x ? p.y_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_y, 0, p.bs_y ? p.y_bytes : 0u, 0x00020000);
@@ -371,7 +384,7 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
                 f32x4 acc = (Y[nb][4 * i + j] + b) + av[j];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = fmaxf(acc[c], floor_);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc), rY, voff, soff, 0);
+                store_b128(acc, rsY, voff, soff);
                 if (EP == 2) {
                     f32x4 gq;
 #pragma unroll
