@@ -22,3 +22,25 @@ def hip():
     assert torch.cuda.is_available(), "GPU test selected but no HIP device is visible"
     from denet_amd import lib
     return lib.load()
+
+
+@pytest.fixture(autouse=True)
+def _memory_pressure(request):
+    """DENET_TEST_PRESSURE=1 (opt-in; GPU runs only): every test starts with ~40 ms of 512 MB copies queued on a side stream,
+    so its first kernels run beside a saturated memory system and beside another kernel's waves on every CU - the condition
+    under which the store hazard of csrc/wino4f.hip (EXPERIMENTS.md, fused F(4x4) kernel, item 14) showed. Results must not
+    depend on it."""
+    if os.environ.get("DENET_TEST_PRESSURE") != "1" or request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import torch
+    st = _memory_pressure.__dict__.setdefault("state", {})
+    if not st:
+        st["side"] = torch.cuda.Stream()
+        st["a"] = torch.empty(1 << 27, device="cuda")
+        st["b"] = torch.empty(1 << 27, device="cuda")
+    with torch.cuda.stream(st["side"]):
+        for _ in range(200):
+            st["b"].copy_(st["a"], non_blocking=True)
+    yield
+    st["side"].synchronize()
