@@ -214,18 +214,36 @@ int grid_for(long total) {
 }  // namespace
 
 // Pillow precompute_coeffs + normalize_coeffs_8bpc (Resample.c) for one axis: filter 1 = LANCZOS, 2 = BILINEAR, 3 = BICUBIC
-// (Pillow's Resampling enum). bounds_host: [out_size][2] = (first input index, tap count); kk_host: [out_size][ksize]
+// (Pillow's Resampling enum); 4 = NEAREST (not Pillow's number for it, which is 0: a nearest-neighbour index table, below). bounds_host: [out_size][2] = (first input index, tap count); kk_host: [out_size][ksize]
 // fixed-point taps (22 fractional bits), zero padded. Returns ksize (> 0), or a negative error code.
 extern "C" int denet_host_resample_coeffs(int in_size, double in0, double in1, int out_size, int filter, int* bounds_host,
                                           int* kk_host, long kk_capacity) {
     DENET_CHECK_ARG(bounds_host && kk_host, "resample_coeffs: null pointer");
     DENET_CHECK_ARG(in_size > 0 && out_size > 0 && in1 > in0, "resample_coeffs: bad sizes");
+    if (filter == 4) {
+        // NEAREST is no convolution in Pillow: Image.resize hands it to ImagingScaleAffine (Geometry.c), which steps a double
+        // through the source, xo = in0 + a/2, += a with a = (in1 - in0) / out_size, and copies pixel (int)xo (COORD: -1 below
+        // zero). The same additions in the same order here; as a table it is one tap of weight 1 (the pass kernel's rounding
+        // term and shift return the byte unchanged), no tap where Pillow leaves the fill colour (0).
+        DENET_CHECK_ARG(out_size <= kk_capacity, "resample_coeffs: table needs %d ints, capacity %ld", out_size, kk_capacity);
+        const double a = (in1 - in0) / out_size;
+        double xo = in0 + a * 0.5;
+        for (int xx = 0; xx < out_size; ++xx) {
+            const int xin = xo < 0.0 ? -1 : (int)xo;
+            const bool inside = xin >= 0 && xin < in_size;
+            bounds_host[2 * xx] = inside ? xin : 0;
+            bounds_host[2 * xx + 1] = inside ? 1 : 0;
+            kk_host[xx] = inside ? (1 << PRECISION_BITS) : 0;
+            xo += a;
+        }
+        return 1;
+    }
     double (*f)(double) = nullptr;
     double support = 0.0;
     if (filter == 1) { f = lanczos_filter; support = 3.0; }
     else if (filter == 2) { f = bilinear_filter; support = 1.0; }
     else if (filter == 3) { f = bicubic_filter; support = 2.0; }
-    DENET_CHECK_ARG(f != nullptr, "resample_coeffs: filter %d is not a convolution filter (1 lanczos, 2 bilinear, 3 bicubic)", filter);
+    DENET_CHECK_ARG(f != nullptr, "resample_coeffs: filter %d is none of 1 lanczos, 2 bilinear, 3 bicubic, 4 nearest", filter);
     double scale, filterscale;
     filterscale = scale = (in1 - in0) / out_size;
     if (filterscale < 1.0) filterscale = 1.0;

@@ -13,7 +13,8 @@ from PIL import Image
 
 from . import plan as planmod
 
-FILTER_ID = {int(Image.LANCZOS): 1, int(Image.BILINEAR): 2, int(Image.BICUBIC): 3}
+# Pillow's resampling filter -> the native table builder's (denet_host_resample_coeffs): NEAREST is a one-tap index table there
+FILTER_ID = {int(Image.LANCZOS): 1, int(Image.BILINEAR): 2, int(Image.BICUBIC): 3, int(Image.NEAREST): 4}
 
 
 def _align(n, a=16):
@@ -48,11 +49,11 @@ class DeviceRenderer:
         def add_pass(horizontal, cur, out_n, filt, box_end):
             fid = FILTER_ID.get(int(filt))
             if fid is None:
-                raise NotImplementedError("device rendering supports the LANCZOS / BILINEAR / BICUBIC filters only")
+                raise NotImplementedError("device rendering supports the NEAREST / LANCZOS / BILINEAR / BICUBIC filters only")
             ops.append((2, horizontal, cur[0], cur[1], out_n, fid, 0, 0))
             wh.append((0, 0))
             in1s.append(box_end)
-            support = {1: 3.0, 2: 1.0, 3: 2.0}[fid] * max(box_end / out_n, 1.0)
+            support = {1: 3.0, 2: 1.0, 3: 2.0, 4: 0.0}[fid] * max(box_end / out_n, 1.0)
             return out_n * (2 + int(numpy.ceil(support)) * 2 + 1) + 8
 
         for st in steps:
@@ -72,6 +73,8 @@ class DeviceRenderer:
                     # reduce() comes first and the convolution maps the fractional box (w / fx, h / fy), which Pillow
                     # hands to its C code as float32
                     fx, fy = int(cur[0] / t[0] / 2.0) or 1, int(cur[1] / t[1] / 2.0) or 1
+                    if int(filt) == int(Image.NEAREST):       # Image.resize: "reducing_gap is not None and resample != NEAREST"
+                        fx = fy = 1
                     box = (float(cur[0]), float(cur[1]))
                     if fx > 1 or fy > 1:
                         ops.append((1, cur[0], cur[1], fx, fy, 0, 0, 0))
@@ -222,7 +225,7 @@ class DeviceImageLoader:
         import random
         args_list = [self.params.make_args(image) for image in images]
         state, np_state = random.getstate(), numpy.random.get_state()
-        plans = [planmod.plan_sample(a) for a in args_list]
+        plans = [p for a in args_list for p in planmod.plan_views(a)]      # ten per image under test-time multicrop
         random.setstate(state)
         numpy.random.set_state(np_state)
         for p in plans:       # the device program of each plan, so that the prefetch thread has no Python work left to do
@@ -230,6 +233,12 @@ class DeviceImageLoader:
         return plans
 
     def _decode(self, plans):
+        """decoded u8 image of every plan; a file that several plans of the batch share (the ten multicrop views) is decoded once"""
+        first = {}
+        uniq = [p for p in plans if first.setdefault(p["fname"], len(first)) == len(first) - 1]
+        if len(uniq) < len(plans):
+            images = self._decode(uniq)
+            return [images[first[p["fname"]]] for p in plans]
         if self.decode_mode != "process":
             return list(self.pool.map(DeviceRenderer.decode, [p["fname"] for p in plans]))
         from multiprocessing import shared_memory

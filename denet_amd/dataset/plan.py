@@ -100,7 +100,17 @@ def plan_train_view(im_size, a, bboxs):
         steps, new, sx, sy = scale_steps(im_size, a["scale"], a.get("scaleMode", "small"))
         c, ox, oy = (random_crop_step if mode == "default" else center_crop_step)(new, crop)
         return steps + [c], sx, sy, ox, oy
-    raise Exception("crop mode '%s' has no plan (ssd picks a random filter incl. NEAREST; resnet is unusable)" % mode)
+    if mode == "ssd":
+        # augment.ssd_crop draw for draw: the candidate windows, the pick, then one of four resampling filters
+        side = max(im_size)
+        canvas = border_geometry(im_size, side)
+        bx, by = -canvas[2], -canvas[3]
+        win = augment.plan_ssd_crop(im_size, side, bx, by, crop, bboxs)
+        sx, sy, ox, oy = augment._window_geometry(win, crop, bx, by)
+        interp_mode = random.choice([Image.NEAREST, Image.BILINEAR, Image.BICUBIC, augment.LANCZOS])
+        steps, _, _, _ = scale_steps((win[2] - win[0], win[3] - win[1]), crop, "warp", interp_mode)
+        return [_crop_step(win, canvas)] + steps, sx, sy, ox, oy
+    raise Exception("crop mode '%s' has no plan (resnet is unusable in the reference)" % mode)
 
 
 def center_crop_step(size_in, size):
@@ -142,7 +152,7 @@ def plan_sample(args, im_size=None):
         mirrored = bool(args.get("augmentMirror", False) and random.random() >= 0.5)
     else:
         if args.get("multicrop", False):
-            raise Exception("multicrop views have no single-view plan; use load_sample_proc")
+            raise Exception("multicrop has ten views per image: use plan_views")
         steps, new, sx, sy = scale_steps(im_size, args["scale"], args.get("scaleMode", "small"))
         c, ox, oy = center_crop_step(new, crop)
         steps = steps + [c]
@@ -153,6 +163,40 @@ def plan_sample(args, im_size=None):
                         args.get("checkCenter", False))
     return {"fname": image["fname"], "steps": steps, "photo": photo, "noise": noise, "mean_std": mean_std,
             "mirror": mirrored, "meta": meta}
+
+
+def plan_views(args, im_size=None):
+    """the plans of ALL views of one image, in load_sample_proc's order: one (plan_sample), or - test-time `multicrop`,
+    augment.multi_crop_mirror - ten: centre and four corner crops of the scaled image, then the same five mirrored. Every
+    view is a complete plan (scaling steps + its crop window), so either executor renders it like any other."""
+    if args["isTraining"] or not args.get("multicrop", False):
+        return [plan_sample(args, im_size)]
+    image = args["image"]
+    image_bboxs = image.get("bboxs", [])
+    crop = args["crop"]
+    seed = args.get("seed", None)
+    random.seed(seed)
+    numpy.random.seed(seed)
+    if im_size is None:
+        with Image.open(image["fname"]) as im:
+            im_size = im.size
+    steps, new, sx, sy = scale_steps(im_size, args["scale"], args.get("scaleMode", "small"))
+    centre, cx, cy = center_crop_step(new, crop)
+    w, h = new
+    plain = (new[0], new[1], 0, 0)            # the corner crops are taken from the scaled image itself (no border canvas)
+    corners = [(0, 0), (w - crop, 0), (0, h - crop), (w - crop, h - crop)]
+    windows = [(centre, cx, cy)] + [(_crop_step((x, y, x + crop, y + crop), plain), x, y) for x, y in corners]
+    mean_std = None
+    if args.get("subtractMean", False):
+        mean_std = [float(v) for v in args["rgbMean"]] + [float(v) for v in args["rgbStd"]]
+    plans = []
+    for mirrored in (False, True):
+        for c, ox, oy in windows:
+            meta = _sample_meta(image, image_bboxs, crop, sx, sy, ox, oy, mirrored, im_size, args.get("checkOnscreen", 0.0),
+                                args.get("checkCenter", False))
+            plans.append({"fname": image["fname"], "steps": steps + [c], "photo": [], "noise": None, "mean_std": mean_std,
+                          "mirror": mirrored, "meta": meta})
+    return plans
 
 
 # ---- host executor (Pillow): the reference's pixel path ---------------------------------------------------------------

@@ -37,6 +37,9 @@ VARIANTS = [
     {"cropMode": "lenet", "maxTrials": 0},
     {"isTraining": False},
     {"isTraining": False, "scale": 30, "subtractMean": True},
+    {"cropMode": "ssd", "augmentMirror": True, "checkOnscreen": 0.5},          # one of NEAREST / BILINEAR / BICUBIC / LANCZOS per image
+    {"cropMode": "ssd", "augmentPhoto": True, "crop": 96, "subtractMean": True},
+    {"cropMode": "ssd", "crop": 20},                                           # strong shrinks (NEAREST: no reduce() pre-pass)
 ]
 
 
@@ -83,6 +86,21 @@ def test_native_coefficient_tables_equal_oracle():
                                           kk.ctypes.data_as(ctypes.c_void_p), cap)
         assert ks == k_ref.shape[1]
         assert np.array_equal(bounds.reshape(-1, 2), b_ref) and np.array_equal(kk.reshape(n_out, ks), k_ref)
+    # filter 4 = NEAREST: a one-tap index table, against Pillow's own resize (ImagingScaleAffine's accumulated double steps)
+    for trial in range(80):
+        n_in, n_out = int(rng.randint(1, 700)), int(rng.randint(1, 600))
+        bounds = np.empty(2 * n_out, dtype=np.int32)
+        kk = np.empty(n_out, dtype=np.int32)
+        assert L.denet_host_resample_coeffs(n_in, 0.0, float(n_in), n_out, 4, bounds.ctypes.data_as(ctypes.c_void_p),
+                                            kk.ctypes.data_as(ctypes.c_void_p), n_out) == 1
+        b2 = bounds.reshape(-1, 2)
+        assert np.all(b2[:, 1] == 1) and np.all(kk == 1 << 22)
+        row = np.arange(n_in, dtype=np.int64)
+        a = np.stack([row % 256, (row // 256) % 256, np.zeros_like(row)], -1).astype(np.uint8)[None]       # pixel value = its index
+        ref = np.array(Image.fromarray(a, "RGB").resize((n_out, 1), Image.NEAREST))[0]
+        assert np.array_equal(a[0][b2[:, 0]], ref), (n_in, n_out)
+        col = np.array(Image.fromarray(a.transpose(1, 0, 2).copy(), "RGB").resize((1, n_out), Image.NEAREST))[:, 0]
+        assert np.array_equal(a[0][b2[:, 0]], col), (n_in, n_out)
     # argument validation
     assert L.denet_host_resample_coeffs(10, 0.0, 10.0, 5, 0, bounds.ctypes.data_as(ctypes.c_void_p),
                                         kk.ctypes.data_as(ctypes.c_void_p), 4) == -1000
@@ -119,8 +137,62 @@ def test_plan_with_pillow_equals_load_sample_proc(coco, capsys):
             assert np.array_equal(x, P.render_pil(pl)), (vi, ii)
             n += 1
     assert n == len(VARIANTS) * 12
+    # the ssd variants really drew all four filters
+    used = set()
+    for vi, var in enumerate(VARIANTS):
+        if var.get("cropMode") == "ssd":
+            for ii, image in enumerate(coco.images):
+                used |= {int(st[-1]) for st in P.plan_sample(_args(var, image, 31 * vi + 7 * ii))["steps"] if st[0] != "crop"}
+    assert used == {int(Image.NEAREST), int(Image.BILINEAR), int(Image.BICUBIC), int(Image.LANCZOS)}, used
     with pytest.raises(Exception):
-        P.plan_sample(_args({"cropMode": "ssd"}, coco.images[0], 0))
+        P.plan_sample(_args({"cropMode": "resnet"}, coco.images[0], 0))
+
+
+MULTICROP = [{"isTraining": False, "multicrop": True, "scale": 56, "crop": 48, "subtractMean": True},
+             {"isTraining": False, "multicrop": True, "scale": 40, "crop": 48},            # corner windows reach outside the scaled image
+             {"isTraining": False, "multicrop": True, "scale": 64, "crop": 32, "scaleMode": "large"}]
+
+
+def test_multicrop_plans_equal_load_sample_proc(coco):
+    """test-time 10-crop (augment.multi_crop_mirror): ten plans per image = the loader's ten views, metas and pixels"""
+    for vi, var in enumerate(MULTICROP):
+        for ii, image in enumerate(coco.images[:6]):
+            args = _args(var, image, 5 * vi + ii)
+            views = IL.load_sample_proc(args)
+            plans = P.plan_views(args)
+            assert len(views) == len(plans) == 10
+            for (f, x, m), pl in zip(views, plans):
+                assert m == pl["meta"]
+                assert np.array_equal(x, P.render_pil(pl)), (vi, ii)
+    with pytest.raises(Exception):
+        P.plan_sample(_args(MULTICROP[0], coco.images[0], 0))
+
+
+@pytest.mark.gpu
+def test_device_render_multicrop_equals_host_path(hip, coco):
+    from denet_amd import ops
+    from denet_amd.dataset.device_render import DeviceImageLoader
+    for vi, var in enumerate(MULTICROP):
+        fmt = {"crop": var["crop"], "multicrop": True, "scale": var["scale"], "scale_mode": var.get("scaleMode", "small"),
+               "subtract_mean": var.get("subtractMean", False)}
+        loader = DeviceImageLoader(2, False, fmt)
+        loader.params.rgb_mean = np.array(BASE["rgbMean"], np.float32)      # a bare loader has zero statistics (division by 0)
+        loader.params.rgb_std = np.array(BASE["rgbStd"], np.float32)
+        try:
+            images = coco.images[:5]
+            random.seed(3 + vi)
+            x, metas = loader.load_batch(images)
+            assert tuple(x.shape) == (50, var["crop"], var["crop"], 4) and len(metas) == 50
+            got = ops.nhwc_to_nchw(x, 3).cpu().numpy()
+            random.seed(3 + vi)
+            k = 0
+            for image in images:
+                for f, ref, m in IL.load_sample_proc(loader.params.make_args(image)):
+                    assert m == metas[k]
+                    assert np.array_equal(got[k], ref), (vi, k, float(np.abs(got[k] - ref).max()))
+                    k += 1
+        finally:
+            loader.close()
 
 
 @pytest.mark.gpu
