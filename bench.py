@@ -12,7 +12,7 @@ Inputs are resident in HBM before the timed region. Rank 0 prints ONE JSON line.
 process group reports it, per-rank ms/step, all-reduce bytes and buckets per step, event-timed exposed collective time).
 
 Extra legs (rank 0, N=1 only; outside the timed region):
-  roofline      the dominant kernel (implicit-GEMM convolution instantiation with the largest total time) is timed
+  roofline      the dominant kernel (the matrix-kernel SYMBOL with the largest total time, named as rocprofv3 names it) is timed
                 live with HIP events on the launch stream over `steps` further instrumented steps;
                 achieved = algorithmic FLOPs per launch / average launch duration; peak = fp32 MFMA 157.3 TFLOP/s.
   warm_regime / stress_regime
@@ -433,6 +433,18 @@ def main():
                                              "ms_per_step": round(v["ms"] / nprof, 3),
                                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
                                          for k, v in sorted(agg.items())}}
+        # the same records grouped by source kernel (all instantiations of a template together): the fused F(4x4) kernel's
+        # tile-block / epilogue variants add up to more step time than any single symbol
+        fam = {}
+        for k, v in agg.items():
+            f = fam.setdefault(k.split("<")[0].replace("_32x2", "").replace("_32k", "").replace("_32", "").replace("_64", "")
+                               if k.startswith("wino4f") else k.split("<")[0], {"launches": 0, "ms": 0.0, "flops": 0.0})
+            for q in ("launches", "ms", "flops"):
+                f[q] += v[q]
+        out["roofline"]["by_family"] = {k: {"launches_per_step": v["launches"] // nprof, "ms_per_step": round(v["ms"] / nprof, 3),
+                                            "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                            "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+                                        for k, v in sorted(fam.items())}
 
     if rank == 0 and world == 1 and not args.no_warm and args.regime == "cold":
         # the headline regime has no detector RoIs (cold corner head). The same step with a firing corner head

@@ -725,7 +725,7 @@ extern "C" int denet_conv_wino2f_sums(const float* x, const float* u, const floa
         }
         attr_set = true;
     }
-    const int prof = denet_prof_begin(10, 0, 0, 0, stream);
+    const int prof = denet_prof_begin(10, (p.add || p.bs_x) ? 1 : 0, 0, 0, stream);      // which instantiation runs
     // the variant that prefetches the output phase's operands only where there are any (it costs the plain pass 4 %)
     if (p.add || p.bs_x) hipLaunchKernelGGL(wino2f_ws_kernel<true>, dim3((unsigned)grid), dim3(512), S_LDS_BYTES, stream, p);
     else hipLaunchKernelGGL(wino2f_ws_kernel<false>, dim3((unsigned)grid), dim3(512), S_LDS_BYTES, stream, p);

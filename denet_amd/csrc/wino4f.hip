@@ -546,7 +546,7 @@ int denet_wino4f_run(int tb, const float* V, const float* U, const float* bias, 
         }
         attr_done[which][ep] = true;
     }
-    const int prof = denet_prof_begin(14, tb, kbw, which >= 2 ? 3 : 4, stream);
+    const int prof = denet_prof_begin(14, tb, ep, which >= 2 ? 3 : 4, stream);      // (tile block, epilogue) = the instantiation
     hipLaunchKernelGGL(fn, dim3((unsigned)(tiles_t * p.tiles_k)), dim3(which >= 2 ? 256 : 512), lds, stream, p);
     denet_prof_end(prof, stream);
     DENET_CHECK_LAUNCH("conv_wino4f");

@@ -38,6 +38,18 @@ WS = Workspace()
 WGRAD_WS_BYTES = 1024 << 20
 
 
+def kernel_symbol(kind, a, b, c):
+    """a profile record -> the kernel's name as rocprofv3 prints it (one row of profiles/*_kernel_stats.md per name)"""
+    if kind == 10:
+        return "wino2f_ws_kernel<%s>" % ("true" if a else "false")
+    if kind == 14:
+        return "%s<%d>" % ({32: "wino4f_kernel_32", 64: "wino4f_kernel_64", 33: "wino4f_kernel_32x2", 34: "wino4f_kernel_32k"}[a], b)
+    if kind == 15:
+        return "wino4g_kernel<%d>" % c
+    fixed = {11: "wino2f_wgrad_kernel", 12: "stem_fwd_kernel", 13: "stem_wgrad_kernel"}.get(kind)
+    return fixed or "igemm_kernel<%d, %d, %d, 2, 2, %d>" % (kind, a, b, c)
+
+
 class KernelProfile:
     """Live per-kernel timing (bench.py's roofline leg). The C side records one HIP event pair around every igemm
     kernel launch, on the stream it is launched on (denet_conv_profile, include/denet_hip.h); this side keeps the
@@ -60,8 +72,7 @@ class KernelProfile:
         ms, v = ctypes.c_float(), [ctypes.c_int() for _ in range(4)]
         for i, flops in enumerate(self.flops):
             check(L.denet_conv_profile_read(i, ctypes.byref(ms), *[ctypes.byref(x) for x in v]), "conv_profile_read")
-            name = {10: "wino2f_ws_kernel", 11: "wino2f_wgrad_kernel", 12: "stem_fwd_kernel", 13: "stem_wgrad_kernel", 14: "wino4f_kernel", 15: "wino4g_kernel"}.get(v[0].value) or \
-                "igemm_kernel<%d, %d, %d, 2, 2, %d>" % tuple(x.value for x in v)
+            name = kernel_symbol(*[x.value for x in v])
             a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
             a["launches"] += 1
             a["ms"] += ms.value
