@@ -83,6 +83,8 @@ class BatchNormLayer(AbstractLayer):
         """res / relu / out_act let ResnetLayer fuse the residual add + ReLU into the normalisation pass"""
         if not self.enabled:
             return
+        if relu is None and out_act is None and getattr(self, "act_fused", False):
+            relu, out_act = True, self.act_behind.output          # `BN A`: see ActivationLayer
         relu = self.fused_relu if relu is None else relu
         out_act = self.output if out_act is None else out_act
         x = self.input.data
@@ -91,7 +93,8 @@ class BatchNormLayer(AbstractLayer):
             pre = getattr(self.input, "stats", None)
             self.input.stats = None
             pool = getattr(self, "pool_behind", None)
-            if pool is not None and ctx is not None and relu and res is None and out_act is self.output and ops.BN_POOL_FUSE:
+            own_out = self.act_behind.output if getattr(self, "act_fused", False) else self.output
+            if pool is not None and ctx is not None and relu and res is None and out_act is own_out and ops.BN_POOL_FUSE:
                 # a max pool is the only reader of this layer's output (ModelCNN.build_train_func links it): one pass
                 # writes the pooled tensor, relu(bn(x)) itself is never materialised (its gradient neither)
                 k, s, p = pool.size[0], pool.stride[0], pool.pad[0]

@@ -123,7 +123,7 @@ class ResnetLayer(AbstractLayer):
         return self.layers[self.n_main:]
 
     def _fold_plan(self):
-        """inference: [(conv, bn, relu)] of the main path and of the shortcut when every batch norm sits directly behind
+        """inference: [(conv, bn, relu, output tensor or None)] of the main path and of the shortcut when every batch norm sits directly behind
         a convolution (the `original` blocks with fused BN-ReLU), else None"""
         if "pre-activation" in self.version or not self.bn_json_param.get("enabled", True):
             return None
@@ -135,7 +135,12 @@ class ResnetLayer(AbstractLayer):
                 if ls[i].type_name != "conv" or i + 1 >= len(ls) or ls[i + 1].type_name not in ("batchnorm", "batchnorm-relu") \
                         or not ls[i].enabled or not ls[i + 1].enabled:
                     return None
-                out.append((ls[i], ls[i + 1], ls[i + 1].type_name == "batchnorm-relu"))
+                bn = ls[i + 1]
+                if getattr(bn, "act_fused", False) and i + 2 < len(ls) and ls[i + 2] is bn.act_behind:
+                    out.append((ls[i], bn, True, bn.act_behind.output))       # `BN A`: the folded pass writes the activation's output
+                    i += 3
+                    continue
+                out.append((ls[i], bn, bn.type_name == "batchnorm-relu", None))
                 i += 2
             return out
         pm, ps = pairs(main), pairs(sc)
@@ -149,10 +154,10 @@ class ResnetLayer(AbstractLayer):
         plan = None if get_train() or not ops.INFER_FOLD else self.__dict__.setdefault("_plan", self._fold_plan())
         if plan:
             pm, ps = plan
-            for conv, bn, relu in pm[:-1]:
-                conv.forward_folded(ctx, bn, relu=relu)
-            for conv, bn, relu in ps:
-                conv.forward_folded(ctx, bn, relu=relu)
+            for conv, bn, relu, oa in pm[:-1]:
+                conv.forward_folded(ctx, bn, relu=relu, out_act=oa)
+            for conv, bn, relu, oa in ps:
+                conv.forward_folded(ctx, bn, relu=relu, out_act=oa)
             res = ps[-1][1].output.data if ps else self.input.data
             relu = self.activation in ("relu", "relu-safe")
             assert relu or self.activation == "none", self.activation

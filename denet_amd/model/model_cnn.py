@@ -292,11 +292,20 @@ class ModelCNN:
         if self.gradient_clip > 0.0:
             raise NotImplementedError("gradient clipping is outside the hot path")
         self.use_split_mode = False   # split points are identities here (288 GB of HBM)
+        # `BN A` pairs whose batch-norm output nobody else reads run as the fused BN + ReLU (ActivationLayer; DENET_BN_ACT_FUSE=0: apart)
+        for l in walk_layers(self.layers):
+            if l.type_name == "batchnorm" and getattr(l, "act_behind", None) is not None:
+                l.act_fused = os.environ.get("DENET_BN_ACT_FUSE", "1") != "0" and self._consumers(l.output) == 1
         # a max pool that is the only reader of a BN + ReLU layer's output (the ResNet stem): the two run as one pass in training
         for a, b in zip(self.layers[:-1], self.layers[1:]):
             a.pool_behind = None
             if a.type_name == "batchnorm-relu" and b.type_name == "pool" and b.mode == "max" and b.input is a.output \
                     and self._consumers(a.output) == 1:
+                a.pool_behind = b
+        for a, act, b in zip(self.layers[:-2], self.layers[1:-1], self.layers[2:]):
+            # the same for `BN A P` written as three layers: the batch norm writes the fused activation's output
+            if a.type_name == "batchnorm" and getattr(a, "act_fused", False) and a.act_behind is act and b.type_name == "pool" \
+                    and b.mode == "max" and b.input is act.output and self._consumers(act.output) == 1:
                 a.pool_behind = b
         # a SKIP layer that adds its tap (same channel count: no projection) to the output of the convolution right in front of it
         # (the up-sampling path of the skip models, skip.py:81-86): the addition goes into that convolution's epilogue, and with it the statistics of the batch
@@ -375,7 +384,9 @@ class ModelCNN:
                         and self._consumers(layer.output) == 1:
                     # folded only when the batch norm is the ONLY reader of the convolution's output: the folded pass
                     # writes normalised values into it, any other consumer (skip source, split, detection tail) needs the raw ones
-                    layer.forward_folded(ctx, nxt, relu=nxt.type_name == "batchnorm-relu")
+                    act = nxt.act_behind if getattr(nxt, "act_fused", False) else None      # `BN A` as one pass: ActivationLayer
+                    layer.forward_folded(ctx, nxt, relu=nxt.type_name == "batchnorm-relu" or act is not None,
+                                         out_act=act.output if act is not None else None)
                     skip_next = True
                     continue
             if train and data_m is not None:

@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 
 from denet_amd import ops
 from denet_amd.model import zoo
+from denet_amd.model.model_cnn import walk_layers as model_cnn_walk
 from oracle import model as OM
 from oracle import layers as OL
 
@@ -207,6 +208,8 @@ def _force_list(model):
         t = layer.type_name
         if t == "conv" and getattr(layer, "skip_behind", None) is not None and layer.output.data is None:
             out.append(None)              # the SKIP layer behind adds its tap in this convolution's epilogue: only the sum exists
+        elif t == "batchnorm" and getattr(layer, "act_fused", False):
+            out.append(None)              # `BN A` run as one fused pass: only the activation's output exists
         elif t in ("conv", "batchnorm", "batchnorm-relu", "pool", "pool-inv", "deconv", "border", "crop-mirror"):
             out.append(nchw(layer.output))
         elif t == "dropout":
@@ -220,7 +223,7 @@ def _force_list(model):
                 fused_tail = (s is main[-1])     # original: last BN fused with add+ReLU; pre-activation: the
                 if s.type_name == "activation" and s.activation == "none":   # residual add rides in the last conv
                     continue
-                out.append(None if fused_tail else nchw(s.output))
+                out.append(None if fused_tail or (s.type_name == "batchnorm" and getattr(s, "act_fused", False)) else nchw(s.output))
             for s in sc:
                 out.append(nchw(s.output))
             out.append(nchw(layer.output))
@@ -692,6 +695,31 @@ def test_bn_pool_fusion_leaves_training_unchanged(hip):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
     for ca, cb in zip(res[0][3], res[1][3]):
         assert abs(ca - cb) <= 1e-5 * abs(cb)
+
+
+def test_bn_followed_by_activation_runs_fused_and_trains_the_same(hip, monkeypatch):
+    """`BN A` as two layers (un-converted ResNet-34, examples/resnet34-imagenet.sh:7): the batch norm runs the fused BN + ReLU
+    passes into the activation's output where that activation is its only reader (ActivationLayer.fused_into; the stem's
+    `BN A P` becomes the one-pass BN + ReLU + max pool). Against DENET_BN_ACT_FUSE=0 (three layers, three passes): same costs
+    and state after two steps to rounding (the fused backward takes its reductions from other kernels), same class
+    probabilities in test mode"""
+    res = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("DENET_BN_ACT_FUSE", fuse)
+        model = zoo.resnet34(2, 224, 10, seed=1)
+        model.build_train_func("nesterov")
+        pairs = [l for l in model_cnn_walk(model.layers) if l.type_name == "batchnorm" and getattr(l, "act_behind", None) is not None]
+        assert len(pairs) == 17 and all(l.act_fused == (fuse == "1") for l in pairs)
+        x, metas = zoo.synthetic_batch(2, 224, 10, seed=3, image_class=True)
+        costs = [model.train_step(x, metas, 0, it, 0.05, [0.9], 1e-4)[0] for it in range(2)]
+        torch.cuda.synchronize()
+        assert (pairs[1].output.data is None) == (fuse == "1")
+        res.append((model.P.clone(), model.M.clone(), model.S.clone(), costs, model.predict_output_step(x)))
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    for ca, cb in zip(res[0][3], res[1][3]):
+        assert abs(ca - cb) <= 1e-5 * abs(cb)
+    np.testing.assert_allclose(res[0][4], res[1][4], rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize("img,tile", [(128, 4), (256, 4), (128, 2)])
