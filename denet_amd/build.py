@@ -57,7 +57,7 @@ def build(force=False, verbose=False):
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     version = _hipcc_version(hipcc)
-    objs = []
+    objs, todo = [], []
     headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "denet_hip.h")]
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -66,11 +66,35 @@ def build(force=False, verbose=False):
         flags = COMMON + (["-ffp-contract=off"] if src in NO_CONTRACT else [])
         digest = _digest([version] + flags, [s] + headers)
         if force or _stale(o, digest):
-            cmd = [hipcc] + flags + ["-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
+            todo.append(([hipcc] + flags + ["-c", s, "-o", o], o, digest))
+    # the stale translation units side by side (one hipcc process each; the largest files first)
+    todo.sort(key=lambda t: -os.path.getsize(t[0][-3]))
+    running = []
+    jobs = max(1, min(len(todo), int(os.environ.get("DENET_BUILD_JOBS", os.cpu_count() or 1))))
+
+    def reap(block):
+        for ent in list(running):
+            proc, cmd, o, digest = ent
+            rc = proc.wait() if block else proc.poll()
+            if rc is None:
+                continue
+            running.remove(ent)
+            if rc != 0:
+                for other in running:
+                    other[0].kill()
+                raise subprocess.CalledProcessError(rc, cmd)
             _stamp(o, digest)
+            if block:
+                return
+
+    for cmd, o, digest in todo:
+        while len(running) >= jobs:
+            reap(block=True)
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        running.append((subprocess.Popen(cmd), cmd, o, digest))
+    while running:
+        reap(block=True)
     link = ["--offload-arch=gfx950", "-shared", "-fPIC"]
     digest = _digest([version] + link, objs)
     if force or _stale(LIB, digest):

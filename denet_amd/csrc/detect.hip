@@ -226,14 +226,18 @@ __global__ __launch_bounds__(64) void soft_nms_pair_kernel(const float* __restri
     const float discard = -6.9f;
     int kept = 0;
     while (true) {
-        // the live candidate with the largest score, the earliest position among equals. NaN scores never win a `>`:
-        // like the reference, a list whose head is NaN selects the head (position order decides) - the comparison below
-        // treats "no candidate yet" (pos = INT_MAX) as beaten by any live one
+        // the reference's scan (denet_detect.cc:44-52): best = the list's head, a later element replaces it only if strictly
+        // greater. Without NaNs that is the largest score, the earliest position among equals. A NaN never wins a `>` and,
+        // as the running best, is never beaten: the scan returns the HEAD if the head is NaN, else the largest non-NaN score.
+        // The lanes own interleaved positions, so the butterfly runs over the non-NaN candidates only and carries the
+        // earliest live position beside it; a NaN head is then selected explicitly ([3, NaN, 5] -> 5, [NaN, 3] -> NaN).
         float best = 0.f;
-        int pos = 0x7fffffff;
+        int pos = 0x7fffffff, first = 0x7fffffff;
         for (int k = lane; k < n; k += 64) {
             if (!s_alive[k]) continue;
+            if (first == 0x7fffffff) first = k;
             const float v = s_score[k];
+            if (v != v) continue;
             if (pos == 0x7fffffff || v > best) {
                 best = v;
                 pos = k;
@@ -243,11 +247,20 @@ __global__ __launch_bounds__(64) void soft_nms_pair_kernel(const float* __restri
         for (int off = 32; off > 0; off >>= 1) {
             const float ob = __shfl_xor(best, off, 64);
             const int op = __shfl_xor(pos, off, 64);
+            const int of = __shfl_xor(first, off, 64);
+            first = min(first, of);
             // the reference's scan keeps the EARLIER element unless a later one is strictly greater
             const bool take = (op != 0x7fffffff) && (pos == 0x7fffffff || (op < pos ? !(best > ob) : (ob > best)));
             if (take) {
                 best = ob;
                 pos = op;
+            }
+        }
+        if (first != 0x7fffffff) {
+            const float hv = s_score[first];
+            if (hv != hv || pos == 0x7fffffff) {      // the head is NaN (or every live score is): the head is the selection
+                best = hv;
+                pos = first;
             }
         }
         if (pos == 0x7fffffff) break;

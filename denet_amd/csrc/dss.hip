@@ -620,6 +620,22 @@ extern "C" size_t denet_sparse_sort_workspace_bytes(int B, int H, int W, int roi
     return L.total * sizeof(int);
 }
 
+namespace {
+// the one-kernel form (sparse_sort_image_kernel: one 1024-thread workgroup per image) serves this problem
+bool sort_is_single(const SortLayout& L) {
+    static const int one_kernel = [] { const char* e = getenv("DENET_SORT_ONE_KERNEL"); return e ? atoi(e) : 1; }();
+    return one_kernel && L.HW <= 4096 && L.n <= 65535;
+}
+}  // namespace
+
+// 1 if denet_sparse_sort runs as ONE kernel for this problem (the host then keeps it on the compute stream: alone it takes
+// ~50 us, on a side stream its workgroups starve for LDS beside the head's matrix kernels), 0 for the three-kernel form
+extern "C" int denet_sparse_sort_is_single(int B, int H, int W, int rois_per_image, int gs) {
+    SortLayout L;
+    if (sort_layout(B, H, W, rois_per_image, gs, &L)) return 0;
+    return sort_is_single(L) ? 1 : 0;
+}
+
 // groups the tap list of every image by cell (see sparse_count_kernel); depends only on `taps`, so the host may queue it
 // on a side stream right after the forward gather, off the critical path of the backward sweep
 extern "C" int denet_sparse_sort(const int* taps, void* sort_ws, size_t sort_ws_bytes, int B, int H, int W,
@@ -646,8 +662,7 @@ extern "C" int denet_sparse_sort(const int* taps, void* sort_ws, size_t sort_ws_
         }
         attr_set = true;
     }
-    static const int one_kernel = [] { const char* e = getenv("DENET_SORT_ONE_KERNEL"); return e ? atoi(e) : 1; }();
-    if (one_kernel && L.HW <= 4096 && L.n <= 65535) {
+    if (sort_is_single(L)) {
         const size_t lds1 = (size_t)SORT1_WAVES * ((L.HW + 1) & ~1) * sizeof(unsigned short);
         static bool attr1 = false;
         if (!attr1) {

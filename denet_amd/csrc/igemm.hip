@@ -801,12 +801,18 @@ struct ProfRec {
 };
 std::vector<ProfRec> g_prof;
 bool g_prof_on = false;
+bool g_prof_events = true;       // false: launch trace only (denet_conv_profile(2)): which instantiation ran, no events, no timing
 
 // opens a record (event on `stream` before the launch); -1 when profiling is off or an event cannot be created
 int prof_begin(int mode, int bm, int bn, int nbuf, hipStream_t stream) {
     if (!g_prof_on) return -1;
     ProfRec rec;
     rec.cfg[0] = mode; rec.cfg[1] = bm; rec.cfg[2] = bn; rec.cfg[3] = nbuf;
+    rec.a = rec.b = nullptr;
+    if (!g_prof_events) {
+        g_prof.push_back(rec);
+        return -1;                   // nothing to close
+    }
     if (hipEventCreate(&rec.a) != hipSuccess) return -1;
     if (hipEventCreate(&rec.b) != hipSuccess) {
         (void)hipEventDestroy(rec.a);
@@ -1055,11 +1061,12 @@ void denet_prof_end(int idx, hipStream_t stream) { prof_end(idx, stream); }
 
 extern "C" int denet_conv_profile(int enable) {
     for (auto& r : g_prof) {
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        if (r.a) (void)hipEventDestroy(r.a);
+        if (r.b) (void)hipEventDestroy(r.b);
     }
     g_prof.clear();
     g_prof_on = enable != 0;
+    g_prof_events = enable != 2;
     return DENET_OK;
 }
 
@@ -1067,11 +1074,14 @@ extern "C" int denet_conv_profile_count(void) { return (int)g_prof.size(); }
 
 extern "C" int denet_conv_profile_read(int i, float* ms, int* mode, int* bm, int* bn, int* nbuf) {
     DENET_CHECK_ARG(i >= 0 && i < (int)g_prof.size() && ms, "conv_profile_read: index %d out of range", i);
-    hipError_t e = hipEventSynchronize(g_prof[i].b);
-    if (e == hipSuccess) e = hipEventElapsedTime(ms, g_prof[i].a, g_prof[i].b);
-    if (e != hipSuccess) {
-        denet_set_error("conv_profile_read: %s", hipGetErrorString(e));
-        return -(int)e;
+    *ms = 0.f;
+    if (g_prof[i].a) {               // (a launch-trace record has no events: duration 0)
+        hipError_t e = hipEventSynchronize(g_prof[i].b);
+        if (e == hipSuccess) e = hipEventElapsedTime(ms, g_prof[i].a, g_prof[i].b);
+        if (e != hipSuccess) {
+            denet_set_error("conv_profile_read: %s", hipGetErrorString(e));
+            return -(int)e;
+        }
     }
     if (mode) *mode = g_prof[i].cfg[0];
     if (bm) *bm = g_prof[i].cfg[1];

@@ -121,7 +121,9 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
         const bool isv = q < VP;
         const int row = 4 * (isv ? q : q - VP) + prow;
         const int chunk16 = pslot ^ (row & 15);
-        pv_off[j] = ((isv ? t0 : k0) + row) * p.C * 4 + chunk16 * 16;
+        // a V row beyond the last tile (T % TB != 0, last tile block) is zero-filled explicitly: out-of-range offset, like the
+        // trailing pieces below - not left to whatever lies behind the component (for component 35: behind V)
+        pv_off[j] = (!isv || t0 + row < p.T) ? ((isv ? t0 : k0) + row) * p.C * 4 + chunk16 * 16 : W4_OOB;
     }
     const int compV = p.T * p.C * 4, compU = p.K * p.C * 4;     // bytes per component
     int d_cc = 0, d_sV = 0, d_sU = 0, d_left = 36 * p.chunks, d_buf = 0;
@@ -478,6 +480,9 @@ extern "C" int denet_conv_wino4f_mode(int mode) {
 // with ONE round of workgroups, each of which walks all 36 components
 int denet_wino4f_block(int tile, long T, int C, int K) {
     if (tile != 4 || C % 128 != 0 || K % 64 != 0 || T <= 0 || T * 64 * K >= (1L << 31)) return 0;
+    // V / U go through 32-bit buffer descriptors and the kernel steps through the components with a signed 32-bit byte offset
+    // (d_sV reaches 36 * T * C * 4): a problem beyond that takes the un-fused path instead of failing in denet_wino4f_run
+    if (36L * T * C * 4 >= (1L << 31) || 36L * K * C * 4 >= (1L << 31)) return 0;
     static const int env_on = [] { const char* e = getenv("DENET_WINO4F"); return e ? atoi(e) : 1; }();
     static const int env_tb = [] { const char* e = getenv("DENET_WINO4F_TB"); return e ? atoi(e) : 0; }();
     const int mode = g_w4_mode >= 0 ? g_w4_mode : (env_on ? env_tb : 0);

@@ -338,7 +338,9 @@ class DeNetDetectLayer(AbstractLayer):
             # launches and two dependent copies: 2.21 against 2.44 ms at B = 1, 21.7 against 14.4 ms at B = 32).
             # DENET_SOFT_NMS_HOST=1 / 0 forces the host / device form
             on_host = os.environ.get("DENET_SOFT_NMS_HOST")
-            if (on_host == "1") if on_host in ("0", "1") else B < 4:
+            # (the device form keeps a (class, image) pair's candidates in LDS: S <= 4096 RoIs per image; beyond that - sample_num
+            # > 64 - the host call, which has no such limit)
+            if S > 4096 or ((on_host == "1") if on_host in ("0", "1") else B < 4):
                 det_h = numpy.ascontiguousarray(det_pr.cpu().numpy())
                 scores, cls_idx, rows, per = ops.soft_nms_batch_host(det_h, numpy.ascontiguousarray(fit_h), numpy.ascontiguousarray(box_h),
                                                                      counts, B, S, self.class_num, pr_threshold, nms_threshold)

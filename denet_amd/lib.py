@@ -129,6 +129,7 @@ SIGNATURES = {
     "denet_corner_loss": (I, [P] * 5 + [I] * 5 + [F, P]),
     "denet_sparse_fwd": (I, [P, P, P, P] + [I] * 10 + [P]),
     "denet_sparse_sort_workspace_bytes": (Z, [I] * 5),
+    "denet_sparse_sort_is_single": (I, [I] * 5),
     "denet_sparse_sort": (I, [P, P, Z] + [I] * 5 + [P]),
     "denet_sparse_bwd": (I, [P, P, P, Z, P] + [I] * 10 + [P]),
     "denet_detect_loss": (I, [P] * 9 + [I] * 6 + [F, F, F, I, P]),

@@ -83,6 +83,47 @@ class KernelProfile:
 
 PROFILE = None
 
+
+class LaunchTrace:
+    """Which matrix kernel every convolution pass launches, in launch order (denet_conv_profile(2): the C side notes the
+    instantiation of each launch - no events, no change of streams or timing). mark(label) closes the stretch of launches
+    since the previous mark; by_label() -> {label: [kernel symbols as rocprofv3 prints them]}. Used by
+    denet_amd.model.audit (bench.py's kernels_used, the parity tests' per-layer assertions)."""
+
+    def __init__(self):
+        self.marks = []
+        self.symbols = None
+
+    def __enter__(self):
+        assert PROFILE is None, "a live kernel profile is being recorded"
+        check(_L().denet_conv_profile(2), "conv_profile")
+        return self
+
+    def mark(self, label):
+        self.marks.append((label, int(_L().denet_conv_profile_count())))
+
+    def __exit__(self, *a):
+        import ctypes
+        L = _L()
+        n = int(L.denet_conv_profile_count())
+        ms, v = ctypes.c_float(), [ctypes.c_int() for _ in range(4)]
+        self.symbols = []
+        for i in range(n):
+            check(L.denet_conv_profile_read(i, ctypes.byref(ms), *[ctypes.byref(x) for x in v]), "conv_profile_read")
+            self.symbols.append(kernel_symbol(*[x.value for x in v]))
+        check(L.denet_conv_profile(0), "conv_profile")
+        return False
+
+    def by_label(self):
+        out, lo = {}, 0
+        for label, hi in self.marks:
+            out.setdefault(label, []).extend(self.symbols[lo:hi])
+            lo = hi
+        if lo < len(self.symbols):
+            out.setdefault(None, []).extend(self.symbols[lo:])
+        return out
+
+
 _COPY_STREAM = None
 
 
@@ -277,7 +318,7 @@ def _load_tuned_once():
 def _tune_first(mode, g, a, b, bias, add, out, ws):
     """True if this call was served by the tuner (which leaves the pass's result in `out`)"""
     _load_tuned_once()
-    if not AUTOTUNE or PROFILE is not None or (mode, g) in _TUNED:
+    if not AUTOTUNE or POLICY is not None or PROFILE is not None or (mode, g) in _TUNED:
         return False
     _TUNED.add((mode, g))
     check(_L().denet_conv_tune(mode, ptr(a), ptr(b), ptr(bias), ptr(add), ptr(out), ptr(ws), ws.numel() if ws is not None
@@ -309,7 +350,7 @@ def _conv_wino_fwd_linked(link, g, tile, w, bias, add, out, cache, bn_stats):
     cache["fwd_tile"] = tile
     u = _cached_u(cache, 0, tile)
     v_keep = None
-    if _WINO.get((2, g)) == tile:            # the filter gradient of this layer reuses the transformed input
+    if _decided(2, g) == tile:               # the filter gradient of this layer reuses the transformed input
         v_keep = cache.get("V")
         nv = (tile + 2) * (tile + 2) * (N * (H // tile) * (W // tile)) * C
         if v_keep is None or v_keep.numel() != nv:
@@ -338,8 +379,8 @@ def conv_backward_linked(link, x, w, w_shape, add, dw_out, cache, stride=1, pad=
         sums = None                  # DENET_BN_BWD_SUMS bit 0: the Winograd passes leave the backward reductions to the batch norm
     g = conv_geom(x.shape, w_shape, stride, pad, s_real)
     N, H, W, C, K = g[0], g[1], g[2], g[3], g[4]
-    tile = _WINO.get((1, g))
-    if not (LINK_BN and tile in (2, 4) and _WINO.get((2, g)) == tile and not _bf16x3_geom(g)):
+    tile = _decided(1, g)
+    if not (LINK_BN and tile in (2, 4) and _decided(2, g) == tile and not _bf16x3_geom(g)):
         return None
     if PROFILE is not None:          # two implicit-GEMM launches follow, in this order: data-gradient, filter-gradient products
         PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])
@@ -422,7 +463,7 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
     it inside its input transform, every other implementation materialises it first. link.result is the activation afterwards."""
     if link is not None:
         g = conv_geom(link.x.shape, w.shape, stride, pad, s_real)
-        tile = _WINO.get((0, g))
+        tile = _decided(0, g)
         if not (tile in (2, 4) and cache is not None and cache.get("train") and not relu and not _bf16x3_geom(g)):
             x = link.materialise()             # direct / fused-64 / undecided implementations read the tensor itself
             link = None
@@ -435,7 +476,7 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
         # un-fused Winograd kernels (already decided for this geometry) reads the small tensor in its input transform; every other
         # case writes the up-sampled tensor first
         gu = conv_geom(up.shape, w.shape, stride, pad, s_real)
-        if not (_WINO.get((0, gu)) in (2, 4) and ((0, gu) in _TUNED or not AUTOTUNE) and cache is not None and cache.get("train") and bn_stats
+        if not (_decided(0, gu) in (2, 4) and ((0, gu) in _TUNED or not AUTOTUNE or POLICY is not None) and cache is not None and cache.get("train") and bn_stats
                 and not relu and not _bf16x3_geom(gu)):
             x = up.materialise()
             up = None
@@ -486,7 +527,7 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
                     ent = cache["u_test"] = (tile, conv_wino_filter(w, _filter_tile(tile), dgrad=False), WEIGHTS_VERSION, w.data_ptr())
                 u = ent[1]
             # the filter gradient of this layer uses the same transformed input when it runs with the same tile
-            if cache.get("train") and _WINO.get((2, g)) == tile:
+            if cache.get("train") and _decided(2, g) == tile:
                 v_keep = cache.get("V")
                 nv = (tile + 2) * (tile + 2) * (N * (H // tile) * (W // tile)) * C
                 if v_keep is None or v_keep.numel() != nv:
@@ -516,6 +557,32 @@ _WINO = {}
 FUSED2 = 22
 WINO2F = int(os.environ.get("DENET_WINO2F", "7"))
 _WINO_GAIN = {2: 2.25, 4: 4.0, FUSED2: 2.25}      # direct multiplications / Winograd multiplications
+
+
+# POLICY (None by default): a callable (mode, geometry) -> tile that DECIDES the implementation of a pass that has no entry in
+# _WINO yet, instead of measuring the candidates on the first call (static_policy below; the parity tests set it so that the
+# kernels a test covers do not depend on a timing race - at the benchmark geometries the committed tuned file decides).
+# With a policy set no launch configuration is measured either (the C side's heuristics apply).
+POLICY = None
+
+
+def static_policy(mode, g):
+    """the fused 64-channel kernels where they apply, else F(4x4), else F(2x2), else the direct kernel"""
+    if _tile_allowed(mode, FUSED2) and conv_wino2f_ok(mode, g):
+        return FUSED2
+    for t in (4, 2):
+        if t <= WINOGRAD and conv_wino_ok(g, t):
+            return t
+    return 0
+
+
+def _decided(mode, g):
+    """the implementation fixed for this pass (0 direct, 2 / 4 Winograd tile, FUSED2), None while undecided"""
+    _load_tuned_once()
+    use = _WINO.get((mode, g))
+    if use is None and POLICY is not None:
+        use = _WINO[(mode, g)] = int(POLICY(mode, g))
+    return use
 
 
 def _tile_allowed(mode, tile):
@@ -566,7 +633,7 @@ def _wino_tile(mode, g, direct, wino):
     """decides (once) between the direct kernel (0) and the Winograd tiles (2, 4) for this pass by timing them;
     wino(tile) runs the pass with the given tile"""
     key = (mode, g)
-    use = _WINO.get(key)
+    use = _decided(mode, g)
     if use is None:
         tiles = [t for t in (2, 4) if t <= WINOGRAD and conv_wino_ok(g, t)] if AUTOTUNE else []
         if AUTOTUNE and _tile_allowed(mode, FUSED2) and conv_wino2f_ok(mode, g):
@@ -1445,7 +1512,7 @@ def sparse_sort_async(taps, B, H, W, rois_per_image, gs):
     if _SORT_STREAM is None:
         init_streams()
     ws = WS.get("sparse_sort", _L().denet_sparse_sort_workspace_bytes(B, H, W, rois_per_image, gs))
-    if H * W <= 4096 and rois_per_image * gs * gs <= 65535:
+    if bool(_L().denet_sparse_sort_is_single(B, H, W, rois_per_image, gs)):
         # the one-kernel sort (one 1024-thread workgroup per image, 128 KB of LDS): on a side stream its workgroups starve for
         # LDS beside the head's matrix kernels until those drain (1.5-1.9 ms in the trace); alone it takes ~50 us, so it runs
         # here, on the compute stream, right behind the gather
@@ -1583,10 +1650,12 @@ def soft_nms_batch(det_pr, fitness, bbox, count, B, S, class_num, pr_threshold, 
     import numpy
     P = B * class_num
     ws_bytes = int(_L().denet_soft_nms_workspace_bytes(B, S, class_num))
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda")
-    score = torch.empty(P * S, dtype=torch.float32, device="cuda")
-    cr = torch.empty((2, P * S), dtype=torch.int32, device="cuda")
-    head = torch.empty(B + 1, dtype=torch.int32, device="cuda")          # per-image counts, then the total
+    # workspace and outputs from the grow-only pool (118 MB at B=32, S=2304, 80 classes: not through the caching allocator on
+    # every call of the inference loop)
+    ws = WS.get("soft_nms", ws_bytes)
+    score = WS.get("soft_nms_score", P * S * 4).view(torch.float32)[:P * S]
+    cr = WS.get("soft_nms_cr", 2 * P * S * 4).view(torch.int32)[:2 * P * S].view(2, P * S)
+    head = WS.get("soft_nms_head", (B + 1) * 4).view(torch.int32)[:B + 1]       # per-image counts, then the total
     check(_L().denet_soft_nms_batch(ptr(det_pr), ptr(fitness), ptr(bbox), ptr(count), B, S, class_num, float(pr_threshold),
                                     float(nms_threshold), ptr(score), ptr(cr[0]), ptr(cr[1]), ptr(head),
                                     ptr(head) + 4 * B, ptr(ws), ws_bytes, stream_ptr()), "soft_nms_batch")

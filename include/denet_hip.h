@@ -267,7 +267,9 @@ int denet_tune_clear(void);
 int denet_conv_last_config(int* mode, int* bm, int* bn, int* nbuf, int* grid_y);
 /* live timing of the igemm kernel alone (bench.py roofline leg): denet_conv_profile(1) starts recording one HIP event
  * pair per convolution launch on the launch stream, (0) stops and frees; _read returns the duration of launch i and the
- * instantiation <mode,BM,BN,2,2,NBUF> it used (the name rocprofv3 --kernel-trace shows).                       */
+ * instantiation <mode,BM,BN,2,2,NBUF> it used (the name rocprofv3 --kernel-trace shows). denet_conv_profile(2) records the
+ * instantiations only - no events, no effect on timing or stream order (the per-layer "which kernel ran" audit of the parity
+ * tests and of bench.py's kernels_used); _read then returns a duration of 0.                                     */
 /* the fused F(4x4,3x3) product + output-transform kernel (csrc/wino4f.hip) inside the denet_conv_wino_* passes: 0 = never,
  * 32 / 64 = that tile block wherever the geometry allows (33 / 34: 32-tile blocks as 4-wave workgroups on 64 / 32 output channels, several per CU), -1 = the default
  * policy (DENET_WINO4F, DENET_WINO4F_TB); returns the previous setting. Same operator as the un-fused passes (convolution.py:80-83), other rounding.                       */
@@ -460,6 +462,9 @@ int denet_sparse_fwd(const float* fmap, const float* bbox, float* out, int* taps
  * side stream during the forward pass); denet_sparse_bwd with taps == NULL then consumes the lists. sort_ws holds
  * denet_sparse_sort_workspace_bytes(...) bytes; H*W <= 32768 cells.                                               */
 size_t denet_sparse_sort_workspace_bytes(int B, int H, int W, int rois_per_image, int gs);
+/* 1: denet_sparse_sort serves this problem with ONE kernel (H*W <= 4096 cells, <= 65535 taps per image, DENET_SORT_ONE_KERNEL
+ * not 0) - the host keeps it on the compute stream; 0: the three-kernel form, which a host may queue on a side stream */
+int denet_sparse_sort_is_single(int B, int H, int W, int rois_per_image, int gs);
 int denet_sparse_sort(const int* taps, void* sort_ws, size_t sort_ws_bytes, int B, int H, int W, int rois_per_image,
                       int gs, hipStream_t stream);
 int denet_sparse_bwd(const float* dy, const int* taps, void* sort_ws, size_t sort_ws_bytes, float* dfmap, int B, int H,

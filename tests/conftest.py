@@ -20,8 +20,13 @@ def hip():
     """The loaded C-ABI library; GPU tests fail loudly (not skip) if it is missing."""
     import torch
     assert torch.cuda.is_available(), "GPU test selected but no HIP device is visible"
-    from denet_amd import lib
-    return lib.load()
+    from denet_amd import lib, ops
+    L = lib.load()
+    # the committed launch configurations / algorithm decisions (denet_amd/tuned/gfx950.json) are loaded BEFORE any test saves and
+    # restores ops._WINO around itself: a test that snapshots the empty table and restores it would otherwise drop them for the
+    # rest of the session (the file is read once per process), and the tests at the benchmark geometries would measure again
+    ops._load_tuned_once()
+    return L
 
 
 @pytest.fixture(autouse=True)
