@@ -269,6 +269,9 @@ def main():
     ap.add_argument("--no-warm", action="store_true", help="skip the warm / stress corner-regime legs (rank 0, N=1)")
     ap.add_argument("--no-dp-selftest", action="store_true", help="skip the single-GPU RCCL self-test leg (rank 0, N=1)")
     ap.add_argument("--no-configs", action="store_true", help="skip the config2 / config5 legs (rank 0, N=1)")
+    ap.add_argument("--no-instep", action="store_true", help="skip the in-step kernel timing leg (roofline.dominant_by_time_in_step)")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the input_h2d leg (host batch uploaded every step; rank 0, N=1)")
+    ap.add_argument("--no-audit", action="store_true", help="skip the per-layer kernel audit (config.kernels_used; rank 0)")
     ap.add_argument("--no-split-bf16", action="store_true",
                     help="skip the leg of the OPT-IN variant (head GEMMs as 3-term bf16 splits; own key, never the headline)")
     ap.add_argument("--regime", default="cold", choices=["cold", "warm"],
@@ -324,6 +327,8 @@ def main():
             dp.barrier()
             torch.cuda.synchronize()
 
+    from denet_amd.model import audit
+    undecided = len(audit.decisions_cover(model))      # 3x3 passes the committed tuned file does not decide (measured in the warm-up)
     it = 0
     # launch configurations are measured during the first two steps (one-off setup, like kernel compilation): they are
     # taken out of the timed region even when fewer warm-up steps were asked for
@@ -407,6 +412,20 @@ def main():
     if dp_info is not None:
         out["data_parallel"] = dp_info
 
+    # ---- self-audit: WHICH kernels the timed steps ran, layer by layer, and under which switches (one more step outside the
+    # timed region; the C side notes the instantiation of every matrix-kernel launch, no events, no effect on streams) ----
+    out["config"]["denet_switches"] = audit.active_switches()          # DENET_* environment switches: {} is the product default
+    out["config"]["product_default_switches"] = not [k for k in out["config"]["denet_switches"] if k not in ("DENET_FORCE_DP",
+                                                                                                             "DENET_BENCH_SHARE_GPU")]
+    out["config"]["tuned_file"] = os.path.relpath(ops.TUNE_CACHE, os.path.dirname(os.path.abspath(__file__))) if ops._TUNE_LOADED else None
+    if rank == 0 and not args.no_audit:
+        out["config"]["passes_measured_in_the_warmup"] = undecided       # 0: every implementation came from the committed file
+        with audit.KernelAudit(model) as ka:
+            model.train_step(xd, metas, 0, it, lr, mom, decay)
+            it += 1
+            torch.cuda.synchronize()
+        out["config"]["kernels_used"] = {g: {k: v for k, v in e.items()} for g, e in ka.summary().items()}
+
     if rank == 0 and world == 1 and not args.no_roofline:
         prof = ops.KernelProfile()
         ops.PROFILE = prof
@@ -445,6 +464,69 @@ def main():
                                             "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                             "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
                                         for k, v in sorted(fam.items())}
+
+    if rank == 0 and world == 1 and not args.no_roofline and not args.no_instep:
+        # the same event pairs with the step's two kernel chains LEFT ON: what every matrix kernel costs inside the step (beside the
+        # other chain's kernels, the wait for CU slots included) next to its alone figure above
+        try:
+            prof2 = ops.KernelProfile(alone=False)
+            ops.PROFILE = prof2
+            for _ in range(nprof):
+                model.train_step(xd, metas, 0, it, lr, mom, decay)
+                it += 1
+            ops.PROFILE = None
+            agg2 = prof2.summary()
+            name2, a2 = max(agg2.items(), key=lambda kv: kv[1]["ms"])
+            tf2 = a2["flops"] / (a2["ms"] * 1e-3) / 1e12
+            out["roofline"]["dominant_by_time_in_step"] = {
+                "kernel": name2, "launches_per_step": a2["launches"] // nprof, "ms_per_step_in_step": round(a2["ms"] / nprof, 3),
+                "ms_per_step_alone": round(agg[name2]["ms"] / nprof, 3) if name2 in agg else None,
+                "tflops_in_step": round(tf2, 2), "frac_in_step": round(tf2 / PEAK_FP32_MFMA_TFLOPS, 4),
+                "note": "event pair per launch on its own stream while BOTH backward chains run (the events themselves cost the "
+                        "step a few per cent): a kernel's in-step duration includes what it waits for CU slots beside the other chain"}
+            out["roofline"]["in_step_ms_per_step"] = {k: round(v["ms"] / nprof, 3) for k, v in sorted(agg2.items())}
+        except Exception as exc:          # an extra leg must never cost the headline line
+            ops.PROFILE = None
+            out["roofline"]["dominant_by_time_in_step"] = {"error": repr(exc)[:300]}
+
+    if rank == 0 and world == 1 and not args.no_h2d:
+        # the reference's train_step takes HOST arrays (model_cnn.py:407): the same steps with the batch coming from pinned host
+        # memory every step - uploaded into one of two device buffers on a copy stream while the previous step trains (the buffer is
+        # free again when the step that read it has recorded model.input_consumed)
+        try:
+            xh = torch.from_numpy(x).pin_memory()
+            bufs = [torch.empty_like(xd), torch.empty_like(xd)]
+            copy_stream = ops.side_stream(2)
+            ready = [None, None]
+
+            def upload(i, after):
+                with torch.cuda.stream(copy_stream):
+                    if after is not None:
+                        copy_stream.wait_event(after)
+                    bufs[i].copy_(xh, non_blocking=True)
+                    ready[i] = torch.cuda.Event()
+                    ready[i].record(copy_stream)
+
+            upload(0, None)
+            nh = max(1, min(args.steps, 20))
+            for s_ in range(2 + nh):
+                if s_ == 2:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                i_ = s_ & 1
+                upload(1 - i_, getattr(model, "input_consumed", None) if s_ > 0 else None)      # the NEXT batch, beside this step
+                torch.cuda.current_stream().wait_event(ready[i_])
+                hcost, _ = model.train_step(bufs[i_], metas, 0, it, lr, mom, decay)
+                it += 1
+            torch.cuda.synchronize()
+            hdt = time.perf_counter() - t0
+            out["input_h2d"] = {"value": round(BATCH_PER_GPU * nh / hdt, 2), "unit": "images/sec", "ms_per_step": round(1e3 * hdt / nh, 3),
+                                "steps": nh, "h2d_bytes_per_step": int(xh.numel() * 4), "final_cost": round(float(hcost), 5),
+                                "note": "the batch is uploaded from pinned host memory EVERY step (double-buffered on a copy stream, "
+                                        "hidden behind the previous step); `value` above keeps it resident in HBM as the contract asks"}
+            del bufs, xh
+        except Exception as exc:          # an extra leg must never cost the headline line
+            out["input_h2d"] = {"error": repr(exc)[:300]}
 
     if rank == 0 and world == 1 and not args.no_warm and args.regime == "cold":
         # the headline regime has no detector RoIs (cold corner head). The same step with a firing corner head

@@ -55,8 +55,13 @@ class KernelProfile:
     kernel launch, on the stream it is launched on (denet_conv_profile, include/denet_hip.h); this side keeps the
     algorithmic FLOPs (2 * MACs of the layer) of the same launches, in the same order."""
 
-    def __init__(self):
+    def __init__(self, alone=True):
+        """alone (the roofline leg): while the profile is recorded every kernel runs alone on ONE stream (the second stream of the
+        backward sweep is off), so that a launch's duration is the kernel's own. alone=False: the step keeps its two chains and
+        the event pairs measure every matrix kernel INSIDE the step - beside the other chain's kernels, waits for CU slots included
+        (bench.py: roofline.dominant_by_time_in_step)"""
         self.flops = []
+        self.alone = bool(alone)
         check(_L().denet_conv_profile(1), "conv_profile")
 
     def add(self, flops):
@@ -415,7 +420,7 @@ def conv_backward_linked(link, x, w, w_shape, add, dw_out, cache, stride=1, pad=
     global _ON_WGRAD_STREAM
     if WGRAD_STREAM and _WGRAD_STREAM is None:
         init_streams()
-    side = _WGRAD_STREAM if (WGRAD_STREAM and PROFILE is None) else None      # a live kernel profile runs every kernel alone
+    side = _WGRAD_STREAM if (WGRAD_STREAM and (PROFILE is None or not PROFILE.alone)) else None      # a live kernel profile runs every kernel alone
     if side is not None:
         side.wait_event(ev)                           # only the transform kernel: the products of the two chains run side by side
         dm.record_stream(side)
@@ -754,7 +759,7 @@ class wgrad_stream:
 
     def __enter__(self):
         global _WGRAD_STREAM, _ON_WGRAD_STREAM
-        self.active = WGRAD_STREAM and PROFILE is None
+        self.active = WGRAD_STREAM and (PROFILE is None or not PROFILE.alone)
         if not self.active:
             return self
         if _WGRAD_STREAM is None:
