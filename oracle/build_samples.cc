@@ -255,6 +255,30 @@ extern "C" int oracle_build_samples(const float* corner_pr, int B, int Cn, int H
     return 0;
 }
 
+// apply_cluster (denet_sparse.cc:165-242) + the final ranking (:543-545) on a candidate list that is ALREADY ranked (the n <=
+// 10 * output_num best of an image, rows of pr, x0, y0, x1, y1 in ranked order): the grouping walks the candidates in the order
+// given. Tests hand over the PRODUCT's ranked list, whose order inside a group of exactly equal scores the reference leaves to
+// std::partial_sort (README: ties) - the clustered result is then comparable exactly although the inputs hold ties.
+extern "C" int oracle_cluster_ranked(const float* ranked, int n, float cluster_threshold, int output_num, float* out_samples,
+                                     int* out_count) {
+    std::vector<Sample> s((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const float* r = ranked + (size_t)i * 5;
+        Sample t = Sample();
+        t.pr = r[0]; t.x0 = r[1]; t.y0 = r[2]; t.x1 = r[3]; t.y1 = r[4];
+        s[(size_t)i] = t;
+    }
+    if ((size_t)n > (size_t)output_num && cluster_threshold < 1.0f) apply_cluster(s, cluster_threshold, (size_t)n, (size_t)output_num);
+    std::stable_sort(s.begin(), s.end());          // (stable: equal scores keep the clustered order; tests compare such groups as sets)
+    if (s.size() > (size_t)output_num) s.resize((size_t)output_num);
+    *out_count = (int)s.size();
+    for (size_t i = 0; i < s.size(); ++i) {
+        float* o = out_samples + i * 5;
+        o[0] = s[i].pr; o[1] = s[i].x0; o[2] = s[i].y0; o[3] = s[i].x1; o[4] = s[i].y1;
+    }
+    return 0;
+}
+
 // number of corners per type after thresholding / local max / truncation (diagnostics for tests)
 extern "C" int oracle_count_corners(const float* corner_pr, int B, int Cn, int H, int W, float corner_threshold,
                                     int max_corners, int local_max_r, int* out_counts) {

@@ -533,3 +533,17 @@ def oracle_build_samples(corner_pr, corner_threshold, sample_num, max_corners=10
         rows = out[b, :cnt[b]].tolist()
         res.append([(r[0], (r[1], r[2], r[3], r[4])) for r in rows])
     return res
+
+
+def oracle_cluster_ranked(ranked, cluster_threshold, output_num):
+    """apply_cluster + final ranking (denet_sparse.cc:165-242, 543-545) on an already ranked candidate list [n, 5] (pr, x0, y0,
+    x1, y1) -> clustered list [m, 5]; see oracle/build_samples.cc"""
+    r = np.ascontiguousarray(ranked, dtype=F32)
+    out = np.zeros((max(output_num, 1), 5), F32)
+    cnt = ctypes.c_int(0)
+    f = oracle_lib().oracle_cluster_ranked
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    f.restype = ctypes.c_int
+    if f(r.ctypes.data, int(r.shape[0]), float(cluster_threshold), int(output_num), out.ctypes.data, ctypes.addressof(cnt)) != 0:
+        raise RuntimeError("oracle_cluster_ranked failed")
+    return out[:cnt.value]
