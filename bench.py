@@ -362,7 +362,10 @@ def main():
                    "bucket_bytes": [4 * (hi - lo) for lo, hi, _ in (dp._buckets or [])],
                    # time the compute stream stood waiting for collectives after its last backward kernel (HIP events
                    # around the wait in DataParallel.finish_step): the part of the exchange the backward pass did not hide
-                   "exposed_collective_ms_per_step_per_rank": [round(v, 3) for v in exposed]}
+                   "exposed_collective_ms_per_step_per_rank": [round(v, 3) for v in exposed],
+                   # rank 0: per bucket, the window between its collective's issue and the end of the backward sweep, and what the
+                   # compute stream still waited for it afterwards
+                   "bucket_overlap": dp.bucket_overlap_table()}
         if share:
             dp_info["launch_path_test_only"] = ("all %d ranks share cuda:0 and gloo carries the tensors through the host: this "
                                                 "line proves the launch / rendezvous / exchange path, it is NOT a scaling "
@@ -587,10 +590,33 @@ def main():
                 "collectives_per_step": sdp.collectives_per_step(), "allreduce_bytes_per_step": sdp.bytes_per_step(),
                 "bucket_bytes": [4 * (hi - lo) for lo, hi, _ in (sdp._buckets or [])],
                 "exposed_collective_ms_per_step": round(sdp.exposed_ms_per_step(), 3),
+                # per bucket: bytes, how long before the end of the backward sweep the collective was issued (the window a real
+                # exchange has to hide in: at ~100 GB/s per direction a ring moves 2 (N-1)/N x bytes), how long the compute stream
+                # still waited for it after the sweep
+                "bucket_overlap": sdp.bucket_overlap_table(),
                 "ms_per_step": round(1e3 * sdt / nst, 3), "value": round(BATCH_PER_GPU * nst / sdt, 2), "unit": "images/sec",
                 "final_cost": round(float(scost), 5),
                 "note": "single GPU, world size 1, collectives forced on: exercises the RCCL launch path inside the step; the "
                         "exposed time is a self-copy's, not an xGMI exchange - never a scaling measurement"}
+            # the recipe's actual multi-GPU mode (papers/dss/denet34.sh:43 `--batch-size-factor 2`, train_multi.py:104-119): F = 2
+            # full LOCAL steps per rank, then parameters, momentum and BN statistics averaged over the ranks (three all-reduces:
+            # DataParallel.average_state) - no gradient exchange inside the steps
+            sm.dist = None
+            nit = max(1, min(args.steps, 10) // 2)
+            for k in range(1 + nit):
+                if k == 1:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                for _ in range(2):
+                    scost, _ = sm.train_step(xd, metas, 0, sit, lr, mom, decay)
+                    sit += 1
+                sdp.average_state(sm)
+            torch.cuda.synchronize()
+            bdt = time.perf_counter() - t0
+            out["data_parallel_selftest"]["local_sgd_bsf2"] = {
+                "ms_per_iteration_of_2_steps": round(1e3 * bdt / nit, 3), "value": round(2 * BATCH_PER_GPU * nit / bdt, 2),
+                "unit": "images/sec", "allreduce_bytes_per_iteration": int(sum(t.numel() * 4 for t in sdp._state(sm))),
+                "final_cost": round(float(scost), 5)}
             del sm
             sdp.dist.destroy_process_group()
         except Exception as exc:          # an extra leg must never cost the headline line

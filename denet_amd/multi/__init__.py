@@ -52,8 +52,32 @@ class DataParallel:
 
     # ---- instrumentation (bench.py) ----------------------------------------------------------------------
     def start_timing(self):
-        """from now on finish_step brackets its wait for the collectives with two HIP events on the compute stream"""
+        """from now on finish_step brackets its wait for the collectives with two HIP events on the compute stream, and every
+        bucket leaves three events: issued (on the filter-gradient stream, where its collective is queued), the end of the backward
+        sweep, and the point at which the compute stream had waited for it"""
         self._timing = []
+        self._bucket_timing = []           # per step: [(bytes, issued event, sweep-end event, waited-for event)] per bucket
+
+    def bucket_overlap_table(self):
+        """per bucket, averaged over the timed steps: bytes, how long BEFORE the end of the backward sweep its collective was issued
+        (the window the exchange has to hide in), and how long AFTER the end of the sweep the compute stream still waited for it
+        (what the backward pass did not hide). The first real multi-GPU run is read against this table."""
+        if not getattr(self, "_bucket_timing", None):
+            return []
+        import torch
+        torch.cuda.synchronize()
+        n = len(self._bucket_timing)
+        rows = None
+        for step in self._bucket_timing:
+            if rows is None:
+                rows = [{"bytes": b, "issued_before_sweep_end_ms": 0.0, "waited_after_sweep_end_ms": 0.0} for b, _, _, _ in step]
+            for r, (_, e_issue, e_end, e_done) in zip(rows, step):
+                r["issued_before_sweep_end_ms"] += e_issue.elapsed_time(e_end) / n
+                r["waited_after_sweep_end_ms"] += max(0.0, e_end.elapsed_time(e_done)) / n
+        for r in rows or []:
+            r["issued_before_sweep_end_ms"] = round(r["issued_before_sweep_end_ms"], 3)
+            r["waited_after_sweep_end_ms"] = round(r["waited_after_sweep_end_ms"], 3)
+        return rows or []
 
     def exposed_ms_per_step(self):
         """mean time the compute stream stood in finish_step's wait: collective time the backward pass did not hide"""
@@ -137,6 +161,7 @@ class DataParallel:
             for lo, hi, layer in self._buckets:
                 self._trigger[id(layer)] = (lo, hi)
         self._pending = []
+        self._issue_events = []
         self._step_bytes = 0
         self._step_colls = 0
 
@@ -147,6 +172,11 @@ class DataParallel:
             # the bucket holds convolution weight gradients only: they are produced on the wgrad stream, so the
             # collective is ordered behind THAT stream and the data-gradient chain on the compute stream never waits
             with self._wgrad_ctx():
+                if self._timing is not None:
+                    import torch
+                    e_issue = torch.cuda.Event(enable_timing=True)
+                    e_issue.record()               # on the stream the collective is ordered behind
+                    self._issue_events.append(e_issue)
                 if lo == self._buckets[-1][0]:
                     # the sweep has passed the first layer: every gradient of the step is queued. The last collective carries
                     # [this bucket | bias and BN-affine gradients | BN running statistics] as one packed tensor
@@ -192,8 +222,17 @@ class DataParallel:
                 import torch
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
+            done = []
             for w in self._pending:
                 w.wait()
+                if ev is not None:
+                    import torch
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record()                     # the compute stream has waited for this bucket's collective
+                    done.append(e)
+            if ev is not None and len(done) == len(self._issue_events) == len(self._buckets or []):
+                self._bucket_timing.append([(4 * (hi - lo), ei, ev[0], ed)
+                                            for (lo, hi, _), ei, ed in zip(self._buckets, self._issue_events, done)])
             tail = self.__dict__.pop("_tail", None)
             if tail is None:          # a model without bucketed weights: the packed collective is all there is
                 tail = self._pack_tail(model, 0, 0)

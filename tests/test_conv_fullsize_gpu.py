@@ -49,6 +49,20 @@ GEOMS = [
     ("r34_l2", 64, 28, 28, 128, 128, 3, 3, 3, 1, 1),
     ("r34_l3", 64, 14, 14, 256, 256, 3, 3, 3, 1, 1),
     ("r34_l4", 64, 7, 7, 512, 512, 3, 3, 3, 1, 1),
+    # config 5: DeNet-101 wide at 512x512, batch 16 (papers/dss/denet101.sh:13-19): bottleneck 1x1 pairs 64/256, 256/1024, 512/2048
+    # channels, the strided projection into the last stage, the deepest up-sampling convolution (18 432-term sums), the 128x128
+    # corner convolution and the first two head layers at M = 16 x 2304 RoIs
+    ("d101_b1_1x1", 16, 128, 128, 64, 256, 1, 1, 1, 1, 0),
+    ("d101_b1_1x1r", 16, 128, 128, 256, 64, 1, 1, 1, 1, 0),
+    ("d101_l3_1x1", 16, 32, 32, 256, 1024, 1, 1, 1, 1, 0),
+    ("d101_l3_1x1r", 16, 32, 32, 1024, 256, 1, 1, 1, 1, 0),
+    ("d101_l4_1x1", 16, 16, 16, 512, 2048, 1, 1, 1, 1, 0),
+    ("d101_l4_1x1r", 16, 16, 16, 2048, 512, 1, 1, 1, 1, 0),
+    ("d101_l4_1x1s2", 16, 32, 32, 1024, 2048, 1, 1, 1, 2, 0),
+    ("d101_up1_3x3", 16, 32, 32, 2048, 1024, 3, 3, 3, 1, 1),
+    ("d101_dnc_1x1", 16, 128, 128, 256, 160, 1, 1, 1, 1, 0),
+    ("d101_head1", 16, 48, 48, 6304, 2048, 1, 1, 1, 1, 0),
+    ("d101_head2", 16, 48, 48, 2048, 1536, 1, 1, 1, 1, 0),
 ]
 
 RESULTS = {}

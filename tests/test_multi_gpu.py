@@ -226,5 +226,12 @@ def test_bench_self_launches_two_ranks_on_a_shared_gpu():
     # ride in the last bucket's packed collective, none is issued behind the backward sweep
     assert dp["allreduce_bytes_per_step"] > 100e6 and dp["collectives_per_step"] == len(dp["bucket_bytes"]) <= 5, dp
     assert abs(sum(dp["bucket_bytes"]) + 0 - dp["allreduce_bytes_per_step"]) < 0.05 * dp["allreduce_bytes_per_step"]
+    # per bucket: issued from inside the backward sweep (the head's bucket first, with the longest window before the sweep ends; the
+    # last one when the sweep has passed the first layer), and what the compute stream still waited for it after the sweep
+    ov = dp["bucket_overlap"]
+    assert [r["bytes"] for r in ov] == dp["bucket_bytes"], ov
+    win = [r["issued_before_sweep_end_ms"] for r in ov]
+    assert all(a >= b for a, b in zip(win, win[1:])) and win[0] > 5.0 and win[-1] >= 0.0, ov
+    assert all(r["waited_after_sweep_end_ms"] >= 0.0 for r in ov)
     for k in ("roofline", "cpu_baseline", "warm_regime"):          # rank 0 at N = 1 only
         assert k not in d

@@ -719,6 +719,50 @@ def test_full_size_properties(hip):
     assert float(out[:, 49 * F + 2:].abs().max()) == 0.0
 
 
+def test_denet101_wide_full_size_properties(hip):
+    """BASELINE config 5 at full size (DeNet-101 wide, 512x512, B = 16, 2304 RoIs per image, `DND.JB`: joint fitness + bounded-IoU
+    loss; papers/dss/denet101.sh:13-19): two runs of two training steps are finite and bit-identical (no floating-point atomics
+    anywhere on this path either), the RoI proposal on the 128x128 corner map - 2304 of up to 2 x 1024^2 candidates through the
+    two-level final sort - is sorted, idempotent and equal to the oracle's on the same map, the gather is a copy of feature rows
+    at the recorded taps. The per-layer numerics at these shapes: tests/test_conv_fullsize_gpu.py (d101_*)."""
+    B = 16
+    x, metas = zoo.synthetic_batch(B, 512, seed=1)
+    xd = torch.from_numpy(x).cuda()
+    desc = zoo.DENET101_WIDE_DESC.replace("DND[0.5,1,1]", "DND.JB[0.5,1,1]")
+    results = []
+    for run in range(2):
+        model = zoo.denet101(B, "wide", 512, 80, seed=1, head_desc=desc)
+        _warm_corner_head(model, 7.5, 0.3)
+        model.build_train_func("nesterov")
+        random.seed(1)
+        c0 = model.train_step(xd, metas, 0, 0, 0.1, [0.9], 1e-4)
+        c1 = model.train_step(xd, metas, 0, 1, 0.1, [0.9], 1e-4)
+        results.append((c0, c1, model.P.clone()))
+        assert np.isfinite(c0[0]) and np.isfinite(c1[0])
+    assert results[0][0] == results[1][0] and results[0][1] == results[1][1]
+    assert torch.equal(results[0][2], results[1][2])
+    by_type = lambda t: [l for l in model.layers if l.type_name == t][0]
+    cl, dns = by_type("denet-corner"), by_type("denet-sparse")
+    assert dns.sample_count == 2304 and cl.corner_pr.shape[-1] == 128
+    pr = cl.corner_pr
+    b1 = ops.build_samples(pr, 0.01, 2304, 1024, 0)
+    b2 = ops.build_samples(pr, 0.01, 2304, 1024, 0)
+    assert all(torch.equal(a, b) for a, b in zip(b1, b2))
+    cnt, absd = b1[2].cpu().numpy(), b1[1].cpu().numpy()
+    assert cnt.sum() > 0
+    for b in range(B):
+        assert np.all(np.diff(absd[b, :cnt[b]]) >= 0)
+    check_samples(pr.cpu().numpy(), 0.01, 48, 1024, 0)
+    fmap, coff, F = cl.sample_map()
+    out = dns.output.data.view(B * 2304, -1)
+    taps = dns._taps.long()
+    rows = torch.arange(B * 2304, device="cuda") // 2304
+    for t in (0, 24, 48):
+        src = fmap.view(B, -1, fmap.shape[-1])[rows, taps[:, t], coff:coff + F]
+        assert torch.equal(out[:, t * F:(t + 1) * F], src)
+    assert float(out[:, 49 * F + 2:].abs().max()) == 0.0
+
+
 def _generic_step_check(desc, data_shape, B, solver="nesterov", steps=2, convert=False, class_num=10, seed=11):
     from denet_amd.model import model_cnn, modify
     np.random.seed(seed)
