@@ -741,6 +741,13 @@ def test_denet101_wide_full_size_properties(hip):
         assert np.isfinite(c0[0]) and np.isfinite(c1[0])
     assert results[0][0] == results[1][0] and results[0][1] == results[1][1]
     assert torch.equal(results[0][2], results[1][2])
+    # the proposal / gather properties on the map of a FIRST step (two steps at lr 0.1 train this corner head silent again)
+    del model
+    model = zoo.denet101(B, "wide", 512, 80, seed=1, head_desc=desc)
+    _warm_corner_head(model, 4.0, 0.3)
+    model.build_train_func("nesterov")
+    random.seed(1)
+    model.train_step(xd, metas, 0, 0, 0.1, [0.9], 1e-4)
     by_type = lambda t: [l for l in model.layers if l.type_name == t][0]
     cl, dns = by_type("denet-corner"), by_type("denet-sparse")
     assert dns.sample_count == 2304 and cl.corner_pr.shape[-1] == 128
@@ -1363,7 +1370,15 @@ def test_roi_clustering_device_path_vs_oracle(hip, sn_model):
     from tests.test_host import _distinct_corner_map
     sn = 6 if sn_model == 24 else 48
     S = sn * sn
-    pr = _distinct_corner_map(11, 4, 64, 64, 90) if sn_model == 24 else _lattice_corner_map(11, 2, 128, 128, 420, 420)
+    if sn_model == 24:
+        # random continuous maps: ~2 000 candidates per image, an exact fp32 tie among the 360 best is rare - the first seed without
+        for seed in range(11, 40):
+            pr = _distinct_corner_map(seed, 4, 64, 64, 90)
+            top, _, _, tc = OM.oracle_build_samples_raw(pr, 0.01, 19, 1024, 0)
+            if all(tc[b] >= 10 * S and len(np.unique(top[b, :10 * S, 0])) == 10 * S for b in range(4)):
+                break
+    else:
+        pr = _lattice_corner_map(11, 2, 128, 128, 420, 420)
     Hm = pr.shape[3]
     d = torch.from_numpy(pr).cuda()
     box, absd, cnt = ops.build_samples(d, 0.01, 10 * S, 1024, 0)
@@ -1457,13 +1472,13 @@ def test_denet101_wide_train_step_vs_oracle(hip, IMG):
     _warm_corner_head(model, 4.0, 0.3)
     x, metas = zoo.synthetic_batch(B, IMG, seed=3)
     om = OM.OracleModel(model.export_json(), B)
+    om_free = OM.OracleModel(model.export_json(), B) if IMG == 512 else None      # (the weights BEFORE the step)
     model.build_train_func("nesterov")
     random.seed(9)
     cost, costs = model.train_step(x, metas, 0, 0, 0.05, [0.9], 1e-4)
     roi_lists = dns.sample_bbox_list
     assert len(roi_lists[0]) == 2304
     if IMG == 512:
-        om_free = OM.OracleModel(model.export_json(), B)
         random.seed(9)
         fcost, fcosts = om_free.train_step(x, metas, 0, 0.05, 0.9, 1e-4, "nesterov", sample_override=roi_lists)
         assert abs(cost - fcost) <= 1e-3 * abs(fcost), (cost, fcost)
