@@ -58,7 +58,7 @@ def build(force=False, verbose=False):
         hipcc = "hipcc"
     version = _hipcc_version(hipcc)
     objs, todo = [], []
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "denet_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "bn_final.h"), os.path.join(HERE, "..", "include", "denet_hip.h")]
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))

@@ -17,6 +17,7 @@
 //                 reduction order is a fixed permutation of k (legal: the sum is over the same terms).
 // Launch:         1-D grid over tiles with an XCD-aware remap (8 XCDs, private L2 each).
 #include "common.h"
+#include "bn_final.h"
 #include "../../include/denet_hip.h"
 #include <map>
 #include <vector>
@@ -67,6 +68,7 @@ struct IgemmParams {
     long batch_act, batch_wgt, batch_out;  // fwd / wgrad: element strides of blockIdx.y (batched GEMMs of the Winograd path)
     int batch;          // wgrad: number of batch members (grid.y), 0 = 1
     unsigned act_bytes, wgt_bytes;  // extents of `act` / `wgt` (buffer descriptors: out-of-range lanes read 0)
+    BnFinalDev fin;     // with stats: the last row tile of a column tile to arrive reduces the rows itself (bn_final.h); null: off
 };
 
 // Guarded operand loads are BRANCH-FREE: a lane whose tap falls into the zero padding (or beyond the tensor) gets
@@ -732,9 +734,13 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
             }
             // one row per (parity class, row tile): every pixel of dx is in exactly one
             double* ps = p.stats + ((MODE == MODE_DGRAD ? (long)blockIdx.y * p.tiles_m : 0L) + tile_m) * 2 * p.NC;
-            ps[n0 + tid] = a;
-            ps[p.NC + n0 + tid] = b;
+            bnf_store(ps + n0 + tid, a);
+            bnf_store(ps + p.NC + n0 + tid, b);
         }
+        // the last row tile (and parity class) of this column tile to arrive finishes the batch norm's reduction (bn_final.h)
+        const int rows_all = p.tiles_m * (MODE == MODE_DGRAD ? (int)gridDim.y : 1);
+        bnf_tail<256>(p.fin, p.stats, rows_all, n0, (p.NC - n0 < BN) ? p.NC - n0 : BN, tile_n, (unsigned)rows_all,
+                      (int*)(redd + WM * 2 * BN));
         return;
     }
 #pragma unroll
@@ -863,6 +869,16 @@ int launch_igemm(const IgemmParams& p, int splits, hipStream_t stream) {
 // 3 with the single buffer); a grid that needs a partial extra round wastes up to a whole round. The launchers
 // price each candidate (tile, buffering) by rounds x tile area / relative tile efficiency and take the cheapest.
 // DENET_IGEMM_NBUF=1|2 forces the buffering (experiments).
+// the batch norm whose sums this launch writes, if the caller armed it (bn_final.h): the last row tile of a column tile then reads
+// rows x bn columns x 16 bytes - taken over only while that stays below 1 MB (the head: 144 rows; a 64x64 map at batch 32 leaves
+// 1024 rows, which the separate kernel's C / 2 workgroups reduce faster than one workgroup could)
+void take_final(IgemmParams& p, int bn, int classes) {
+    if (!p.stats) return;
+    const long rows = (long)p.tiles_m * classes;
+    if (rows * bn * 16 > (1L << 20)) return;
+    p.fin = denet_bn_final_take(p.bs_x ? 2 : 1, p.NC, p.tiles_n);
+}
+
 int forced_nbuf() {
     static int forced = -1;
     if (forced < 0) {
@@ -1432,9 +1448,11 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
         p.tiles_m = (int)tm;
         if (tile == 0) {
             p.tiles_n = ceil_div(K, 128);
+            take_final(p, 128, 1);
             return LAUNCH_NBUF(MODE_FWD, 128, 128, c.nbuf, p, 1, stream);
         }
         p.tiles_n = ceil_div(K, 64);
+        take_final(p, 64, 1);
         return LAUNCH_NBUF(MODE_FWD, 128, 64, c.nbuf, p, 1, stream);
     }
 }
@@ -1528,9 +1546,11 @@ static int conv_dgrad_impl(const float* dy, const float* w, const float* add, fl
         p.tiles_m = (int)tm;
         if (tile == 0) {
             p.tiles_n = ceil_div(C, 128);
+            take_final(p, 128, classes);
             return LAUNCH_NBUF(MODE_DGRAD, 128, 128, c.nbuf, p, classes, stream);
         }
         p.tiles_n = ceil_div(C, 64);
+        take_final(p, 64, classes);
         return LAUNCH_NBUF(MODE_DGRAD, 128, 64, c.nbuf, p, classes, stream);
     }
 }

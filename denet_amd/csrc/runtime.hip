@@ -2,6 +2,7 @@
 // PyErr_Format + %(fail)s (denet_sparse_op.py:137-142); here every entry point returns an int status and
 // leaves a thread-local message behind.
 #include "common.h"
+#include <stdlib.h>
 #include <stdarg.h>
 #include <math.h>
 #include <string.h>
@@ -14,6 +15,46 @@ void denet_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- the batch norm whose reductions the next producing pass finishes itself (bn_final.h) ------------------------------------------
+#include "bn_final.h"
+static thread_local BnFinalDev t_bnf = {};
+static thread_local int t_bnf_groups = 0;       // counters the armed buffer holds
+static thread_local int t_bnf_state = 0;        // 0 nothing armed, 1 armed, 2 taken by a pass
+
+static int bnf_arm(int kind, long M, int C, float momentum, float eps, float* o0, float* o1, float* o2, float* o3, unsigned* counters,
+                   int ncounters) {
+    DENET_CHECK_ARG(M > 0 && C > 0 && o0 && o1 && counters && ncounters > 0, "bn_final_arm: bad arguments");
+    t_bnf.counter = counters; t_bnf.kind = kind; t_bnf.C = C; t_bnf.M = M; t_bnf.eps = eps; t_bnf.momentum = momentum;
+    t_bnf.o0 = o0; t_bnf.o1 = o1; t_bnf.o2 = o2; t_bnf.o3 = o3;
+    t_bnf_groups = ncounters;
+    t_bnf_state = 1;
+    return DENET_OK;
+}
+
+extern "C" int denet_bn_final_arm_stats(long M, int C, float momentum, float eps, float* run_mean, float* run_stdinv, float* save_mean,
+                                        float* save_invstd, unsigned* counters, int ncounters) {
+    return bnf_arm(1, M, C, momentum, eps, save_mean, save_invstd, run_mean, run_stdinv, counters, ncounters);
+}
+
+extern "C" int denet_bn_final_arm_sums(long M, int C, float* dgamma, float* dbeta, float* coef, unsigned* counters, int ncounters) {
+    DENET_CHECK_ARG(coef, "bn_final_arm_sums: null pointer");
+    return bnf_arm(2, M, C, 0.f, 0.f, dgamma, dbeta, coef, nullptr, counters, ncounters);
+}
+
+extern "C" int denet_bn_final_disarm(void) {
+    const int taken = t_bnf_state == 2 ? 1 : 0;
+    t_bnf_state = 0;
+    t_bnf = BnFinalDev{};
+    return taken;
+}
+
+BnFinalDev denet_bn_final_take(int kind, int C, int groups) {
+    static const int env_on = [] { const char* e = getenv("DENET_BN_FINAL_FOLD"); return e ? atoi(e) : 1; }();
+    if (!env_on || t_bnf_state != 1 || t_bnf.kind != kind || t_bnf.C != C || groups <= 0 || groups > t_bnf_groups) return BnFinalDev{};
+    t_bnf_state = 2;
+    return t_bnf;
 }
 
 extern "C" const char* denet_last_error(void) { return g_err; }

@@ -10,6 +10,7 @@
 // is multiplied): wino2f_ws_kernel (forward / data gradient) and wino2f_wgrad_kernel (filter gradient) + its two reducers.
 // Exact fp32 FMA chains; the association differs from the direct kernel (F(2x2): ~1e-6 relative).
 #include "common.h"
+#include "bn_final.h"
 #include "../../include/denet_hip.h"
 
 namespace {
@@ -40,6 +41,7 @@ struct W2Params {
     int items;           // N * by * bx * nco work items: (block, 64 output channels)
     int relu;            // y = max(y, 0) (the inference fold of a ReLU layer)
     unsigned x_bytes, y_bytes;
+    BnFinalDev fin;      // Co = 64 with stats: the last workgroup reduces the rows itself (bn_final.h); counter null: off
 };
 
 constexpr int CI = 64;
@@ -170,8 +172,7 @@ __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
     f32x4 d[2][3];
     load_d(0, 0, d);
     f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
-    if (p.stats && p.nco == 1 && tid < 64)
-        for (int c = tid; c < 2 * p.Co; c += 64) p.stats[(long)blockIdx.x * 2 * p.Co + c] = 0.0;
+    double row_a = 0.0, row_b = 0.0;      // Co = 64: the workgroup's row of column sums (lane tid < 64 owns channel tid), stored at the end
     while (true) {
         const int next = item + gridDim.x;
         const bool has_next = next < p.items;
@@ -347,10 +348,9 @@ __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
                     bq += red[(w * 2 + 1) * 64 + tid];
                 }
                 if (p.nco == 1) {
-                    // one row per WORKGROUP (zeroed before the first item): lane tid owns its channel's two sums
-                    double* ps = p.stats + (long)blockIdx.x * 2 * p.Co;
-                    ps[tid] += a;
-                    ps[p.Co + tid] += bq;
+                    // one row per WORKGROUP: lane tid owns its channel's two sums over all items (blocks added in item order)
+                    row_a += a;
+                    row_b += bq;
                 } else {
                     // several output-channel chunks per block: one row per block, each item writes its chunk of it
                     double* ps = p.stats + (long)cur.block * 2 * p.Co;
@@ -367,6 +367,15 @@ __device__ __forceinline__ void w2s_run(const W2Params& p, char* smem) {
         cur = nxt;
     }
     __builtin_amdgcn_s_waitcnt(0);
+    if (p.stats && p.nco == 1) {
+        if (tid < 64) {
+            double* ps = p.stats + (long)blockIdx.x * 2 * p.Co;
+            bnf_store(ps + tid, row_a);
+            bnf_store(ps + p.Co + tid, row_b);
+        }
+        // the last workgroup to arrive finishes the batch norm's reduction over the rows of all workgroups (bn_final.h)
+        bnf_tail<512>(p.fin, p.stats, (int)gridDim.x, 0, 64, 0, gridDim.x, (int*)red);
+    }
 }
 
 template <bool PF>
@@ -707,6 +716,7 @@ extern "C" int denet_conv_wino2f_sums(const float* x, const float* u, const floa
         DENET_CHECK_ARG(stats_rows && stats_bytes >= (size_t)rows * 2 * Co * sizeof(double), "conv_wino2f: statistics buffer too small");
         *stats_rows = (int)rows;
         p.stats = stats_partial;
+        if (p.nco == 1) p.fin = denet_bn_final_take(sums_of ? 2 : 1, Co, 1);     // (armed by the caller: bn_final.h)
         if (sums_of) {
             DENET_CHECK_ARG(sums_of->x && sums_of->mean && sums_of->invstd && (!sums_of->relu || sums_of->y || (sums_of->gamma && sums_of->beta)),
                             "conv_wino2f: incomplete batch-norm description for the backward sums");

@@ -19,6 +19,7 @@
 // Association: Y is accumulated component by component instead of A^T (M A) column by column: same sums, other rounding
 // (measured against fp64 in tests/test_conv_fullsize_gpu.py like every other pass).
 #include "common.h"
+#include "bn_final.h"
 #include "../../include/denet_hip.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -63,6 +64,8 @@ struct W4Params {
     int chunks;          // C / 64
     unsigned v_bytes, u_bytes, y_bytes;
     unsigned long long* dbg;   // -DW4_TRACE builds: s_memtime stamps of workgroup 0 (tools/exp/w4_trace.py)
+    BnFinalDev fin;      // with stats: the last workgroup of a channel block reduces the rows itself (bn_final.h); counter null: off
+    int tiles_t;         // tile blocks = rows of `stats` = workgroups per channel block
 };
 
 constexpr int W4_OOB = (int)0xF0000000u;
@@ -436,8 +439,10 @@ __device__ __forceinline__ void wino4f_body(const W4Params& p) {
         double a = 0.0;
 #pragma unroll
         for (int w = 0; w < TB / 16; ++w) a += red[(w * 2 + which) * KB + ch];
-        if (k0 + ch < p.K) p.stats[((long)tblk * 2 + which) * p.K + k0 + ch] = a;
+        if (k0 + ch < p.K) bnf_store(p.stats + ((long)tblk * 2 + which) * p.K + k0 + ch, a);
     }
+    // the last tile block of this channel block to arrive finishes the batch norm's reduction over all rows (bn_final.h)
+    bnf_tail<NW * 64>(p.fin, p.stats, p.tiles_t, k0, KB, kblk, (unsigned)p.tiles_t, (int*)(smem + 16384));
 }
 
 // 8 waves, up to 256 registers each (two waves per SIMD), one workgroup per CU ...
@@ -536,6 +541,10 @@ int denet_wino4f_run(int tb, const float* V, const float* U, const float* bias, 
     const int tiles_t = (int)((T + tiles - 1) / tiles);
     const int lds = which == 2 ? 3 * (32 * 256 + 16384) : (which == 3 ? 3 * (32 * 256 + 32 * 256) : 4 * 32768);
     const int ep = !stats ? 0 : (bs_x ? 2 : 1);
+    p.tiles_t = tiles_t;
+    // the batch norm these sums belong to, if the caller armed it (one counter per channel block; a last workgroup reads
+    // tiles_t rows of its 32 / 64 columns: a few hundred KB at most)
+    if (ep && (long)tiles_t * kbw * 16 <= (1L << 20)) p.fin = denet_bn_final_take(ep, K, p.tiles_k);
     typedef void (*kern_t)(const W4Params);
     static const kern_t kerns[4][3] = {{wino4f_kernel_32<0>, wino4f_kernel_32<1>, wino4f_kernel_32<2>},
                                        {wino4f_kernel_64<0>, wino4f_kernel_64<1>, wino4f_kernel_64<2>},

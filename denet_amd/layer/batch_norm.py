@@ -33,6 +33,7 @@ class BatchNormLayer(AbstractLayer):
             self.stdinv = Param(numpy.ones((c,)), "bn std inv")
             self.output = Act(self.output_shape, self.input.cp, "bn%i" % self.layer_index)
             self.input.want_stats = True      # a convolution writing this tensor also emits its per-channel sums
+            self.input.stats_bn = self        # ... and may finish this layer's statistics in its own launch (ops.BnFinal)
         else:
             self.output = self.input
         self._save = None
@@ -79,6 +80,18 @@ class BatchNormLayer(AbstractLayer):
             self.stdinv.set_value(numpy.asarray(json_param["std"], dtype=numpy.float32))
 
     # ---- execution ----
+    def stats_final(self, act):
+        """for the convolution pass that writes `act` (this layer's input) in a training step: the description of this layer's
+        statistics, so that the pass can finish them in its own launch (ops.BnFinal; the running statistics are updated there)"""
+        if not (self.enabled and ops.FINAL_FOLD and act is self.input):
+            return None
+        n, c = act.shape[0], act.cp
+        m = 1
+        for d in act.shape[2:]:
+            m *= d
+        return ops.BnFinal(1, n * m, c, self.__dict__.setdefault("_bnf_holder_fwd", {}), momentum=self.momentum, eps=self.eps,
+                           run_mean=self.mean.dev, run_stdinv=self.stdinv.dev)
+
     def forward(self, ctx, res=None, relu=None, out_act=None):
         """res / relu / out_act let ResnetLayer fuse the residual add + ReLU into the normalisation pass"""
         if not self.enabled:
@@ -146,7 +159,13 @@ class BatchNormLayer(AbstractLayer):
         sm, si, relu, out_act, has_res = self._save
         if out_act is not act:
             return None
-        return ops.BnSums(self.input.data, out_act.data if (relu and has_res) else None, self.omega.dev, self.beta.dev, sm, si, relu)
+        # the data-gradient pass may also FINISH the two reductions (dgamma, dbeta, their means) in its own launch (ops.BnFinal)
+        x = self.input.data
+        fin = None
+        if ops.FINAL_FOLD and self.omega.grad is not None and self.beta.grad is not None:
+            fin = ops.BnFinal(2, x.numel() // x.shape[-1], x.shape[-1], self.__dict__.setdefault("_bnf_holder", {}),
+                              dgamma=self.omega.grad, dbeta=self.beta.grad)
+        return ops.BnSums(x, out_act.data if (relu and has_res) else None, self.omega.dev, self.beta.dev, sm, si, relu, final=fin)
 
     def backward(self, ctx, want_dres=False):
         if not self.enabled:

@@ -157,6 +157,7 @@ class ConvLayer(AbstractLayer):
         cache["train"] = bool(get_train()) and self.enabled and self.omega.grad is not None
         # a batch norm directly behind this layer (it flags its input Act) gets its statistics from this pass's epilogue
         want_stats = bool(get_train()) and getattr(self.output, "want_stats", False)
+        cache["bn_final"] = None
         self._planar_x = None
         if isinstance(link, ops.NchwLink):
             # the network input, still in the reference's planar layout: the first layer's kernels read it as it is (forward and,
@@ -178,6 +179,8 @@ class ConvLayer(AbstractLayer):
             # the SKIP layer behind adds its tap to this layer's output: here, in the epilogue (ModelCNN.build_train_func links the
             # two); the sum is the SKIP layer's output, and what a batch norm behind THAT wants to know about it is measured here
             want_skip_stats = getattr(skip.output, "want_stats", False)
+            sbn = getattr(skip.output, "stats_bn", None) if want_skip_stats else None
+            cache["bn_final"] = sbn.stats_final(skip.output) if sbn is not None else None
             y = ops.conv_fwd(x, self._w(), bias=None, add=skip.y.data, stride=self.stride[0], pad=self.pad,
                              s_real=self.filter_shape[3], logical=self._logical(), cache=cache, bn_stats=want_skip_stats, link=link,
                              up=up)
@@ -190,6 +193,8 @@ class ConvLayer(AbstractLayer):
             skip.output.stats = cache.pop("bn_stats", None) if want_skip_stats else None
             skip._fused_in = ctx
             return
+        sbn = getattr(self.output, "stats_bn", None) if (want_stats and ctx is not None) else None
+        cache["bn_final"] = sbn.stats_final(self.output) if sbn is not None else None
         self.output.data = ops.conv_fwd(x, self._w(), bias=self.beta.dev if self.use_bias else None, add=add,
                                         stride=self.stride[0], pad=self.pad, s_real=self.filter_shape[3],
                                         logical=self._logical(), cache=cache, bn_stats=want_stats, link=link, up=up)

@@ -71,6 +71,9 @@ SIGNATURES = {
     "denet_conv_profile_count": (I, []),
     "denet_conv_profile_read": (I, [I] + [P] * 5),
     "denet_conv_wgrad": (I, [P, P, P, P, Z] + [I] * 12 + [P]),
+    "denet_bn_final_arm_stats": (I, [L, I, F, F, P, P, P, P, P, I]),
+    "denet_bn_final_arm_sums": (I, [L, I, P, P, P, P, I]),
+    "denet_bn_final_disarm": (I, []),
     "denet_bn_workspace_bytes": (Z, [L, I]),
     "denet_bn_fwd_train": (I, [P] * 10 + [L, I, F, F, I, P]),
     "denet_bn_fwd_train_pre": (I, [P] * 10 + [I, L, I, F, F, I, P]),

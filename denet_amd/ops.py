@@ -337,6 +337,72 @@ def _tune_first(mode, g, a, b, bias, add, out, ws):
 HEAD_BF16X3 = os.environ.get("DENET_HEAD_BF16X3", "0") == "1"
 
 
+# The second stage of a batch norm's reductions inside the launch that writes the partial sums (csrc/bn_final.h, denet_bn_final_arm_*):
+# the last workgroup of the producing convolution pass reduces the rows, and the 84 bn_stats_final / bn_bwd_final launches of a
+# DeNet-34 step - 5 us of work each, but 25-37 us on the backward sweep's critical chain, where such a launch waits for a CU slot
+# beside the other stream's matrix kernels - leave the streams. Bit-identical to the separate launches. DENET_BN_FINAL_FOLD=0: off.
+FINAL_FOLD = os.environ.get("DENET_BN_FINAL_FOLD", "1") != "0"
+FINAL_COUNT = [0, 0]        # forward statistics / backward sums finished by their producers (tests, bench)
+
+
+class BnFinal:
+    """the batch norm whose reduction the next producing pass may finish itself. kind 1 (forward statistics): run_mean / run_stdinv
+    are updated, save_mean / save_invstd come back; kind 2 (backward sums): dgamma / dbeta are written, coef [2][C] comes back.
+    holder: a dict that keeps the counters alive (one producing pass at a time uses them). arm() right before the producing call,
+    disarm() right after: self.taken says whether the pass took the final over."""
+
+    def __init__(self, kind, M, C, holder, momentum=0.0, eps=0.0, run_mean=None, run_stdinv=None, dgamma=None, dbeta=None):
+        self.kind, self.M, self.C = int(kind), int(M), int(C)
+        self.momentum, self.eps, self.run_mean, self.run_stdinv = float(momentum), float(eps), run_mean, run_stdinv
+        self.dgamma, self.dbeta = dgamma, dbeta
+        self.holder = holder
+        self.taken = False
+        self.save_mean = self.save_invstd = self.coef = None
+
+    def arm(self):
+        cnt = self.holder.get("bnf_counters")
+        if cnt is None:
+            cnt = self.holder["bnf_counters"] = torch.zeros(64, dtype=torch.int32, device="cuda")
+        if self.kind == 1:
+            self.save_mean, self.save_invstd = empty(self.C), empty(self.C)
+            check(_L().denet_bn_final_arm_stats(self.M, self.C, self.momentum, self.eps, ptr(self.run_mean), ptr(self.run_stdinv),
+                                                ptr(self.save_mean), ptr(self.save_invstd), ptr(cnt), 64), "bn_final_arm_stats")
+        else:
+            self.coef = empty(2 * self.C)
+            check(_L().denet_bn_final_arm_sums(self.M, self.C, ptr(self.dgamma), ptr(self.dbeta), ptr(self.coef), ptr(cnt), 64),
+                  "bn_final_arm_sums")
+
+    def disarm(self):
+        self.taken = bool(_L().denet_bn_final_disarm())
+        if self.taken:
+            FINAL_COUNT[self.kind - 1] += 1
+        return self.taken
+
+
+class _armed:
+    """with _armed(fin): <one producing C call>   (fin None or the fold switched off: nothing happens)"""
+
+    def __init__(self, fin):
+        self.fin = fin if (fin is not None and FINAL_FOLD) else None
+
+    def __enter__(self):
+        if self.fin is not None:
+            self.fin.arm()
+        return self.fin
+
+    def __exit__(self, *a):
+        if self.fin is not None:
+            self.fin.disarm()
+        return False
+
+
+def _stats_result(st, rows, fin):
+    """what a producing forward pass leaves in cache["bn_stats"]: (partial sums, rows[, the BnFinal it finished])"""
+    if rows <= 0:
+        return None
+    return (st, rows, fin) if (fin is not None and fin.taken) else (st, rows)
+
+
 def _conv_wino_fwd_linked(link, g, tile, w, bias, add, out, cache, bn_stats):
     """conv_fwd's Winograd branch with the input transform that evaluates the batch norm in front (denet_conv_wino_fwd_fold)"""
     import ctypes
@@ -363,11 +429,12 @@ def _conv_wino_fwd_linked(link, g, tile, w, bias, add, out, cache, bn_stats):
         cache["V_tile"] = tile
     ws = _wino_ws(tile, N, H, W, C, K)
     bn = link.c_struct(act)
-    check(_L().denet_conv_wino_fwd_fold(ctypes.byref(bn), ptr(w), ptr(u), ptr(v_keep), ptr(bias), ptr(add), ptr(y), 0, ptr(st),
-                                        st.numel() * 8 if st is not None else 0, ctypes.byref(rows), ptr(ws), ws.numel(), tile,
-                                        N, H, W, C, K, stream_ptr()), "conv_wino_fwd_fold")
+    with _armed(cache.get("bn_final") if st is not None else None) as fin:
+        check(_L().denet_conv_wino_fwd_fold(ctypes.byref(bn), ptr(w), ptr(u), ptr(v_keep), ptr(bias), ptr(add), ptr(y), 0, ptr(st),
+                                            st.numel() * 8 if st is not None else 0, ctypes.byref(rows), ptr(ws), ws.numel(), tile,
+                                            N, H, W, C, K, stream_ptr()), "conv_wino_fwd_fold")
     if st is not None:
-        cache["bn_stats"] = (st, rows.value) if rows.value > 0 else None
+        cache["bn_stats"] = _stats_result(st, rows.value, fin)
     link.result = act
     LINK_COUNT[0] += 1
     return y
@@ -407,12 +474,13 @@ def conv_backward_linked(link, x, w, w_shape, add, dw_out, cache, stride=1, pad=
     rows = ctypes.c_int(0)
     sb = sums.buffer(cache, (T * (C // 4) + 255) // 256, C) if sums is not None else None
     so = sums.c_struct() if sums is not None else None
-    check(_L().denet_conv_wino_dgrad_fold(ctypes.byref(bn), ptr(dm), ptr(w), ptr(u), ptr(add), ptr(dx),
-                                          ctypes.byref(so) if so is not None else None, ptr(sb), sb.numel() * 8 if sb is not None else 0,
-                                          ctypes.byref(rows), ptr(ws), ws.numel(), tile, N, H, W, C, K, ev.cuda_event, stream_ptr()),
-          "conv_wino_dgrad_fold")
+    with _armed(sums.final if sums is not None else None) as fin:
+        check(_L().denet_conv_wino_dgrad_fold(ctypes.byref(bn), ptr(dm), ptr(w), ptr(u), ptr(add), ptr(dx),
+                                              ctypes.byref(so) if so is not None else None, ptr(sb), sb.numel() * 8 if sb is not None else 0,
+                                              ctypes.byref(rows), ptr(ws), ws.numel(), tile, N, H, W, C, K, ev.cuda_event, stream_ptr()),
+              "conv_wino_dgrad_fold")
     if sums is not None:
-        sums.done(sb, rows.value)
+        sums.done(sb, rows.value, fin)
     v = None
     if cache is not None and cache.get("V_tile") == tile:
         v = cache.get("V")
@@ -509,9 +577,10 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
         if final and st is not None:
             import ctypes
             rows = ctypes.c_int(0)
-            check(_L().denet_conv_fwd_stats(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), ptr(st), st.numel() * 8,
-                                            ctypes.byref(rows), *g, stream_ptr()), "conv_fwd_stats")
-            cache["bn_stats"] = (st, rows.value)
+            with _armed(cache.get("bn_final")) as fin:
+                check(_L().denet_conv_fwd_stats(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), ptr(st), st.numel() * 8,
+                                                ctypes.byref(rows), *g, stream_ptr()), "conv_fwd_stats")
+            cache["bn_stats"] = _stats_result(st, rows.value, fin)
             return
         check(_L().denet_conv_fwd_act(ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), int(relu), *g, stream_ptr()), "conv_fwd")
 
@@ -800,10 +869,11 @@ def conv_wino_fwd(x, w, bias=None, add=None, out=None, tile=2, u=None, v_keep=No
             u = conv_wino_filter(w, 2, dgrad=False)
         st, cache = stats if stats is not None and not relu else (None, None)
         rows = ctypes.c_int(0)
-        check(_L().denet_conv_wino2f(ptr(x), ptr(u), ptr(bias), ptr(add), ptr(y), int(relu), ptr(st), st.numel() * 8 if st is not None
-                                     else 0, ctypes.byref(rows), N, H, W, C, K, stream_ptr()), "conv_wino2f")
+        with _armed(cache.get("bn_final") if st is not None else None) as fin:
+            check(_L().denet_conv_wino2f(ptr(x), ptr(u), ptr(bias), ptr(add), ptr(y), int(relu), ptr(st), st.numel() * 8 if st is not None
+                                         else 0, ctypes.byref(rows), N, H, W, C, K, stream_ptr()), "conv_wino2f")
         if st is not None:
-            cache["bn_stats"] = (st, rows.value)
+            cache["bn_stats"] = _stats_result(st, rows.value, fin)
         return y
     ws = _wino_ws(tile, N, H, W, C, K)
     if stats is not None and not relu:
@@ -811,9 +881,10 @@ def conv_wino_fwd(x, w, bias=None, add=None, out=None, tile=2, u=None, v_keep=No
         st, cache = stats
         rows = ctypes.c_int(0)
         fn = _L().denet_conv_wino_fwd_stats_up if up is not None else _L().denet_conv_wino_fwd_stats
-        check(fn(ptr(up.src if up is not None else x), ptr(w), ptr(u), ptr(v_keep), ptr(bias), ptr(add), ptr(y), ptr(st),
-                 st.numel() * 8, ctypes.byref(rows), ptr(ws), ws.numel(), tile, N, H, W, C, K, stream_ptr()), "conv_wino_fwd_stats")
-        cache["bn_stats"] = (st, rows.value) if rows.value > 0 else None
+        with _armed(cache.get("bn_final")) as fin:
+            check(fn(ptr(up.src if up is not None else x), ptr(w), ptr(u), ptr(v_keep), ptr(bias), ptr(add), ptr(y), ptr(st),
+                     st.numel() * 8, ctypes.byref(rows), ptr(ws), ws.numel(), tile, N, H, W, C, K, stream_ptr()), "conv_wino_fwd_stats")
+        cache["bn_stats"] = _stats_result(st, rows.value, fin)
         return y
     assert up is None, "an up-sampled input is only read by the statistics form"
     check(_L().denet_conv_wino_fwd_act(ptr(x), ptr(w), ptr(u), ptr(v_keep), ptr(bias), ptr(add), ptr(y), int(relu), ptr(ws),
@@ -833,20 +904,22 @@ def conv_wino_dgrad(dy, w, add=None, out=None, tile=2, u=None, sums=None, cache=
         if u is None:
             u = conv_wino_filter(w, 2, dgrad=True)
         sb = sums.buffer(cache, N * ((H + 15) // 16) * ((W + 15) // 16), C) if sums is not None else None
-        check(_L().denet_conv_wino2f_sums(ptr(dy), ptr(u), None, ptr(add), ptr(dx), 0, ptr(sb), sb.numel() * 8 if sb is not None else 0,
-                                          ctypes.byref(rows), ctypes.byref(so) if so is not None else None, N, H, W, K, C,
-                                          stream_ptr()), "conv_wino2f")
+        with _armed(sums.final if sums is not None else None) as fin:
+            check(_L().denet_conv_wino2f_sums(ptr(dy), ptr(u), None, ptr(add), ptr(dx), 0, ptr(sb), sb.numel() * 8 if sb is not None else 0,
+                                              ctypes.byref(rows), ctypes.byref(so) if so is not None else None, N, H, W, K, C,
+                                              stream_ptr()), "conv_wino2f")
         if sums is not None:
-            sums.done(sb, rows.value)
+            sums.done(sb, rows.value, fin)
         return dx
     ws = _wino_ws(tile, N, H, W, C, K)
     if sums is not None:
         T = N * (H // tile) * (W // tile)
         sb = sums.buffer(cache, (T * (C // 4) + 255) // 256, C)
-        check(_L().denet_conv_wino_dgrad_sums(ptr(dy), ptr(w), ptr(u), ptr(add), ptr(dx), ctypes.byref(so), ptr(sb), sb.numel() * 8,
-                                              ctypes.byref(rows), ptr(ws), ws.numel(), tile, N, H, W, C, K, stream_ptr()),
-              "conv_wino_dgrad_sums")
-        sums.done(sb, rows.value)
+        with _armed(sums.final) as fin:
+            check(_L().denet_conv_wino_dgrad_sums(ptr(dy), ptr(w), ptr(u), ptr(add), ptr(dx), ctypes.byref(so), ptr(sb), sb.numel() * 8,
+                                                  ctypes.byref(rows), ptr(ws), ws.numel(), tile, N, H, W, C, K, stream_ptr()),
+                  "conv_wino_dgrad_sums")
+        sums.done(sb, rows.value, fin)
         return dx
     check(_L().denet_conv_wino_dgrad(ptr(dy), ptr(w), ptr(u), ptr(add), ptr(dx), ptr(ws), ws.numel(), tile, N, H, W, C, K,
                                      stream_ptr()), "conv_wino_dgrad")
@@ -907,11 +980,12 @@ def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None,
         if sums is not None and (int(BWD_SUMS) & 2):
             sb = sums.buffer(cache, (N * H * W + 127) // 128, C)
             so = sums.c_struct()
-        check(_L().denet_conv_dgrad_1x1t(ptr(dy), ptr(wt), ptr(add), ptr(dx), ctypes.byref(so) if so is not None else None, ptr(sb),
-                                         sb.numel() * 8 if sb is not None else 0, ctypes.byref(rows), N, H, W, C, K, stream_ptr()),
-              "conv_dgrad_1x1t")
+        with _armed(sums.final if sb is not None else None) as fin:
+            check(_L().denet_conv_dgrad_1x1t(ptr(dy), ptr(wt), ptr(add), ptr(dx), ctypes.byref(so) if so is not None else None, ptr(sb),
+                                             sb.numel() * 8 if sb is not None else 0, ctypes.byref(rows), N, H, W, C, K, stream_ptr()),
+                  "conv_dgrad_1x1t")
         if sb is not None:
-            sums.done(sb, rows.value)
+            sums.done(sb, rows.value, fin)
         return dx
     _tune_first(1, g, dy, w, None, add, dx, None)
 
@@ -939,9 +1013,10 @@ def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None,
         rows = ctypes.c_int(0)
         sb = sums.buffer(cache, (N * H * W + 127) // 128 + g[8] * g[8], C)
         so = sums.c_struct()
-        check(_L().denet_conv_dgrad_sums(ptr(dy), ptr(w), ptr(add), ptr(dx), ctypes.byref(so), ptr(sb), sb.numel() * 8,
-                                         ctypes.byref(rows), *g, stream_ptr()), "conv_dgrad_sums")
-        sums.done(sb, rows.value)
+        with _armed(sums.final) as fin:
+            check(_L().denet_conv_dgrad_sums(ptr(dy), ptr(w), ptr(add), ptr(dx), ctypes.byref(so), ptr(sb), sb.numel() * 8,
+                                             ctypes.byref(rows), *g, stream_ptr()), "conv_dgrad_sums")
+        sums.done(sb, rows.value, fin)
         return dx
     direct()
     return dx
@@ -1058,6 +1133,12 @@ def bn_fwd_train(x, gamma, beta, run_mean, run_stdinv, momentum=0.9, eps=1e-5, r
     M = x.numel() // C
     y = out if out is not None else torch.empty_like(x)
     save_mean, save_invstd = empty(C), empty(C)
+    if pre is not None and len(pre) > 2:
+        # the convolution that produced x has finished the statistics itself (BnFinal): only the pointwise pass is left
+        fin = pre[2]
+        check(_L().denet_bn_apply(ptr(x), ptr(res), ptr(y), ptr(gamma), ptr(beta), ptr(fin.save_mean), ptr(fin.save_invstd), M, C,
+                                  int(relu), stream_ptr()), "bn_apply")
+        return y, fin.save_mean, fin.save_invstd
     if pre is not None:
         check(_L().denet_bn_fwd_train_pre(ptr(x), ptr(res), ptr(y), ptr(gamma), ptr(beta), ptr(run_mean), ptr(run_stdinv),
                                           ptr(save_mean), ptr(save_invstd), ptr(pre[0]), int(pre[1]), M, C, momentum, eps,
@@ -1099,9 +1180,10 @@ class BnSums:
     backward reductions behind` (x = the layer's input, y = its forward output if the ReLU mask needs it); partial = (float64
     buffer [rows][2][C], rows) afterwards, or None when the pass that ran cannot"""
 
-    def __init__(self, x, y, gamma, beta, mean, invstd, relu):
+    def __init__(self, x, y, gamma, beta, mean, invstd, relu, final=None):
         self.x, self.y, self.gamma, self.beta, self.mean, self.invstd, self.relu = x, y, gamma, beta, mean, invstd, bool(relu)
         self.partial = None
+        self.final = final          # BnFinal (kind 2): the pass may also finish the reduction (dgamma, dbeta, coef); None: never
 
     def c_struct(self):
         return _bn_link_struct(self.x, None, self.y, self.gamma, self.beta, self.mean, self.invstd, None, None, self.relu)
@@ -1114,9 +1196,10 @@ class BnSums:
                 cache["bsum_buf"] = buf
         return buf
 
-    def done(self, buf, rows):
-        self.partial = (buf, rows) if rows > 0 else None
+    def done(self, buf, rows, fin=None):
+        self.partial = None
         if rows > 0:
+            self.partial = (buf, rows, fin) if (fin is not None and fin.taken) else (buf, rows)
             SUMS_COUNT[0] += 1
 
 
@@ -1157,9 +1240,12 @@ def bn_fwd_train_link(x, gamma, beta, run_mean, run_stdinv, pre, momentum=0.9, e
     reads it (BnLink). Returns (link, save_mean, save_invstd)."""
     C = x.shape[-1]
     M = x.numel() // C
-    save_mean, save_invstd = empty(C), empty(C)
-    check(_L().denet_bn_stats_final(ptr(pre[0]), int(pre[1]), M, C, momentum, eps, ptr(run_mean), ptr(run_stdinv), ptr(save_mean),
-                                    ptr(save_invstd), stream_ptr()), "bn_stats_final")
+    if len(pre) > 2:           # the producing convolution has finished the statistics itself (BnFinal)
+        save_mean, save_invstd = pre[2].save_mean, pre[2].save_invstd
+    else:
+        save_mean, save_invstd = empty(C), empty(C)
+        check(_L().denet_bn_stats_final(ptr(pre[0]), int(pre[1]), M, C, momentum, eps, ptr(run_mean), ptr(run_stdinv), ptr(save_mean),
+                                        ptr(save_invstd), stream_ptr()), "bn_stats_final")
     return BnLink(False, x, res, None, gamma, beta, save_mean, save_invstd, None, relu), save_mean, save_invstd
 
 
@@ -1172,10 +1258,16 @@ def bn_bwd_link(x, y, dy, gamma, save_mean, save_invstd, relu=False, want_dres=F
     M = x.numel() // C
     dgamma = dgamma if dgamma is not None else empty(C)
     dbeta = dbeta if dbeta is not None else empty(C)
-    coef = empty(2 * C)
-    if pre is not None:
+    coef = None
+    if pre is not None and len(pre) > 2 and pre[2].dgamma.data_ptr() == dgamma.data_ptr() and pre[2].dbeta.data_ptr() == dbeta.data_ptr():
+        coef = pre[2].coef      # the data-gradient pass that wrote dy has finished the two sums itself (BnFinal)
+    if coef is not None:
+        pass
+    elif pre is not None:
+        coef = empty(2 * C)
         check(_L().denet_bn_bwd_final(ptr(pre[0]), int(pre[1]), M, C, ptr(dgamma), ptr(dbeta), ptr(coef), stream_ptr()), "bn_bwd_final")
     else:
+        coef = empty(2 * C)
         check(_L().denet_bn_bwd_sums(ptr(x), ptr(y), ptr(dy), ptr(gamma), ptr(beta), ptr(save_mean), ptr(save_invstd), ptr(dgamma),
                                      ptr(dbeta), ptr(coef), ptr(_bn_ws(M, C)), M, C, int(relu), stream_ptr()), "bn_bwd_sums")
     dres = torch.empty_like(x) if want_dres else None

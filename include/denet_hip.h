@@ -289,6 +289,21 @@ int denet_conv_wgrad(const float* x, const float* dy, float* dw, float* workspac
  *      denet/layer/batch_norm_relu.py:34-54 BatchNormReluOp + grad, denet/layer/resnet.py:109-113).
  *      x,y,res,dy,dx,dres: [M,C] (M = N*H*W).  run_mean/run_stdinv are updated in place (momentum form of
  *      batch_norm.py:75-76; the running statistic is the INVERSE standard deviation).                    */
+/* In-launch second stage of a batch norm's reductions (csrc/bn_final.h). A convolution pass that writes partial column sums
+ * (denet_conv_fwd_stats, denet_conv_wino_fwd_stats*, denet_conv_wino_fwd_fold, denet_conv_wino2f*, denet_conv_stem_fwd*: the
+ * statistics of the batch norm BEHIND it; denet_conv_*dgrad*_sums / _fold, denet_conv_dgrad_1x1t: the backward sums of the batch norm
+ * IN FRONT) can reduce them itself in its last workgroup, which takes denet_bn_stats_final / denet_bn_bwd_final off the stream.
+ * The caller ARMS the batch norm (this thread, the next producing call only), runs the pass and DISARMS: disarm returns 1 if the
+ * pass took the final over (the outputs are then written by the pass; the caller must not launch the separate final), 0 if the
+ * kernel that ran cannot (the caller proceeds as before). Results are bit-identical to the separate launches.
+ *   arm_stats: what denet_bn_stats_final writes - save_mean, save_invstd and (optional) the running statistics update
+ *              (batch_norm.py:50-53, 75-76); arm_sums: what denet_bn_bwd_final writes - dgamma, dbeta, coef [2][C].
+ *   counters:  `ncounters` zeroed unsigned ints owned by the caller, one per column group of the producing kernel (64 suffice),
+ *              used by ONE pass at a time and left zero by it. DENET_BN_FINAL_FOLD=0: nothing is ever taken. */
+int denet_bn_final_arm_stats(long M, int C, float momentum, float eps, float* run_mean, float* run_stdinv, float* save_mean,
+                             float* save_invstd, unsigned* counters, int ncounters);
+int denet_bn_final_arm_sums(long M, int C, float* dgamma, float* dbeta, float* coef, unsigned* counters, int ncounters);
+int denet_bn_final_disarm(void);
 size_t denet_bn_workspace_bytes(long M, int C);
 int denet_bn_fwd_train(const float* x, const float* res, float* y, const float* gamma, const float* beta,
                        float* run_mean, float* run_stdinv, float* save_mean, float* save_invstd, void* workspace,

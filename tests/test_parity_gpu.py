@@ -25,7 +25,7 @@ from oracle import layers as OL
 ELEMENTWISE = {}      # what -> (max-norm relative error, p99.99 of the element-wise statistic): tests print the worst at the end
 
 
-def rel_close(a, b, rtol=1e-3, what="", atol=0.0):
+def rel_close(a, b, rtol=1e-3, what="", atol=0.0, rtol_elem=None):
     """two clauses, both asserted:
       max-norm      max|a - b| <= rtol * max|b| (+ atol)
       element-wise  |a - b| <= rtol * (|b| + rms(b)) (+ atol) for 99.99 % of the elements (the 99.99th percentile of
@@ -44,8 +44,9 @@ def rel_close(a, b, rtol=1e-3, what="", atol=0.0):
     if what:
         prev = ELEMENTWISE.get(what.split(" ")[0], (0.0, 0.0))
         ELEMENTWISE[what.split(" ")[0]] = (max(prev[0], err / scale), max(prev[1], q))
-    assert q <= rtol, "%s: element-wise p99.99 of |a-b| / (|b| + rms) = %.3e > %.1e (max-norm rel %.2e, rms %.3e)" % (
-        what, q, rtol, err / scale, rms)
+    rtol_elem = rtol if rtol_elem is None else rtol_elem
+    assert q <= rtol_elem, "%s: element-wise p99.99 of |a-b| / (|b| + rms) = %.3e > %.1e (max-norm rel %.2e, rms %.3e)" % (
+        what, q, rtol_elem, err / scale, rms)
 
 
 def random_corner_map(rng, B, H, W, frac, Cn=4):
@@ -684,6 +685,7 @@ def test_full_size_properties(hip):
     x, metas = zoo.synthetic_batch(B, 512, seed=1)
     xd = torch.from_numpy(x).cuda()
     results = []
+    ops.FINAL_COUNT[:] = [0, 0]
     for run in range(2):
         model = zoo.denet34(B, "skip", 512, seed=1)
         _warm_corner_head(model, 7.5, 0.3)
@@ -696,6 +698,23 @@ def test_full_size_properties(hip):
     # determinism: no atomics on floating point anywhere in the step
     assert results[0][0] == results[1][0] and results[0][1] == results[1][1]
     assert torch.equal(results[0][2], results[1][2])
+    # the batch-norm reductions finished inside the producing launches (ops.BnFinal: last-workgroup tickets, write-through rows)
+    # against the separate final launches: bit-identical parameters after two steps - a stale partial row would show as a bit
+    assert ops.FINAL_COUNT[0] >= 30 and ops.FINAL_COUNT[1] >= 30, ops.FINAL_COUNT
+    saved_fold = ops.FINAL_FOLD
+    ops.FINAL_FOLD = False
+    try:
+        m2 = zoo.denet34(B, "skip", 512, seed=1)
+        _warm_corner_head(m2, 7.5, 0.3)
+        m2.build_train_func("nesterov")
+        random.seed(1)
+        d0 = m2.train_step(xd, metas, 0, 0, 0.1, [0.9], 1e-4)
+        d1 = m2.train_step(xd, metas, 0, 1, 0.1, [0.9], 1e-4)
+    finally:
+        ops.FINAL_FOLD = saved_fold
+    assert d0 == results[0][0] and d1 == results[0][1]
+    assert torch.equal(m2.P, results[0][2]) and torch.equal(m2.S, model.S) and torch.equal(m2.M, model.M)
+    del m2
     # RoI proposal: sortedness + idempotence at full size, against the oracle on the same map
     cl, dns = model.layers[30], model.layers[31]
     pr = cl.corner_pr
@@ -902,6 +921,56 @@ def test_direct_and_measured_paths_agree(hip):
         ops.AUTOTUNE = saved[0]
         ops._WINO.clear()
         ops._WINO.update(saved[1])
+
+
+@pytest.mark.parametrize("mode", [33, 64])
+def test_bn_reductions_finished_in_the_producing_launch_are_bit_identical(hip, mode):
+    """ops.BnFinal / csrc/bn_final.h: the second stage of a batch norm's reductions (forward statistics: batch_norm.py:50-53, 75-76;
+    backward sums of tensor.grad, model_cnn.py:318) runs in the LAST workgroup of the convolution pass that writes the partial rows
+    (write-through rows, an agent-scope ticket per column group, reads past the caches) instead of a launch of its own. By
+    construction the arithmetic is the separate kernels': six training steps of DeNet-34 skip (B = 4, 256x256; the fused F(4x4)
+    kernel forced on so that every producer takes part: fused F(4x4) forward / data gradient, fused F(2x2), implicit-GEMM
+    epilogues of the head and the 1x1 layers) with the fold on and off give bit-identical parameters, momentum and running
+    statistics - under uneven load (a second stream hammers the memory system with copies of changing size), several times over.
+    A stale row, a lost ticket or a counter that is not at rest would show as a different bit (or a hang: the suite's timeout)."""
+    L = lib.load()
+    B, IMG = 4, 256
+    x, metas = zoo.synthetic_batch(B, IMG, seed=2)
+    xd = torch.from_numpy(x).cuda()
+    side = torch.cuda.Stream()
+    a, b = torch.empty(1 << 26, device="cuda"), torch.empty(1 << 26, device="cuda")
+    old = (L.denet_conv_wino4f_mode(mode), ops.FINAL_FOLD)
+
+    def run(fold, pressure):
+        ops.FINAL_FOLD = fold
+        ops.FINAL_COUNT[:] = [0, 0]
+        model = zoo.denet34(B, "skip", IMG, class_num=80, seed=1)
+        _warm_corner_head(model, 4.0, 0.3)
+        model.build_train_func("nesterov")
+        random.seed(5)
+        costs = []
+        for it in range(6):
+            if pressure:
+                with torch.cuda.stream(side):
+                    for k in range(40):
+                        n = 1 << (18 + (k * 7 + it) % 9)
+                        b[:n].copy_(a[:n], non_blocking=True)
+            costs.append(model.train_step(xd, metas, 0, it, 0.05, [0.9], 1e-4)[0])
+        torch.cuda.synchronize()
+        return costs, model.P.clone(), model.M.clone(), model.S.clone(), list(ops.FINAL_COUNT)
+
+    try:
+        ref = run(False, False)
+        assert ref[4] == [0, 0]
+        for rep in range(3):
+            got = run(True, True)
+            assert got[4][0] >= 6 * 25 and got[4][1] >= 6 * 25, "too few reductions were finished in their producers: %s" % (got[4],)
+            assert got[0] == ref[0], (rep, got[0], ref[0])
+            for k in (1, 2, 3):
+                assert torch.equal(got[k], ref[k]), "run %d: %s differs" % (rep, "PMS"[k - 1])
+    finally:
+        L.denet_conv_wino4f_mode(old[0])
+        ops.FINAL_FOLD = old[1]
 
 
 def test_bn_pool_fusion_leaves_training_unchanged(hip):
@@ -1457,9 +1526,14 @@ def test_denet101_wide_train_step_vs_oracle(hip, IMG):
     """BASELINE config 5 at reduced size: ResNet-101 bottleneck backbone, three skip scales (one through a plain
     SKIPSRC), SPLIT points, 48x48 = 2304 RoIs per image, joint-fitness + bounded-IoU head (papers/dss/denet101.sh).
     IMG = 512 (the recipe's resolution, 128x128 corner map, 16x16 last-stage maps): FREE-RUNNING forward as well - every layer's
-    activation, the corner map and both costs against the oracle's own forward pass, max-norm and element-wise (at 128x128 the last
-    stage normalises over 16 values per channel and the element-wise statistic of a 101-layer free run reaches 1.05e-3 there: only
-    the teacher-forced pass is asserted at that size)"""
+    activation, the corner map and both costs against the oracle's own forward pass. What a free run of 101 layers at B = 1 can
+    show was measured layer by layer (tools/exp/d101_free.py, MI355X): the element-wise p99.99 grows by ~4 % per residual block -
+    3e-6 behind the stem, 3.3e-4 at layer 24, 9.6e-4 at layer 37, 3.5e-3 behind the last stage (batch statistics over 256 values),
+    4.2e-3 at the head's last layer; max-norm 1.0e-3 there - and it grows the SAME way with the direct fp32 kernels only
+    (DENET_WINOGRAD=0: 8.4e-4 / 3.1e-3 at layers 37 / 40): it is the distance between two fp32 evaluations of this depth (the
+    oracle's BLAS sums in another order), not a property of the Winograd passes. Asserted: costs 1e-3, every activation 2e-3
+    max-norm and 6e-3 element-wise, the first 24 layers at the north star's 1e-3 in both clauses; the op-by-op pass behind it
+    (every op on the product's own inputs) holds 2e-4 per op."""
     B = 1           # IMG = 512: the resolution of papers/dss/denet101.sh:19 (BASELINE config 5), 128x128 corner map
     model = zoo.denet101(B, "wide", IMG, class_num=80, seed=1,
                          head_desc=zoo.DENET101_WIDE_DESC.replace("DND[0.5,1,1]", "DND.JB[0.5,1,1]"))
@@ -1486,8 +1560,10 @@ def test_denet101_wide_train_step_vs_oracle(hip, IMG):
             assert abs(c - oc) <= 1e-3 * max(abs(oc), 1e-6), (costs, fcosts)
         ELEMENTWISE.clear()
         for i, a in _product_acts(model).items():
-            rel_close(a, om_free.acts[i], 1e-3, "activation L%d %s" % (i, model.layers[i].type_name))
-        rel_close(by_type("denet-corner").corner_pr.cpu().numpy(), om_free.corner_pr, 1e-3, "corner_pr")
+            deep = i > 24
+            rel_close(a, om_free.acts[i], 2e-3 if deep else 1e-3, "activation L%d %s" % (i, model.layers[i].type_name),
+                      rtol_elem=6e-3 if deep else 1e-3)
+        rel_close(by_type("denet-corner").corner_pr.cpu().numpy(), om_free.corner_pr, 2e-3, "corner_pr", rtol_elem=6e-3)
         print("DeNet-101 wide 512x512 free-running: element-wise p99.99 / max-norm:",
               {k: ("%.2e" % v[1], "%.2e" % v[0]) for k, v in ELEMENTWISE.items()})
         del om_free
