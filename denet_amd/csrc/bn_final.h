@@ -99,6 +99,26 @@ __device__ __forceinline__ void bnf_reduce_partials_multi(const double* __restri
         cs[u] = c[u] < C ? c[u] : 0;
     }
     int j = jl;
+    // two groups of four rows per lane at a time (the loads of 2 x 4 x 2 x U values leave together: 256 rows - what a fused
+    // kernel's launch leaves - are ONE round trip for the last workgroup, on whose latency the end of the launch waits)
+    for (; j + 7 * BNF_FJ < gy; j += 8 * BNF_FJ) {
+        double a[U][8], b[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const double* row = partial + (long)(j + r * BNF_FJ) * 2 * C;
+                a[u][r] = bnf_load<SC1>(row + cs[u]);
+                b[u][r] = bnf_load<SC1>(row + C + cs[u]);
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            s[u] += (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
+            ss[u] += (b[u][0] + b[u][1]) + (b[u][2] + b[u][3]);
+            s[u] += (a[u][4] + a[u][5]) + (a[u][6] + a[u][7]);
+            ss[u] += (b[u][4] + b[u][5]) + (b[u][6] + b[u][7]);
+        }
+    }
     for (; j + 3 * BNF_FJ < gy; j += 4 * BNF_FJ) {
         double a[U][4], b[U][4];
 #pragma unroll

@@ -50,9 +50,27 @@ extern "C" int denet_bn_final_disarm(void) {
     return taken;
 }
 
+// which reductions a producing pass may finish itself: bit 0 the forward statistics, bit 1 the backward sums. OFF by default
+// (DENET_BN_FINAL_FOLD, denet_bn_final_mode): measured on MI355X the last workgroup's serial tail (ticket round trip under 256
+// simultaneous arrivals + one or two dependent round trips of row loads, with the launch's own store burst on the fabric) costs
+// the producing kernels +5...23 us each, more than the 5 us launches it replaces - 1 025 against 1 050 img/s (EXPERIMENTS.md).
+static int g_bnf_mode = -1;
+static int bnf_mode() {
+    if (g_bnf_mode < 0) {
+        const char* e = getenv("DENET_BN_FINAL_FOLD");
+        g_bnf_mode = e ? (atoi(e) & 3) : 0;
+    }
+    return g_bnf_mode;
+}
+extern "C" int denet_bn_final_mode(int bits) {
+    const int old = bnf_mode();
+    if (bits >= 0) g_bnf_mode = bits & 3;
+    return old;
+}
+
 BnFinalDev denet_bn_final_take(int kind, int C, int groups) {
-    static const int env_on = [] { const char* e = getenv("DENET_BN_FINAL_FOLD"); return e ? atoi(e) : 1; }();
-    if (!env_on || t_bnf_state != 1 || t_bnf.kind != kind || t_bnf.C != C || groups <= 0 || groups > t_bnf_groups) return BnFinalDev{};
+    const int env_on = bnf_mode();
+    if (!((env_on >> (kind - 1)) & 1) || t_bnf_state != 1 || t_bnf.kind != kind || t_bnf.C != C || groups <= 0 || groups > t_bnf_groups) return BnFinalDev{};
     t_bnf_state = 2;
     return t_bnf;
 }

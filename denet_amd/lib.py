@@ -74,6 +74,7 @@ SIGNATURES = {
     "denet_bn_final_arm_stats": (I, [L, I, F, F, P, P, P, P, P, I]),
     "denet_bn_final_arm_sums": (I, [L, I, P, P, P, P, I]),
     "denet_bn_final_disarm": (I, []),
+    "denet_bn_final_mode": (I, [I]),
     "denet_bn_workspace_bytes": (Z, [L, I]),
     "denet_bn_fwd_train": (I, [P] * 10 + [L, I, F, F, I, P]),
     "denet_bn_fwd_train_pre": (I, [P] * 10 + [I, L, I, F, F, I, P]),

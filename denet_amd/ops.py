@@ -340,8 +340,22 @@ HEAD_BF16X3 = os.environ.get("DENET_HEAD_BF16X3", "0") == "1"
 # The second stage of a batch norm's reductions inside the launch that writes the partial sums (csrc/bn_final.h, denet_bn_final_arm_*):
 # the last workgroup of the producing convolution pass reduces the rows, and the 84 bn_stats_final / bn_bwd_final launches of a
 # DeNet-34 step - 5 us of work each, but 25-37 us on the backward sweep's critical chain, where such a launch waits for a CU slot
-# beside the other stream's matrix kernels - leave the streams. Bit-identical to the separate launches. DENET_BN_FINAL_FOLD=0: off.
-FINAL_FOLD = os.environ.get("DENET_BN_FINAL_FOLD", "1") != "0"
+# beside the other stream's matrix kernels - leave the streams. Bit-identical to the separate launches.
+# OFF by default: measured (MI355X, A / B on one box, tools/exp/ab_fold.sh) 1 021-1 027 img/s with both kinds folded, 1 013-1 046 with
+# the backward sums only, 1 047-1 055 without - the last workgroup's serial tail (ticket round trip under 256 simultaneous arrivals
+# + the dependent row loads behind the launch's own store burst) costs a producing kernel +5...23 us, the launch it replaces 5 us,
+# and what that launch waits for a CU slot inside the step is time the other chain uses anyway. DENET_BN_FINAL_FOLD=3 (bit 0 forward
+# statistics, bit 1 backward sums) / set_final_fold() switch it on; the bit-identity tests run it.
+FINAL_FOLD = os.environ.get("DENET_BN_FINAL_FOLD", "0") not in ("0", "")
+
+
+def set_final_fold(bits):
+    """which batch-norm reductions the producing passes finish themselves (bit 0 forward statistics, bit 1 backward sums; 0 = the
+    separate final launches, the default); returns the previous setting"""
+    global FINAL_FOLD
+    old = int(_L().denet_bn_final_mode(int(bits)))
+    FINAL_FOLD = bool(bits)
+    return old
 FINAL_COUNT = [0, 0]        # forward statistics / backward sums finished by their producers (tests, bench)
 
 

@@ -299,11 +299,14 @@ int denet_conv_wgrad(const float* x, const float* dy, float* dw, float* workspac
  *   arm_stats: what denet_bn_stats_final writes - save_mean, save_invstd and (optional) the running statistics update
  *              (batch_norm.py:50-53, 75-76); arm_sums: what denet_bn_bwd_final writes - dgamma, dbeta, coef [2][C].
  *   counters:  `ncounters` zeroed unsigned ints owned by the caller, one per column group of the producing kernel (64 suffice),
- *              used by ONE pass at a time and left zero by it. DENET_BN_FINAL_FOLD=0: nothing is ever taken. */
+ *              used by ONE pass at a time and left zero by it. Nothing is taken unless denet_bn_final_mode enables the kind. */
 int denet_bn_final_arm_stats(long M, int C, float momentum, float eps, float* run_mean, float* run_stdinv, float* save_mean,
                              float* save_invstd, unsigned* counters, int ncounters);
 int denet_bn_final_arm_sums(long M, int C, float* dgamma, float* dbeta, float* coef, unsigned* counters, int ncounters);
 int denet_bn_final_disarm(void);
+/* which reductions a pass may take over: bit 0 forward statistics, bit 1 backward sums; bits < 0 only queries. Returns the previous
+ * setting. Default 0 (DENET_BN_FINAL_FOLD): measured slower than the separate launches on MI355X - kept as a tested option. */
+int denet_bn_final_mode(int bits);
 size_t denet_bn_workspace_bytes(long M, int C);
 int denet_bn_fwd_train(const float* x, const float* res, float* y, const float* gamma, const float* beta,
                        float* run_mean, float* run_stdinv, float* save_mean, float* save_invstd, void* workspace,

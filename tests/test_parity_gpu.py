@@ -698,11 +698,11 @@ def test_full_size_properties(hip):
     # determinism: no atomics on floating point anywhere in the step
     assert results[0][0] == results[1][0] and results[0][1] == results[1][1]
     assert torch.equal(results[0][2], results[1][2])
-    # the batch-norm reductions finished inside the producing launches (ops.BnFinal: last-workgroup tickets, write-through rows)
-    # against the separate final launches: bit-identical parameters after two steps - a stale partial row would show as a bit
-    assert ops.FINAL_COUNT[0] >= 30 and ops.FINAL_COUNT[1] >= 30, ops.FINAL_COUNT
-    saved_fold = ops.FINAL_FOLD
-    ops.FINAL_FOLD = False
+    # the OPTION of finishing the batch-norm reductions inside the producing launches (ops.BnFinal: last-workgroup tickets,
+    # write-through rows; off by default, measured slower) against the separate final launches at the full size: bit-identical
+    # parameters after two steps - a stale partial row would show as a bit
+    assert ops.FINAL_COUNT == [0, 0], ops.FINAL_COUNT
+    saved_fold = ops.set_final_fold(3)
     try:
         m2 = zoo.denet34(B, "skip", 512, seed=1)
         _warm_corner_head(m2, 7.5, 0.3)
@@ -711,7 +711,8 @@ def test_full_size_properties(hip):
         d0 = m2.train_step(xd, metas, 0, 0, 0.1, [0.9], 1e-4)
         d1 = m2.train_step(xd, metas, 0, 1, 0.1, [0.9], 1e-4)
     finally:
-        ops.FINAL_FOLD = saved_fold
+        ops.set_final_fold(saved_fold)
+    assert ops.FINAL_COUNT[0] >= 30 and ops.FINAL_COUNT[1] >= 30, ops.FINAL_COUNT
     assert d0 == results[0][0] and d1 == results[0][1]
     assert torch.equal(m2.P, results[0][2]) and torch.equal(m2.S, model.S) and torch.equal(m2.M, model.M)
     del m2
@@ -925,7 +926,7 @@ def test_direct_and_measured_paths_agree(hip):
 
 @pytest.mark.parametrize("mode", [33, 64])
 def test_bn_reductions_finished_in_the_producing_launch_are_bit_identical(hip, mode):
-    """ops.BnFinal / csrc/bn_final.h: the second stage of a batch norm's reductions (forward statistics: batch_norm.py:50-53, 75-76;
+    """ops.BnFinal / csrc/bn_final.h (an OPTION, off by default: measured slower than the launches it replaces): the second stage of a batch norm's reductions (forward statistics: batch_norm.py:50-53, 75-76;
     backward sums of tensor.grad, model_cnn.py:318) runs in the LAST workgroup of the convolution pass that writes the partial rows
     (write-through rows, an agent-scope ticket per column group, reads past the caches) instead of a launch of its own. By
     construction the arithmetic is the separate kernels': six training steps of DeNet-34 skip (B = 4, 256x256; the fused F(4x4)
@@ -939,10 +940,10 @@ def test_bn_reductions_finished_in_the_producing_launch_are_bit_identical(hip, m
     xd = torch.from_numpy(x).cuda()
     side = torch.cuda.Stream()
     a, b = torch.empty(1 << 26, device="cuda"), torch.empty(1 << 26, device="cuda")
-    old = (L.denet_conv_wino4f_mode(mode), ops.FINAL_FOLD)
+    old = (L.denet_conv_wino4f_mode(mode), ops.set_final_fold(0))
 
     def run(fold, pressure):
-        ops.FINAL_FOLD = fold
+        ops.set_final_fold(3 if fold else 0)
         ops.FINAL_COUNT[:] = [0, 0]
         model = zoo.denet34(B, "skip", IMG, class_num=80, seed=1)
         _warm_corner_head(model, 4.0, 0.3)
@@ -970,7 +971,7 @@ def test_bn_reductions_finished_in_the_producing_launch_are_bit_identical(hip, m
                 assert torch.equal(got[k], ref[k]), "run %d: %s differs" % (rep, "PMS"[k - 1])
     finally:
         L.denet_conv_wino4f_mode(old[0])
-        ops.FINAL_FOLD = old[1]
+        ops.set_final_fold(old[1])
 
 
 def test_bn_pool_fusion_leaves_training_unchanged(hip):
