@@ -421,7 +421,7 @@ def main():
     out["config"]["product_default_switches"] = not [k for k in out["config"]["denet_switches"] if k not in ("DENET_FORCE_DP",
                                                                                                              "DENET_BENCH_SHARE_GPU")]
     out["config"]["tuned_file"] = os.path.relpath(ops.TUNE_CACHE, os.path.dirname(os.path.abspath(__file__))) if ops._TUNE_LOADED else None
-    if rank == 0 and not args.no_audit:
+    if not args.no_audit:       # (every rank: the step holds collectives when the job is data parallel)
         out["config"]["passes_measured_in_the_warmup"] = undecided       # 0: every implementation came from the committed file
         with audit.KernelAudit(model) as ka:
             model.train_step(xd, metas, 0, it, lr, mom, decay)
