@@ -29,7 +29,10 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;  // padded K-inner row (floats): 144 B rows -> conflict-free ds_read_b128
 
-enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
+enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2, MODE_DGRAD_T = 3 };
+// MODE_DGRAD_T: the data gradient with the filter given TRANSPOSED, wt [R][S][C][K] (denet_transpose_f32 of w [K][R*S*C]): the
+// B operand is then reduction-contiguous like the forward pass's, goes into LDS K-inner and is read back as one ds_read_b128 per
+// fragment instead of four scalar reads - the same products in the same order as MODE_DGRAD (bit-identical results).
 
 struct IgemmParams {
     const float* act;   // fwd: x        dgrad: dy       wgrad: x
@@ -85,7 +88,8 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, int elem_of
 template <int MODE, int BM, int BN, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (NBUF == 2 ? 2 : 1))) void igemm_kernel(const IgemmParams p) {
     constexpr bool A_KIN = (MODE != MODE_WGRAD);
-    constexpr bool B_KIN = (MODE == MODE_FWD);
+    constexpr bool B_KIN = (MODE == MODE_FWD || MODE == MODE_DGRAD_T);
+    constexpr bool IS_DGRAD = (MODE == MODE_DGRAD || MODE == MODE_DGRAD_T);
     constexpr int TM = BM / (32 * WM);
     constexpr int TN = BN / (32 * WN);
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
     // (py,px) only receives taps r = r0 + stride*r', s = s0 + stride*s' (the others hit "holes" of the strided
     // output), so each class is a dense problem over its own tap subset: no wasted MFMA work.
     int dg_py = 0, dg_px = 0, dg_r0 = 0, dg_s0 = 0, dg_rc = p.R, dg_sc = p.S;
-    if (MODE == MODE_DGRAD && p.stride > 1) {
+    if (IS_DGRAD && p.stride > 1) {
         dg_py = blockIdx.y >> p.sshift;
         dg_px = blockIdx.y & (p.stride - 1);
         dg_r0 = (dg_py + p.pad) & (p.stride - 1);
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
             b_ok[i] = n < p.K;
             b_off[i] = n * kred + 4 * q8;
         }
-    } else if (MODE == MODE_DGRAD) {
+    } else if (IS_DGRAD) {
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int m = m0 + row8 + 32 * i;
@@ -217,9 +221,15 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
         const int rsc = p.R * p.S * p.C;
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            const int col = n0 + 4 * qb;
-            b_ok[i] = col < p.C;
-            b_off[i] = (krb + RPP_B * i) * rsc + col;
+            if (MODE == MODE_DGRAD_T) {          // wt [R][S][C][K]: row = output channel c of the tap, K-inner
+                const int n = n0 + row8 + 32 * i;
+                b_ok[i] = n < p.C;
+                b_off[i] = n * p.K + 4 * q8;
+            } else {
+                const int col = n0 + 4 * qb;
+                b_ok[i] = col < p.C;
+                b_off[i] = (krb + RPP_B * i) * rsc + col;
+            }
         }
     } else {  // WGRAD
 #pragma unroll
@@ -259,11 +269,12 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
         if (MODE == MODE_FWD) {
             u_off = (cur_r * p.W + cur_s) * p.C + cur_c;
             u_offb = kc * BK;
-        } else if (MODE == MODE_DGRAD) {
+        } else if (IS_DGRAD) {
             u_ty = cur_r << p.sshift;
             u_tx = cur_s << p.sshift;
             u_off = cur_c;
-            u_offb = cur_c * (p.R * p.S * p.C) + ((dg_r0 + u_ty) * p.S + dg_s0 + u_tx) * p.C;
+            if (MODE == MODE_DGRAD_T) u_offb = ((dg_r0 + u_ty) * p.S + dg_s0 + u_tx) * p.C * p.K + cur_c;
+            else u_offb = cur_c * (p.R * p.S * p.C) + ((dg_r0 + u_ty) * p.S + dg_s0 + u_tx) * p.C;
         } else {
             u_pix0 = kc * BK;
         }
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
         if (MODE == MODE_FWD) {
             const bool ok = ((unsigned)(a_y[i] + cur_r) < (unsigned)p.H) && ((unsigned)(a_x[i] + cur_s) < (unsigned)p.W);
             ra[i] = buf_load4(r_act, a_off[i] + u_off, ok);
-        } else if (MODE == MODE_DGRAD) {
+        } else if (IS_DGRAD) {
             // (iy + pad - r) is a multiple of the stride by construction of the class
             const int ty = a_y[i] - u_ty;
             const int tx = a_x[i] - u_tx;
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
         }
     };
     auto load_b = [&](int i) {
-        if (MODE == MODE_FWD || MODE == MODE_DGRAD) {
+        if (MODE == MODE_FWD || IS_DGRAD) {
             rb[i] = buf_load4(r_wgt, b_off[i] + u_offb, b_ok[i]);
         } else {
             const int pix = u_pix0 + krb + RPP_B * i;
@@ -312,7 +323,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
                     cur_r += 1;
                 }
             }
-        } else if (MODE == MODE_DGRAD) {
+        } else if (IS_DGRAD) {
             cur_c += BK;
             if (cur_c >= p.K) {
                 cur_c = 0;
@@ -625,7 +636,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
     float* out = p.out;
     if (MODE == MODE_WGRAD) out += (long)split_id * p.split_stride;
     if (MODE == MODE_FWD || MODE == MODE_WGRAD) out += by * p.batch_out;
-    if ((MODE == MODE_FWD || MODE == MODE_DGRAD) && p.stats) {
+    if ((MODE == MODE_FWD || IS_DGRAD) && p.stats) {
         // ---- store + batch-norm column sums. Lane (li, lh) holds row m and, per (j, g), 4 consecutive columns: the sums
         // over the rows of the tile are a reduction over li (shuffles inside each 32-lane half), then over the two waves
         // stacked along M (LDS), written as doubles: partial[tile_m][0][n] = sum, [1][n] = sum of squares.
@@ -655,7 +666,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
                         const int m = m0 + (wm * TM + i) * 32 + li;
                         if (m < p.M) {
                             long row = (long)m * p.NC;
-                            if (MODE == MODE_DGRAD && p.stride > 1) {      // pixel m of this parity class (see the plain epilogue)
+                            if (IS_DGRAD && p.stride > 1) {      // pixel m of this parity class (see the plain epilogue)
                                 const uint32_t ni = p.div_row_hw.div(m);
                                 const uint32_t rem = m - ni * (p.Hc * p.Wc);
                                 const uint32_t ya = p.div_row_w.div(rem);
@@ -733,12 +744,12 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
                 b += redd[(w * 2 + 1) * BN + tid];
             }
             // one row per (parity class, row tile): every pixel of dx is in exactly one
-            double* ps = p.stats + ((MODE == MODE_DGRAD ? (long)blockIdx.y * p.tiles_m : 0L) + tile_m) * 2 * p.NC;
+            double* ps = p.stats + ((IS_DGRAD ? (long)blockIdx.y * p.tiles_m : 0L) + tile_m) * 2 * p.NC;
             bnf_store(ps + n0 + tid, a);
             bnf_store(ps + p.NC + n0 + tid, b);
         }
         // the last row tile (and parity class) of this column tile to arrive finishes the batch norm's reduction (bn_final.h)
-        const int rows_all = p.tiles_m * (MODE == MODE_DGRAD ? (int)gridDim.y : 1);
+        const int rows_all = p.tiles_m * (IS_DGRAD ? (int)gridDim.y : 1);
         bnf_tail<256>(p.fin, p.stats, rows_all, n0, (p.NC - n0 < BN) ? p.NC - n0 : BN, tile_n, (unsigned)rows_all,
                       (int*)(redd + WM * 2 * BN));
         return;
@@ -748,7 +759,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 ? (BM * BN <= 128 * 64 ? 4 : 3) : (
         const int m = m0 + (wm * TM + i) * 32 + li;
         if (m >= p.M) continue;
         long row = (long)m * p.NC;
-        if (MODE == MODE_DGRAD && p.stride > 1) {
+        if (IS_DGRAD && p.stride > 1) {
             const uint32_t ni = p.div_row_hw.div(m);
             const uint32_t rem = m - ni * (p.Hc * p.Wc);
             const uint32_t ya = p.div_row_w.div(rem);

@@ -587,6 +587,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
             for (int j = 0; j < MO; ++j) {
                 f32x4 acc = z;
                 WINO_DOT(acc, TS, WT::AT[j][l_], s[i][l_]);
+                if (MO * ty + i >= H || MO * tx + j >= W) continue;     // a tile that reaches beyond the map: nothing stored or summed
                 const long o = (((long)n * H + MO * ty + i) * W + MO * tx + j) * K + k4 * 4;
                 acc += b;
                 if (add) acc += ld4(add + o);
@@ -679,7 +680,13 @@ __global__ __launch_bounds__(256) void wino_dout_kernel(const float* __restrict_
     for (int j = 0; j < MO; ++j) {
         f32x4 d[MO];
 #pragma unroll
-        for (int i = 0; i < MO; ++i) d[i] = ld4(dy + (((long)n * H + MO * ty + i) * W + MO * tx + j) * K + k4 * 4);
+        for (int i = 0; i < MO; ++i) {
+            // (a tile that reaches beyond the map: those pixels carry no gradient; the address is clamped, the value dropped)
+            const int oy = MO * ty + i, ox = MO * tx + j;
+            const bool in = oy < H && ox < W;
+            const f32x4 v = ld4(dy + (((long)n * H + (in ? oy : 0)) * W + (in ? ox : 0)) * K + k4 * 4);
+            d[i] = in ? v : z;
+        }
 #pragma unroll
         for (int i = 0; i < TS; ++i) {
             f32x4 acc = z;
@@ -738,12 +745,13 @@ struct WinoDims {
 
 int wino_dims(int mo, int N, int H, int W, int C, int K, WinoDims* d) {
     DENET_CHECK_ARG(mo == 2 || mo == 4, "conv_wino: output tile must be 2 or 4 (got %d)", mo);
-    DENET_CHECK_ARG(H % mo == 0 && W % mo == 0 && C % 32 == 0 && K % 32 == 0,
-                    "conv_wino: H, W must be multiples of the tile (%d) and the channel counts multiples of 32", mo);
+    DENET_CHECK_ARG(H > 0 && W > 0 && C % 32 == 0 && K % 32 == 0, "conv_wino: the channel counts must be multiples of 32");
+    // a map that is no multiple of the tile is covered by ceil(H / mo) x ceil(W / mo) tiles: the input side reads zeros beyond the
+    // image (it does so for the halo anyway), the output side drops the pixels beyond it (stores, sums, operand reads)
     d->TS = mo + 2;
     d->NX = d->TS * d->TS;
-    d->TH = H / mo;
-    d->TW = W / mo;
+    d->TH = (H + mo - 1) / mo;
+    d->TW = (W + mo - 1) / mo;
     d->T = (long)N * d->TH * d->TW;
     d->nU = (size_t)d->NX * C * K;
     d->nV = (size_t)d->NX * d->T * C;
@@ -834,7 +842,8 @@ int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u
     // out_sums (with stats): the sums written are the backward reductions of the batch norm whose output gradient `out` is
     BnFoldDev bs = {};
     if (out_sums && stats) bs = *out_sums;
-    if (const int tb4 = denet_wino4f_block(mo, d.T, Cin, Cout))      // products + output transform in one kernel: no M
+    // (the fused kernel's epilogue writes whole 4x4 blocks: maps that are multiples of the tile only)
+    if (const int tb4 = (H % mo == 0 && W % mo == 0) ? denet_wino4f_block(mo, d.T, Cin, Cout) : 0)      // products + output transform in one kernel: no M
         return denet_wino4f_run(tb4, V, U, bias, add, out, stats, bs.x, bs.y, bs.gamma, bs.beta, bs.mean, bs.invstd, bs.relu, N, H, W,
                                 Cin, Cout, relu, stream);
     rc = denet_gemm_batched_nt(V, U, Mx, d.NX, (int)d.T, Cout, Cin, d.T * Cin, kc, d.T * Cout, stream);
@@ -847,9 +856,9 @@ int wino_run(int mo, bool dgrad, const float* in, const float* w, const float* u
 // rows of partial column sums the output side of a pass writes ([rows][2][Kout] doubles), 0 = this pass cannot: the fused
 // F(4x4) kernel leaves one row per tile block, the output transform one per 256 threads (needs 256 % (Kout / 4) == 0)
 int wino_stats_rows(int tile, int N, int H, int W, int Cin, int Kout, size_t stats_bytes) {
-    const long T = (long)N * (H / tile) * (W / tile);
+    const long T = (long)N * ((H + tile - 1) / tile) * ((W + tile - 1) / tile);
     long rows;
-    if (const int tb4 = denet_wino4f_block(tile, T, Cin, Kout)) rows = denet_wino4f_stats_rows(tb4, T);
+    if (const int tb4 = (H % tile == 0 && W % tile == 0) ? denet_wino4f_block(tile, T, Cin, Kout) : 0) rows = denet_wino4f_stats_rows(tb4, T);
     else {
         const int k4n = Kout / 4;
         if (!(k4n > 0 && k4n <= 256 && 256 % k4n == 0)) return 0;
@@ -1013,7 +1022,7 @@ extern "C" int denet_conv_wino_tune(float* workspace, size_t workspace_bytes, fl
 
 extern "C" size_t denet_conv_wino_workspace_bytes(int tile, int N, int H, int W, int C, int K) {
     const size_t nx = (size_t)(tile + 2) * (tile + 2);
-    const size_t T = (size_t)N * (H / tile) * (W / tile);
+    const size_t T = (size_t)N * ((H + tile - 1) / tile) * ((W + tile - 1) / tile);
     return (nx * C * K + nx * T * C + nx * T * K) * sizeof(float);
 }
 

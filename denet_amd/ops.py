@@ -437,7 +437,7 @@ def _conv_wino_fwd_linked(link, g, tile, w, bias, add, out, cache, bn_stats):
     v_keep = None
     if _decided(2, g) == tile:               # the filter gradient of this layer reuses the transformed input
         v_keep = cache.get("V")
-        nv = (tile + 2) * (tile + 2) * (N * (H // tile) * (W // tile)) * C
+        nv = (tile + 2) * (tile + 2) * (N * -(-H // tile) * -(-W // tile)) * C
         if v_keep is None or v_keep.numel() != nv:
             v_keep = cache["V"] = torch.empty(nv, dtype=torch.float32, device="cuda")
         cache["V_tile"] = tile
@@ -473,7 +473,7 @@ def conv_backward_linked(link, x, w, w_shape, add, dw_out, cache, stride=1, pad=
         PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])
     if cache is not None:
         cache["dgrad_tile"] = tile
-    T = N * (H // tile) * (W // tile)
+    T = N * -(-H // tile) * -(-W // tile)
     dm = torch.empty((tile + 2) * (tile + 2) * T * K, dtype=torch.float32, device="cuda")
     dx = empty(N, H, W, C)
     u = _cached_u(cache, 1, tile) if cache is not None else None
@@ -617,7 +617,7 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
             # the filter gradient of this layer uses the same transformed input when it runs with the same tile
             if cache.get("train") and _decided(2, g) == tile:
                 v_keep = cache.get("V")
-                nv = (tile + 2) * (tile + 2) * (N * (H // tile) * (W // tile)) * C
+                nv = (tile + 2) * (tile + 2) * (N * -(-H // tile) * -(-W // tile)) * C
                 if v_keep is None or v_keep.numel() != nv:
                     v_keep = cache["V"] = torch.empty(nv, dtype=torch.float32, device="cuda")
                 cache["V_tile"] = tile
@@ -638,6 +638,7 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
 # once per (pass, geometry) right after the direct kernel has been tuned. DENET_WINOGRAD=0 disables the paths,
 # DENET_WINOGRAD=2 allows only F(2x2,3x3).
 WINOGRAD = int(os.environ.get("DENET_WINOGRAD", "4"))
+WINO_RAGGED = os.environ.get("DENET_WINO_RAGGED", "1") != "0"
 _WINO = {}
 # A third alternative for the 64-input-channel layers: FUSED2, F(2x2,3x3) with the transforms and the products in one kernel
 # (csrc/wino2f.hip). DENET_WINO2F: bit 0 allows it for the forward pass, bit 1 for the data gradient, bit 2 for the filter
@@ -710,11 +711,12 @@ def _time_ms(fn, reps=3):
 
 
 def conv_wino_ok(g, tile=2):
-    """geometry the Winograd F(tile x tile, 3x3) path covers: 3x3, stride 1, pad 1, H/W multiples of the tile,
-    channels multiples of 32"""
+    """geometry the Winograd F(tile x tile, 3x3) path covers: 3x3, stride 1, pad 1, channels multiples of 32. A map that is no
+    multiple of the tile is covered by ceil(H / tile) x ceil(W / tile) tiles (zeros read, results dropped beyond the map: the 14x14 and
+    7x7 maps of ResNet-34 at 224x224 run F(4x4) on 16x16 / 8x8 tile grids); DENET_WINO_RAGGED=0 restores the multiples-only rule"""
     N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
-    return R == 3 and S == 3 and s_real == 3 and stride == 1 and pad == 1 and H % tile == 0 and W % tile == 0 \
-        and C % 32 == 0 and K % 32 == 0
+    return R == 3 and S == 3 and s_real == 3 and stride == 1 and pad == 1 and (WINO_RAGGED or (H % tile == 0 and W % tile == 0)) \
+        and H >= tile and W >= tile and C % 32 == 0 and K % 32 == 0
 
 
 def _wino_tile(mode, g, direct, wino):
@@ -927,7 +929,7 @@ def conv_wino_dgrad(dy, w, add=None, out=None, tile=2, u=None, sums=None, cache=
         return dx
     ws = _wino_ws(tile, N, H, W, C, K)
     if sums is not None:
-        T = N * (H // tile) * (W // tile)
+        T = N * -(-H // tile) * -(-W // tile)
         sb = sums.buffer(cache, (T * (C // 4) + 255) // 256, C)
         with _armed(sums.final) as fin:
             check(_L().denet_conv_wino_dgrad_sums(ptr(dy), ptr(w), ptr(u), ptr(add), ptr(dx), ctypes.byref(so), ptr(sb), sb.numel() * 8,

@@ -20,12 +20,12 @@ from denet_amd import ops  # noqa: E402
 from denet_amd.model import zoo  # noqa: E402
 
 
-def run_configs():
+def run_configs(only=None):
     random.seed(1)
-    for name, build, B, img in [("denet34-skip", lambda: zoo.denet34(32, "skip", 512), 32, 512),
+    for name, build, B, img in [c for c in [("denet34-skip", lambda: zoo.denet34(32, "skip", 512), 32, 512),
                                 ("resnet34", lambda: zoo.resnet34(64, 224), 64, 224),
                                 ("denet101-wide", lambda: zoo.denet101(16, "wide", 512), 16, 512),
-                                ("cifar3", lambda: zoo.cifar3(32), 32, 32)]:
+                                ("cifar3", lambda: zoo.cifar3(32), 32, 32)] if only in (None, c[0])]:
         model = build()
         x, metas = zoo.synthetic_batch(B, img, class_num=model.class_num if model.class_num <= 80 else 80, image_class=True)
         model.build_train_func("nesterov")
@@ -51,13 +51,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join("gpurun_out", "gfx950.json"))
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--only", default=None, help="measure ONE configuration (denet34-skip / resnet34 / denet101-wide / cifar3)")
+    ap.add_argument("--merge-into", default=None,
+                    help="with --only: an existing file whose records of OTHER batch sizes are kept as they are; the measured "
+                         "configuration's convolution records and decisions (batch = its batch size) replace theirs, batched-product "
+                         "records are added where the file has none")
     args = ap.parse_args()
     votes_k, votes_w = collections.defaultdict(list), collections.defaultdict(list)
     for rep in range(args.reps):
         ops._L().denet_tune_clear()
         ops._WINO.clear()
         ops._TUNED.clear()
-        run_configs()
+        run_configs(args.only)
         kern, wino = snapshot()
         for k, v in kern.items():
             votes_k[k].append(v)
@@ -74,6 +79,24 @@ def main():
     ops.check(ops._L().denet_tune_import(flat, len(rec)), "tune_import")
     for k, vs in votes_w.items():
         ops._WINO[k] = collections.Counter(vs).most_common(1)[0][0]
+    if args.merge_into:
+        import json
+        batch = {"denet34-skip": 32, "resnet34": 64, "denet101-wide": 16, "cifar3": 32}[args.only]
+        old = json.load(open(args.merge_into))
+        new_k = {tuple(r[:11]): r[11:] for r in rec}
+        kept = [r for r in old["kernels"] if not (r[0] <= 2 and r[1] == batch)]
+        have = {tuple(r[:11]) for r in kept}
+        add = [list(k) + list(v) for k, v in new_k.items() if (k[0] <= 2 and k[1] == batch) or (k[0] > 2 and k not in have)]
+        wkept = [w for w in old["winograd"] if w[1][0] != batch]
+        wadd = [[m, list(g), t] for (m, g), t in ops._WINO.items() if g[0] == batch]
+        old["kernels"] = sorted(kept + add)
+        old["winograd"] = sorted(wkept + wadd)
+        old.setdefault("meta", {})["merged"] = old["meta"].get("merged", []) + ["%s re-measured (%d reps)" % (args.only, args.reps)]
+        with open(args.out, "w") as f:
+            json.dump(old, f, separators=(",", ":"))
+        print("merged %s into %s -> %s: %d kernel records, %d decisions" % (args.only, args.merge_into, args.out, len(old["kernels"]),
+                                                                            len(old["winograd"])))
+        return
     n = ops.save_tuned(args.out, {"device": torch.cuda.get_device_name(0), "reps": args.reps,
                                   "configs": ["denet34-skip b32 512", "resnet34 b64 224", "denet101-wide b16 512", "cifar3 b32"]})
     unstable = sum(1 for vs in votes_k.values() if len(set(vs)) > 1), sum(1 for vs in votes_w.values() if len(set(vs)) > 1)
