@@ -847,7 +847,7 @@ template <int MODE, int BM, int BN, int WM, int WN, int NBUF = 2>
 int launch_igemm(const IgemmParams& p, int splits, hipStream_t stream) {
     g_last_cfg[0] = MODE; g_last_cfg[1] = BM; g_last_cfg[2] = BN; g_last_cfg[3] = NBUF; g_last_cfg[4] = splits;
     constexpr bool A_KIN = (MODE != MODE_WGRAD);
-    constexpr bool B_KIN = (MODE == MODE_FWD);
+    constexpr bool B_KIN = (MODE == MODE_FWD || MODE == MODE_DGRAD_T);
     constexpr int SZA = A_KIN ? BM * LDK : BK * BM;
     constexpr int SZB = B_KIN ? BN * LDK : BK * BN;
     constexpr size_t lds = NBUF * (size_t)(SZA + SZB) * sizeof(float);
@@ -1470,7 +1470,7 @@ static int conv_fwd_impl(const float* x, const float* w, const float* bias, cons
 
 static int conv_dgrad_impl(const float* dy, const float* w, const float* add, float* dx, const denet_bn_link* sums_of,
                            double* stats, int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH,
-                           int OW, hipStream_t stream);
+                           int OW, hipStream_t stream, bool transposed = false);
 
 extern "C" int denet_conv_dgrad(const float* dy, const float* w, const float* add, float* dx, int N, int H, int W,
                                 int C, int K, int R, int S, int S_real, int stride, int pad, int OH, int OW,
@@ -1494,6 +1494,27 @@ extern "C" int denet_conv_dgrad_sums(const float* dy, const float* w, const floa
     *stats_rows = ok ? (int)rows : 0;
     return conv_dgrad_impl(dy, w, add, dx, ok ? sums_of : nullptr, ok ? stats_partial : nullptr, N, H, W, C, K, R, S, S_real, stride,
                            pad, OH, OW, stream);
+}
+
+// denet_conv_dgrad / denet_conv_dgrad_sums with the filter given transposed: wt [R][S][C][K] = denet_transpose_f32 of w [K][R*S*C]
+// (K rows, R*S*C columns). The filter operand is then reduction-contiguous like the forward pass's (one 16-byte LDS read per
+// fragment instead of four scalar ones); the products and their order are those of denet_conv_dgrad: bit-identical results.
+// sums_of / stats_partial / stats_rows as in denet_conv_dgrad_sums, or all null.
+extern "C" int denet_conv_dgrad_t(const float* dy, const float* wt, const float* add, float* dx, const denet_bn_link* sums_of,
+                                  double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int C, int K,
+                                  int R, int S, int S_real, int stride, int pad, int OH, int OW, hipStream_t stream) {
+    bool ok = false;
+    if (sums_of) {
+        DENET_CHECK_ARG(stats_partial && stats_rows, "conv_dgrad_t: null pointer");
+        DENET_CHECK_ARG(sums_of->x && sums_of->mean && sums_of->invstd && (!sums_of->relu || sums_of->y || (sums_of->gamma && sums_of->beta)),
+                        "conv_dgrad_t: incomplete batch-norm description");
+        const bool geom = stride >= 1 && H % stride == 0 && W % stride == 0;
+        const long rows = geom ? (long)stride * stride * (((long)N * (H / stride) * (W / stride) + 127) / 128) : 0;
+        ok = geom && stats_bytes >= (size_t)rows * 2 * C * sizeof(double);
+        *stats_rows = ok ? (int)rows : 0;
+    }
+    return conv_dgrad_impl(dy, wt, add, dx, ok ? sums_of : nullptr, ok ? stats_partial : nullptr, N, H, W, C, K, R, S, S_real, stride,
+                           pad, OH, OW, stream, true);
 }
 
 // the data gradient of a 1x1 stride-1 convolution as a FORWARD product over the transposed filter wt [C][K]
@@ -1520,7 +1541,7 @@ extern "C" int denet_conv_dgrad_1x1t(const float* dy, const float* wt, const flo
 
 static int conv_dgrad_impl(const float* dy, const float* w, const float* add, float* dx, const denet_bn_link* sums_of,
                            double* stats, int N, int H, int W, int C, int K, int R, int S, int S_real, int stride, int pad, int OH,
-                           int OW, hipStream_t stream) {
+                           int OW, hipStream_t stream, bool transposed) {
     int rc = check_geom(N, H, W, C, K, R, S, S_real, stride, pad, OH, OW);
     if (rc) return rc;
     DENET_CHECK_ARG(dy && w && dx, "conv_dgrad: null pointer");
@@ -1555,6 +1576,23 @@ static int conv_dgrad_impl(const float* dy, const float* w, const float* add, fl
             c.nbuf = tv.nbuf;
         }
         p.tiles_m = (int)tm;
+        if (transposed) {
+            // w is wt [R][S][C][K] (MODE_DGRAD_T): both operands reduction-contiguous, as in the forward pass - whose loop choice
+            // applies (the pipelined two-buffer loop from 24 chunks per parity class on); DENET_DGRAD_T_NBUF / _TILE: experiments
+            static const int env_nbuf = [] { const char* e = getenv("DENET_DGRAD_T_NBUF"); return e ? atoi(e) : 0; }();
+            static const int env_tile = [] { const char* e = getenv("DENET_DGRAD_T_TILE"); return e ? atoi(e) : 0; }();
+            const int per_class = p.ksteps / classes;
+            const int nbuf = env_nbuf ? env_nbuf : (per_class >= 24 ? 2 : 1);
+            const int wide = env_tile ? (env_tile == 1) : (C >= 128 && nbuf == 2 && nb[0] >= 512);
+            if (wide) {
+                p.tiles_n = ceil_div(C, 128);
+                take_final(p, 128, classes);
+                return LAUNCH_NBUF(MODE_DGRAD_T, 128, 128, nbuf, p, classes, stream);
+            }
+            p.tiles_n = ceil_div(C, 64);
+            take_final(p, 64, classes);
+            return LAUNCH_NBUF(MODE_DGRAD_T, 128, 64, nbuf, p, classes, stream);
+        }
         if (tile == 0) {
             p.tiles_n = ceil_div(C, 128);
             take_final(p, 128, classes);

@@ -773,7 +773,7 @@ def wino_prefetch_filters(caches_and_weights, after=None):
     pass on a side stream, right at the start of a training step (the ~60 small launches leave the critical path)."""
     global _SIDE_FILTER
     todo = [(c, w) for c, w in caches_and_weights if c.get("fwd_tile") or c.get("dgrad_tile")]
-    tr = [(c, w) for c, w in caches_and_weights if c.get("dgrad_1x1t")]
+    tr = [(c, w) for c, w in caches_and_weights if c.get("dgrad_1x1t") or c.get("dgrad_t")]
     if not todo and not tr:
         return
     if _SIDE_FILTER is None:
@@ -811,7 +811,8 @@ def wino_prefetch_filters(caches_and_weights, after=None):
         if tr:
             # the transposed filters of the large 1x1 layers' data-gradient products (conv_dgrad)
             for c, w in tr:
-                K, _, _, C = w.shape
+                K = w.shape[0]
+                C = w.numel() // K                 # (R * S * C columns: wt [R][S][C][K] for denet_conv_dgrad_t; [C][K] for a 1x1 layer)
                 ent = c.get("wt")
                 if ent is None or ent[0].numel() != K * C:
                     ent = c["wt"] = [torch.empty(C, K, dtype=torch.float32, device="cuda"), False]
@@ -834,6 +835,12 @@ DGRAD_FIRST_GFLOP = float(os.environ.get("DENET_DGRAD_FIRST_GFLOP", "100"))
 # a 1x1 stride-1 layer whose data-gradient GEMM is at least this large runs it as a forward product over the transposed filter
 # (conv_dgrad; 0 = never)
 DGRAD_1X1T_GFLOP = float(os.environ.get("DENET_DGRAD_1X1T_GFLOP", "100"))
+# OPT-IN (measured no faster): the other implicit-GEMM data gradients (strided 3x3, 1x1 projections, the smaller head layers) over
+# the transposed filter (conv_dgrad -> denet_conv_dgrad_t: the filter operand reduction-contiguous like the forward pass's,
+# bit-identical results). Per launch, alone (tools/exp/per_launch.py): the strided 3x3 layers 352 -> 356 / 228 -> 224 / 202 -> 229 us,
+# the head layers 517 -> 538 / 267 -> 306 us - what holds these launches back is not the filter's fragment reads (short reductions
+# of 4-16 chunks per parity class, the strided gather of dy), so the default stays the k-major mode
+DGRAD_T = os.environ.get("DENET_DGRAD_T", "0") != "0"
 
 
 class wgrad_stream:
@@ -1021,6 +1028,28 @@ def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None,
         cache["dgrad_tile"] = 0
     if PROFILE is not None:
         PROFILE.add(_conv_flops(g, logical))
+    if DGRAD_T and g[3] % 32 == 0 and g[4] % 32 == 0:
+        # the implicit-GEMM data gradient over the TRANSPOSED filter wt [R][S][C][K] (denet_conv_dgrad_t: the filter operand
+        # reduction-contiguous like the forward pass's; same products in the same order, bit-identical). The transposed copy comes
+        # from the side stream (wino_prefetch_filters) when a training step prepared it
+        import ctypes
+        N, H, W, C, K = g[0], g[1], g[2], g[3], g[4]
+        wt = _cached_wt(cache)
+        if wt is None:
+            wt = _transpose(w, K, w.numel() // K)
+        if cache is not None:
+            cache["dgrad_t"] = True
+        rows = ctypes.c_int(0)
+        sb = so = None
+        if sums is not None and (int(BWD_SUMS) & 2) and g[1] % g[8] == 0 and g[2] % g[8] == 0:
+            sb = sums.buffer(cache, (N * H * W + 127) // 128 + g[8] * g[8], C)
+            so = sums.c_struct()
+        with _armed(sums.final if sb is not None else None) as fin:
+            check(_L().denet_conv_dgrad_t(ptr(dy), ptr(wt), ptr(add), ptr(dx), ctypes.byref(so) if so is not None else None, ptr(sb),
+                                          sb.numel() * 8 if sb is not None else 0, ctypes.byref(rows), *g, stream_ptr()), "conv_dgrad_t")
+        if sb is not None:
+            sums.done(sb, rows.value, fin)
+        return dx
     if sums is not None and (int(BWD_SUMS) & 2) and g[1] % g[8] == 0 and g[2] % g[8] == 0:
         # the epilogue of the implicit-GEMM kernel leaves the batch norm's backward reductions behind as well (a row of sums per
         # row tile, and per parity class of input pixels when the layer strides)

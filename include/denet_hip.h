@@ -232,6 +232,12 @@ int denet_conv_dgrad_sums(const float* dy, const float* w, const float* add, flo
  * TRANSPOSED filter wt [C][K] (denet_transpose_f32 of w [K][C]): dx [N][H][W][C] = dy [N][H][W][K] . wt^T (+ add). The forward
  * loop reads both operands reduction-contiguous: 118 -> 137 TFLOP/s on the 4736 <- 1536 head layer; bit-identical to
  * denet_conv_dgrad. sums_of / stats_partial / stats_rows as in denet_conv_dgrad_sums, or all null.                    */
+/* denet_conv_dgrad / _sums with the filter TRANSPOSED, wt [R][S][C][K] (denet_transpose_f32(w, wt, K, R*S*C)): the same products in
+ * the same order (bit-identical), the filter operand reduction-contiguous like the forward pass's. tensor.grad w.r.t. the input
+ * of conv2d, model_cnn.py:318 / convolution.py:80-83. sums_of / stats_partial / stats_rows as in denet_conv_dgrad_sums, or null. */
+int denet_conv_dgrad_t(const float* dy, const float* wt, const float* add, float* dx, const denet_bn_link* sums_of,
+                       double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int C, int K, int R, int S,
+                       int S_real, int stride, int pad, int OH, int OW, hipStream_t stream);
 int denet_conv_dgrad_1x1t(const float* dy, const float* wt, const float* add, float* dx, const denet_bn_link* sums_of,
                           double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int C, int K,
                           hipStream_t stream);

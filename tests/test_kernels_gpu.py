@@ -668,6 +668,71 @@ def test_data_gradient_pass_leaves_the_batch_norm_backward_sums(hip, path, relu,
         ops.BWD_SUMS = saved[1]
 
 
+@pytest.mark.parametrize("case", [
+    # N, H, W, C, K, R, stride, pad, add, sums
+    (4, 32, 32, 64, 128, 3, 2, 1, True, True),       # strided 3x3 (first convolution of a stage): four parity classes, 1..4 taps
+    (4, 32, 32, 64, 128, 1, 2, 0, False, True),      # strided 1x1 projection
+    (2, 24, 24, 1536, 1024, 1, 1, 0, False, True),   # a head layer below the 1x1t threshold: pipelined 128x128 tile
+    (3, 20, 20, 96, 160, 3, 1, 1, True, False),      # 3x3 stride 1 on the direct kernel, ragged tiles in every dimension
+    (2, 16, 16, 256, 512, 3, 2, 1, False, False),
+])
+def test_data_gradient_over_the_transposed_filter_is_bit_identical(hip, case):
+    """denet_conv_dgrad_t (igemm MODE_DGRAD_T: the filter operand wt [R][S][C][K] reduction-contiguous, ops.DGRAD_T) against
+    denet_conv_dgrad / denet_conv_dgrad_sums on the same tensors: same products in the same order - the gradient (with and without
+    an earlier contribution) and the batch norm's backward sums bit for bit, from a prepared transposed copy and from the call's own;
+    and against fp64. Reference op: tensor.grad w.r.t. the input of conv2d (model_cnn.py:318, convolution.py:80-83)."""
+    from denet_amd import ops
+    N, H, W, C, K, R, stride, pad, with_add, with_sums = case
+    g = torch.Generator().manual_seed(17)
+    OH = (H + 2 * pad - R) // stride + 1
+    dy = torch.randn(N, OH, OH, K, generator=g).cuda()
+    w = (torch.randn(K, R, R, C, generator=g) * 0.05).cuda()
+    addt = torch.randn(N, H, W, C, generator=g).cuda() if with_add else None
+    x = (torch.randn(N, H, W, C, generator=g) * 1.5 + 0.3).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    y, sm, si = ops.bn_fwd_train(x, gamma, beta, torch.zeros(C).cuda(), torch.ones(C).cuda(), relu=True)
+    saved = (ops.DGRAD_T, ops.BWD_SUMS, dict(ops._WINO), ops.DGRAD_1X1T_GFLOP, ops.POLICY)
+    out = {}
+    try:
+        ops.BWD_SUMS = 3
+        ops.DGRAD_1X1T_GFLOP = 0.0
+        ops.POLICY = lambda mode, geom: 0            # the direct kernels (no Winograd pass, nothing measured)
+        for mode in ("plain", "transposed", "prepared"):
+            ops.DGRAD_T = mode != "plain"
+            ops._WINO.clear()
+            sums = ops.BnSums(x, None, gamma, beta, sm, si, True) if with_sums else None
+            cache = {"train": True}
+            if mode == "prepared":
+                cache["dgrad_t"] = True
+                ops.wino_prefetch_filters([(cache, w)])
+                assert cache["wt"][1]
+            dx = ops.conv_dgrad(dy, w, (N, H, W, C), add=addt, stride=stride, pad=pad, cache=cache, sums=sums)
+            assert ops._last_igemm_name().startswith("igemm_kernel<%d," % (1 if mode == "plain" else 3)), ops._last_igemm_name()
+            if mode == "prepared":
+                assert not cache["wt"][1]
+            if with_sums:
+                assert sums.partial is not None
+                la, _ = ops.bn_bwd_link(x, None, dx, gamma, sm, si, relu=True, beta=beta, pre=sums.partial)
+                out[mode] = (dx.clone(), la.coef.clone())
+            else:
+                out[mode] = (dx.clone(),)
+    finally:
+        ops.DGRAD_T, ops.BWD_SUMS, ops.DGRAD_1X1T_GFLOP, ops.POLICY = saved[0], saved[1], saved[3], saved[4]
+        ops._WINO.clear()
+        ops._WINO.update(saved[2])
+    for mode in ("transposed", "prepared"):
+        for a, b in zip(out[mode], out["plain"]):
+            assert torch.equal(a, b), "%s: differs from denet_conv_dgrad" % mode
+    # fp64: dx = conv_transpose of dy with the (already flipped, KRSC) filter
+    import torch.nn.functional as Fn
+    w64 = w.double().permute(0, 3, 1, 2).contiguous()                     # [K][C][R][S]
+    ref = Fn.conv_transpose2d(dy.double().permute(0, 3, 1, 2), w64, stride=stride, padding=pad,
+                              output_padding=(H + 2 * pad - R) % stride).permute(0, 2, 3, 1)
+    if with_add:
+        ref = ref + addt.double()
+    _close(out["transposed"][0], ref.float(), rtol=2e-5)
+
+
 @pytest.mark.parametrize("case", [(2, 12, 12, 448, 160, False, False), (2, 12, 12, 256, 96, True, False), (3, 8, 8, 160, 256, True, True),
                                   (1, 5, 7, 96, 64, False, True)])
 def test_data_gradient_of_a_1x1_layer_over_the_transposed_filter(hip, case):
@@ -684,10 +749,11 @@ def test_data_gradient_of_a_1x1_layer_over_the_transposed_filter(hip, case):
     x = (torch.randn(N, H, W, C, generator=g) * 1.5 + 0.3).cuda()
     gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
     y, sm, si = ops.bn_fwd_train(x, gamma, beta, torch.zeros(C).cuda(), torch.ones(C).cuda(), relu=True)
-    saved = (ops.DGRAD_1X1T_GFLOP, ops.BWD_SUMS, dict(ops._WINO))
+    saved = (ops.DGRAD_1X1T_GFLOP, ops.BWD_SUMS, dict(ops._WINO), ops.DGRAD_T)
     out = {}
     try:
         ops.BWD_SUMS = 3
+        ops.DGRAD_T = False                 # "plain" = denet_conv_dgrad itself (the k-major filter reads)
         for mode in ("plain", "transposed", "prepared"):
             ops.DGRAD_1X1T_GFLOP = 0.0 if mode == "plain" else 1e-9
             sums = ops.BnSums(x, None, gamma, beta, sm, si, True) if with_sums else None
@@ -709,6 +775,7 @@ def test_data_gradient_of_a_1x1_layer_over_the_transposed_filter(hip, case):
                 out[mode] = (dx.clone(),)
     finally:
         ops.DGRAD_1X1T_GFLOP, ops.BWD_SUMS = saved[:2]
+        ops.DGRAD_T = saved[3]
         ops._WINO.clear()
         ops._WINO.update(saved[2])
     ref = torch.einsum("nhwk,kc->nhwc", dy.double(), w[:, 0, 0, :].double())
