@@ -421,8 +421,8 @@ def main():
     # ---- self-audit: WHICH kernels the timed steps ran, layer by layer, and under which switches (one more step outside the
     # timed region; the C side notes the instantiation of every matrix-kernel launch, no events, no effect on streams) ----
     out["config"]["denet_switches"] = audit.active_switches()          # DENET_* environment switches: {} is the product default
-    out["config"]["product_default_switches"] = not [k for k in out["config"]["denet_switches"] if k not in ("DENET_FORCE_DP",
-                                                                                                             "DENET_BENCH_SHARE_GPU")]
+    from denet_amd import switches
+    out["config"]["product_default_switches"] = not switches.changes_kernels(out["config"]["denet_switches"])
     out["config"]["tuned_file"] = os.path.relpath(ops.TUNE_CACHE, os.path.dirname(os.path.abspath(__file__))) if ops._TUNE_LOADED else None
     if not args.no_audit:       # (every rank: the step holds collectives when the job is data parallel)
         out["config"]["passes_measured_in_the_warmup"] = undecided       # 0: every implementation came from the committed file

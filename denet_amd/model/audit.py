@@ -114,5 +114,7 @@ class KernelAudit:
 
 
 def active_switches():
-    """the DENET_* environment switches set in this process (they change which kernels run; the product default is none)"""
-    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("DENET_")}
+    """the DENET_* environment switches set in this process (denet_amd/switches.py lists all of them with their defaults; the
+    product default is none set)"""
+    from .. import switches
+    return switches.active()

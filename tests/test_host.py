@@ -751,3 +751,24 @@ def test_desc_grammar_matches_the_executed_reference_parser():
     finally:
         for m, name, cls in patched:
             setattr(m, name, cls)
+
+
+def test_every_environment_switch_is_registered():
+    """denet_amd/switches.py lists every DENET_* environment switch the sources read (Python: os.environ.get, C++: getenv), with its
+    default - the one place that says what the product default is; bench.py reports the switches a run was taken with against it"""
+    import re
+    from denet_amd import switches
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = set()
+    for base in ("denet_amd", "tests", "bench.py", "__graft_entry__.py"):
+        path = os.path.join(root, base)
+        files = [path] if os.path.isfile(path) else [os.path.join(d, f) for d, _, fs in os.walk(path) for f in fs
+                                                      if f.endswith((".py", ".hip", ".h")) and "native" not in d]
+        for f in files:
+            with open(f, errors="ignore") as fh:
+                found |= set(re.findall(r'(?:getenv\(|environ\.get\(|environ\[)"(DENET_[A-Z0-9_]+)"', fh.read()))
+    missing = sorted(found - set(switches.SWITCHES))
+    assert not missing, "switches read by the sources but not listed in denet_amd/switches.py: %s" % missing
+    stale = sorted(k for k in switches.SWITCHES if k not in found)
+    assert not stale, "listed switches nothing reads any more: %s" % stale
+    assert switches.changes_kernels({"DENET_WINO4F": "0"}) and not switches.changes_kernels({"DENET_BUILD_JOBS": "2", "DENET_FORCE_DP": "1"})
