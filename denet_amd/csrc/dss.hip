@@ -148,94 +148,101 @@ __global__ __launch_bounds__(256) void sparse_fwd_kernel(const float* __restrict
 // The reference scatters with atomicAdd (denet_sparse_op.py:171-212); here the (roi, tap) slots that sampled a cell are
 // listed per cell in ASCENDING SLOT ORDER and summed in that order: deterministic, no floating-point atomics.
 // A slot is s = roi * ntap + tap (n = rois_per_image * ntap per image); slots are cut into chunks of SORT_CHUNK; one
-// wave owns one chunk (B x nchunk waves fill the chip - the per-image LDS bitonic sort this replaces ran on B workgroups):
+// workgroup owns one chunk (B x nchunk of them fill the chip - the per-image LDS bitonic sort this replaces ran on B workgroups):
 //   sparse_count    chunk histogram over the cells (LDS integer atomics)         -> table[b][chunk][cell]
-//   sparse_offsets  per (image, 256-cell slab): cell totals, exclusive scan -> cell_start[b][0..HW]; table becomes the
-//                   first output position of (chunk, cell)
-//   sparse_scatter  the wave walks its chunk in slot order, 64 slots at a time; the lanes holding the same cell are
+//   sparse_offsets  thread per (image, cell): the cell's slots in the chunks in front of each chunk -> table_pos, its total
+//   sparse_scan     workgroup per image: exclusive scan of the cell totals -> cell_start[b][0..HW]
+//   sparse_scatter  one wave walks the chunk in slot order, 64 slots at a time; the lanes holding the same cell are
 //                   found with one ballot per key bit (no match-any instruction on gfx950), a lane's rank among them is
 //                   a popcount below its lane id, the lowest lane advances the cell's LDS cursor: stable by construction
 constexpr int SORT_CHUNK = 2048;
 
-__global__ __launch_bounds__(64) void sparse_count_kernel(const int* __restrict__ taps, int* __restrict__ table, int n,
-                                                          int HW, int nchunk) {
+// workgroup (chunk, image), four waves: the histogram's 4 HW bytes of LDS are cleared and written out by all of them (one wave
+// took 2 x HW / 64 dependent rounds for it: 1.2 ms on the 128 x 128 map of DeNet-101 wide)
+__global__ __launch_bounds__(256) void sparse_count_kernel(const int* __restrict__ taps, int* __restrict__ table, int n,
+                                                           int HW, int nchunk) {
     extern __shared__ int s_hist[];
     const int b = blockIdx.y, chunk = blockIdx.x;
-    for (int c = threadIdx.x; c < HW; c += 64) s_hist[c] = 0;
+    for (int c = threadIdx.x; c < HW; c += 256) s_hist[c] = 0;
     __syncthreads();
     const int lo = chunk * SORT_CHUNK, hi = min(n, lo + SORT_CHUNK);
     const int* t = taps + (long)b * n;
-    for (int i = lo + threadIdx.x; i < hi; i += 64) atomicAdd(&s_hist[t[i]], 1);
+    for (int i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&s_hist[t[i]], 1);
     __syncthreads();
     int* row = table + ((long)b * nchunk + chunk) * HW;
-    for (int c = threadIdx.x; c < HW; c += 64) row[c] = s_hist[c];
+    for (int c = threadIdx.x; c < HW; c += 256) row[c] = s_hist[c];
 }
 
-// workgroup (slab, image): the 256 cells [256 slab, 256 slab + 256) of one image. base = number of slots in the cells in
-// front of the slab (recomputed from the table by every workgroup: coalesced, a few thousand loads), then a block scan of
-// the slab's own cell totals; table_pos[chunk][cell] = first output position of (chunk, cell)
+// thread (image, cell): the cell's slots in the chunks in front of chunk k -> table_pos[k][cell]; the cell's total -> cell_start
+// (sparse_scan_kernel turns the totals into starts)
 __global__ __launch_bounds__(256) void sparse_offsets_kernel(const int* __restrict__ table, int* __restrict__ table_pos,
-                                                            int* __restrict__ cell_start, int HW, int nchunk, int n) {
-    __shared__ int s_red[256];
-    const int b = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x;
-    const int* tb = table + (long)b * nchunk * HW;
-    int* tp = table_pos + (long)b * nchunk * HW;       // a second table: other workgroups still read the counts
-    int before = 0;
+                                                            int* __restrict__ cell_start, int HW, int nchunk) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= HW) return;
+    const int* tb = table + (long)b * nchunk * HW + c;
+    int* tp = table_pos + (long)b * nchunk * HW + c;
+    int run = 0;
     for (int k = 0; k < nchunk; ++k) {
-        const int* row = tb + (long)k * HW;
-        for (int c = tid; c < slab * 256; c += 256) before += row[c];
+        const int cnt = tb[(long)k * HW];
+        tp[(long)k * HW] = run;
+        run += cnt;
     }
-    const int c = slab * 256 + tid;
-    int tot = 0;
-    if (c < HW)
-        for (int k = 0; k < nchunk; ++k) tot += tb[(long)k * HW + c];
-    // block sum of `before`, inclusive block scan of `tot`
-    s_red[tid] = before;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if (tid < st) s_red[tid] += s_red[tid + st];
-        __syncthreads();
-    }
-    const int base = s_red[0];
-    __syncthreads();
-    s_red[tid] = tot;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const int v = (tid >= off) ? s_red[tid - off] : 0;
-        __syncthreads();
-        s_red[tid] += v;
-        __syncthreads();
-    }
-    int pos = base + s_red[tid] - tot;
-    int* cs = cell_start + (long)b * (HW + 1);
-    if (c < HW) {
-        cs[c] = pos;
-        for (int k = 0; k < nchunk; ++k) {
-            const int cnt = tb[(long)k * HW + c];
-            tp[(long)k * HW + c] = pos;
-            pos += cnt;
-        }
-    }
-    if (slab == gridDim.x - 1 && tid == 0) cs[HW] = n;
+    cell_start[(long)b * (HW + 1) + c] = run;
 }
 
-__global__ __launch_bounds__(64) void sparse_scatter_kernel(const int* __restrict__ taps, const int* __restrict__ table,
-                                                            int* __restrict__ order, int n, int HW, int nchunk,
-                                                            int key_bits) {
+// workgroup per image: cell_start[0..HW) from totals to their exclusive prefix sums, cell_start[HW] = n
+__global__ __launch_bounds__(1024) void sparse_scan_kernel(int* __restrict__ cell_start, int HW, int n) {
+    __shared__ int s_wave[16];
+    __shared__ int s_carry;
+    int* cs = cell_start + (long)blockIdx.x * (HW + 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < HW; c0 += 1024) {
+        const int c = c0 + tid;
+        const int v = c < HW ? cs[c] : 0;
+        int inc = v;                                    // inclusive scan over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int u = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += u;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        int before = s_carry;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        if (c < HW) cs[c] = before + inc - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = before + inc;
+        __syncthreads();
+    }
+    if (tid == 0) cs[HW] = n;
+}
+
+// workgroup (chunk, image): all four waves fill the chunk's cursors (first output position of (chunk, cell)), wave 0 then walks
+// the chunk in slot order
+__global__ __launch_bounds__(256) void sparse_scatter_kernel(const int* __restrict__ taps, const int* __restrict__ table,
+                                                             const int* __restrict__ cell_start, int* __restrict__ order,
+                                                             int n, int HW, int nchunk, int key_bits) {
     extern __shared__ int s_cur[];
-    const int b = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.y, chunk = blockIdx.x, lane = threadIdx.x & 63;
     const int lo = chunk * SORT_CHUNK, hi = min(n, lo + SORT_CHUNK);
     const int* t = taps + (long)b * n;
     // the whole chunk's cells first: SORT_CHUNK / 64 independent loads in flight per lane (the walk below is serial)
     int cells[SORT_CHUNK / 64];
+    if (threadIdx.x < 64) {
 #pragma unroll
-    for (int r = 0; r < SORT_CHUNK / 64; ++r) {
-        const int i = lo + r * 64 + lane;
-        cells[r] = (i < hi) ? t[i] : 0;
+        for (int r = 0; r < SORT_CHUNK / 64; ++r) {
+            const int i = lo + r * 64 + lane;
+            cells[r] = (i < hi) ? t[i] : 0;
+        }
     }
     const int* row = table + ((long)b * nchunk + chunk) * HW;
-    for (int c = lane; c < HW; c += 64) s_cur[c] = row[c];
+    const int* cs = cell_start + (long)b * (HW + 1);
+    for (int c = threadIdx.x; c < HW; c += 256) s_cur[c] = cs[c] + row[c];
     __syncthreads();
+    if (threadIdx.x >= 64) return;
     int* o = order + (long)b * n;
     const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
@@ -678,12 +685,13 @@ extern "C" int denet_sparse_sort(const int* taps, void* sort_ws, size_t sort_ws_
         DENET_CHECK_LAUNCH("sparse_sort");
         return DENET_OK;
     }
-    hipLaunchKernelGGL(sparse_count_kernel, dim3(L.nchunk, B), dim3(64), lds, stream, taps, table, L.n, L.HW, L.nchunk);
+    hipLaunchKernelGGL(sparse_count_kernel, dim3(L.nchunk, B), dim3(256), lds, stream, taps, table, L.n, L.HW, L.nchunk);
     int* table_pos = table + (size_t)B * L.nchunk * L.HW;
     hipLaunchKernelGGL(sparse_offsets_kernel, dim3((L.HW + 255) / 256, B), dim3(256), 0, stream, table, table_pos, cell_start,
-                       L.HW, L.nchunk, L.n);
-    hipLaunchKernelGGL(sparse_scatter_kernel, dim3(L.nchunk, B), dim3(64), lds, stream, taps, table_pos, order, L.n, L.HW,
-                       L.nchunk, L.key_bits);
+                       L.HW, L.nchunk);
+    hipLaunchKernelGGL(sparse_scan_kernel, dim3(B), dim3(1024), 0, stream, cell_start, L.HW, L.n);
+    hipLaunchKernelGGL(sparse_scatter_kernel, dim3(L.nchunk, B), dim3(256), lds, stream, taps, table_pos, cell_start, order, L.n,
+                       L.HW, L.nchunk, L.key_bits);
     DENET_CHECK_LAUNCH("sparse_sort");
     return DENET_OK;
 }

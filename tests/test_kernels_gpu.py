@@ -1136,7 +1136,8 @@ def test_sparse_bwd_summation_order(hip, Fc):
     assert most > 128                                                  # more than two chunks of slots on one cell
 
 
-@pytest.mark.parametrize("case", [(32, 64, 64, 576, 7), (3, 20, 36, 100, 5), (2, 128, 128, 2304, 7), (1, 9, 7, 3000, 2)])
+@pytest.mark.parametrize("case", [(32, 64, 64, 576, 7), (3, 20, 36, 100, 5), (2, 128, 128, 2304, 7), (1, 9, 7, 3000, 2),
+                                  (2, 90, 77, 1500, 7), (1, 33, 31, 30000, 3)])
 def test_sparse_tap_counting_sort(hip, case):
     """the grouping of the (roi, tap) slots by cell that the gather gradient sums over (replaces the reference's atomicAdd
     scatter, denet_sparse_op.py:171-212): per image it must be exactly the STABLE sort of the tap list by cell - every
