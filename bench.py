@@ -344,12 +344,16 @@ def main():
     dns_layer = [l for l in model.layers if l.type_name == "denet-sparse"][0]
     dns_layer.proposed_total = dns_layer.proposed_steps = 0
     dns_layer.handoff_modes = {k: 0 for k in dns_layer.handoff_modes}
+    import gc
+    gc.collect()
+    gc.disable()      # no collector pause of the host thread inside the timed region (a full collection is milliseconds)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         cost, _ = model.train_step(xd, metas, 0, it, lr, mom, decay)
         it += 1
     sync()
     dt_rank = dt = time.perf_counter() - t0
+    gc.enable()
     # what the corner detector did during the timed steps: as initialised it is silent (bias +5), but the corner cost (factor 100,
     # lr 0.1) has it firing within the warm-up steps and cooling down over the next ~30 - the timed steps see a detector that
     # proposes, and the RoI lists are trimmed by random.sample
