@@ -1,7 +1,13 @@
 #!/bin/bash
-# A/B of one environment switch inside the training step, interleaved on ONE box: bash tools/exp/ab_env.sh DENET_WINO4G 0 1
-VAR=$1; shift
-for rep in 1 2; do for v in "$@"; do env $VAR=$v python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-warm --no-split-bf16 --no-configs --no-dp-selftest 2>&1 | grep "^{" | python -c "
-import sys, json
-d = json.loads(sys.stdin.read()); a = d['roofline']['all_igemm']
-print('$VAR=$v', d['value'], d['ms_per_step'], {k: (v['ms_per_step'], v['tflops']) for k, v in a.items() if 'wino4' in k or k.startswith('igemm_kernel<2, 128, 128, 2, 2, 1')})"; done; done
+# A / B of environment settings on the headline leg: bash tools/exp/ab_env.sh "VAR=a" "VAR=b" [pairs]
+A="$1"; B="$2"; N=${3:-4}
+CMD="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-warm --no-split-bf16 --no-configs --no-dp-selftest --no-h2d --no-instep --no-audit --no-roofline"
+val() { python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        print(json.loads(l)['value'])
+"; }
+for i in $(seq 1 $N); do
+  echo "A[$A] $(env $A $CMD 2>/dev/null | val)   B[$B] $(env $B $CMD 2>/dev/null | val)"
+done
