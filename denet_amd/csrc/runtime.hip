@@ -2,6 +2,7 @@
 // PyErr_Format + %(fail)s (denet_sparse_op.py:137-142); here every entry point returns an int status and
 // leaves a thread-local message behind.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 #include <stdarg.h>
 #include <math.h>
@@ -159,9 +160,18 @@ extern "C" int denet_host_py_random_sample(uint32_t* mt, int* pos, int n, int k,
     return py_random_sample_from(src, n, k, pool_ws, out);
 }
 
+// the same on a prefetched stretch, written without a data-dependent branch: _randbelow's rejection loop ("draw again while the
+// value is not below m") is taken or not with a probability of up to one half, and every wrong guess of the branch predictor costs
+// more than the rest of the draw - the RoI hand-off spends most of its host time here while the device stands idle. One iteration
+// per OUTPUT: the value is taken (pool entry out, last entry in, i + 1) or not (a dummy slot is written, i stays) by selects.
+static int py_random_sample_stream(MtStream& src, int n, int k, int* pool_ws, int* out);
+
 template <class Src>
 static int py_random_sample_from(Src& src, int n, int k, int* pool_ws, int* out) {
     DENET_CHECK_ARG(n > 0 && k >= 0 && k <= n, "py_random_sample: need 0 <= k <= n");
+    if constexpr (std::is_same<Src, MtStream>::value) {
+        if (src.ok()) return py_random_sample_stream(src, n, k, pool_ws, out);
+    }
     // setsize of random.sample (CPython Lib/random.py): 21, plus 4**ceil(log(3k, 4)) when k > 5
     long setsize = 21;
     if (k > 5) {
@@ -181,6 +191,41 @@ static int py_random_sample_from(Src& src, int n, int k, int* pool_ws, int* out)
         out[i] = pool_ws[r];
         pool_ws[r] = pool_ws[n - i - 1];
     }
+    return DENET_OK;
+}
+
+static int py_random_sample_stream(MtStream& src, int n, int k, int* pool_ws, int* out) {
+    long setsize = 21;
+    if (k > 5) {
+        long p = 1;
+        while (p < 3L * k) p *= 4;
+        setsize += p;
+    }
+    DENET_CHECK_ARG(n <= setsize, "py_random_sample: the set-based branch of random.sample is not provided (n=%d k=%d)", n, k);
+    for (int i = 0; i < n; ++i) pool_ws[i] = i;
+    const uint32_t* const o = src.out;
+    long cur = src.cursor;
+    const long end = src.n;
+    int dummy = 0;
+    int i = 0;
+    while (i < k && cur < end) {
+        // m = n - i keeps its bit length while it stays >= 2^(bits - 1): the shift is constant over the segment
+        const int bits = 32 - __builtin_clz((uint32_t)(n - i));
+        const int sh = 32 - bits;
+        const long seg = (long)n - (1L << (bits - 1)) + 1;
+        const int seg_end = seg < k ? (int)seg : k;
+        while (i < seg_end && cur < end) {
+            const uint32_t r = o[cur++] >> sh;
+            const uint32_t m = (uint32_t)(n - i);
+            const bool take = r < m;
+            int* const slot = take ? pool_ws + r : &dummy;
+            out[i] = *slot;                     // (not taken: overwritten by the draw that is)
+            *slot = pool_ws[m - 1];
+            i += take ? 1 : 0;
+        }
+    }
+    src.cursor = cur;
+    if (i < k) src.good = false;          // the stretch ran dry inside the selection: the caller redoes the batch on the live generator
     return DENET_OK;
 }
 
@@ -323,9 +368,12 @@ extern "C" int denet_host_handoff_stream(const uint32_t* stream, long n_stream, 
 // packed proposal's integer boxes - the same selection (random.sample on the same outputs), the same random boxes, the same
 // float32 values as denet_host_handoff_stream writes, without the score arithmetic (expf) and the double-precision lists, which
 // the caller produces later with that call from the same cursor (nothing has been consumed for good: *cursor is its own copy).
-extern "C" int denet_host_handoff_boxes_stream(const uint32_t* stream, long n_stream, long* cursor, int* exhausted,
-                                               const int* box_host, const int* count_host, int H, int W, int B, int S, int n_keep,
-                                               const double* gt, const int* gt_off, int sample_gt, int* ws, float* out_box_f32) {
+// uniforms_host (may be null): uniforms_host[p] = the double random.random() returns when it starts at output p of the stretch
+// (denet_host_mt_uniforms, computed ahead like the stretch itself): the random boxes then cost four table reads each
+extern "C" int denet_host_handoff_boxes_stream_u(const uint32_t* stream, long n_stream, long* cursor, int* exhausted,
+                                                 const int* box_host, const int* count_host, int H, int W, int B, int S, int n_keep,
+                                                 const double* gt, const int* gt_off, int sample_gt, int* ws, float* out_box_f32,
+                                                 const double* uniforms_host) {
 #pragma clang fp contract(off)
     DENET_CHECK_ARG(stream && cursor && exhausted && *cursor >= 0 && *cursor <= n_stream, "handoff_boxes_stream: bad stream arguments");
     DENET_CHECK_ARG(box_host && count_host && ws && out_box_f32, "handoff_boxes_stream: null pointer");
@@ -351,21 +399,52 @@ extern "C" int denet_host_handoff_boxes_stream(const uint32_t* stream, long n_st
             if (!src.ok()) break;
             n = n_keep;
         }
+        unsigned bad = 0;
         for (int i = 0; i < n; ++i) {
             const int* r = bx + (size_t)(trim ? pick[i] : i) * 4;
-            DENET_CHECK_ARG((unsigned)r[0] <= (unsigned)W && (unsigned)r[2] <= (unsigned)W && (unsigned)r[1] <= (unsigned)H &&
-                            (unsigned)r[3] <= (unsigned)H, "handoff_boxes_stream: box outside the map");
-            f[i * 4 + 0] = tw[r[0]];
-            f[i * 4 + 1] = th[r[1]];
-            f[i * 4 + 2] = tw[r[2] + 1];
-            f[i * 4 + 3] = th[r[3] + 1];
+            bad |= (unsigned)((unsigned)r[0] > (unsigned)W) | (unsigned)((unsigned)r[2] > (unsigned)W) |
+                   (unsigned)((unsigned)r[1] > (unsigned)H) | (unsigned)((unsigned)r[3] > (unsigned)H);
+            // (an index beyond the tables is clamped here and reported behind the loop)
+            f[i * 4 + 0] = tw[(unsigned)r[0] > 256u ? 256 : r[0]];
+            f[i * 4 + 1] = th[(unsigned)r[1] > 256u ? 256 : r[1]];
+            f[i * 4 + 2] = tw[((unsigned)r[2] > 256u ? 256 : r[2]) + 1];
+            f[i * 4 + 3] = th[((unsigned)r[3] > 256u ? 256 : r[3]) + 1];
         }
-        for (int i = n; i < S; ++i) {
-            const double x0 = 0.0 + (1.0 - 0.0) * mt_random(src);
-            const double y0 = 0.0 + (1.0 - 0.0) * mt_random(src);
-            const double x1 = x0 + (1.0 - x0) * mt_random(src);
-            const double y1 = y0 + (1.0 - y0) * mt_random(src);
-            f[i * 4 + 0] = (float)x0; f[i * 4 + 1] = (float)y0; f[i * 4 + 2] = (float)x1; f[i * 4 + 3] = (float)y1;
+        DENET_CHECK_ARG(!bad, "handoff_boxes_stream: box outside the map");
+        const long need = 8L * (S - n);
+        if (src.cursor + need <= src.n) {
+            // the whole image's random boxes lie inside the stretch: no per-output bounds test (and table reads with `uniforms_host`)
+            const long c0 = src.cursor;
+            if (uniforms_host) {
+                const double* u = uniforms_host + c0;
+                for (int i = n; i < S; ++i, u += 8) {
+                    const double x0 = 0.0 + (1.0 - 0.0) * u[0];
+                    const double y0 = 0.0 + (1.0 - 0.0) * u[2];
+                    const double x1 = x0 + (1.0 - x0) * u[4];
+                    const double y1 = y0 + (1.0 - y0) * u[6];
+                    f[i * 4 + 0] = (float)x0; f[i * 4 + 1] = (float)y0; f[i * 4 + 2] = (float)x1; f[i * 4 + 3] = (float)y1;
+                }
+            } else {
+                const uint32_t* o = stream + c0;
+                for (int i = n; i < S; ++i, o += 8) {
+                    double u[4];
+                    for (int q = 0; q < 4; ++q) u[q] = ((o[2 * q] >> 5) * 67108864.0 + (o[2 * q + 1] >> 6)) * (1.0 / 9007199254740992.0);
+                    const double x0 = 0.0 + (1.0 - 0.0) * u[0];
+                    const double y0 = 0.0 + (1.0 - 0.0) * u[1];
+                    const double x1 = x0 + (1.0 - x0) * u[2];
+                    const double y1 = y0 + (1.0 - y0) * u[3];
+                    f[i * 4 + 0] = (float)x0; f[i * 4 + 1] = (float)y0; f[i * 4 + 2] = (float)x1; f[i * 4 + 3] = (float)y1;
+                }
+            }
+            src.cursor = c0 + need;
+        } else {
+            for (int i = n; i < S; ++i) {
+                const double x0 = 0.0 + (1.0 - 0.0) * mt_random(src);
+                const double y0 = 0.0 + (1.0 - 0.0) * mt_random(src);
+                const double x1 = x0 + (1.0 - x0) * mt_random(src);
+                const double y1 = y0 + (1.0 - y0) * mt_random(src);
+                f[i * 4 + 0] = (float)x0; f[i * 4 + 1] = (float)y0; f[i * 4 + 2] = (float)x1; f[i * 4 + 3] = (float)y1;
+            }
         }
         if (sample_gt) {
             const int g0 = gt_off[b], ng = gt_off[b + 1] - g0;
@@ -376,6 +455,24 @@ extern "C" int denet_host_handoff_boxes_stream(const uint32_t* stream, long n_st
     }
     *cursor = src.cursor;
     *exhausted = src.good ? 0 : 1;
+    return DENET_OK;
+}
+
+extern "C" int denet_host_handoff_boxes_stream(const uint32_t* stream, long n_stream, long* cursor, int* exhausted,
+                                               const int* box_host, const int* count_host, int H, int W, int B, int S, int n_keep,
+                                               const double* gt, const int* gt_off, int sample_gt, int* ws, float* out_box_f32) {
+    return denet_host_handoff_boxes_stream_u(stream, n_stream, cursor, exhausted, box_host, count_host, H, W, B, S, n_keep, gt, gt_off,
+                                             sample_gt, ws, out_box_f32, nullptr);
+}
+
+// uniforms_host[p] = genrand_res53 of the outputs p, p + 1 of a prefetched stretch (the value random.random() returns when the
+// generator stands at output p), for every p < n - 1; uniforms_host[n - 1] = 0 (never read: a box needs 8 outputs)
+extern "C" int denet_host_mt_uniforms(const uint32_t* stream, long n, double* uniforms_host) {
+#pragma clang fp contract(off)
+    DENET_CHECK_ARG(stream && uniforms_host && n >= 1, "mt_uniforms: bad arguments");
+    for (long p = 0; p + 1 < n; ++p)
+        uniforms_host[p] = ((stream[p] >> 5) * 67108864.0 + (stream[p + 1] >> 6)) * (1.0 / 9007199254740992.0);
+    uniforms_host[n - 1] = 0.0;
     return DENET_OK;
 }
 

@@ -140,7 +140,15 @@ class DeNetSparseLayer(RoiHandoff, AbstractLayer):
         if store_shared:
             cl.sample_shared = cl.conv.output.data
         self._res_host.copy_(r, non_blocking=True)
-        ops.wait_stream()
+        # everything the hand-off can settle without the proposal is settled BEFORE the wait (the device stands idle from the
+        # moment the copy lands until the gather is queued): the checks of the short forms, the gather's output buffers
+        ready = self._short_handoff_ready() if raw_only else None
+        if raw_only and get_train():
+            self._gather_pre = ops.sparse_fwd_buffers(self.batch_size * self.sample_count, self.grid_size, self.output.cp)
+        # ... and while it waits (the device is a whole backbone behind), the host repeats a dry run of the fast form's native call
+        # every quarter of a millisecond: the call finds its code, tables and the generator stretch in cache when the proposal lands
+        warm = (lambda: self._warm_fast_handoff(ready)) if (raw_only and get_train() and _RH.WARM_PERIOD > 0) else None
+        ops.wait_stream(idle=warm, period=_RH.WARM_PERIOD)
         # from here to the upload of the bbox array the device stands idle: numpy views of the pinned buffer made once, every
         # property of the counts computed once
         timer.mark()
@@ -152,7 +160,7 @@ class DeNetSparseLayer(RoiHandoff, AbstractLayer):
         self._deferred = None
         self.proposed_total = getattr(self, "proposed_total", 0) + tot      # (what regime a run was in: bench.py)
         self.proposed_steps = getattr(self, "proposed_steps", 0) + 1
-        if raw_only and self._short_handoff(hc, tot):
+        if raw_only and self._short_handoff(hc, tot, ready):
             # the bbox array is on its way (edited on the device, or by ONE native host call); everything else of the host's share
             # - the Python-side list, the generator's state - waits for its first reader
             self._deferred = timer
@@ -327,10 +335,16 @@ class DeNetSparseLayer(RoiHandoff, AbstractLayer):
             if _RH.DEVICE_EDIT and self._on_device() and not self.cluster:
                 self._upload_for_device_edit(metas, prep)
 
+    _ON_DEVICE = None
+
     @staticmethod
     def _on_device():
-        import torch
-        return torch.cuda.is_available()
+        # asked inside the RoI hand-off, where the device stands idle: torch.cuda.is_available() queries the runtime's device count on
+        # every call (tens of microseconds), the answer cannot change
+        if DeNetSparseLayer._ON_DEVICE is None:
+            import torch
+            DeNetSparseLayer._ON_DEVICE = bool(torch.cuda.is_available())
+        return DeNetSparseLayer._ON_DEVICE
 
     def edit_samples_native(self, det, cnt, metas, out_f32, defer_push=False):
         """edit_samples for the whole batch in one native host call (denet_host_edit_samples): same generator
@@ -426,7 +440,7 @@ class DeNetSparseLayer(RoiHandoff, AbstractLayer):
             fmap, coff, F = cl.sample_shared, cl.corner_num, cl.sample_feat
         assert self.sample_bbox is not None, "set_samples() must run before the sparse layer"
         out, self._taps = ops.sparse_fwd(fmap, self.sample_bbox, coff, F, self.sample_count, self.grid_size,
-                                         self.output.cp, self.tap_rule)
+                                         self.output.cp, self.tap_rule, buffers=self.__dict__.pop("_gather_pre", None))
         self.output.data = out.view(self.batch_size, self.sample_num, self.sample_num, self.output.cp)
         self._sorted_ev = None
         if get_train() and os.environ.get("DENET_SIDE_SORT", "1") == "1":

@@ -20,6 +20,9 @@ from .. import ops
 # DENET_SHORT_HANDOFF=0 is the one switch: the ordinary path only. The three names below are test hooks, not configuration.
 SHORT_HANDOFF = os.environ.get("DENET_SHORT_HANDOFF", "1") != "0"
 PREFETCH_RANDOM = DEVICE_EDIT = FAST_HANDOFF = SHORT_HANDOFF
+WARM_HANDOFF = SHORT_HANDOFF          # dry runs of the fast form's native call while the host waits (test hook like the others)
+# seconds between two dry runs while the host waits for the proposal (DENET_HANDOFF_WARM_MS; 0: none)
+WARM_PERIOD = float(os.environ.get("DENET_HANDOFF_WARM_MS", "0.25")) * 1e-3
 
 
 class PyRandomMirror:
@@ -108,6 +111,7 @@ class RoiHandoff:
             else:
                 out0 = numpy.empty(n, dtype=numpy.uint32)
             buf = self._pf_buf = (out0, numpy.empty((max_snaps, 624), dtype=numpy.uint32), numpy.empty(max_snaps, dtype=numpy.int64))
+            self._pf_uniforms = numpy.empty(n, dtype=numpy.float64)
         prev = self.__dict__.pop("_pf_upload", None)
         if prev is not None:
             prev.synchronize()            # the previous step's upload out of this buffer (a whole step old: done)
@@ -117,6 +121,9 @@ class RoiHandoff:
         ns = ctypes.c_int(0)
         _lib.check(_lib.load().denet_host_mt_prefetch(key.ctypes.data, pos.ctypes.data, n, out.ctypes.data, snaps.ctypes.data,
                                                       first.ctypes.data, max_snaps, ctypes.byref(ns)), "mt_prefetch")
+        # the doubles random.random() would return from every position of the stretch (the random boxes of the fast hand-off read
+        # them from this table: denet_host_handoff_boxes_stream_u) - made here, while the device runs the backbone
+        _lib.check(_lib.load().denet_host_mt_uniforms(out.ctypes.data, n, self._pf_uniforms.ctypes.data), "mt_uniforms")
         self._prefetch = {"mirror": mirror, "n": n, "ns": ns.value, "pos0": int(mirror.pos[0])}
 
     def _upload_for_device_edit(self, metas, prep):
@@ -147,13 +154,24 @@ class RoiHandoff:
         self._pf_upload = ev
         self._dev_edit = {"metas": metas, "mt": mt, "gt": gtd, "off": offd, "ev": ev, "n": pf["n"]}
 
-    def _short_handoff(self, hc, tot):
-        """the two short forms of the hand-off (what they share is checked once)"""
+    def _short_handoff_ready(self):
+        """what the two short forms of the hand-off share, checked BEFORE the host starts waiting for the proposal (nothing between
+        here and the hand-off draws from the generator: the host only waits): the prefetched stretch, the prepared ground truth,
+        a generator that has not moved since. (pf, prep) or None"""
         pf, prep = self.__dict__.get("_prefetch"), self.__dict__.get("_prep")
         if pf is None or prep is None or self.cluster or self.proposal_count != self.sample_count or not self._on_device():
-            return False
+            return None
         if not (DEVICE_EDIT or FAST_HANDOFF) or not pf["mirror"].fresh():
+            return None
+        return pf, prep
+
+    def _short_handoff(self, hc, tot, ready=False):
+        """the two short forms of the hand-off; `ready`: what _short_handoff_ready returned ahead of the wait (False: check now)"""
+        if ready is False:
+            ready = self._short_handoff_ready()
+        if ready is None:
             return False
+        pf, prep = ready
         return self._device_edit(hc, tot, pf, prep) or self._fast_handoff(hc, pf, prep)
 
     def _device_edit(self, hc, tot, pf, prep):
@@ -222,6 +240,26 @@ class RoiHandoff:
         self._lazy_edit = job
         return True
 
+    def _warm_fast_handoff(self, ready):
+        """A dry run of the fast hand-off's native call, repeated WHILE the host waits for the proposal (ops.wait_stream(idle=...)):
+        the same code over the step's generator stretch, the previous step's counts and whatever the result buffer holds, into a
+        scratch array. The call takes ~55 us with warm caches and 190-350 us cold - and cold is how the hand-off found it, with the
+        device idle meanwhile: the host has queued a whole forward pass and polled for ~19 ms since it drew the stretch
+        (`tools/exp/handoff_native_cold.py`, `handoff_host.py`: one dry run ahead of the wait does not last, one every quarter
+        millisecond does). Nothing of a dry run is kept (its cursor, its status and its output are its own)."""
+        bufs = self.__dict__.get("_ho_bufs")
+        if not WARM_HANDOFF or not FAST_HANDOFF or ready is None or bufs is None or self.__dict__.get("_pf_uniforms") is None:
+            return
+        import ctypes
+        pf, prep = ready
+        out = self._pf_buf[0]
+        cursor, dry = ctypes.c_long(0), ctypes.c_int(0)
+        H, W = bufs["hw"]
+        cnt = bufs["cnt"][bufs["turn"]]
+        bufs["fn"](out.ctypes.data, pf["n"], ctypes.byref(cursor), ctypes.byref(dry), bufs["hp"], cnt.ctypes.data, H, W, self.batch_size,
+                   self.sample_count, bufs["n_keep"], prep["gt"].ctypes.data, prep["off"].ctypes.data, int(bool(self.sample_gt)),
+                   bufs["ws"].ctypes.data, bufs["scratch"].ctypes.data, self._pf_uniforms.ctypes.data)       # (return value ignored)
+
     def _fast_handoff(self, hc, pf, prep):
         """The hand-off with the device idle as short as the host can make it: ONE native call that writes the bbox array alone
         (denet_host_handoff_boxes_stream: the selection and the random boxes on the prefetched generator outputs, no score
@@ -245,7 +283,7 @@ class RoiHandoff:
                 "det": [numpy.empty((B, S, 5), dtype=numpy.float32) for _ in range(2)],
                 "cnt": [numpy.empty(B, dtype=numpy.int32) for _ in range(2)],
                 "dev": [torch.empty((B * S, 4), dtype=torch.float32, device="cuda") for _ in range(2)],
-                "cursor": ctypes.c_long(0), "dry": ctypes.c_int(0), "fn": _lib.load().denet_host_handoff_boxes_stream,
+                "cursor": ctypes.c_long(0), "dry": ctypes.c_int(0), "fn": _lib.load().denet_host_handoff_boxes_stream_u,
                 "hp": self._res_host.data_ptr(), "f32": self._pinned.numpy(), "hw": (cl.height, cl.width),
                 "n_keep": S - math.floor(self.random_sample * S)}
         bufs["turn"] ^= 1
@@ -259,7 +297,7 @@ class RoiHandoff:
         H, W = bufs["hw"]
         _lib.check(bufs["fn"](out.ctypes.data, pf["n"], ctypes.byref(cursor), ctypes.byref(dry), bufs["hp"], cnt.ctypes.data, H, W, B, S,
                               bufs["n_keep"], gt.ctypes.data, off.ctypes.data, int(bool(self.sample_gt)), bufs["ws"].ctypes.data,
-                              bufs["f32"].ctypes.data), "handoff_boxes_stream")
+                              bufs["f32"].ctypes.data, self._pf_uniforms.ctypes.data), "handoff_boxes_stream")
         if dry.value:
             return False
         dev = bufs["dev"][turn]

@@ -28,6 +28,8 @@ SIGNATURES = {
     "denet_host_edit_samples_stream": (I, [P, L, P, P, P, P, I, I, I, P, P, I, P, P, P, P]),
     "denet_host_handoff_stream": (I, [P, L, P, P, P, P, P, I, I, I, I, I, P, P, I, P, P, P, P, P]),
     "denet_host_handoff_boxes_stream": (I, [P, L, P, P, P, P, I, I, I, I, I, P, P, I, P, P]),
+    "denet_host_handoff_boxes_stream_u": (I, [P, L, P, P, P, P, I, I, I, I, I, P, P, I, P, P, P]),
+    "denet_host_mt_uniforms": (I, [P, L, P]),
     "denet_host_detect_targets": (I, [P, P, P, P, I, I, I, I, I, I, ctypes.c_double, ctypes.c_double, P, P, P, P]),
     "denet_conv_fwd": (I, [P, P, P, P, P] + [I] * 12 + [P]),
     "denet_conv_fwd_act": (I, [P, P, P, P, P] + [I] * 13 + [P]),

@@ -217,14 +217,24 @@ def wait_upload(ev):
         torch.cuda.current_stream().wait_event(ev)
 
 
-def wait_stream():
+def wait_stream(idle=None, period=0.0):
     """host wait for everything queued on the current stream. Polls an event instead of a blocking
     hipStreamSynchronize: the interrupt-driven wait was measured to wake up 10-30 ms late now and then on the
-    GPU box, which is a third of a training step; the mid-step RoI hand-off is latency critical."""
+    GPU box, which is a third of a training step; the mid-step RoI hand-off is latency critical.
+    idle / period: a callable the host runs every `period` seconds while it polls (the RoI hand-off keeps its native call warm)"""
     ev = torch.cuda.Event()
     ev.record()
+    if idle is None or period <= 0:
+        while not ev.query():
+            pass
+        return
+    import time
+    last = time.perf_counter()
     while not ev.query():
-        pass
+        now = time.perf_counter()
+        if now - last >= period:
+            idle()
+            last = time.perf_counter()
 
 
 def _last_igemm_name():
@@ -1634,11 +1644,17 @@ def corner_loss(corner_pr, target, dconv, cost_out, cost_factor):
                                  cn, cost_factor, stream_ptr()), "corner_loss")
 
 
-def sparse_fwd(fmap, bbox, coff, F, rois_per_image, gs, kp, tap_rule=0):
+def sparse_fwd_buffers(M, gs, kp):
+    """the two outputs of sparse_fwd for M RoIs, allocated ahead of the call (the training step makes them before it waits for the RoI
+    proposal: nothing but the launch stands between the bbox array and the gather)"""
+    return empty(M, kp), torch.empty((M, gs * gs), dtype=torch.int32, device="cuda")
+
+
+def sparse_fwd(fmap, bbox, coff, F, rois_per_image, gs, kp, tap_rule=0, buffers=None):
     B, H, W, CP = fmap.shape
     M = B * rois_per_image
-    out = empty(M, kp)
-    taps = torch.empty((M, gs * gs), dtype=torch.int32, device="cuda")
+    out, taps = buffers if buffers is not None else sparse_fwd_buffers(M, gs, kp)
+    assert tuple(out.shape) == (M, kp) and tuple(taps.shape) == (M, gs * gs)
     check(_L().denet_sparse_fwd(ptr(fmap), ptr(bbox), ptr(out), ptr(taps), B, H, W, CP, coff, F, rois_per_image, gs,
                                 kp, tap_rule, stream_ptr()), "sparse_fwd")
     return out, taps

@@ -40,6 +40,7 @@ SWITCHES = {
     # ---- streams, RoI path ---------------------------------------------------------------------------------------------
     "DENET_WGRAD_STREAM": ("1", "kernels", "the filter-gradient chain of the backward sweep on a second stream"),
     "DENET_SHORT_HANDOFF": ("1", "host", "the short forms of the RoI hand-off (device-side editing / one native call)"),
+    "DENET_HANDOFF_WARM_MS": ("0.25", "host", "milliseconds between dry runs of the hand-off's native call while the host waits for the proposal (0: none)"),
     "DENET_SIDE_SORT": ("1", "kernels", "the gather gradient's tap sort queued right behind the forward gather"),
     "DENET_SORT_ONE_KERNEL": ("1", "kernels", "the tap sort as one 1024-thread workgroup per image"),
     "DENET_SOFT_NMS_HOST": ("unset", "host", "inference: force the host (1) / device (0) form of Gaussian soft-NMS"),

@@ -75,6 +75,16 @@ int denet_host_handoff_stream(const unsigned* stream_host, long n_stream, long* 
 int denet_host_handoff_boxes_stream(const unsigned* stream_host, long n_stream, long* cursor_host, int* exhausted_host,
                                     const int* box_host, const int* count_host, int H, int W, int B, int S, int n_keep,
                                     const double* gt_host, const int* gt_off_host, int sample_gt, int* ws_host, float* out_box_f32_host);
+/* the same with the uniform doubles of the stretch read from a table made ahead of the hand-off (uniforms_host [n_stream],
+ * denet_host_mt_uniforms; NULL: computed in place): a random box is then four table reads. The values random.uniform would
+ * return (denet/layer/denet_sparse.py:189-194) - same bits either way. */
+int denet_host_handoff_boxes_stream_u(const unsigned* stream_host, long n_stream, long* cursor_host, int* exhausted_host,
+                                      const int* box_host, const int* count_host, int H, int W, int B, int S, int n_keep,
+                                      const double* gt_host, const int* gt_off_host, int sample_gt, int* ws_host, float* out_box_f32_host,
+                                      const double* uniforms_host);
+/* uniforms_host[p] = the double random.random() returns when the generator stands at output p of the stretch (genrand_res53 of
+ * outputs p and p + 1; CPython Modules/_randommodule.c), p < n - 1; [n - 1] = 0. */
+int denet_host_mt_uniforms(const unsigned* stream_host, long n, double* uniforms_host);
 /* detection targets of a batch (denet/layer/denet_detect.py:147-235) in RoI-major layout: fp32 IoU matrix in the
  * operation order of common/theano_util.py:38-59, class / class x fitness-bin targets for IoU > t0, box-regression
  * target of the arg-max ground truth for IoU > t1, rows normalised and divided by S. gt: concatenated [n,4] doubles,

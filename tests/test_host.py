@@ -669,6 +669,53 @@ def test_prefetched_generator_outputs_give_the_same_editing():
         DS.PREFETCH_RANDOM = saved
 
 
+def test_uniform_table_of_a_prefetched_stretch_is_random_random():
+    """denet_host_mt_uniforms: entry p of the table is the double `random.random()` returns when the stdlib generator stands at output
+    p of the prefetched stretch (checked against the stdlib itself at even AND odd positions: getrandbits(32) moves it by one), and the
+    hand-off that reads the table (denet_host_handoff_boxes_stream_u) writes the same bytes and stops at the same cursor as the one that
+    forms the doubles in place - trimmed / short / empty lists, and a stretch that runs dry inside the random boxes"""
+    import ctypes
+    L = dlib.load()
+    random.seed(11)
+    random.random()
+    st = random.getstate()
+    key = np.array(st[1][:-1], dtype=np.uint32)
+    pos = np.array([st[1][-1]], dtype=np.int32)
+    n = 5000
+    out, snaps, first, ns = np.empty(n, np.uint32), np.empty((n // 624 + 3, 624), np.uint32), np.empty(n // 624 + 3, np.int64), ctypes.c_int(0)
+    assert L.denet_host_mt_prefetch(key.ctypes.data, pos.ctypes.data, n, out.ctypes.data, snaps.ctypes.data, first.ctypes.data,
+                                    snaps.shape[0], ctypes.byref(ns)) == 0
+    uni = np.empty(n, np.float64)
+    assert L.denet_host_mt_uniforms(out.ctypes.data, n, uni.ctypes.data) == 0
+    p = 0
+    for i in range(700):
+        assert random.random() == uni[p], (i, p)
+        p += 2
+        if i % 7 == 3:                       # one output: the next double starts at an odd position
+            assert random.getrandbits(32) == int(out[p])
+            p += 1
+    B, S, H, W = 5, 96, 64, 48
+    n_keep = S - S // 4
+    rng = np.random.RandomState(2)
+    x0, y0 = rng.randint(0, W - 1, (B, S)), rng.randint(0, H - 1, (B, S))
+    box = np.ascontiguousarray(np.stack([x0, y0, np.minimum(W - 1, x0 + rng.randint(0, 9, (B, S))),
+                                         np.minimum(H - 1, y0 + rng.randint(0, 9, (B, S)))], -1).astype(np.int32))
+    gt, off = rng.rand(B * 2, 4), (np.arange(B + 1) * 2).astype(np.int32)
+    ws = np.empty(2 * S, np.int32)
+    for counts, n_stream in (([96, 80, 0, 73, 96], n), ([96, 96, 96, 96, 96], n), ([0, 0, 0, 0, 0], n), ([10, 96, 3, 0, 50], 900)):
+        cnt = np.array(counts, np.int32)
+        res = []
+        for table in (None, uni):
+            f32 = np.full((B, S, 4), -1.0, np.float32)
+            cur, dry = ctypes.c_long(3), ctypes.c_int(0)
+            assert L.denet_host_handoff_boxes_stream_u(out.ctypes.data, n_stream, ctypes.byref(cur), ctypes.byref(dry), box.ctypes.data,
+                                                       cnt.ctypes.data, H, W, B, S, n_keep, gt.ctypes.data, off.ctypes.data, 1, ws.ctypes.data,
+                                                       f32.ctypes.data, table.ctypes.data if table is not None else None) == 0
+            res.append((f32.tobytes(), cur.value, dry.value))
+        assert res[0] == res[1], counts
+        assert res[0][2] == (1 if n_stream == 900 else 0)
+
+
 def test_detect_targets_match_executed_reference_method():
     """RoI -> class / fitness / box-regression targets: DeNetDetectLayer.get_target of the build (native host path and numpy
     path) and the oracle against the reference's own method loop (denet_detect.py:147-236, executed by the fixture script with
