@@ -387,11 +387,17 @@ extern "C" int denet_host_handoff_boxes_stream_u(const uint32_t* stream, long n_
     DENET_CHECK_ARG(H <= 256 && W <= 256, "handoff_boxes_stream: map %dx%d unsupported", H, W);
     for (int v = 0; v <= W + 1; ++v) tw[v] = (float)((double)v / W);
     for (int v = 0; v <= H + 1; ++v) th[v] = (float)((double)v / H);
+    // box_host is what the device has just written (a pinned buffer: its lines are in nobody's cache) and random.sample's picks
+    // walk an image's rows in random order - a DRAM latency per row. The rows of an image are copied front to back first (the
+    // prefetcher's pattern), the picks then read the copy
+    static thread_local std::vector<int> rows;
+    rows.resize((size_t)S * 4);
     for (int b = 0; b < B && src.ok(); ++b) {
-        const int* bx = box_host + (size_t)b * S * 4;
         float* f = out_box_f32 + (size_t)b * S * 4;
         int n = count_host[b];
         DENET_CHECK_ARG(n >= 0 && n <= S, "handoff_boxes_stream: count[%d] = %d out of range", b, n);
+        memcpy(rows.data(), box_host + (size_t)b * S * 4, (size_t)n * 4 * sizeof(int));
+        const int* bx = rows.data();
         const bool trim = n > n_keep;
         if (trim) {
             int rc = py_random_sample_from(src, n, n_keep, pool, pick);
