@@ -714,6 +714,24 @@ def test_uniform_table_of_a_prefetched_stretch_is_random_random():
             res.append((f32.tobytes(), cur.value, dry.value))
         assert res[0] == res[1], counts
         assert res[0][2] == (1 if n_stream == 900 else 0)
+    # the kept boxes are cell coordinates turned into fractions of the map: (x0 / W, y0 / H, (x1 + 1) / W, (y1 + 1) / H) as float32 of
+    # the double quotient, up to the largest map the tables cover (256 cells: coordinate 256 itself is a legal x0 / y0), and a
+    # coordinate beyond the map is an argument error, not a read past the tables
+    Hb = Wb = 256
+    bx = np.array([[[0, 0, 0, 0], [256, 256, 255, 255], [17, 200, 255, 201], [3, 4, 5, 6]]], np.int32)
+    cnt1, f1 = np.array([4], np.int32), np.zeros((1, 4, 4), np.float32)
+    cur, dry = ctypes.c_long(0), ctypes.c_int(0)
+    ws1 = np.empty(8, np.int32)
+    args = lambda b: (out.ctypes.data, n, ctypes.byref(cur), ctypes.byref(dry), b.ctypes.data, cnt1.ctypes.data, Hb, Wb, 1, 4, 4, None,
+                      np.zeros(2, np.int32).ctypes.data, 0, ws1.ctypes.data, f1.ctypes.data, uni.ctypes.data)
+    assert L.denet_host_handoff_boxes_stream_u(*args(bx)) == 0
+    want = np.stack([bx[0, :, 0] / Wb, bx[0, :, 1] / Hb, (bx[0, :, 2] + 1) / Wb, (bx[0, :, 3] + 1) / Hb], -1).astype(np.float32)
+    assert np.array_equal(f1[0], want)
+    bad = bx.copy()
+    bad[0, 2, 2] = 257
+    assert L.denet_host_handoff_boxes_stream_u(*args(bad)) == -1000
+    bad[0, 2, 2] = -1
+    assert L.denet_host_handoff_boxes_stream_u(*args(bad)) == -1000
 
 
 def test_detect_targets_match_executed_reference_method():
