@@ -163,6 +163,17 @@ class RoiHandoff:
             return None
         if not (DEVICE_EDIT or FAST_HANDOFF) or not pf["mirror"].fresh():
             return None
+        de = self.__dict__.get("_dev_edit")
+        if DEVICE_EDIT and de is not None and de["metas"] is prep["metas"] and not de.get("staged"):
+            # the device-side editing, should the counts allow it: its stream dependencies and its output buffer are set up here
+            # as well (the uploads it waits for were queued when the step began)
+            import torch
+            cur = torch.cuda.current_stream()
+            cur.wait_event(de["ev"])
+            for t in (de["mt"], de["gt"], de["off"]):
+                t.record_stream(cur)
+            de["out"] = torch.empty((self.batch_size * self.sample_count, 4), dtype=torch.float32, device="cuda")
+            de["staged"] = True
         return pf, prep
 
     def _short_handoff(self, hc, tot, ready=False):
@@ -190,11 +201,14 @@ class RoiHandoff:
             return False                 # random.sample would trim a list: the fast hand-off's case
         from .. import lib as _lib
         cl = self.corner_layer
-        cur = torch.cuda.current_stream()
-        cur.wait_event(de["ev"])
-        for t in (de["mt"], de["gt"], de["off"]):
-            t.record_stream(cur)
-        out = torch.empty((B * S, 4), dtype=torch.float32, device="cuda")
+        if de.get("staged"):
+            out = de["out"]
+        else:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(de["ev"])
+            for t in (de["mt"], de["gt"], de["off"]):
+                t.record_stream(cur)
+            out = torch.empty((B * S, 4), dtype=torch.float32, device="cuda")
         r, st = self._res_dev, self._de_static
         _lib.check(_lib.load().denet_edit_samples_device(
             _lib.ptr(r[:B * S * 4]), _lib.ptr(r[B * S * 5:]), cl.height, cl.width, _lib.ptr(de["mt"]), de["n"], 0,
