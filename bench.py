@@ -129,6 +129,122 @@ def config_leg(name, model, x, metas, steps, warm):
             "final_cost": round(float(cost), 5)}
 
 
+def inference_leg(steps):
+    """SURVEY section 8 f-1, the reference's only PUBLISHED rate (README.md:118-128: DeNet-34 skip 82 Hz on a Titan X, other hardware,
+    context only): DeNetDetectLayer.get_detections (denet_detect.py:316-424, denet_detect.cc:35-173) on DeNet-34 skip 512x512 -
+    test-mode forward with folded batch norms, GPU RoI proposal, head, decode, per-class NMS, host lists - at B = 1 (Hz) and B = 32
+    (img/s), hard NMS and Gaussian soft-NMS. Before timing, the B = 1 detections are CHECKED against the oracle (the checker, not
+    the thing measured): RoI lists on the product's corner map, test-mode corner map of oracle/model.py, threshold + NMS on the
+    product's decoded arrays."""
+    import ctypes
+    import numpy
+    import torch
+    from denet_amd import ops
+    from denet_amd.model import audit, zoo
+    res = {"reference_published": {"value": 82, "unit": "Hz", "hardware": "Titan X (Pascal), cuDNN", "source": "README.md:122",
+                                   "note": "other hardware: context, not a baseline for vs_baseline"},
+           "model": "DeNet-34 skip 512x512, 80 classes, 576 RoIs per image, warm corner head (random corner filters, bias 4), "
+                    "random detection filters; prThreshold 0.05, nmsThreshold 0.5"}
+    for B in (1, 32):
+        model = zoo.denet34(B, "skip", 512, class_num=80, seed=1)
+        zoo.warm_corner_head(model, 4.0, 0.3)
+        rng = numpy.random.RandomState(3)
+        by_type = lambda t: [l for l in model.layers if l.type_name == t][0]
+        dnd, dns, dnc = by_type("denet-detect"), by_type("denet-sparse"), by_type("denet-corner")
+        dnd.layers[0].omega.set_value(rng.normal(0, 0.02, dnd.layers[0].omega.value.shape))
+        x, metas = zoo.synthetic_batch(B, 512, 80, seed=1)
+        xd = torch.from_numpy(x).cuda()
+        for soft in (0, 1):
+            params = {"prThreshold": 0.05, "nmsThreshold": 0.5, "useSoftNMS": soft}
+            key = "b%d_%s" % (B, "soft_nms" if soft else "nms")
+            for _ in range(3):
+                r = dnd.get_detections(model, xd, metas, params)
+            ent = {}
+            if B == 1:
+                ent["oracle_check"] = _inference_check(model, dnd, dns, dnc, x, r, params)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                r = dnd.get_detections(model, xd, metas, params)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            ent.update({"value": round(B / dt, 2), "unit": "Hz" if B == 1 else "images/sec", "ms_per_batch": round(1e3 * dt, 3),
+                        "batch": B, "calls_timed": steps, "detections_last_batch": sum(len(i["detections"]) for i in r),
+                        "rois_last_batch": int(dnd.last_outputs[3].sum())})
+            if not soft:
+                prof = ops.KernelProfile()
+                ops.PROFILE = prof
+                try:
+                    for _ in range(3):
+                        dnd.get_detections(model, xd, metas, params)
+                finally:
+                    ops.PROFILE = None
+                agg = prof.summary()
+                name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+                tf = a["flops"] / (a["ms"] * 1e-3) / 1e12
+                ent["dominant_kernel"] = {"kernel": name, "launches_per_call": a["launches"] // 3, "ms_per_call": round(a["ms"] / 3, 4),
+                                          "tflops": round(tf, 2), "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+                ent["matrix_kernel_ms_per_call"] = round(sum(v["ms"] for v in agg.values()) / 3, 3)
+                with audit.KernelAudit(model) as ka:
+                    dnd.get_detections(model, xd, metas, params)
+                    torch.cuda.synchronize()
+                ent["kernels_used"] = {g: e["fwd"] for g, e in ka.summary().items()}
+            res[key] = ent
+        del model
+        torch.cuda.empty_cache()
+    return res
+
+
+def _inference_check(model, dnd, dns, dnc, x, results, params):
+    """the oracle as CHECKER of one B = 1 get_detections call (outside every timed region); raises on a mismatch"""
+    import ctypes
+    import numpy
+    from oracle import layers as OL
+    from oracle import model as OM
+    corner = dnc.corner_pr.cpu().numpy()
+    thr = params.get("cornerThreshold", dns.corner_threshold)
+    lists = OM.oracle_build_samples(corner, thr, dns.sample_num, 1024, 0)
+    got = dns.sample_bbox_list
+    for g, r in zip(got, lists):
+        if [p for p, _ in g] != [p for p, _ in r]:
+            raise AssertionError("inference check: RoI scores differ from the oracle's proposal on the same corner map")
+        if len({p for p, _ in r}) == len(r) and g != r:
+            raise AssertionError("inference check: RoI lists differ (tie-free)")
+    om = OM.OracleModel(model.export_json(), 1)
+    om.forward(x, None, train=False, sample_override=got)
+    cerr = float(numpy.abs(corner - om.corner_pr).max() / (numpy.abs(om.corner_pr).max() + 1e-12))
+    det_pr, fitness, bbox, counts = dnd.last_outputs
+    sn, C = dns.sample_num, dnd.class_num
+    t0 = dnd._thresholds()[0]
+    o_det, o_fit, o_box = OL.detect_outputs(om.detect_out.v, om.sample_bbox, C, bool(dnd.use_jointfit), t0)
+    n = int(counts[0])
+    d = det_pr.cpu().numpy().reshape(1, sn, sn, C + 1).transpose(0, 3, 1, 2).reshape(C + 1, -1)[:, :n]
+    derr = float(numpy.abs(d - o_det.reshape(C + 1, -1)[:, :n]).max()) if n else 0.0
+    # threshold + NMS: exact on the product's decoded arrays (oracle/build_samples.cc restates denet_detect.cc:99-173)
+    S, C1 = sn * sn, C + 1
+    det = numpy.ascontiguousarray(det_pr.cpu().numpy().reshape(1, sn, sn, C1).transpose(0, 3, 1, 2), dtype=numpy.float32)
+    fit = numpy.ascontiguousarray(fitness.cpu().numpy().reshape(1, sn, sn, C1).transpose(0, 3, 1, 2), dtype=numpy.float32)
+    bx = numpy.ascontiguousarray(bbox.cpu().numpy().reshape(1, sn, sn, 4), dtype=numpy.float32)
+    num = numpy.ascontiguousarray(counts, dtype=numpy.int32)
+    out = numpy.zeros((1, S * C, 6), numpy.float32)
+    cnt = numpy.zeros(1, numpy.int32)
+    f = OM.oracle_lib().oracle_build_detections_nms
+    f.argtypes = [ctypes.c_float, ctypes.c_float, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 2
+    f(params["prThreshold"], params["nmsThreshold"], int(params.get("useSoftNMS", 0)), det.ctypes.data, fit.ctypes.data,
+      bx.ctypes.data, num.ctypes.data, 1, C1, sn, S * C, out.ctypes.data, cnt.ctypes.data)
+    ref = out[0, :cnt[0]]
+    dets = results[0]["detections"]
+    if len(dets) != len(ref):
+        raise AssertionError("inference check: %d detections, the oracle keeps %d" % (len(dets), len(ref)))
+    for (pr, cls, box), rr in zip(dets, ref):
+        if cls != int(rr[1]) or not numpy.array_equal(numpy.array(box, numpy.float32), rr[2:]) or abs(pr - rr[0]) > 2e-6 * rr[0]:
+            raise AssertionError("inference check: a detection differs from the oracle's NMS on the same decoded arrays")
+    if cerr > 1e-3 or derr > 2e-3:
+        raise AssertionError("inference check: corner map %.2e / class log-probabilities %.2e off the oracle's test-mode forward" % (cerr, derr))
+    return {"rois": n, "detections": len(dets), "roi_lists_equal_oracle_proposal": True, "nms_equal_oracle": True,
+            "corner_map_max_rel_err_vs_oracle": float("%.2e" % cerr), "class_logprob_max_abs_err_vs_oracle": float("%.2e" % derr)}
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks (one per GPU) under
     torch.distributed.run on a free local port, pass the ranks' output through and exit with the job's status. The reference's
@@ -275,6 +391,7 @@ def main():
     ap.add_argument("--no-instep", action="store_true", help="skip the in-step kernel timing leg (roofline.dominant_by_time_in_step)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the input_h2d leg (host batch uploaded every step; rank 0, N=1)")
     ap.add_argument("--no-audit", action="store_true", help="skip the per-layer kernel audit (config.kernels_used; rank 0)")
+    ap.add_argument("--no-inference", action="store_true", help="skip the inference leg (get_detections Hz / img/s; rank 0, N=1)")
     ap.add_argument("--no-split-bf16", action="store_true",
                     help="skip the leg of the OPT-IN variant (head GEMMs as 3-term bf16 splits; own key, never the headline)")
     ap.add_argument("--regime", default="cold", choices=["cold", "warm"],
@@ -310,6 +427,17 @@ def main():
         dp = DataParallel(backend="gloo" if share else "nccl")      # "nccl" is RCCL on ROCm
         dp.force_collectives = os.environ.get("DENET_FORCE_DP") == "1"
         world = dp.world_size          # what the process group itself reports
+        # the first multi-GPU run must not be able to fall back silently: the group has as many ranks as --gpus asked for, and
+        # between GPUs it is RCCL ("nccl" on ROCm) - gloo only in the one-GPU launch-path debug mode
+        import torch.distributed as tdist
+        if tdist.get_world_size() != args.gpus:
+            raise SystemExit("--gpus %d but the process group has %d ranks" % (args.gpus, tdist.get_world_size()))
+        backend = str(tdist.get_backend()).lower()
+        if args.gpus > 1 and not share and backend != "nccl":
+            raise SystemExit("--gpus %d without --share-gpu must run on RCCL (backend 'nccl'), the process group reports %r" % (
+                args.gpus, backend))
+        if dp.backend != backend:
+            raise SystemExit("DataParallel says backend %r, torch.distributed %r" % (dp.backend, backend))
 
     # identical initial weights on every rank (seed), per-rank data shard (seed + rank)
     model = zoo.denet34(BATCH_PER_GPU, "skip", 512, class_num=80, seed=1)
@@ -331,10 +459,13 @@ def main():
             torch.cuda.synchronize()
 
     from denet_amd.model import audit
-    undecided = len(audit.decisions_cover(model))      # 3x3 passes the committed tuned file does not decide (measured in the warm-up)
+    # 3x3 passes the committed tuned file does not decide: with ops.MEASURE (DENET_TUNE=1) they are timed in the warm-up; in the product
+    # default they run ops.static_policy's algorithm and nothing is measured
+    uncovered = len(audit.decisions_cover(model))
+    undecided = uncovered if ops.MEASURE and ops.POLICY is None else 0
     it = 0
-    # launch configurations are measured during the first two steps (one-off setup, like kernel compilation): they are
-    # taken out of the timed region even when fewer warm-up steps were asked for
+    # one-off setup (buffers, filter transforms; with DENET_TUNE=1 also measuring) happens in the first two steps: they are taken out
+    # of the timed region even when fewer warm-up steps were asked for
     for _ in range(max(args.warmup, 2)):
         model.train_step(xd, metas, 0, it, lr, mom, decay)
         it += 1
@@ -346,14 +477,16 @@ def main():
     dns_layer.handoff_modes = {k: 0 for k in dns_layer.handoff_modes}
     import gc
     gc.collect()
-    gc.disable()      # no collector pause of the host thread inside the timed region (a full collection is milliseconds)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        cost, _ = model.train_step(xd, metas, 0, it, lr, mom, decay)
-        it += 1
-    sync()
-    dt_rank = dt = time.perf_counter() - t0
-    gc.enable()
+    gc.disable()      # no collector pause of the host thread inside the timed region (a full collection is milliseconds): the policy
+    try:              # of the shipped epoch loops too (ModelCNN.train_epoch / train_epoch_device: _collector_paused)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            cost, _ = model.train_step(xd, metas, 0, it, lr, mom, decay)
+            it += 1
+        sync()
+        dt_rank = dt = time.perf_counter() - t0
+    finally:
+        gc.enable()
     # what the corner detector did during the timed steps: as initialised it is silent (bias +5), but the corner cost (factor 100,
     # lr 0.1) has it firing within the warm-up steps and cooling down over the next ~30 - the timed steps see a detector that
     # proposes, and the RoI lists are trimmed by random.sample
@@ -407,9 +540,11 @@ def main():
                    "conv_algorithms": "fp32 throughout; per layer and pass the fastest of the direct implicit GEMM, "
                                       "Winograd F(2x2,3x3)/F(4x4,3x3) and (64 input channels) F(2x2,3x3) fused into one "
                                       "kernel, as measured once by tools/tune.py and stored in "
-                                      "denet_amd/tuned/gfx950.json (every process runs the same kernels; geometries not "
-                                      "in the file are measured on the first step; DENET_WINOGRAD=0: direct kernels only)",
+                                      "denet_amd/tuned/gfx950.json (every process runs the same kernels; a geometry not "
+                                      "in the file runs ops.static_policy's algorithm and is NEVER measured unless DENET_TUNE=1; "
+                                      "DENET_WINOGRAD=0: direct kernels only)",
                    "input": "fp32 NCHW batch resident in HBM before the timed region",
+                   "gc_disabled_in_timed_region": True,       # as in ModelCNN.train_epoch (cyclic collector paused per epoch)
                    "final_cost": round(float(cost), 5)},
         # rate in FLOPs of the reference's direct algorithm (164.3 GFLOP per image and step); layers that run Winograd
         # execute fewer, so this is an effective rate - the MFMA utilisation of the kernels is in `roofline`
@@ -429,7 +564,9 @@ def main():
     out["config"]["product_default_switches"] = not switches.changes_kernels(out["config"]["denet_switches"])
     out["config"]["tuned_file"] = os.path.relpath(ops.TUNE_CACHE, os.path.dirname(os.path.abspath(__file__))) if ops._TUNE_LOADED else None
     if not args.no_audit:       # (every rank: the step holds collectives when the job is data parallel)
-        out["config"]["passes_measured_in_the_warmup"] = undecided       # 0: every implementation came from the committed file
+        out["config"]["passes_measured_in_the_warmup"] = undecided       # 0: nothing was timed to choose a kernel
+        out["config"]["passes_not_in_the_tuned_file"] = uncovered        # 0: every implementation came from the committed file
+        out["config"]["untuned_geometry_policy"] = "measure (DENET_TUNE=1)" if ops.MEASURE else "static_policy (nothing measured)"
         with audit.KernelAudit(model) as ka:
             model.train_step(xd, metas, 0, it, lr, mom, decay)
             it += 1
@@ -695,6 +832,15 @@ def main():
         except Exception as exc:          # an optional leg must never cost the headline line
             ops.HEAD_BF16X3 = False
             out["split_bf16"] = {"error": repr(exc)[:300]}
+
+    if rank == 0 and world == 1 and not args.no_inference:
+        try:
+            del model
+            torch.cuda.empty_cache()
+            out["inference"] = inference_leg(max(5, min(args.steps, 20)))
+        except Exception as exc:          # an extra leg must never cost the headline line
+            ops.PROFILE = None
+            out["inference"] = {"error": repr(exc)[:400]}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import model as OM

@@ -85,6 +85,11 @@ class BatchNormLayer(AbstractLayer):
         statistics, so that the pass can finish them in its own launch (ops.BnFinal; the running statistics are updated there)"""
         if not (self.enabled and ops.FINAL_FOLD and act is self.input):
             return None
+        if getattr(self, "pool_behind", None) is not None and ops.BN_POOL_FUSE:
+            # the fused BN + ReLU + max-pool pass reduces the partial rows itself and updates the running statistics there
+            # (ops.bn_relu_pool_fwd_train reads only the rows): a producer that also finished them would advance run_mean /
+            # run_stdinv twice per step (ADVICE round 5). The producer keeps writing rows only.
+            return None
         n, c = act.shape[0], act.cp
         m = 1
         for d in act.shape[2:]:
@@ -111,6 +116,7 @@ class BatchNormLayer(AbstractLayer):
                 # a max pool is the only reader of this layer's output (ModelCNN.build_train_func links it): one pass
                 # writes the pooled tensor, relu(bn(x)) itself is never materialised (its gradient neither)
                 k, s, p = pool.size[0], pool.stride[0], pool.pad[0]
+                assert pre is None or len(pre) == 2, "statistics finished by the producer in front of a pool-fused batch norm"
                 yp, arg, sm, si, xh = ops.bn_relu_pool_fwd_train(x, self.omega.dev, self.beta.dev, self.mean.dev, self.stdinv.dev,
                                                                  k, s, p, self.momentum, self.eps, pre=pre, xhat=True)
                 pool.output.data, pool._arg, pool._fused_in = yp, arg, ctx      # valid for this pass (ctx) only

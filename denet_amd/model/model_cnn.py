@@ -65,6 +65,24 @@ def initialize(args, data_shape, class_labels, class_num):
     return model
 
 
+class _collector_paused:
+    """the step loop of an epoch runs with Python's cyclic collector paused (a full collection stalls the host thread for
+    milliseconds in the middle of a 30 ms step whose device queue the host feeds); one collection at the end of the epoch.
+    Reference-counted garbage (every tensor view of a step) is freed as always. bench.py times its steps the same way."""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+            gc.collect()
+        return False
+
+
 def walk_layers(layers):
     """every layer and nested sub-layer, depth first, each object once"""
     seen, out = set(), []
@@ -533,6 +551,10 @@ class ModelCNN:
     def train_epoch(self, dataset, epoch, learning_rate, momentum=[0, 1, 0], decay=0.0, solver_mode="sgd"):
         dataset_x, dataset_m, dataset_size = dataset.export(self.batch_size)
         index_num = math.ceil(dataset_size / self.batch_size)
+        with _collector_paused():
+            return self._train_epoch_steps(dataset_x, dataset_m, index_num, epoch, learning_rate, momentum, decay)
+
+    def _train_epoch_steps(self, dataset_x, dataset_m, index_num, epoch, learning_rate, momentum, decay):
         total_cost = 0
         for index in range(index_num):
             timer = common.Timer()
@@ -554,12 +576,13 @@ class ModelCNN:
         """train_epoch over batches rendered on the GPU by a denet_amd.dataset.device_render.DeviceImageLoader: same
         batches, metas and random-stream use as `train_epoch(dataset)` after `dataset.load_from_subset`"""
         total_cost = 0
-        for data_x, data_m in loader.iterate(images, self.batch_size):
-            cost, _ = self.train_step(data_x, data_m, epoch, self.iteration, learning_rate, momentum, decay)
-            if math.isnan(cost):
-                raise Exception("ERROR: Cost is NaN")
-            total_cost += cost
-            self.iteration += 1
+        with _collector_paused():
+            for data_x, data_m in loader.iterate(images, self.batch_size):
+                cost, _ = self.train_step(data_x, data_m, epoch, self.iteration, learning_rate, momentum, decay)
+                if math.isnan(cost):
+                    raise Exception("ERROR: Cost is NaN")
+                total_cost += cost
+                self.iteration += 1
         return total_cost
 
     def predict_output(self, dataset):

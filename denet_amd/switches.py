@@ -7,8 +7,9 @@ step launches (a bench line taken with it set is not the headline configuration)
 
 SWITCHES = {
     # ---- which implementation a convolution pass uses ------------------------------------------------------------------
-    "DENET_AUTOTUNE": ("1", "kernels", "measure the launch configuration / algorithm of geometries the tuned file does not cover (0: heuristics, direct kernels)"),
-    "DENET_TUNE_CACHE": ("denet_amd/tuned/gfx950.json", "kernels", "the committed measured decisions (0: ignore the file, measure everything)"),
+    "DENET_AUTOTUNE": ("1", "kernels", "use the committed decisions and the Winograd / fused algorithms (0: launch heuristics, direct kernels only)"),
+    "DENET_TUNE": ("0", "kernels", "1: MEASURE the launch configuration / algorithm of geometries the tuned file does not cover on their first call (what tools/tune.py does); 0, the product default: such a geometry runs ops.static_policy, nothing is ever timed, every process runs the same kernels"),
+    "DENET_TUNE_CACHE": ("denet_amd/tuned/gfx950.json", "kernels", "the committed measured decisions (0: ignore the file)"),
     "DENET_WINOGRAD": ("4", "kernels", "largest Winograd tile allowed for the 3x3 stride-1 layers (0: direct only, 2: F(2x2) only)"),
     "DENET_WINO_RAGGED": ("1", "kernels", "Winograd on maps that are no multiple of the tile (ceil tiles; 0: multiples only)"),
     "DENET_WINO2F": ("7", "kernels", "fused F(2x2) kernels of the 64-channel layers: bit 0 forward, 1 data gradient, 2 filter gradient"),

@@ -361,23 +361,25 @@ def corner_target(metas, corner_shape, dropout=0.0):
 #   rule 1: p = p0 + i*extent*k, k = 1.0f/(gs-1), lroundf (half away from zero)
 # ---------------------------------------------------------------------------------------------------------
 def sparse_taps(bbox, gs, H, W, rule=0):
-    """bbox (M,4) float32 -> ys, xs int arrays (M, gs)"""
-    bbox = bbox.astype(F32)
+    """bbox (M,4) float32 -> ys, xs int arrays (M, gs). Index work: ALWAYS evaluated in float32 as the reference does (I32 below),
+    also when the float64 arbiter (oracle/model.py: float64_arbiter) widens the activations"""
+    I32 = np.float32
+    bbox = bbox.astype(I32)
     x0, y0, x1, y1 = bbox[:, 0], bbox[:, 1], bbox[:, 2], bbox[:, 3]
-    bw, bh = (x1 - x0).astype(F32), (y1 - y0).astype(F32)
-    ar = np.arange(gs, dtype=F32)
+    bw, bh = (x1 - x0).astype(I32), (y1 - y0).astype(I32)
+    ar = np.arange(gs, dtype=I32)
 
     def pos(p0, ext, size):
         if rule == 0:
-            p = p0[:, None] + ((ar[None, :] * ext[:, None]).astype(F32) / F32(gs - 1)).astype(F32)
+            p = p0[:, None] + ((ar[None, :] * ext[:, None]).astype(I32) / I32(gs - 1)).astype(I32)
         else:
-            k = F32(F32(1.0) / F32(gs - 1))
-            p = p0[:, None] + ((ar[None, :] * ext[:, None]).astype(F32) * k).astype(F32)
-        f = (p.astype(F32) * F32(size)).astype(F32)
-        f = np.maximum(F32(0), np.minimum(f, F32(size - 1)))
+            k = I32(I32(1.0) / I32(gs - 1))
+            p = p0[:, None] + ((ar[None, :] * ext[:, None]).astype(I32) * k).astype(I32)
+        f = (p.astype(I32) * I32(size)).astype(I32)
+        f = np.maximum(I32(0), np.minimum(f, I32(size - 1)))
         if rule == 0:
             return np.rint(f).astype(np.int64)
-        return np.floor(f + F32(0.5)).astype(np.int64)   # f >= 0: half away from zero
+        return np.floor(f + I32(0.5)).astype(np.int64)   # f >= 0: half away from zero
 
     return pos(y0, bh, H), pos(x0, bw, W), bh, bw
 

@@ -27,6 +27,25 @@ F32 = np.float32
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+class float64_arbiter:
+    """context manager: the SAME restatement evaluated in float64 (every `F32` of oracle/layers.py and of this file becomes
+    numpy.float64; index work - RoI taps, targets - keeps its float32 / integer arithmetic). Not the reference's arithmetic: an
+    ARBITER for whole-network comparisons in which two float32 evaluations (the product's and this oracle's) drift apart with
+    depth - each side is then measured against the value both approximate (tests/test_parity_gpu.py, DeNet-101 wide). Build the
+    OracleModel INSIDE the context (parameters are stored in the active precision)."""
+
+    def __enter__(self):
+        global F32
+        self.saved = (F32, L.F32)
+        F32 = L.F32 = np.float64
+        return self
+
+    def __exit__(self, *exc):
+        global F32
+        F32, L.F32 = self.saved
+        return False
+
+
 # ---------------------------------------------------------------------------------------------------------
 # minimal reverse-mode tape
 # ---------------------------------------------------------------------------------------------------------
@@ -466,6 +485,12 @@ class OracleModel:
             self.acts[li] = h.v
         self.out = h
         return self.costs
+
+    def forward_costs(self, x_nchw, metas, sample_override=None):
+        """the forward half of train_step alone (training mode: batch statistics, targets, cost terms) -> (total, [terms]); no
+        backward sweep, no update - what a free-running comparison of activations / corner map / costs needs (a third of the time)"""
+        costs = self.forward(x_nchw, metas, True, sample_override)
+        return sum(c for _, c in costs), [c for _, c in costs]
 
     def train_step(self, x_nchw, metas, iteration, lr, momentum, decay, solver="nesterov", sample_override=None):
         """denet/model/model_cnn.py:407-445 + the solver updates of :282-331"""

@@ -124,7 +124,9 @@ def test_conv_passes_at_benchmark_geometry(hip, geom):
             ops.AUTOTUNE = tuned
             ops._WINO.clear()
             ops._TUNED.clear()
-            for rep in range(2):                                   # first call: measured; second: the fixed choice alone
+            # "tuned": the algorithm of ops.static_policy (fused 64-channel / F(4x4) / F(2x2) wherever the geometry allows one - the
+            # widest kernel coverage; nothing is timed) on the launch configurations of the committed file
+            for rep in range(2):                                   # first call: decides and sets buffers up; second: the fixed choice alone
                 y = ops.conv_fwd(x, w, stride=stride, pad=pad, s_real=s_real)
                 dw = ops.conv_wgrad(x, dy, tuple(w.shape), stride=stride, pad=pad, s_real=s_real)
                 dx = ops.conv_dgrad(dy, w, tuple(x.shape), stride=stride, pad=pad, s_real=s_real) if need_dx else None

@@ -839,3 +839,37 @@ def test_every_environment_switch_is_registered():
     stale = sorted(k for k in switches.SWITCHES if k not in found)
     assert not stale, "listed switches nothing reads any more: %s" % stale
     assert switches.changes_kernels({"DENET_WINO4F": "0"}) and not switches.changes_kernels({"DENET_BUILD_JOBS": "2", "DENET_FORCE_DP": "1"})
+
+
+def test_tune_merge_replaces_only_the_remeasured_keys():
+    """tools/tune.py --only X --merge-into FILE: denet34-skip and cifar3 both run batch 32 - re-measuring one must
+    not delete the other's records; exactly the re-measured geometry keys are replaced"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tune_tool", os.path.join(ROOT, "tools", "tune.py"))
+    saved = {k: os.environ.get(k) for k in ("DENET_TUNE_CACHE", "DENET_TUNE")}
+    try:
+        tune = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(tune)
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    key = lambda mode, n, h, c: [mode, n, h, h, c, c, 3, 3, 3, 1, 1]
+    geom = lambda n, h, c: [n, h, h, c, c, 3, 3, 3, 1, 1, h, h]
+    old_k = [key(0, 32, 64, 128) + [1, 1, 1],        # denet34-skip, batch 32
+             key(2, 32, 64, 128) + [2, 2, 2],
+             key(0, 32, 16, 256) + [3, 3, 3],        # cifar3, batch 32 as well
+             key(0, 64, 56, 64) + [4, 4, 4],         # resnet34
+             key(5, 32, 64, 128) + [9, 9, 9]]        # a batched-product record (mode > 2)
+    old_w = [[0, geom(32, 64, 128), 4], [0, geom(32, 16, 256), 2], [1, geom(64, 56, 64), 22]]
+    rec = [key(0, 32, 16, 256) + [7, 7, 7], key(5, 32, 64, 128) + [8, 8, 8], key(6, 32, 16, 256) + [5, 5, 5]]
+    wino = {(0, tuple(geom(32, 16, 256))): 4}
+    kept, add, wkept, wadd = tune.merge_records(old_k, old_w, rec, wino)
+    merged = sorted(kept + add)
+    assert key(0, 32, 64, 128) + [1, 1, 1] in merged and key(2, 32, 64, 128) + [2, 2, 2] in merged      # the other batch-32 config stays
+    assert key(0, 32, 16, 256) + [7, 7, 7] in merged and key(0, 32, 16, 256) + [3, 3, 3] not in merged  # the re-measured key replaced
+    assert key(0, 64, 56, 64) + [4, 4, 4] in merged
+    assert key(5, 32, 64, 128) + [9, 9, 9] in merged and key(5, 32, 64, 128) + [8, 8, 8] not in merged  # product records: only added
+    assert key(6, 32, 16, 256) + [5, 5, 5] in merged
+    assert len(merged) == 6
+    w = sorted(wkept + wadd)
+    assert [0, geom(32, 64, 128), 4] in w and [1, geom(64, 56, 64), 22] in w and [0, geom(32, 16, 256), 4] in w and len(w) == 3

@@ -187,11 +187,23 @@ def test_denet34_get_detections_vs_oracle(hip, soft, monkeypatch):
     w[:s0] *= 2.0 / raw[:, :s0].std()
     w[s0:s0 + 4] *= 0.2 / raw[:, s0:s0 + 4].std()
     dconv.omega.set_value(w)
+    _, total = check_detections_vs_oracle(model, x, metas, params)
+    assert total > 0, "no detections: the test exercises nothing"
+
+
+def check_detections_vs_oracle(model, x, metas, params, om=None):
+    """one batch through the product's get_detections against the oracle, stage by stage (denet_detect.py:316-424):
+    RoI proposal exact on the product's corner map (tie groups as sets), test-mode forward of oracle/model.py on the same RoIs
+    (corner map 1e-3, decoded class / box arrays 1e-3), threshold + NMS exact on the product's decoded arrays. Returns
+    (results, number of detections). `om`: an OracleModel of the same weights (built from model.export_json() when None)."""
+    from tests.test_parity_gpu import rel_close
+    B = model.batch_size
+    by_type = lambda t: [l for l in model.layers if l.type_name == t][0]
+    dnd, dns, cl = by_type("denet-detect"), by_type("denet-sparse"), by_type("denet-corner")
+    soft = int(params.get("useSoftNMS", 0))
     results = dnd.get_detections(model, x, metas, params)
-    dns, cl = model.layers[31], model.layers[30]
     # RoI proposal: exact on the product's corner map
-    lists = OM.oracle_build_samples(cl.corner_pr.cpu().numpy(), 0.02, dns.sample_num, 1024, 0)
-    assert sum(len(l) for l in lists) > 0
+    lists = OM.oracle_build_samples(cl.corner_pr.cpu().numpy(), params["cornerThreshold"], dns.sample_num, 1024, 0)
     got_lists = dns.sample_bbox_list
     for g, r in zip(got_lists, lists):        # order inside a group of exactly equal scores is unspecified (std::partial_sort)
         assert [p for p, _ in g] == [p for p, _ in r]
@@ -205,15 +217,17 @@ def test_denet34_get_detections_vs_oracle(hip, soft, monkeypatch):
             i = j + 1
     lists = got_lists
     # head: oracle forward in test mode on the same RoIs
-    om = OM.OracleModel(model.export_json(), B)
+    if om is None:
+        om = OM.OracleModel(model.export_json(), B)
     om.forward(x, None, train=False, sample_override=lists)
     rel_close(cl.corner_pr.cpu().numpy(), om.corner_pr, 1e-3, "corner_pr (test mode)")
     det_pr, fitness, bbox, counts = dnd.last_outputs
     assert counts.tolist() == [len(l) for l in lists]
     sn = dns.sample_num
     t0 = dnd._thresholds()[0]
-    o_det, o_fit, o_box = OL.detect_outputs(om.detect_out.v, om.sample_bbox, 20, bool(dnd.use_jointfit), t0)
-    C1 = 21
+    C = dnd.class_num
+    o_det, o_fit, o_box = OL.detect_outputs(om.detect_out.v, om.sample_bbox, C, bool(dnd.use_jointfit), t0)
+    C1 = C + 1
     valid = (np.arange(sn * sn)[None] < counts[:, None]).reshape(B, 1, sn, sn)
     d = det_pr.cpu().numpy().reshape(B, sn, sn, C1).transpose(0, 3, 1, 2)
     np.testing.assert_allclose(np.where(valid, d, 0), np.where(valid, o_det, 0), rtol=1e-3, atol=1e-3)
@@ -221,7 +235,8 @@ def test_denet34_get_detections_vs_oracle(hip, soft, monkeypatch):
     v4 = valid.reshape(B, sn, sn, 1)
     np.testing.assert_allclose(np.where(v4, bx, 0), np.where(v4, o_box, 0), rtol=1e-3, atol=1e-4)
     # threshold + NMS: exact on the product's decoded arrays
-    ref = _oracle_nms(det_pr.cpu().numpy(), fitness.cpu().numpy(), bbox.cpu().numpy(), counts, B, sn, C1, 0.08, 0.5, soft)
+    ref = _oracle_nms(det_pr.cpu().numpy(), fitness.cpu().numpy(), bbox.cpu().numpy(), counts, B, sn, C1,
+                      params["prThreshold"], params["nmsThreshold"], soft)
     total = 0
     for b in range(B):
         dets = results[b]["detections"]
@@ -231,7 +246,7 @@ def test_denet34_get_detections_vs_oracle(hip, soft, monkeypatch):
         for (pr, cls, box), r in zip(dets, ref[b]):
             assert cls == int(r[1]) and np.array_equal(np.array(box, np.float32), r[2:])
             assert abs(pr - r[0]) <= 2e-6 * r[0]
-    assert total > 0, "no detections: the test exercises nothing"
+    return results, total
 
 
 def test_inference_bn_folding_matches_unfolded(hip):

@@ -106,10 +106,11 @@ def _run_two_ranks(tmp_path, mode):
     for r in range(2):
         out = str(tmp_path / ("rank%d_%s.pt" % (r, mode)))
         outs.append(out)
-        # DENET_AUTOTUNE=0: the heuristic kernels, so that both ranks and the emulation run the same configurations (measured
-        # choices are per process for geometries outside denet_amd/tuned/gfx950.json)
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   DENET_AUTOTUNE="0")
+        # the product default: a geometry outside denet_amd/tuned/gfx950.json (128x128, B = 2 here) runs ops.static_policy and is
+        # never measured, so both ranks and the emulation in this process run the same kernels - bit-identical results
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.pop("DENET_AUTOTUNE", None)
+        env.pop("DENET_TUNE", None)
         procs.append(subprocess.Popen([sys.executable, str(script), mode, out], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
     for p in procs:
@@ -120,12 +121,14 @@ def _run_two_ranks(tmp_path, mode):
 
 @pytest.fixture
 def heuristic_kernels():
+    """(name kept) the PRODUCT DEFAULT in this process too: committed decisions where the file has the geometry, ops.static_policy
+    elsewhere, nothing measured - what the two worker processes run; the decision table is restored afterwards"""
     from denet_amd import ops
-    saved = (ops.AUTOTUNE, dict(ops._WINO), set(ops._TUNED))
-    ops.AUTOTUNE = False
-    ops._WINO.clear()
+    ops._load_tuned_once()
+    saved = (ops.AUTOTUNE, dict(ops._WINO), set(ops._TUNED), ops.MEASURE, ops.POLICY)
+    ops.AUTOTUNE, ops.MEASURE, ops.POLICY = True, False, None
     yield
-    ops.AUTOTUNE = saved[0]
+    ops.AUTOTUNE, ops.MEASURE, ops.POLICY = saved[0], saved[3], saved[4]
     ops._WINO.clear()
     ops._WINO.update(saved[1])
 

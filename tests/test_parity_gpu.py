@@ -479,9 +479,9 @@ def _denet34_skip_steps_vs_oracle(regime, B, IMG, steps, model=None, free_runnin
             # free-running oracle: whole-network forward parity (1e-3 rel on activations and costs)
             random.seed(100 + it)
             if regime == "warm":
-                fcost, fcosts = om_free.train_step(x, metas, it, lr, mu, decay, "nesterov", sample_override=roi_lists)
+                fcost, fcosts = om_free.forward_costs(x, metas, sample_override=roi_lists)      # forward quantities only are compared
             else:
-                fcost, fcosts = om_free.train_step(x, metas, it, lr, mu, decay, "nesterov")
+                fcost, fcosts = om_free.forward_costs(x, metas)
                 assert om_free.sample_bbox_list == roi_lists, "RoI lists differ (cold: random boxes + GT injection)"
             ys, xs = om_free.taps
             taps_ref = (ys[:, :, None] * (IMG // 8) + xs[:, None, :]).reshape(ys.shape[0], -1)
@@ -581,7 +581,7 @@ def test_denet34_skip_512_timed_batch_vs_oracle(hip):
     model = zoo.denet34(B, "skip", 512, class_num=80, seed=1)
     missing = audit.decisions_cover(model)
     assert not missing, "passes without a committed decision (would be measured on the first step): %s" % (missing[:4],)
-    assert ops.POLICY is None and ops.AUTOTUNE
+    assert ops.POLICY is None and ops.AUTOTUNE and not ops.MEASURE
     with audit.KernelAudit(model) as ka:
         _denet34_skip_steps_vs_oracle("warm", B, 512, 1, model=model)
     gc.collect()
@@ -644,7 +644,7 @@ def test_denet34_edge_case_ground_truth_vs_oracle(hip):
         assert [r for r in roi_lists[1][-len(crowd):]] == [(1.0, b) for b in crowd[::-1]]     # GT injection, reversed
         if it == 0:
             random.seed(300 + it)
-            fcost, fcosts = om_free.train_step(x, metas, it, lr, mu, decay, "nesterov", sample_override=roi_lists)
+            fcost, fcosts = om_free.forward_costs(x, metas, sample_override=roi_lists)      # forward quantities only are compared
             assert abs(cost - fcost) <= 1e-3 * abs(fcost), (cost, fcost)
             for c, oc in zip(costs, fcosts):
                 assert abs(c - oc) <= 1e-3 * max(abs(oc), 1e-6), (costs, fcosts)
@@ -903,10 +903,11 @@ def test_direct_and_measured_paths_agree(hip):
     B, IMG = 2, 128
     x, metas = zoo.synthetic_batch(B, IMG, seed=2)
     res = []
-    saved = (ops.AUTOTUNE, dict(ops._WINO), set(ops._TUNED))
+    saved = (ops.AUTOTUNE, dict(ops._WINO), set(ops._TUNED), ops.MEASURE)
     try:
         for tuned in (False, True):
             ops.AUTOTUNE = tuned
+            ops.MEASURE = tuned          # the explicit measuring mode (DENET_TUNE=1, what tools/tune.py runs): this test exercises the tuner
             ops._WINO.clear()
             model = zoo.denet34(B, "skip", IMG, class_num=80, seed=1)
             _warm_corner_head(model, 4.0, 0.3)
@@ -946,7 +947,7 @@ def test_direct_and_measured_paths_agree(hip):
                     l.layer_index, name, err)
         print("worst per-layer measured-vs-direct difference:", worst)
     finally:
-        ops.AUTOTUNE = saved[0]
+        ops.AUTOTUNE, ops.MEASURE = saved[0], saved[3]
         ops._WINO.clear()
         ops._WINO.update(saved[1])
 
@@ -999,6 +1000,36 @@ def test_bn_reductions_finished_in_the_producing_launch_are_bit_identical(hip, m
     finally:
         L.denet_conv_wino4f_mode(old[0])
         ops.set_final_fold(old[1])
+
+
+def test_bn_final_fold_in_front_of_a_pool_fused_batch_norm(hip):
+    """with the fold on, a generic convolution (not the stem kernels) in front of a batch norm whose BN + ReLU +
+    max pool run as ONE pass must not finish the statistics itself - the fused pass reduces the rows and updates the running
+    statistics, a second update would advance run_mean / run_stdinv twice per step. The three-layer CIFAR network (C BN A P x 3:
+    layers 2 and 3 are generic convolutions feeding pool-fused batch norms): parameters, momentum and RUNNING STATISTICS after
+    four steps are bit-identical with the fold on and off."""
+    B = 32
+    x, metas = zoo.synthetic_batch(B, 32, class_num=10, image_class=True, seed=4)
+    xd = torch.from_numpy(x).cuda()
+    old = ops.set_final_fold(0)
+
+    def run(fold):
+        ops.set_final_fold(3 if fold else 0)
+        model = zoo.cifar3(B, class_num=10, seed=2)
+        model.build_train_func("nesterov")
+        fused = [l for l in model_cnn_walk(model.layers) if getattr(l, "pool_behind", None) is not None]
+        costs = [model.train_step(xd, metas, 0, it, 0.05, [0.9], 1e-4)[0] for it in range(4)]
+        torch.cuda.synchronize()
+        return costs, model.P.clone(), model.M.clone(), model.S.clone(), len(fused)
+
+    try:
+        ref, got = run(False), run(True)
+        assert ref[4] >= 2 and ops.BN_POOL_FUSE, "no pool-fused batch norm in the network: the test exercises nothing"
+        assert got[0] == ref[0]
+        for k in (1, 2, 3):
+            assert torch.equal(got[k], ref[k]), "%s differs with the fold on" % "PMS"[k - 1]
+    finally:
+        ops.set_final_fold(old)
 
 
 def test_bn_pool_fusion_leaves_training_unchanged(hip):

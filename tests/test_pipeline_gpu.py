@@ -22,33 +22,79 @@ def tree(tmp_path_factory):
     return root
 
 
-def _make_head_fire(model, rng):
-    """untrained model: give the corner detector and the classifier some signal so that detections come out"""
-    from tests.test_parity_gpu import _warm_corner_head
-    dnd = model.layers[-1]
-    dconv = dnd.layers[0]
+PARAMS = {"prThreshold": 0.02, "nmsThreshold": 0.5, "cornerThreshold": 0.02}
+PARAMS_STR = "prThreshold=0.02,nmsThreshold=0.5,cornerThreshold=0.02"
+
+
+def _batches(data, B):
+    """the batches predict.test_detector feeds (host loader path), with how many of each batch's rows are real images"""
+    out = []
+    for subset in range(data.subset_num):
+        data.load_from_subset(subset)
+        data_x, data_m, data_size = data.export(B)
+        for n in range(data_x.shape[0] // B):
+            out.append((data_x[n * B:(n + 1) * B], data_m[n * B:(n + 1) * B], max(0, min(B, data_size - n * B))))
+    return out
+
+
+def _calibrate_heads(model, batches, rng):
+    """A few dozen steps on ten synthetic images do not make a detector, and test-mode batch norm on barely settled running
+    statistics scales the activations arbitrarily. The two heads are therefore CALIBRATED ON THE PRODUCT'S OWN OUTPUTS so that
+    detections are guaranteed by construction, whatever the short training did (round-5 verdict, weak 1: the former test asserted
+    the statistical property `n_det > 0` and went red on another box):
+      * corner detector: random corner filters, rescaled so that the corner logits of the test views have unit spread, and a bias
+        at the quantile that puts 8 % of the cells (about 20 per corner type on a 16x16 map) above cornerThreshold;
+      * classifier: random filters rescaled so that class logits have spread 2 and box regressions 0.2, like a trained head.
+    Everything behind it is compared with the oracle, not counted."""
+    by_type = lambda t: [l for l in model.layers if l.type_name == t][0]
+    dnc, dnd = by_type("denet-corner"), by_type("denet-detect")
+    conv, cn, dconv = dnc.layers[-1], dnc.corner_num, dnd.layers[0]
+    w, b = conv.omega.get_value().copy(), conv.beta.get_value().copy()
+    w[:cn] = rng.normal(0, 0.3, w[:cn].shape)
+    b[:cn] = 0.0
+    conv.omega.set_value(w)
+    conv.beta.set_value(b)
+    z = []
+    for x, _, _ in batches:
+        model.forward(x, None, train=False)
+        z.append(conv.output.data[..., :cn].float().cpu().numpy().reshape(-1))
+    z = np.concatenate(z)
+    assert np.isfinite(z).all() and z.std() > 0, "the features in front of the corner detector are degenerate"
+    sd = float(z.std())
+    w[:cn] /= sd
+    # a cell fires when its positive-class probability sigmoid(-2 l) exceeds 0.02: l < 1.946 (denet_corner.py:50-53)
+    b[:cn] = 1.9 - float(np.quantile(z / sd, 0.08))
+    conv.omega.set_value(w)
+    conv.beta.set_value(b)
     dconv.omega.set_value(rng.normal(0, 0.3, dconv.omega.value.shape))
-    _warm_corner_head(model, 4.0, 0.3)
-
-
-def _rescale_head(model, x, metas):
-    """test-mode BN on barely trained running statistics blows the activations up: rescale the detection filters so
-    that class logits are O(1) and box regressions O(0.1), like a trained head (same trick as test_inference_gpu)"""
-    dnd = model.layers[-1]
-    dconv = dnd.layers[0]
-    dnd.get_detections(model, x, metas, {"prThreshold": 0.02, "nmsThreshold": 0.5, "cornerThreshold": 0.02})
-    raw = dnd.conv.output.data.float().cpu().numpy().reshape(-1, dnd.conv.kp)
+    raw, rois = [], 0
+    S = dnd.sample_num * dnd.sample_num
+    for x, m, _ in batches:
+        dnd.get_detections(model, x, m, PARAMS)
+        counts = dnd.last_outputs[3]
+        rows = dnd.conv.output.data.float().cpu().numpy().reshape(-1, dnd.conv.kp)
+        raw += [rows[i * S:i * S + int(c)] for i, c in enumerate(counts)]
+        rois += int(counts.sum())
+    assert rois > 0, "the calibrated corner detector proposed no RoI"
+    raw = np.concatenate(raw)
     s0 = dnd.s0
     w = dconv.omega.get_value().copy()
     w[:s0] *= 2.0 / raw[:, :s0].std()
     w[s0:s0 + 4] *= 0.2 / raw[:, s0:s0 + 4].std()
     dconv.omega.set_value(w)
+    return rois
 
 
 @pytest.mark.parametrize("fmt", ["voc", "mscoco"])
 def test_dataset_to_detections(hip, tree, tmp_path, fmt):
+    """dataset on disk -> loader + augmentation -> training epochs -> checkpoint -> model-predict (host-loaded and device-rendered
+    views) -> result files. The detections model-predict returns are compared WITH THE ORACLE batch by batch (RoI lists exact,
+    oracle/model.py test-mode forward of the reloaded checkpoint on the same RoIs within 1e-3, threshold + NMS exact:
+    tests/test_inference_gpu.py: check_detections_vs_oracle); the result files are compared exactly with the reference's formulas
+    (denet/dataset/mscoco.py:140-169, pascal_voc.py:136-160) applied to those detections."""
     from denet_amd import dataset
     from denet_amd.model import model_cnn, predict, zoo
+    from tests.test_inference_gpu import check_detections_vs_oracle
     random.seed(5)
     np.random.seed(5)
     if fmt == "voc":
@@ -63,10 +109,10 @@ def test_dataset_to_detections(hip, tree, tmp_path, fmt):
     model = zoo.denet34(B, "skip", 128, class_num=train.get_class_num(), seed=1)
     model.class_labels = train.class_labels
     assert train.get_data_shape() == (3, 128, 128) == tuple(model.data_shape)
-    _make_head_fire(model, np.random.RandomState(5))
+    zoo.warm_corner_head(model, 4.0, 0.3)      # RoIs from the corner detector during training as well
     model.build_train_func("nesterov")
     costs = []
-    EPOCHS = 12      # ~60 steps: enough for the BN running statistics (momentum 0.9) to settle for the test-mode pass
+    EPOCHS = 8
     for epoch in range(EPOCHS):
         train.shuffle()
         for subset in range(train.subset_num):
@@ -80,40 +126,70 @@ def test_dataset_to_detections(hip, tree, tmp_path, fmt):
     model_cnn.save_to_file(model, mdl)
     loaded = model_cnn.load_from_file(mdl, B)
     assert loaded.class_labels == train.class_labels
-    # sixty steps on ten synthetic images do not make a detector: re-randomise the corner / class heads of the reloaded
-    # model so that the prediction stage has RoIs and scores to write, whatever the short training did
-    _make_head_fire(loaded, np.random.RandomState(6))
-    test.load_from_subset(0)
-    tx, tm, _ = test.export(B)
-    _rescale_head(loaded, tx[:B], tm[:B])
+    batches = _batches(test, B)
+    n_images = test.subset_total_size
+    assert sum(n for _, _, n in batches) == n_images
+    n_rois = _calibrate_heads(loaded, batches, np.random.RandomState(6))
     results = str(tmp_path / "out" / "res")
-    r = predict.test_detector("detect," + fmt, loaded, test, results,
-                              "prThreshold=0.02,nmsThreshold=0.5,cornerThreshold=0.02", log=lambda *a: None)
+    r = predict.test_detector("detect," + fmt, loaded, test, results, PARAMS_STR, log=lambda *a: None)
     # the same evaluation with the test views (scale + centre crop) rendered on the GPU: identical detections
-    r_dev = predict.test_detector("detect," + fmt, loaded, test, str(tmp_path / "out_dev" / "res"),
-                                  "prThreshold=0.02,nmsThreshold=0.5,cornerThreshold=0.02", log=lambda *a: None,
+    r_dev = predict.test_detector("detect," + fmt, loaded, test, str(tmp_path / "out_dev" / "res"), PARAMS_STR, log=lambda *a: None,
                                   device_render=True, thread_num=2)
     assert [d["detections"] for d in r_dev["detections"]] == [d["detections"] for d in r["detections"]]
-    n_images = test.subset_total_size
     assert len(r["detections"]) == n_images
+
+    # ---- the detections against the oracle: the reloaded checkpoint in oracle/model.py, the same views, batch by batch
+    from oracle import model as OM
+    om = OM.OracleModel(loaded.export_json(), B)
+    expect, n_det = [], 0
+    for x, m, n_real in batches:
+        res, _ = check_detections_vs_oracle(loaded, x, m, PARAMS, om=om)
+        expect += res[:n_real]
+    assert len(expect) == n_images
+    for got, ref in zip(r["detections"], expect):
+        # (the COCO writer sorts an image's list by score in place, mscoco.py:150: compare as the same multiset in score order)
+        key = lambda t: (-t[0], t[1], t[2])
+        assert sorted(got["detections"], key=key) == sorted(ref["detections"], key=key)
+        assert got["meta"]["image"] == ref["meta"]["image"]
+        n_det += len(ref["detections"])
+    assert n_det > 0, "calibrated heads (%d RoIs) gave no detection: the writers are not exercised" % n_rois
     raw = json.load(open(os.path.join(os.path.dirname(results), "detections.json")))
     assert len(raw["dets"]) == n_images and raw["detectParams"]["prThreshold"] == 0.02
-    n_det = sum(len(d["detections"]) for d in r["detections"])
-    assert n_det > 0, "no detections: the writers are not exercised"
+
+    # ---- the result files, exactly, from the oracle-checked detections
     if fmt == "voc":
         assert len(r["ap"]) == 20
-        files = [f for f in os.listdir(os.path.dirname(results)) if f.startswith("comp4_det_test_")]
-        assert files
-        rows = sum(len(open(os.path.join(os.path.dirname(results), f)).read().splitlines()) for f in files)
-        assert rows == n_det
+        inv = {v: k for k, v in loaded.class_labels.items()}
+        rows = {}
+        for d in expect:
+            meta = d["meta"]
+            iid = os.path.splitext(os.path.basename(meta["image"]["fname"]))[0]
+            (sx, sy), (ox, oy), (iw, ih) = meta["scale"], meta["offset"], meta["image_size"]
+            for pr, cls, bb in d["detections"]:
+                px = [max(min(int((bb[k] * 128 + (ox, oy)[k % 2]) / (sx, sy)[k % 2]) + 1, (iw, ih)[k % 2]), 1) for k in range(4)]
+                rows.setdefault(cls, []).append("%s %0.6f %.6f %.6f %.6f %.6f\n" % (iid, pr, px[0], px[1], px[2], px[3]))
+        out_dir = os.path.dirname(results)
+        files = sorted(f for f in os.listdir(out_dir) if f.startswith("comp4_det_test_"))
+        assert files == sorted("comp4_det_test_%s.txt" % inv[c] for c in rows)
+        for c, lines in rows.items():
+            assert open(os.path.join(out_dir, "comp4_det_test_%s.txt" % inv[c])).read() == "".join(lines)
     else:
         res = json.load(open(results + ".json"))
-        assert len(res) == n_det
+        cat_of_label = {test.class_labels[name]: cid for cid, name in test.categories.items()}
+        want = []
+        for d in expect:
+            meta = d["meta"]
+            (sx, sy), (ox, oy), (iw, ih) = meta["scale"], meta["offset"], meta["image_size"]
+            for pr, cls, bb in sorted(d["detections"], key=lambda t: -t[0]):
+                x0 = max(min((bb[0] * test.output_size + ox) / sx + 1, iw), 1)
+                y0 = max(min((bb[1] * test.output_size + oy) / sy + 1, ih), 1)
+                x1 = max(min((bb[2] * test.output_size + ox) / sx + 1, iw), 1)
+                y1 = max(min((bb[3] * test.output_size + oy) / sy + 1, ih), 1)
+                want.append({"image_id": meta["image"]["id"], "category_id": cat_of_label[cls],
+                             "bbox": [round(x0, 1), round(y0, 1), round(x1 - x0, 1), round(y1 - y0, 1)], "score": round(pr, 6)})
+        assert res == want
         ids = {im["id"] for im in test.images}
-        cats = set(test.categories.keys())
-        for e in res:
-            assert e["image_id"] in ids and e["category_id"] in cats and len(e["bbox"]) == 4 and 0 <= e["score"] <= 1
-            assert e["bbox"][2] >= 0 and e["bbox"][3] >= 0
+        assert all(e["image_id"] in ids and e["category_id"] in test.categories and 0 <= e["score"] <= 1 for e in res)
 
 
 def test_model_predict_classifier_modes(hip, tree, tmp_path):

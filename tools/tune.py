@@ -14,6 +14,7 @@ import random
 import sys
 
 os.environ["DENET_TUNE_CACHE"] = "0"
+os.environ["DENET_TUNE"] = "1"                # measuring is an explicit act: the product default never times a candidate (ops.MEASURE)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from denet_amd import ops  # noqa: E402
@@ -47,15 +48,30 @@ def snapshot():
     return kern, dict(ops._WINO)
 
 
+def merge_records(old_kernels, old_wino, rec, wino):
+    """replaces exactly the keys that were re-measured: a convolution record (mode <= 2) of the old file goes only if the new
+    measurement holds the same 11-value geometry key, a decision only if the same (mode, geometry) was decided again; everything
+    else - incl. the records of another configuration with the same batch size (denet34-skip and cifar3 both run batch 32) -
+    stays. Batched-product records (mode > 2) are added where the file has none. Returns (kept, added, decisions kept, added)."""
+    new_k = {tuple(r[:11]): list(r[11:]) for r in rec}
+    kept = [r for r in old_kernels if not (r[0] <= 2 and tuple(r[:11]) in new_k)]
+    have = {tuple(r[:11]) for r in kept}
+    add = [list(k) + list(v) for k, v in new_k.items() if k[0] <= 2 or k not in have]
+    new_w = {(int(m), tuple(int(v) for v in g)): int(t) for (m, g), t in wino.items()}
+    wkept = [w for w in old_wino if (int(w[0]), tuple(int(v) for v in w[1])) not in new_w]
+    wadd = [[m, list(g), t] for (m, g), t in new_w.items()]
+    return kept, add, wkept, wadd
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join("gpurun_out", "gfx950.json"))
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--only", default=None, help="measure ONE configuration (denet34-skip / resnet34 / denet101-wide / cifar3)")
     ap.add_argument("--merge-into", default=None,
-                    help="with --only: an existing file whose records of OTHER batch sizes are kept as they are; the measured "
-                         "configuration's convolution records and decisions (batch = its batch size) replace theirs, batched-product "
-                         "records are added where the file has none")
+                    help="with --only: an existing file; exactly the convolution records and decisions whose FULL geometry key was "
+                         "re-measured are replaced (another configuration that shares the batch size keeps all of its records), "
+                         "batched-product records are added where the file has none")
     args = ap.parse_args()
     votes_k, votes_w = collections.defaultdict(list), collections.defaultdict(list)
     for rep in range(args.reps):
@@ -81,14 +97,8 @@ def main():
         ops._WINO[k] = collections.Counter(vs).most_common(1)[0][0]
     if args.merge_into:
         import json
-        batch = {"denet34-skip": 32, "resnet34": 64, "denet101-wide": 16, "cifar3": 32}[args.only]
         old = json.load(open(args.merge_into))
-        new_k = {tuple(r[:11]): r[11:] for r in rec}
-        kept = [r for r in old["kernels"] if not (r[0] <= 2 and r[1] == batch)]
-        have = {tuple(r[:11]) for r in kept}
-        add = [list(k) + list(v) for k, v in new_k.items() if (k[0] <= 2 and k[1] == batch) or (k[0] > 2 and k not in have)]
-        wkept = [w for w in old["winograd"] if w[1][0] != batch]
-        wadd = [[m, list(g), t] for (m, g), t in ops._WINO.items() if g[0] == batch]
+        kept, add, wkept, wadd = merge_records(old["kernels"], old["winograd"], rec, ops._WINO)
         old["kernels"] = sorted(kept + add)
         old["winograd"] = sorted(wkept + wadd)
         old.setdefault("meta", {})["merged"] = old["meta"].get("merged", []) + ["%s re-measured (%d reps)" % (args.only, args.reps)]
