@@ -146,53 +146,61 @@ def inference_leg(steps):
            "model": "DeNet-34 skip 512x512, 80 classes, 576 RoIs per image, warm corner head (random corner filters, bias 4), "
                     "random detection filters; prThreshold 0.05, nmsThreshold 0.5"}
     for B in (1, 32):
-        model = zoo.denet34(B, "skip", 512, class_num=80, seed=1)
-        zoo.warm_corner_head(model, 4.0, 0.3)
-        rng = numpy.random.RandomState(3)
-        by_type = lambda t: [l for l in model.layers if l.type_name == t][0]
-        dnd, dns, dnc = by_type("denet-detect"), by_type("denet-sparse"), by_type("denet-corner")
-        dnd.layers[0].omega.set_value(rng.normal(0, 0.02, dnd.layers[0].omega.value.shape))
-        x, metas = zoo.synthetic_batch(B, 512, 80, seed=1)
-        xd = torch.from_numpy(x).cuda()
-        for soft in (0, 1):
-            params = {"prThreshold": 0.05, "nmsThreshold": 0.5, "useSoftNMS": soft}
-            key = "b%d_%s" % (B, "soft_nms" if soft else "nms")
-            for _ in range(3):
-                r = dnd.get_detections(model, xd, metas, params)
-            ent = {}
-            if B == 1:
-                ent["oracle_check"] = _inference_check(model, dnd, dns, dnc, x, r, params)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                r = dnd.get_detections(model, xd, metas, params)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / steps
-            ent.update({"value": round(B / dt, 2), "unit": "Hz" if B == 1 else "images/sec", "ms_per_batch": round(1e3 * dt, 3),
-                        "batch": B, "calls_timed": steps, "detections_last_batch": sum(len(i["detections"]) for i in r),
-                        "rois_last_batch": int(dnd.last_outputs[3].sum())})
-            if not soft:
-                prof = ops.KernelProfile()
-                ops.PROFILE = prof
-                try:
-                    for _ in range(3):
-                        dnd.get_detections(model, xd, metas, params)
-                finally:
-                    ops.PROFILE = None
-                agg = prof.summary()
-                name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
-                tf = a["flops"] / (a["ms"] * 1e-3) / 1e12
-                ent["dominant_kernel"] = {"kernel": name, "launches_per_call": a["launches"] // 3, "ms_per_call": round(a["ms"] / 3, 4),
-                                          "tflops": round(tf, 2), "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
-                ent["matrix_kernel_ms_per_call"] = round(sum(v["ms"] for v in agg.values()) / 3, 3)
-                with audit.KernelAudit(model) as ka:
-                    dnd.get_detections(model, xd, metas, params)
-                    torch.cuda.synchronize()
-                ent["kernels_used"] = {g: e["fwd"] for g, e in ka.summary().items()}
-            res[key] = ent
-        del model
+        _inference_batch(B, steps, res)
         torch.cuda.empty_cache()
     return res
+
+
+def _inference_batch(B, steps, res):
+    """one batch size of inference_leg (its model lives and dies in this frame)"""
+    import numpy
+    import torch
+    from denet_amd import ops
+    from denet_amd.model import audit, zoo
+    model = zoo.denet34(B, "skip", 512, class_num=80, seed=1)
+    zoo.warm_corner_head(model, 4.0, 0.3)
+    rng = numpy.random.RandomState(3)
+    by_type = lambda t, layers=model.layers: [l for l in layers if l.type_name == t][0]
+    dnd, dns, dnc = by_type("denet-detect"), by_type("denet-sparse"), by_type("denet-corner")
+    dnd.layers[0].omega.set_value(rng.normal(0, 0.02, dnd.layers[0].omega.value.shape))
+    x, metas = zoo.synthetic_batch(B, 512, 80, seed=1)
+    xd = torch.from_numpy(x).cuda()
+    for soft in (0, 1):
+        params = {"prThreshold": 0.05, "nmsThreshold": 0.5, "useSoftNMS": soft}
+        key = "b%d_%s" % (B, "soft_nms" if soft else "nms")
+        for _ in range(3):
+            r = dnd.get_detections(model, xd, metas, params)
+        ent = {}
+        if B == 1:
+            ent["oracle_check"] = _inference_check(model, dnd, dns, dnc, x, r, params)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = dnd.get_detections(model, xd, metas, params)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ent.update({"value": round(B / dt, 2), "unit": "Hz" if B == 1 else "images/sec", "ms_per_batch": round(1e3 * dt, 3),
+                    "batch": B, "calls_timed": steps, "detections_last_batch": sum(len(i["detections"]) for i in r),
+                    "rois_last_batch": int(dnd.last_outputs[3].sum())})
+        if not soft:
+            prof = ops.KernelProfile()
+            ops.PROFILE = prof
+            try:
+                for _ in range(3):
+                    dnd.get_detections(model, xd, metas, params)
+            finally:
+                ops.PROFILE = None
+            agg = prof.summary()
+            name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+            tf = a["flops"] / (a["ms"] * 1e-3) / 1e12
+            ent["dominant_kernel"] = {"kernel": name, "launches_per_call": a["launches"] // 3, "ms_per_call": round(a["ms"] / 3, 4),
+                                      "tflops": round(tf, 2), "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+            ent["matrix_kernel_ms_per_call"] = round(sum(v["ms"] for v in agg.values()) / 3, 3)
+            with audit.KernelAudit(model) as ka:
+                dnd.get_detections(model, xd, metas, params)
+                torch.cuda.synchronize()
+            ent["kernels_used"] = {g: e["fwd"] for g, e in ka.summary().items()}
+        res[key] = ent
 
 
 def _inference_check(model, dnd, dns, dnc, x, results, params):

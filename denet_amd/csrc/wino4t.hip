@@ -1,0 +1,501 @@
+// Winograd F(4x4,3x3), TILE-PARALLEL: input transform, the 36 component products and the output transform in ONE kernel - neither
+// V nor M ever reaches HBM (verdict item of rounds 4-5: "a tile-parallel fused F(4x4) kernel with the input transform inside").
+// Reference op: the `C[k,3]` layer, denet/layer/convolution.py:80-83 (forward) and its data gradient, model_cnn.py:318 (the same
+// pipeline on dy with the rotated, channel-swapped filters) - here for the layers whose x is a plain tensor (the 64-channel stage,
+// where the fused F(2x2) kernels of wino2f.hip execute 2.25 / 4 x 1.78 = 1.78 times the products of this one).
+//
+// The component-walk kernel (wino4f.hip) keeps 16 output positions per value and reads the 2.25x expanded V from HBM. This one
+// turns the loop nest round: a workgroup owns 32 tiles (4 x 8 tiles = 16 x 32 output pixels) x 64 output channels and keeps ALL 36
+// components of its products as accumulators (a wave: 16 tiles x 16 channels x 36 components = 144 registers per lane), and the
+// reduction runs over chunks of 16 input channels:
+//     patch chunk (18 x 34 pixels x 16 channels, 39 KB)  --LDS-DMA-->  LDS, two buffers, two chunks ahead
+//     transform:  every thread forms half the components of (one tile, two channels): 30 x ds_read_b64, 84 packed fp32
+//                 operations, 18 x ds_write_b64 -> V[36][4 channel quads][32 tiles][4] in LDS (72 KB, one buffer)
+//     products:   per component one ds_read_b128 (V fragment), one global_load_dwordx4 (U fragment, straight from L2: the
+//                 packed filters [C/16][36][K][16] make a wave's fragment one contiguous KB) and four v_mfma_f32_16x16x4_f32
+// and the epilogue is the output transform in registers (the lane holds the 6 x 6 components of its (tile, 4 channels)) followed
+// by the stores of wino4f.hip's epilogue (bias / add / ReLU, batch-norm column sums, backward sums).
+// LDS layouts are chosen so that every access is conflict-free without padding the DMA's linear writes:
+//   patch plane (one channel quad): [18 rows][38 slots of 16 B]: slot q = v * 9 + u holds patch column 4 u + v (q = 36, 37 unused):
+//       the 8 tiles of a tile row read column 4 tx + b = slots 16 B apart, the next tile row lies 4 x 608 B = 128 B (mod 256)
+//       further: 32 lanes x 8 B cover the 64 banks once (ds_read_b64);
+//   V: [xi][channel quad][tile][4]: a transform wave's 16 consecutive lanes write 128 contiguous bytes, a product wave's
+//       ds_read_b128 reads lane r + 16 g at g * 512 + r * 16.
+// vmcnt discipline: LDS-DMA pieces and U fragment loads share one in-order counter, so a fragment load issued behind a piece
+// cannot be consumed before the piece has landed. A chunk's pieces are therefore issued TWO chunks ahead, at the END of a chunk's
+// products - behind the fragment loads of the next chunk's first components: the first load that waits for them is consumed a
+// whole transform and T_D component pairs later.
+#include "common.h"
+#include "bn_final.h"
+#include "../../include/denet_hip.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+// buffer_store_dwordx4 with two wait states behind it (the hazard described in wino4f.hip: a register soffset exempts the store
+// from the compiler's wait state, a VALU write of the data registers in the next cycle corrupts it)
+__device__ __forceinline__ void t_store_b128(const f32x4& v, const i32x4_t& rsrc, int voff, int soff) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+struct W4TParams {
+    const float* x;      // [N,H,W,C]
+    const float* U;      // packed [C/16][36][K][16] (denet_conv_wino4t_pack)
+    const float* bias;   // [K] or null
+    const float* add;    // [N,H,W,K] or null
+    float* y;            // [N,H,W,K]
+    double* stats;       // [tile blocks][2][K] or null
+    const float* bs_x;   // backward sums (wino4f.hip / winograd.hip wino_output_kernel)
+    const float* bs_y;
+    const float* bs_gamma;
+    const float* bs_beta;
+    const float* bs_mean;
+    const float* bs_invstd;
+    int bs_relu;
+    int N, H, W, C, K;
+    int bh, bw;          // tile blocks per image (rows of 4 tiles, columns of 8 tiles)
+    int tiles_k;         // K / 64
+    int chunks;          // C / 16
+    int relu;
+    unsigned x_bytes, y_bytes, u_bytes;
+};
+
+constexpr int T_OOB = (int)0xF0000000u;
+constexpr int T_QS = 38;                          // 16-byte slots per patch row (36 used)
+constexpr int T_PLANE_SLOTS = 18 * T_QS;          // 684
+constexpr int T_PLANE_B = T_PLANE_SLOTS * 16;     // 10 944
+constexpr int T_PATCH_SLOTS = 4 * T_PLANE_SLOTS;  // 2 736
+constexpr int T_PATCH_B = 43 * 1024;              // 44 032: one patch buffer (43 pieces)
+constexpr int T_V_B = 36 * 2048;                  // 73 728
+constexpr int T_SCRATCH = 2 * T_PATCH_B + T_V_B;  // 161 792: 1 KB that the surplus pieces write
+constexpr int T_LDS = T_SCRATCH + 1024;           // 162 816 <= 163 840
+constexpr int T_D = 4;                            // component pairs whose filter fragments are loaded ahead
+
+#define T_WAITCNT(vm) __builtin_amdgcn_s_waitcnt(((vm) & 15) | ((((vm) >> 4) & 3) << 14) | (7 << 4))              /* + lgkmcnt(0) */
+#define T_WAIT_VM(vm) __builtin_amdgcn_s_waitcnt(((vm) & 15) | ((((vm) >> 4) & 3) << 14) | (7 << 4) | (15 << 8))  /* vmcnt only */
+#define T_BARRIER()                        \
+    {                                      \
+        asm volatile("" ::: "memory");     \
+        __builtin_amdgcn_s_barrier();      \
+        asm volatile("" ::: "memory");     \
+    }
+
+// B^T of F(4x4,3x3) applied to a 6-vector, three of its six outputs (LH = 0: rows 0..2 from d0..d4; LH = 1: rows 3..5 from d1..d5)
+template <int LH>
+__device__ __forceinline__ void t_bt3(const f32x2 (&d)[6], f32x2 (&o)[3]) {
+    if (LH == 0) {
+        o[0] = __builtin_elementwise_fma(f32x2{-5.f, -5.f}, d[2], __builtin_elementwise_fma(f32x2{4.f, 4.f}, d[0], d[4]));
+        const f32x2 p = __builtin_elementwise_fma(f32x2{-4.f, -4.f}, d[2], d[4]);
+        const f32x2 q = __builtin_elementwise_fma(f32x2{-4.f, -4.f}, d[1], d[3]);
+        o[1] = p + q;
+        o[2] = p - q;
+    } else {
+        const f32x2 p = d[4] - d[2];
+        const f32x2 q = d[3] - d[1];
+        o[0] = __builtin_elementwise_fma(f32x2{2.f, 2.f}, q, p);
+        o[1] = __builtin_elementwise_fma(f32x2{-2.f, -2.f}, q, p);
+        o[2] = __builtin_elementwise_fma(f32x2{-5.f, -5.f}, d[3], __builtin_elementwise_fma(f32x2{4.f, 4.f}, d[1], d[5]));
+    }
+}
+// all six outputs
+__device__ __forceinline__ void t_bt6(const f32x2 (&t)[6], f32x2 (&o)[6]) {
+    o[0] = __builtin_elementwise_fma(f32x2{-5.f, -5.f}, t[2], __builtin_elementwise_fma(f32x2{4.f, 4.f}, t[0], t[4]));
+    const f32x2 p = __builtin_elementwise_fma(f32x2{-4.f, -4.f}, t[2], t[4]);
+    const f32x2 q = __builtin_elementwise_fma(f32x2{-4.f, -4.f}, t[1], t[3]);
+    o[1] = p + q;
+    o[2] = p - q;
+    const f32x2 p2 = t[4] - t[2];
+    const f32x2 q2 = t[3] - t[1];
+    o[3] = __builtin_elementwise_fma(f32x2{2.f, 2.f}, q2, p2);
+    o[4] = __builtin_elementwise_fma(f32x2{-2.f, -2.f}, q2, p2);
+    o[5] = __builtin_elementwise_fma(f32x2{-5.f, -5.f}, t[3], __builtin_elementwise_fma(f32x2{4.f, 4.f}, t[1], t[5]));
+}
+
+// the input transform of one thread: components (l, m), l = 3 LH .. 3 LH + 2, m = 0 .. 5 of its (tile, channel pair)
+template <int LH>
+__device__ __forceinline__ void t_transform(const char* prd, char* vwr) {
+    f32x2 t[3][6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        f32x2 d[6];
+#pragma unroll
+        for (int a = LH; a < LH + 5; ++a) d[a] = *(const f32x2*)(prd + (a * T_QS + (b & 3) * 9 + (b >> 2)) * 16);
+        if (LH == 0) d[5] = f32x2{0.f, 0.f};
+        else d[0] = f32x2{0.f, 0.f};
+        f32x2 o[3];
+        t_bt3<LH>(d, o);
+        t[0][b] = o[0];
+        t[1][b] = o[1];
+        t[2][b] = o[2];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        f32x2 o[6];
+        t_bt6(t[i], o);
+#pragma unroll
+        for (int m = 0; m < 6; ++m) *(f32x2*)(vwr + (6 * (3 * LH + i) + m) * 2048) = o[m];
+    }
+}
+
+constexpr float T_AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+
+// EP: 0 = store only, 1 = + batch-norm column sums of what is stored, 2 = + backward sums of the batch norm in front
+template <int EP>
+__global__ __launch_bounds__(512, 2) void wino4t_kernel(const W4TParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const vbuf = smem + 2 * T_PATCH_B;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int kblk = (int)(bid % (uint32_t)p.tiles_k);
+    int blk = (int)(bid / (uint32_t)p.tiles_k);
+    const int bx = blk % p.bw;
+    blk /= p.bw;
+    const int by = blk % p.bh;
+    const int n = blk / p.bh;
+    const int k0 = kblk * 64;
+    const int y0 = by * 16, x0 = bx * 32;           // first output pixel of the block
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+
+    // ---- LDS-DMA pieces of this wave: piece = wave + 8 j covers patch slots 64 piece .. 64 piece + 63 ----
+    int pc_off[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int L = (wave + 8 * j) * 64 + lane;
+        const int pl = L / T_PLANE_SLOTS, rem = L - pl * T_PLANE_SLOTS;
+        const int row = rem / T_QS, q = rem - row * T_QS;
+        const int v = q / 9, u = q - v * 9;
+        const int pcx = 4 * u + v;
+        const int iy = y0 - 1 + row, ix = x0 - 1 + pcx;
+        const bool ok = L < T_PATCH_SLOTS && q < 36 && pcx < 34 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        pc_off[j] = ok ? (((n * p.H + iy) * p.W + ix) * p.C + pl * 4) * 4 : T_OOB;
+    }
+    int d_chunk = 0;          // the chunk the next issue fetches
+    auto issue = [&]() {
+        const bool live = d_chunk < p.chunks;
+        char* const dstb = smem + (d_chunk & 1) * T_PATCH_B;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int piece = wave + 8 * j;
+            char* const dst = piece < 43 ? dstb + piece * 1024 : smem + T_SCRATCH;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_ptr_t)dst, 16, live ? pc_off[j] : T_OOB, d_chunk * 64, 0, 0);
+        }
+        d_chunk += 1;
+    };
+
+    // ---- transform role: lane = (half, tile column, tile row); wave = (channel quad, component half) ----
+    const int t_half = lane & 1, t_tx = (lane >> 1) & 7, t_ty = (lane >> 4) & 3;
+    const int t_cq = wave & 3, t_lh = wave >> 2;
+    const int t_rd = t_cq * T_PLANE_B + (4 * t_ty * T_QS + t_tx) * 16 + t_half * 8;
+    char* const t_wr = vbuf + t_cq * 512 + (t_ty * 8 + t_tx) * 16 + t_half * 8;
+
+    // ---- product role: wave = (tile half tw, channel block kw); lane = (r, g) ----
+    const int r15 = lane & 15, g = lane >> 4;
+    const int tw = wave & 1, kw = wave >> 1;
+    const char* const v_rd = vbuf + g * 512 + (16 * tw + r15) * 16;
+    // the filter fragments come through a buffer descriptor: one lane offset, the (chunk, component) offset is scalar
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, p.u_bytes, 0x00020000);
+    const int u_voff = ((k0 + 16 * kw + r15) * 16 + 4 * g) * 4;
+    const int u_xi = p.K * 64;                       // bytes per component
+    const int u_chunk = 36 * u_xi;                   // bytes per chunk
+
+    f32x4 acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // filter fragments of component pairs, T_D pairs ahead (a ring indexed by pair % (T_D + 1); everything is unrolled)
+    f32x4 fu[T_D + 1][2];
+    auto load_u = [&](int chunk, int pair) {
+        const int so = chunk * u_chunk + (2 * pair) * u_xi;
+        fu[pair % (T_D + 1)][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, so, 0));
+        fu[pair % (T_D + 1)][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, so + u_xi, 0));
+    };
+    f32x4 fv[2][2];
+    auto read_v = [&](int pair) {
+        fv[pair & 1][0] = *(const f32x4*)(v_rd + (2 * pair) * 2048);
+        fv[pair & 1][1] = *(const f32x4*)(v_rd + (2 * pair + 1) * 2048);
+    };
+
+#pragma unroll
+    for (int pr = 0; pr < T_D; ++pr) load_u(0, pr);
+    issue();
+    issue();
+
+    for (int s = 0; s < p.chunks; ++s) {
+        // only the newest pieces (chunk s + 1) may still fly: chunk s has landed. (Behind the first chunk this is implied - the
+        // fragment loads of chunk s - 1 were issued behind the pieces of chunk s and have been consumed.) Every wave is done with
+        // the products of chunk s - 1: V is free
+        T_WAIT_VM(6);
+        T_BARRIER();
+        {
+            const char* prd = smem + (s & 1) * T_PATCH_B + t_rd;
+            if (t_lh == 0) t_transform<0>(prd, t_wr);
+            else t_transform<1>(prd, t_wr);
+        }
+        T_WAITCNT(63);                // lgkmcnt(0): this wave's V rows are written (vmcnt left alone)
+        T_BARRIER();
+        const int sn = s + 1 < p.chunks ? s + 1 : s;      // (the last chunk's look-ahead loads re-read its own fragments)
+        read_v(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pr = 0; pr < 18; ++pr) {
+            // the fragment loads T_D pairs ahead (behind pair 17 - T_D: the next chunk's first pairs), the V fragments one pair ahead
+            if (pr + T_D < 18) load_u(s, pr + T_D);
+            else load_u(sn, pr + T_D - 18);
+            if (pr + 1 < 18) read_v(pr + 1);
+            const f32x4 ua = fu[pr % (T_D + 1)][0], ub = fu[pr % (T_D + 1)][1];
+            const f32x4 va = fv[pr & 1][0], vb = fv[pr & 1][1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[2 * pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[j], va[j], acc[2 * pr], 0, 0, 0);
+                acc[2 * pr + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[j], vb[j], acc[2 * pr + 1], 0, 0, 0);
+            }
+            // issue order of the pair: the loads slotted behind the first products (left to the compiler they sink to their uses)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (pr + 1 < 18) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // chunk s + 2 into the buffer chunk s was transformed from, behind every fragment load issued so far: no load that is
+        // consumed before the next transform waits for these pieces except the pairs >= T_D of chunk s + 1, a transform later
+        issue();
+    }
+    __builtin_amdgcn_s_waitcnt(0);       // trailing (out-of-range) pieces and look-ahead loads are done before LDS is reused
+
+    // ---- output transform in registers: Y = A^T M A, M[l][m] = acc[6 l + m] (4 output channels per lane) ----
+    f32x4 Y[16];
+    {
+        f32x4 Z[6][4];
+#pragma unroll
+        for (int l = 0; l < 6; ++l)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                bool first = true;
+#pragma unroll
+                for (int m = 0; m < 6; ++m) {
+                    const float c = T_AT[j][m];
+                    if (c == 0.f) continue;
+                    if (first) a = c == 1.f ? acc[6 * l + m] : acc[6 * l + m] * c;
+                    else if (c == 1.f) a += acc[6 * l + m];
+                    else if (c == -1.f) a -= acc[6 * l + m];
+                    else a = __builtin_elementwise_fma(f32x4{c, c, c, c}, acc[6 * l + m], a);
+                    first = false;
+                }
+                Z[l][j] = a;
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                bool first = true;
+#pragma unroll
+                for (int l = 0; l < 6; ++l) {
+                    const float c = T_AT[i][l];
+                    if (c == 0.f) continue;
+                    if (first) a = c == 1.f ? Z[l][j] : Z[l][j] * c;
+                    else if (c == 1.f) a += Z[l][j];
+                    else if (c == -1.f) a -= Z[l][j];
+                    else a = __builtin_elementwise_fma(f32x4{c, c, c, c}, Z[l][j], a);
+                    first = false;
+                }
+                Y[4 * i + j] = a;
+            }
+    }
+
+    // ---- epilogue (wino4f.hip's): lane = (tile 16 tw + r15 of the block, channels k0 + 16 kw + 4 g .. + 3) ----
+    const int tl = 16 * tw + r15;
+    const int ty = 4 * by + (tl >> 3), tx = 8 * bx + (tl & 7);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const i32x4_t rsY = {(int)(unsigned)(unsigned long long)p.y, (int)(((unsigned long long)p.y >> 32) & 0xffffu), (int)p.y_bytes, 0x00020000};
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.add, 0, p.add ? p.y_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rBX = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_x, 0, p.bs_x ? p.y_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rBY = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_y, 0, p.bs_y ? p.y_bytes : 0u, 0x00020000);
+    const float floor_ = p.relu ? 0.f : -__builtin_inff();
+    const bool mask_y = p.bs_relu && p.bs_y, mask_x = p.bs_relu && !p.bs_y;
+    double ds[8];
+    {
+        const int kc = k0 + 16 * kw + 4 * g;
+        const bool valid = 4 * ty < p.H && 4 * tx < p.W && kc < p.K;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) ds[c] = 0.0;
+        const int voff = valid ? (((n * p.H + 4 * ty) * p.W + 4 * tx) * p.K + kc) * 4 : T_OOB;
+        const int kcs = valid ? kc : 0;
+        f32x4 b = z;
+        if (p.bias) b = *(const f32x4*)(p.bias + kcs);
+        f32x4 bmu = z, bis = z, bsc = z, bsh = z;
+        if (EP == 2) {
+            bmu = *(const f32x4*)(p.bs_mean + kcs);
+            bis = *(const f32x4*)(p.bs_invstd + kcs);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bsc[c] = (p.bs_gamma ? p.bs_gamma[kcs + c] : 1.f) * bis[c];
+                bsh[c] = (p.bs_beta ? p.bs_beta[kcs + c] : 0.f) - bmu[c] * bsc[c];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 ssum = z, ssq = z;          // the four values of an output row in fp32, doubles from there
+            f32x4 av[4], xv[4], yv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int soff = (i * p.W + j) * p.K * 4;
+                av[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, soff, 0));
+                if (EP == 2) {
+                    xv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rBX, voff, soff, 0));
+                    yv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rBY, voff, soff, 0));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int soff = (i * p.W + j) * p.K * 4;
+                f32x4 o = (Y[4 * i + j] + b) + av[j];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], floor_);
+                t_store_b128(o, rsY, voff, soff);
+                if (EP == 2) {
+                    f32x4 gq;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float mk = mask_y ? yv[j][c] : (mask_x ? fmaf(xv[j][c], bsc[c], bsh[c]) : 1.f);
+                        gq[c] = mk > 0.f ? o[c] : 0.f;
+                        ssq[c] += gq[c] * ((xv[j][c] - bmu[c]) * bis[c]);
+                    }
+                    ssum += gq;
+                } else if (EP == 1) {
+                    ssum += o;
+                    ssq += o * o;
+                }
+            }
+            if (EP != 0 && valid) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    ds[c] += (double)ssum[c];
+                    ds[4 + c] += (double)ssq[c];
+                }
+            }
+        }
+    }
+    if (EP == 0) return;
+    // over the 16 tiles of the wave (shuffles inside each group of 16 lanes), then over the two tile waves through LDS
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) ds[c] += __shfl_xor(ds[c], off, 64);
+    __syncthreads();
+    double* red = (double*)smem;                  // [tile wave][2][64 channels]
+    if (r15 == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            red[(tw * 2 + 0) * 64 + 16 * kw + 4 * g + c] = ds[c];
+            red[(tw * 2 + 1) * 64 + 16 * kw + 4 * g + c] = ds[4 + c];
+        }
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int which = tid >> 6, ch = tid & 63;
+        const double a = red[(0 * 2 + which) * 64 + ch] + red[(1 * 2 + which) * 64 + ch];
+        const long row = ((long)n * p.bh + by) * p.bw + bx;
+        if (k0 + ch < p.K) p.stats[(row * 2 + which) * p.K + k0 + ch] = a;
+    }
+}
+
+// U [36][K][C] (denet_conv_wino_filter, tile 4; K = output channels of the pass, C = its reduction) -> [C/16][36][K][16]
+__global__ __launch_bounds__(256) void wino4t_pack_kernel(const float* __restrict__ U, float* __restrict__ P, int K, int C) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;          // one 16-byte quad of the destination
+    const long total = 36L * K * C / 4;
+    if (idx >= total) return;
+    const int q = (int)(idx & 3);
+    long rest = idx >> 2;
+    const int k = (int)(rest % K);
+    rest /= K;
+    const int xi = (int)(rest % 36);
+    const int chunk = (int)(rest / 36);
+    *(f32x4*)(P + idx * 4) = *(const f32x4*)(U + ((long)xi * K + k) * C + chunk * 16 + q * 4);
+}
+
+}  // namespace
+
+// geometry the kernel covers: 3x3 stride 1 pad 1 (the caller's business), H and W multiples of 4, C a multiple of 16, K of 64
+extern "C" int denet_conv_wino4t_ok(int N, int H, int W, int C, int K) {
+    return (N > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0 && C > 0 && C % 16 == 0 && K > 0 && K % 64 == 0 &&
+            (long)N * H * W * C * 4 < 0x7FFFFFFFL && (long)N * H * W * K * 4 < 0x7FFFFFFFL && 36L * K * C * 4 < 0x7FFFFFFFL) ? 1 : 0;
+}
+
+// rows of partial statistics a launch writes: one per block of 4 x 8 tiles
+extern "C" int denet_conv_wino4t_stats_rows(int N, int H, int W) {
+    return N * ((H + 15) / 16) * ((W + 31) / 32);
+}
+
+extern "C" int denet_conv_wino4t_pack(const float* u, float* packed, int C, int K, hipStream_t stream) {
+    DENET_CHECK_ARG(u && packed && C > 0 && C % 16 == 0 && K > 0, "conv_wino4t_pack: bad arguments");
+    const long total = 36L * K * C / 4;
+    hipLaunchKernelGGL(wino4t_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, u, packed, K, C);
+    DENET_CHECK_LAUNCH("conv_wino4t_pack");
+    return DENET_OK;
+}
+
+// y = conv3x3(x) stride 1 pad 1 (+ bias) (+ add) (ReLU) from the packed F(4x4) filters; statistics / backward sums as
+// denet_conv_wino2f_sums (stats_partial [rows][2][K] doubles, rows = denet_conv_wino4t_stats_rows)
+extern "C" int denet_conv_wino4t_sums(const float* x, const float* u_packed, const float* bias, const float* add, float* y, int relu,
+                                      double* stats_partial, size_t stats_bytes, int* stats_rows, const denet_bn_link* sums_of, int N,
+                                      int H, int W, int C, int K, hipStream_t stream) {
+    DENET_CHECK_ARG(x && u_packed && y, "conv_wino4t: null pointer");
+    DENET_CHECK_ARG(denet_conv_wino4t_ok(N, H, W, C, K), "conv_wino4t: needs H, W %% 4 = 0, C %% 16 = 0, K %% 64 = 0");
+    W4TParams p = {};
+    p.x = x; p.U = u_packed; p.bias = bias; p.add = add; p.y = y;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.K = K;
+    p.bh = (H + 15) / 16; p.bw = (W + 31) / 32;
+    p.tiles_k = K / 64; p.chunks = C / 16; p.relu = relu;
+    p.x_bytes = (unsigned)((size_t)N * H * W * C * 4);
+    p.y_bytes = (unsigned)((size_t)N * H * W * K * 4);
+    p.u_bytes = (unsigned)((size_t)36 * K * C * 4);
+    const long blocks = (long)N * p.bh * p.bw;
+    int ep = 0;
+    if (stats_partial) {
+        DENET_CHECK_ARG(stats_rows && stats_bytes >= (size_t)blocks * 2 * K * sizeof(double), "conv_wino4t: statistics buffer too small");
+        *stats_rows = (int)blocks;
+        p.stats = stats_partial;
+        ep = 1;
+        if (sums_of) {
+            DENET_CHECK_ARG(sums_of->x && sums_of->mean && sums_of->invstd && (!sums_of->relu || sums_of->y || (sums_of->gamma && sums_of->beta)),
+                            "conv_wino4t: incomplete batch-norm description for the backward sums");
+            p.bs_x = sums_of->x; p.bs_y = sums_of->relu ? sums_of->y : nullptr; p.bs_gamma = sums_of->gamma; p.bs_beta = sums_of->beta;
+            p.bs_mean = sums_of->mean; p.bs_invstd = sums_of->invstd; p.bs_relu = sums_of->relu;
+            ep = 2;
+        }
+    }
+    typedef void (*kern_t)(const W4TParams);
+    static const kern_t kerns[3] = {wino4t_kernel<0>, wino4t_kernel<1>, wino4t_kernel<2>};
+    static bool attr_done[3] = {};
+    const kern_t fn = kerns[ep];
+    if (!attr_done[ep]) {
+        const hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+        if (e != hipSuccess) {
+            denet_set_error("conv_wino4t: hipFuncSetAttribute(%d B LDS): %s", T_LDS, hipGetErrorString(e));
+            return -(int)e;
+        }
+        attr_done[ep] = true;
+    }
+    const int prof = denet_prof_begin(15, ep, 0, 0, stream);
+    hipLaunchKernelGGL(fn, dim3((unsigned)(blocks * p.tiles_k)), dim3(512), T_LDS, stream, p);
+    denet_prof_end(prof, stream);
+    DENET_CHECK_LAUNCH("conv_wino4t");
+    return DENET_OK;
+}

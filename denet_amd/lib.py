@@ -97,6 +97,10 @@ SIGNATURES = {
     "denet_conv_dgrad_1x1t": (I, [P] * 6 + [Z, P] + [I] * 5 + [P]),
     "denet_conv_dgrad_t": (I, [P] * 6 + [Z, P] + [I] * 12 + [P]),
     "denet_conv_wino2f_sums": (I, [P] * 5 + [I, P, Z, P, P] + [I] * 5 + [P]),
+    "denet_conv_wino4t_ok": (I, [I] * 5),
+    "denet_conv_wino4t_stats_rows": (I, [I] * 3),
+    "denet_conv_wino4t_pack": (I, [P, P, I, I, P]),
+    "denet_conv_wino4t_sums": (I, [P] * 5 + [I, P, Z, P, P] + [I] * 5 + [P]),
     "denet_bn_bwd_final": (I, [P, I, L, I, P, P, P, P]),
     "denet_conv_wino_wgrad_dm": (I, [P, P, P, P, P, Z, P, Z] + [I] * 6 + [P]),
     "denet_bn_fwd_test": (I, [P] * 8 + [I, L, I, F, I, P]),

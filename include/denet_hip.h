@@ -254,6 +254,18 @@ int denet_conv_dgrad_1x1t(const float* dy, const float* wt, const float* add, fl
 int denet_conv_wino2f_sums(const float* x, const float* u, const float* bias, const float* add, float* y, int relu,
                            double* stats_partial, size_t stats_bytes, int* stats_rows, const denet_bn_link* sums_of, int N, int H,
                            int W, int Ci, int Co, hipStream_t stream);
+/* Tile-parallel fused F(4x4,3x3) convolution (csrc/wino4t.hip): input transform, the 36 component products and the output
+ * transform in one kernel, x -> y only (3x3, stride 1, pad 1; H, W multiples of 4; C a multiple of 16; K of 64). Same operator and
+ * arguments as denet_conv_wino2f_sums (forward pass: denet/layer/convolution.py:80-83; data gradient with x = dy and the
+ * data-gradient filters: model_cnn.py:318), with C = the pass's reduction channels, K = the channels it writes. u_packed: the
+ * F(4x4) transformed filters of denet_conv_wino_filter(tile 4) [36][K][C] re-laid as [C/16][36][K][16] by denet_conv_wino4t_pack.
+ * stats_partial [rows][2][K] doubles, rows = denet_conv_wino4t_stats_rows (one per block of 4 x 8 tiles). */
+int denet_conv_wino4t_ok(int N, int H, int W, int C, int K);
+int denet_conv_wino4t_stats_rows(int N, int H, int W);
+int denet_conv_wino4t_pack(const float* u, float* packed, int C, int K, hipStream_t stream);
+int denet_conv_wino4t_sums(const float* x, const float* u_packed, const float* bias, const float* add, float* y, int relu,
+                           double* stats_partial, size_t stats_bytes, int* stats_rows, const denet_bn_link* sums_of, int N, int H,
+                           int W, int C, int K, hipStream_t stream);
 int denet_conv_wino_wgrad_dm(const float* x, const float* dm, const float* v_cached, float* dw, float* workspace,
                              size_t workspace_bytes, float* split_ws, size_t split_ws_bytes, int tile, int N, int H, int W, int C,
                              int K, hipStream_t stream);

@@ -1012,6 +1012,8 @@ def test_bn_final_fold_in_front_of_a_pool_fused_batch_norm(hip):
     x, metas = zoo.synthetic_batch(B, 32, class_num=10, image_class=True, seed=4)
     xd = torch.from_numpy(x).cuda()
     old = ops.set_final_fold(0)
+    saved_fuse = ops.BN_POOL_FUSE
+    ops.BN_POOL_FUSE = True          # (the file's autouse fixture switches the pooled pass off for the teacher-forced tests)
 
     def run(fold):
         ops.set_final_fold(3 if fold else 0)
@@ -1030,6 +1032,7 @@ def test_bn_final_fold_in_front_of_a_pool_fused_batch_norm(hip):
             assert torch.equal(got[k], ref[k]), "%s differs with the fold on" % "PMS"[k - 1]
     finally:
         ops.set_final_fold(old)
+        ops.BN_POOL_FUSE = saved_fuse
 
 
 def test_bn_pool_fusion_leaves_training_unchanged(hip):
