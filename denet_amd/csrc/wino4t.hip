@@ -61,6 +61,7 @@ struct W4TParams {
     int bh, bw;          // tile blocks per image (rows of 4 tiles, columns of 8 tiles)
     int tiles_k;         // K / 64
     int chunks;          // C / 16
+    int items;           // tile blocks x channel blocks
     int relu;
     unsigned x_bytes, y_bytes, u_bytes;
 };
@@ -75,6 +76,8 @@ constexpr int T_V_B = 36 * 2048;                  // 73 728
 constexpr int T_SCRATCH = 2 * T_PATCH_B + T_V_B;  // 161 792: 1 KB that the surplus pieces write
 constexpr int T_LDS = T_SCRATCH + 1024;           // 162 816 <= 163 840
 constexpr int T_D = 4;                            // component pairs whose filter fragments are loaded ahead
+constexpr int T_R = 12;                           // ring of filter fragments (components)
+static_assert(36 % T_R == 0 && T_R >= 2 * T_D + 2, "the ring index must run on across chunks and cover the fragments in flight");
 
 #define T_WAITCNT(vm) __builtin_amdgcn_s_waitcnt(((vm) & 15) | ((((vm) >> 4) & 3) << 14) | (7 << 4))              /* + lgkmcnt(0) */
 #define T_WAIT_VM(vm) __builtin_amdgcn_s_waitcnt(((vm) & 15) | ((((vm) >> 4) & 3) << 14) | (7 << 4) | (15 << 8))  /* vmcnt only */
@@ -144,48 +147,74 @@ __device__ __forceinline__ void t_transform(const char* prd, char* vwr) {
 
 constexpr float T_AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
 
+#ifndef T_EXP
+#define T_EXP 0       // experiment builds (tools/exp/w4t_variants.sh -DT_EXP=bits): 1 no input transform, 2 no products, 4 no epilogue,
+                      // 8 no LDS-DMA - wrong results, the time that is left tells what each phase costs
+#endif
+
 // EP: 0 = store only, 1 = + batch-norm column sums of what is stored, 2 = + backward sums of the batch norm in front
+// PERSISTENT: one workgroup per CU walks work items (tile block, channel block) b, b + grid, ...; the (item, chunk) pairs form
+// ONE sequence for the LDS-DMA look-ahead, so the next item's first two patch chunks stream in under this item's last products
+// and its epilogue.
 template <int EP>
 __global__ __launch_bounds__(512, 2) void wino4t_kernel(const W4TParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const vbuf = smem + 2 * T_PATCH_B;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int kblk = (int)(bid % (uint32_t)p.tiles_k);
-    int blk = (int)(bid / (uint32_t)p.tiles_k);
-    const int bx = blk % p.bw;
-    blk /= p.bw;
-    const int by = blk % p.bh;
-    const int n = blk / p.bh;
-    const int k0 = kblk * 64;
-    const int y0 = by * 16, x0 = bx * 32;           // first output pixel of the block
+    const int grid = (int)gridDim.x;
+    const int first = (int)xcd_remap(blockIdx.x, gridDim.x);       // neighbouring items (channel blocks of one tile block) share an L2
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
 
-    // ---- LDS-DMA pieces of this wave: piece = wave + 8 j covers patch slots 64 piece .. 64 piece + 63 ----
-    int pc_off[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int L = (wave + 8 * j) * 64 + lane;
-        const int pl = L / T_PLANE_SLOTS, rem = L - pl * T_PLANE_SLOTS;
-        const int row = rem / T_QS, q = rem - row * T_QS;
-        const int v = q / 9, u = q - v * 9;
-        const int pcx = 4 * u + v;
-        const int iy = y0 - 1 + row, ix = x0 - 1 + pcx;
-        const bool ok = L < T_PATCH_SLOTS && q < 36 && pcx < 34 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        pc_off[j] = ok ? (((n * p.H + iy) * p.W + ix) * p.C + pl * 4) * 4 : T_OOB;
-    }
-    int d_chunk = 0;          // the chunk the next issue fetches
+    struct Item {
+        int n, y0, x0, k0, row;        // image, first output pixel, first output channel, tile block (= row of the statistics)
+    };
+    auto decode = [&](int item) {
+        Item it;
+        it.k0 = (item % p.tiles_k) * 64;
+        int blk = item / p.tiles_k;
+        it.row = blk;
+        it.x0 = (blk % p.bw) * 32;
+        blk /= p.bw;
+        it.y0 = (blk % p.bh) * 16;
+        it.n = blk / p.bh;
+        return it;
+    };
+
+    // ---- LDS-DMA pieces of this wave: piece = wave + 8 j covers patch slots 64 piece .. 64 piece + 63. The slot -> pixel
+    // arithmetic is redone per piece and chunk (a dozen integer instructions) rather than kept in six registers per lane: the
+    // accumulators leave none to spare ----
+    int d_item = first, d_chunk = 0, d_seq = 0;          // what the next issue fetches
+    Item d_it = decode(first < p.items ? first : 0);
     auto issue = [&]() {
-        const bool live = d_chunk < p.chunks;
-        char* const dstb = smem + (d_chunk & 1) * T_PATCH_B;
+        if (T_EXP & 8) return;
+        const bool live = d_item < p.items;
+        char* const dstb = smem + (d_seq & 1) * T_PATCH_B;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int piece = wave + 8 * j;
             char* const dst = piece < 43 ? dstb + piece * 1024 : smem + T_SCRATCH;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_ptr_t)dst, 16, live ? pc_off[j] : T_OOB, d_chunk * 64, 0, 0);
+            int ln = lane;
+            asm volatile("" : "+v"(ln));                // opaque: keeps this arithmetic here instead of hoisted into six register sets
+            const int L = piece * 64 + ln;
+            const int pl = (L * 6133) >> 22;             // L / 684 for L < 3072
+            const int rem = L - pl * T_PLANE_SLOTS;
+            const int row = (rem * 1725) >> 16;          // rem / 38 for rem < 684
+            const int q = rem - row * T_QS;
+            const int v = (q * 57) >> 9;                 // q / 9 for q < 38
+            const int pcx = 4 * (q - v * 9) + v;
+            const int iy = d_it.y0 - 1 + row, ix = d_it.x0 - 1 + pcx;
+            const bool ok = live && L < T_PATCH_SLOTS && q < 36 && pcx < 34 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const int off = (((d_it.n * p.H + iy) * p.W + ix) * p.C + pl * 4) * 4;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_ptr_t)dst, 16, ok ? off : T_OOB, d_chunk * 64, 0, 0);
         }
+        d_seq += 1;
         d_chunk += 1;
+        if (d_chunk == p.chunks) {
+            d_chunk = 0;
+            d_item += grid;
+            if (d_item < p.items) d_it = decode(d_item);
+        }
     };
 
     // ---- transform role: lane = (half, tile column, tile row); wave = (channel quad, component half) ----
@@ -200,20 +229,17 @@ __global__ __launch_bounds__(512, 2) void wino4t_kernel(const W4TParams p) {
     const char* const v_rd = vbuf + g * 512 + (16 * tw + r15) * 16;
     // the filter fragments come through a buffer descriptor: one lane offset, the (chunk, component) offset is scalar
     const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, p.u_bytes, 0x00020000);
-    const int u_voff = ((k0 + 16 * kw + r15) * 16 + 4 * g) * 4;
+    const int u_lane = ((16 * kw + r15) * 16 + 4 * g) * 4;       // + k0 * 64
     const int u_xi = p.K * 64;                       // bytes per component
     const int u_chunk = 36 * u_xi;                   // bytes per chunk
 
-    f32x4 acc[36];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // filter fragments of component pairs, T_D pairs ahead (a ring indexed by pair % (T_D + 1); everything is unrolled)
-    f32x4 fu[T_D + 1][2];
-    auto load_u = [&](int chunk, int pair) {
+    // filter fragments 2 T_D components (T_D pairs) ahead: a ring indexed by component % T_R - T_R divides 36, so the index runs
+    // on across chunks, and exceeds the 2 T_D + 2 components in flight (everything is unrolled; the registers follow liveness)
+    f32x4 fu[T_R];
+    auto load_u = [&](int voff, int chunk, int pair) {
         const int so = chunk * u_chunk + (2 * pair) * u_xi;
-        fu[pair % (T_D + 1)][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, so, 0));
-        fu[pair % (T_D + 1)][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, so + u_xi, 0));
+        fu[(2 * pair) % T_R] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rU, voff, so, 0));
+        fu[(2 * pair + 1) % T_R] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rU, voff, so + u_xi, 0));
     };
     f32x4 fv[2][2];
     auto read_v = [&](int pair) {
@@ -221,199 +247,235 @@ __global__ __launch_bounds__(512, 2) void wino4t_kernel(const W4TParams p) {
         fv[pair & 1][1] = *(const f32x4*)(v_rd + (2 * pair + 1) * 2048);
     };
 
+    if (first >= p.items) return;
+    Item cur = decode(first);
+    int u_voff = u_lane + cur.k0 * 64;
+    if (!(T_EXP & 2)) {
 #pragma unroll
-    for (int pr = 0; pr < T_D; ++pr) load_u(0, pr);
+        for (int pr = 0; pr < T_D; ++pr) load_u(u_voff, 0, pr);
+    }
     issue();
     issue();
+    int c_seq = 0;            // chunks consumed: the patch buffer of a chunk is its sequence number's parity
 
-    for (int s = 0; s < p.chunks; ++s) {
-        // only the newest pieces (chunk s + 1) may still fly: chunk s has landed. (Behind the first chunk this is implied - the
-        // fragment loads of chunk s - 1 were issued behind the pieces of chunk s and have been consumed.) Every wave is done with
-        // the products of chunk s - 1: V is free
-        T_WAIT_VM(6);
-        T_BARRIER();
-        {
-            const char* prd = smem + (s & 1) * T_PATCH_B + t_rd;
-            if (t_lh == 0) t_transform<0>(prd, t_wr);
-            else t_transform<1>(prd, t_wr);
-        }
-        T_WAITCNT(63);                // lgkmcnt(0): this wave's V rows are written (vmcnt left alone)
-        T_BARRIER();
-        const int sn = s + 1 < p.chunks ? s + 1 : s;      // (the last chunk's look-ahead loads re-read its own fragments)
-        read_v(0);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int item = first; item < p.items; item += grid) {
+        const bool has_next = item + grid < p.items;
+        const Item nxt = decode(has_next ? item + grid : item);
+        const int u_voff_next = u_lane + nxt.k0 * 64;
+        f32x4 acc[36];
 #pragma unroll
-        for (int pr = 0; pr < 18; ++pr) {
-            // the fragment loads T_D pairs ahead (behind pair 17 - T_D: the next chunk's first pairs), the V fragments one pair ahead
-            if (pr + T_D < 18) load_u(s, pr + T_D);
-            else load_u(sn, pr + T_D - 18);
-            if (pr + 1 < 18) read_v(pr + 1);
-            const f32x4 ua = fu[pr % (T_D + 1)][0], ub = fu[pr % (T_D + 1)][1];
-            const f32x4 va = fv[pr & 1][0], vb = fv[pr & 1][1];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[2 * pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[j], va[j], acc[2 * pr], 0, 0, 0);
-                acc[2 * pr + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[j], vb[j], acc[2 * pr + 1], 0, 0, 0);
-            }
-            // issue order of the pair: the loads slotted behind the first products (left to the compiler they sink to their uses)
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            if (pr + 1 < 18) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            } else {
-                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // chunk s + 2 into the buffer chunk s was transformed from, behind every fragment load issued so far: no load that is
-        // consumed before the next transform waits for these pieces except the pairs >= T_D of chunk s + 1, a transform later
-        issue();
-    }
-    __builtin_amdgcn_s_waitcnt(0);       // trailing (out-of-range) pieces and look-ahead loads are done before LDS is reused
+        for (int i = 0; i < 36; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- output transform in registers: Y = A^T M A, M[l][m] = acc[6 l + m] (4 output channels per lane) ----
-    f32x4 Y[16];
-    {
-        f32x4 Z[6][4];
-#pragma unroll
-        for (int l = 0; l < 6; ++l)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                bool first = true;
-#pragma unroll
-                for (int m = 0; m < 6; ++m) {
-                    const float c = T_AT[j][m];
-                    if (c == 0.f) continue;
-                    if (first) a = c == 1.f ? acc[6 * l + m] : acc[6 * l + m] * c;
-                    else if (c == 1.f) a += acc[6 * l + m];
-                    else if (c == -1.f) a -= acc[6 * l + m];
-                    else a = __builtin_elementwise_fma(f32x4{c, c, c, c}, acc[6 * l + m], a);
-                    first = false;
-                }
-                Z[l][j] = a;
+        for (int s = 0; s < p.chunks; ++s, ++c_seq) {
+            // Only the newest pieces (sequence number c_seq + 1) may still fly: this chunk's have landed. Behind the first chunk of a
+            // launch that is implied - the chunk's pieces are older than fragment loads (and epilogue loads) that have been consumed
+            // - and at the first chunk of a later item NOTHING is waited for: the epilogue's stores are still draining.
+            if (c_seq == 0) T_WAIT_VM(6);
+            else if (s != 0) T_WAIT_VM(6);
+            T_BARRIER();
+            if (!(T_EXP & 1)) {
+                const char* prd = smem + (c_seq & 1) * T_PATCH_B + t_rd;
+                if (t_lh == 0) t_transform<0>(prd, t_wr);
+                else t_transform<1>(prd, t_wr);
             }
+            T_WAITCNT(63);                // lgkmcnt(0): this wave's V rows are written (vmcnt left alone)
+            T_BARRIER();
+            if (!(T_EXP & 2)) {
+                const bool last = s + 1 == p.chunks;
+                // (behind the last item the look-ahead loads re-read this chunk's own fragments)
+                const int voff_n = last ? u_voff_next : u_voff;
+                const int chunk_n = last ? (has_next ? 0 : s) : s + 1;
+                read_v(0);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+                for (int pr = 0; pr < 18; ++pr) {
+                    // the fragment loads T_D pairs ahead (behind pair 17 - T_D: the next chunk's first pairs), the V fragments one
+                    // pair ahead
+                    if (pr + T_D < 18) load_u(u_voff, s, pr + T_D);
+                    else load_u(voff_n, chunk_n, pr + T_D - 18);
+                    if (pr + 1 < 18) read_v(pr + 1);
+                    const f32x4 ua = fu[(2 * pr) % T_R], ub = fu[(2 * pr + 1) % T_R];
+                    const f32x4 va = fv[pr & 1][0], vb = fv[pr & 1][1];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                bool first = true;
-#pragma unroll
-                for (int l = 0; l < 6; ++l) {
-                    const float c = T_AT[i][l];
-                    if (c == 0.f) continue;
-                    if (first) a = c == 1.f ? Z[l][j] : Z[l][j] * c;
-                    else if (c == 1.f) a += Z[l][j];
-                    else if (c == -1.f) a -= Z[l][j];
-                    else a = __builtin_elementwise_fma(f32x4{c, c, c, c}, Z[l][j], a);
-                    first = false;
-                }
-                Y[4 * i + j] = a;
-            }
-    }
-
-    // ---- epilogue (wino4f.hip's): lane = (tile 16 tw + r15 of the block, channels k0 + 16 kw + 4 g .. + 3) ----
-    const int tl = 16 * tw + r15;
-    const int ty = 4 * by + (tl >> 3), tx = 8 * bx + (tl & 7);
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    const i32x4_t rsY = {(int)(unsigned)(unsigned long long)p.y, (int)(((unsigned long long)p.y >> 32) & 0xffffu), (int)p.y_bytes, 0x00020000};
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.add, 0, p.add ? p.y_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rBX = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_x, 0, p.bs_x ? p.y_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rBY = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_y, 0, p.bs_y ? p.y_bytes : 0u, 0x00020000);
-    const float floor_ = p.relu ? 0.f : -__builtin_inff();
-    const bool mask_y = p.bs_relu && p.bs_y, mask_x = p.bs_relu && !p.bs_y;
-    double ds[8];
-    {
-        const int kc = k0 + 16 * kw + 4 * g;
-        const bool valid = 4 * ty < p.H && 4 * tx < p.W && kc < p.K;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) ds[c] = 0.0;
-        const int voff = valid ? (((n * p.H + 4 * ty) * p.W + 4 * tx) * p.K + kc) * 4 : T_OOB;
-        const int kcs = valid ? kc : 0;
-        f32x4 b = z;
-        if (p.bias) b = *(const f32x4*)(p.bias + kcs);
-        f32x4 bmu = z, bis = z, bsc = z, bsh = z;
-        if (EP == 2) {
-            bmu = *(const f32x4*)(p.bs_mean + kcs);
-            bis = *(const f32x4*)(p.bs_invstd + kcs);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                bsc[c] = (p.bs_gamma ? p.bs_gamma[kcs + c] : 1.f) * bis[c];
-                bsh[c] = (p.bs_beta ? p.bs_beta[kcs + c] : 0.f) - bmu[c] * bsc[c];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 ssum = z, ssq = z;          // the four values of an output row in fp32, doubles from there
-            f32x4 av[4], xv[4], yv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int soff = (i * p.W + j) * p.K * 4;
-                av[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, soff, 0));
-                if (EP == 2) {
-                    xv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rBX, voff, soff, 0));
-                    yv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rBY, voff, soff, 0));
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int soff = (i * p.W + j) * p.K * 4;
-                f32x4 o = (Y[4 * i + j] + b) + av[j];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], floor_);
-                t_store_b128(o, rsY, voff, soff);
-                if (EP == 2) {
-                    f32x4 gq;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float mk = mask_y ? yv[j][c] : (mask_x ? fmaf(xv[j][c], bsc[c], bsh[c]) : 1.f);
-                        gq[c] = mk > 0.f ? o[c] : 0.f;
-                        ssq[c] += gq[c] * ((xv[j][c] - bmu[c]) * bis[c]);
+                    for (int j = 0; j < 4; ++j) {
+                        acc[2 * pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[j], va[j], acc[2 * pr], 0, 0, 0);
+                        acc[2 * pr + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[j], vb[j], acc[2 * pr + 1], 0, 0, 0);
                     }
-                    ssum += gq;
-                } else if (EP == 1) {
-                    ssum += o;
-                    ssq += o * o;
+                    // issue order of the pair: the loads slotted behind the first products (left to the compiler they sink to
+                    // their uses)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (pr + 1 < 18) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (EP != 0 && valid) {
+            // the chunk two ahead in the sequence, into the buffer this chunk was transformed from, behind every fragment load
+            // issued so far: the first load that waits for these pieces is consumed a whole transform and T_D pairs later
+            issue();
+        }
+        if (T_EXP & 4) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) asm volatile("" ::"v"(acc[i]));
+            cur = nxt;
+            u_voff = u_voff_next;
+            continue;
+        }
+
+        // ---- output transform in registers: Y = A^T M A, M[l][m] = acc[6 l + m] (4 output channels per lane) ----
+        f32x4 Y[16];
+        {
+            f32x4 Z[6][4];
+#pragma unroll
+            for (int l = 0; l < 6; ++l)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                    bool fst = true;
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) {
+                        const float c = T_AT[j][m];
+                        if (c == 0.f) continue;
+                        if (fst) a = c == 1.f ? acc[6 * l + m] : acc[6 * l + m] * c;
+                        else if (c == 1.f) a += acc[6 * l + m];
+                        else if (c == -1.f) a -= acc[6 * l + m];
+                        else a = __builtin_elementwise_fma(f32x4{c, c, c, c}, acc[6 * l + m], a);
+                        fst = false;
+                    }
+                    Z[l][j] = a;
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                    bool fst = true;
+#pragma unroll
+                    for (int l = 0; l < 6; ++l) {
+                        const float c = T_AT[i][l];
+                        if (c == 0.f) continue;
+                        if (fst) a = c == 1.f ? Z[l][j] : Z[l][j] * c;
+                        else if (c == 1.f) a += Z[l][j];
+                        else if (c == -1.f) a -= Z[l][j];
+                        else a = __builtin_elementwise_fma(f32x4{c, c, c, c}, Z[l][j], a);
+                        fst = false;
+                    }
+                    Y[4 * i + j] = a;
+                }
+        }
+
+        // ---- epilogue (wino4f.hip's): lane = (tile 16 tw + r15 of the block, channels k0 + 16 kw + 4 g .. + 3) ----
+        const int tl = 16 * tw + r15;
+        const int oy = cur.y0 + 4 * (tl >> 3), ox = cur.x0 + 4 * (tl & 7);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const i32x4_t rsY = {(int)(unsigned)(unsigned long long)p.y, (int)(((unsigned long long)p.y >> 32) & 0xffffu), (int)p.y_bytes, 0x00020000};
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.add, 0, p.add ? p.y_bytes : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rBX = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_x, 0, p.bs_x ? p.y_bytes : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rBY = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_y, 0, p.bs_y ? p.y_bytes : 0u, 0x00020000);
+        const float floor_ = p.relu ? 0.f : -__builtin_inff();
+        const bool mask_y = p.bs_relu && p.bs_y, mask_x = p.bs_relu && !p.bs_y;
+        double ds[8];
+        {
+            const int kc = cur.k0 + 16 * kw + 4 * g;
+            const bool valid = oy < p.H && ox < p.W && kc < p.K;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) ds[c] = 0.0;
+            const int voff = valid ? (((cur.n * p.H + oy) * p.W + ox) * p.K + kc) * 4 : T_OOB;
+            const int kcs = valid ? kc : 0;
+            f32x4 b = z;
+            if (p.bias) b = *(const f32x4*)(p.bias + kcs);
+            f32x4 bmu = z, bis = z, bsc = z, bsh = z;
+            if (EP == 2) {
+                bmu = *(const f32x4*)(p.bs_mean + kcs);
+                bis = *(const f32x4*)(p.bs_invstd + kcs);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    ds[c] += (double)ssum[c];
-                    ds[4 + c] += (double)ssq[c];
+                    bsc[c] = (p.bs_gamma ? p.bs_gamma[kcs + c] : 1.f) * bis[c];
+                    bsh[c] = (p.bs_beta ? p.bs_beta[kcs + c] : 0.f) - bmu[c] * bsc[c];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 ssum = z, ssq = z;          // the four values of an output row in fp32, doubles from there
+                f32x4 av[4], xv[4], yv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int soff = (i * p.W + j) * p.K * 4;
+                    av[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, soff, 0));
+                    if (EP == 2) {
+                        xv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rBX, voff, soff, 0));
+                        yv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rBY, voff, soff, 0));
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int soff = (i * p.W + j) * p.K * 4;
+                    f32x4 o = (Y[4 * i + j] + b) + av[j];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], floor_);
+                    t_store_b128(o, rsY, voff, soff);
+                    if (EP == 2) {
+                        f32x4 gq;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float mk = mask_y ? yv[j][c] : (mask_x ? fmaf(xv[j][c], bsc[c], bsh[c]) : 1.f);
+                            gq[c] = mk > 0.f ? o[c] : 0.f;
+                            ssq[c] += gq[c] * ((xv[j][c] - bmu[c]) * bis[c]);
+                        }
+                        ssum += gq;
+                    } else if (EP == 1) {
+                        ssum += o;
+                        ssq += o * o;
+                    }
+                }
+                if (EP != 0 && valid) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        ds[c] += (double)ssum[c];
+                        ds[4 + c] += (double)ssq[c];
+                    }
                 }
             }
         }
-    }
-    if (EP == 0) return;
-    // over the 16 tiles of the wave (shuffles inside each group of 16 lanes), then over the two tile waves through LDS
+        if (EP != 0) {
+            // over the 16 tiles of the wave (shuffles inside each group of 16 lanes), then over the two tile waves through LDS: the
+            // V buffer, free between the last products of this item and the next transform (the patch buffers are NOT: the next
+            // item's pieces are landing there). Raw barriers: the stores above and the pieces in flight are not waited for
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1)
+            for (int off = 8; off > 0; off >>= 1)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) ds[c] += __shfl_xor(ds[c], off, 64);
-    __syncthreads();
-    double* red = (double*)smem;                  // [tile wave][2][64 channels]
-    if (r15 == 0) {
+                for (int c = 0; c < 8; ++c) ds[c] += __shfl_xor(ds[c], off, 64);
+            T_BARRIER();                                 // every wave has read its last V fragments
+            double* red = (double*)vbuf;                 // [tile wave][2][64 channels]
+            if (r15 == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            red[(tw * 2 + 0) * 64 + 16 * kw + 4 * g + c] = ds[c];
-            red[(tw * 2 + 1) * 64 + 16 * kw + 4 * g + c] = ds[4 + c];
+                for (int c = 0; c < 4; ++c) {
+                    red[(tw * 2 + 0) * 64 + 16 * kw + 4 * g + c] = ds[c];
+                    red[(tw * 2 + 1) * 64 + 16 * kw + 4 * g + c] = ds[4 + c];
+                }
+            }
+            T_WAITCNT(63);
+            T_BARRIER();
+            if (tid < 128) {
+                const int which = tid >> 6, ch = tid & 63;
+                const double a = red[(0 * 2 + which) * 64 + ch] + red[(1 * 2 + which) * 64 + ch];
+                if (cur.k0 + ch < p.K) p.stats[((long)cur.row * 2 + which) * p.K + cur.k0 + ch] = a;
+            }
+            // (the next transform's first V write lies behind the next top barrier, which every reader of `red` reaches after its read)
         }
+        cur = nxt;
+        u_voff = u_voff_next;
     }
-    __syncthreads();
-    if (tid < 128) {
-        const int which = tid >> 6, ch = tid & 63;
-        const double a = red[(0 * 2 + which) * 64 + ch] + red[(1 * 2 + which) * 64 + ch];
-        const long row = ((long)n * p.bh + by) * p.bw + bx;
-        if (k0 + ch < p.K) p.stats[(row * 2 + which) * p.K + k0 + ch] = a;
-    }
+    __builtin_amdgcn_s_waitcnt(0);       // trailing (out-of-range) pieces and look-ahead loads
 }
 
 // U [36][K][C] (denet_conv_wino_filter, tile 4; K = output channels of the pass, C = its reduction) -> [C/16][36][K][16]
@@ -493,8 +555,21 @@ extern "C" int denet_conv_wino4t_sums(const float* x, const float* u_packed, con
         }
         attr_done[ep] = true;
     }
+    // the LDS footprint allows one workgroup per CU: a persistent grid, work items strided over it
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            denet_set_error("conv_wino4t: cannot query the device");
+            return DENET_ERR_ARG;
+        }
+        cus = prop.multiProcessorCount;
+    }
+    p.items = (int)(blocks * p.tiles_k);
+    const int grid = p.items < cus ? p.items : cus;
     const int prof = denet_prof_begin(15, ep, 0, 0, stream);
-    hipLaunchKernelGGL(fn, dim3((unsigned)(blocks * p.tiles_k)), dim3(512), T_LDS, stream, p);
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(512), T_LDS, stream, p);
     denet_prof_end(prof, stream);
     DENET_CHECK_LAUNCH("conv_wino4t");
     return DENET_OK;

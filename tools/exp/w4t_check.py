@@ -8,6 +8,9 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
+import denet_amd.lib as _lib
+if os.environ.get("W4T_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["W4T_LIB"])          # an experiment build (tools/exp/w4t_variants.sh)
 from denet_amd import ops
 from denet_amd.lib import load, ptr, stream_ptr, check
 
