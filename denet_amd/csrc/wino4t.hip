@@ -2,29 +2,35 @@
 // V nor M ever reaches HBM (verdict item of rounds 4-5: "a tile-parallel fused F(4x4) kernel with the input transform inside").
 // Reference op: the `C[k,3]` layer, denet/layer/convolution.py:80-83 (forward) and its data gradient, model_cnn.py:318 (the same
 // pipeline on dy with the rotated, channel-swapped filters) - here for the layers whose x is a plain tensor (the 64-channel stage,
-// where the fused F(2x2) kernels of wino2f.hip execute 2.25 / 4 x 1.78 = 1.78 times the products of this one).
+// where the fused F(2x2) kernels of wino2f.hip execute 1.78 times the products of this one).
 //
 // The component-walk kernel (wino4f.hip) keeps 16 output positions per value and reads the 2.25x expanded V from HBM. This one
-// turns the loop nest round: a workgroup owns 32 tiles (4 x 8 tiles = 16 x 32 output pixels) x 64 output channels and keeps ALL 36
-// components of its products as accumulators (a wave: 16 tiles x 16 channels x 36 components = 144 registers per lane), and the
-// reduction runs over chunks of 16 input channels:
-//     patch chunk (18 x 34 pixels x 16 channels, 39 KB)  --LDS-DMA-->  LDS, two buffers, two chunks ahead
-//     transform:  every thread forms half the components of (one tile, two channels): 30 x ds_read_b64, 84 packed fp32
-//                 operations, 18 x ds_write_b64 -> V[36][4 channel quads][32 tiles][4] in LDS (72 KB, one buffer)
-//     products:   per component one ds_read_b128 (V fragment), one global_load_dwordx4 (U fragment, straight from L2: the
+// turns the loop nest round: a workgroup of FOUR waves owns 16 tiles (2 x 8 tiles = 8 x 32 output pixels) x 64 output channels
+// and keeps ALL 36 components of its products as accumulators (a wave: 16 tiles x 16 channels x 36 components = 144 registers per
+// lane); the reduction runs over chunks of 16 input channels:
+//     patch chunk (10 x 34 pixels x 16 channels, 24 KB)  --LDS-DMA-->  LDS (one buffer; the next chunk's pieces are issued in the
+//                 middle of this chunk's products, behind the transform that read the buffer)
+//     transform:  every thread forms half the components of (one tile, two channels): 30 x ds_read_b64, 72 packed fp32
+//                 operations, 18 x ds_write_b64 -> V[36][4 channel quads][16 tiles][4] in LDS (36 KB)
+//     products:   per component one ds_read_b128 (V fragment), one buffer_load_dwordx4 (U fragment, straight from L2: the
 //                 packed filters [C/16][36][K][16] make a wave's fragment one contiguous KB) and four v_mfma_f32_16x16x4_f32
 // and the epilogue is the output transform in registers (the lane holds the 6 x 6 components of its (tile, 4 channels)) followed
 // by the stores of wino4f.hip's epilogue (bias / add / ReLU, batch-norm column sums, backward sums).
+// TWO workgroups share a CU (61 KB of LDS, 256 registers per lane each): while one transforms, waits for its patch or streams its
+// epilogue, the other multiplies. (Measured on the way, tools/exp/w4t_check.py with the -DT_EXP ablation builds: ONE 8-wave
+// workgroup per CU on 32 tiles ran 64 -> 64 channels on a 128x128 map at batch 32 in 170 us = products 89 + epilogue 45 + transform
+// 24 + prologue, nothing overlapping - every CU reaches its epilogue at the same time, and the 33 MB store burst holds the next
+// item's fragment loads back; a persistent grid with the LDS-DMA look-ahead running across items changed nothing.)
 // LDS layouts are chosen so that every access is conflict-free without padding the DMA's linear writes:
-//   patch plane (one channel quad): [18 rows][38 slots of 16 B]: slot q = v * 9 + u holds patch column 4 u + v (q = 36, 37 unused):
+//   patch plane (one channel quad): [10 rows][38 slots of 16 B]: slot q = v * 9 + u holds patch column 4 u + v (q = 36, 37 unused):
 //       the 8 tiles of a tile row read column 4 tx + b = slots 16 B apart, the next tile row lies 4 x 608 B = 128 B (mod 256)
 //       further: 32 lanes x 8 B cover the 64 banks once (ds_read_b64);
 //   V: [xi][channel quad][tile][4]: a transform wave's 16 consecutive lanes write 128 contiguous bytes, a product wave's
-//       ds_read_b128 reads lane r + 16 g at g * 512 + r * 16.
+//       ds_read_b128 reads lane r + 16 g at g * 256 + r * 16.
 // vmcnt discipline: LDS-DMA pieces and U fragment loads share one in-order counter, so a fragment load issued behind a piece
-// cannot be consumed before the piece has landed. A chunk's pieces are therefore issued TWO chunks ahead, at the END of a chunk's
-// products - behind the fragment loads of the next chunk's first components: the first load that waits for them is consumed a
-// whole transform and T_D component pairs later.
+// cannot be consumed before the piece has landed. The next chunk's pieces are issued after component pair T_ISSUE of this
+// chunk's products: the fragment loads behind them are consumed four pairs later at the earliest, and the consumption of the
+// last ones implies that the pieces have landed when the next transform starts.
 #include "common.h"
 #include "bn_final.h"
 #include "../../include/denet_hip.h"
@@ -58,25 +64,37 @@ struct W4TParams {
     const float* bs_invstd;
     int bs_relu;
     int N, H, W, C, K;
-    int bh, bw;          // tile blocks per image (rows of 4 tiles, columns of 8 tiles)
+    int bh, bw;          // tile blocks per image (rows of 2 tiles, columns of 8 tiles)
     int tiles_k;         // K / 64
     int chunks;          // C / 16
-    int items;           // tile blocks x channel blocks
     int relu;
     unsigned x_bytes, y_bytes, u_bytes;
 };
 
 constexpr int T_OOB = (int)0xF0000000u;
+constexpr int T_ROWS = 10;                        // patch rows of a block of 2 x 8 tiles
 constexpr int T_QS = 38;                          // 16-byte slots per patch row (36 used)
-constexpr int T_PLANE_SLOTS = 18 * T_QS;          // 684
-constexpr int T_PLANE_B = T_PLANE_SLOTS * 16;     // 10 944
-constexpr int T_PATCH_SLOTS = 4 * T_PLANE_SLOTS;  // 2 736
-constexpr int T_PATCH_B = 43 * 1024;              // 44 032: one patch buffer (43 pieces)
-constexpr int T_V_B = 36 * 2048;                  // 73 728
-constexpr int T_SCRATCH = 2 * T_PATCH_B + T_V_B;  // 161 792: 1 KB that the surplus pieces write
-constexpr int T_LDS = T_SCRATCH + 1024;           // 162 816 <= 163 840
-constexpr int T_D = 4;                            // component pairs whose filter fragments are loaded ahead
+constexpr int T_PLANE_SLOTS = T_ROWS * T_QS;      // 380
+constexpr int T_PLANE_B = T_PLANE_SLOTS * 16;     // 6 080
+constexpr int T_PATCH_SLOTS = 4 * T_PLANE_SLOTS;  // 1 520
+constexpr int T_PATCH_B = 24 * 1024;              // 24 pieces of 64 slots: 6 per wave
+constexpr int T_V_B = 36 * 1024;                  // 36 864
+constexpr int T_LDS = T_PATCH_B + T_V_B;          // 61 440: two workgroups per CU
+#ifndef T_STAG
+#define T_STAG 0
+#endif
+#ifndef T_STAG_N
+#define T_STAG_N 1
+#endif
+#ifndef T_D_
+#define T_D_ 4
+#endif
+#ifndef T_ISSUE_
+#define T_ISSUE_ 9
+#endif
+constexpr int T_D = T_D_;                         // component pairs whose filter fragments are loaded ahead
 constexpr int T_R = 12;                           // ring of filter fragments (components)
+constexpr int T_ISSUE = T_ISSUE_;                      // the next chunk's pieces leave behind this component pair
 static_assert(36 % T_R == 0 && T_R >= 2 * T_D + 2, "the ring index must run on across chunks and cover the fragments in flight");
 
 #define T_WAITCNT(vm) __builtin_amdgcn_s_waitcnt(((vm) & 15) | ((((vm) >> 4) & 3) << 14) | (7 << 4))              /* + lgkmcnt(0) */
@@ -141,341 +159,322 @@ __device__ __forceinline__ void t_transform(const char* prd, char* vwr) {
         f32x2 o[6];
         t_bt6(t[i], o);
 #pragma unroll
-        for (int m = 0; m < 6; ++m) *(f32x2*)(vwr + (6 * (3 * LH + i) + m) * 2048) = o[m];
+        for (int m = 0; m < 6; ++m) *(f32x2*)(vwr + (6 * (3 * LH + i) + m) * 1024) = o[m];
     }
+}
+
+// a double rotated right by N lanes inside its row of 16 lanes (two 32-bit DPP moves)
+template <int N>
+__device__ __forceinline__ double t_row_ror(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x120 + N, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x120 + N, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
 constexpr float T_AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
 
 #ifndef T_EXP
 #define T_EXP 0       // experiment builds (tools/exp/w4t_variants.sh -DT_EXP=bits): 1 no input transform, 2 no products, 4 no epilogue,
-                      // 8 no LDS-DMA - wrong results, the time that is left tells what each phase costs
+                      // 8 no LDS-DMA, 16 stores into a 1 MB window, 32 no filter fragment loads, 64 no V fragment reads - wrong results, the time that is left tells what each phase costs
 #endif
 
 // EP: 0 = store only, 1 = + batch-norm column sums of what is stored, 2 = + backward sums of the batch norm in front
-// PERSISTENT: one workgroup per CU walks work items (tile block, channel block) b, b + grid, ...; the (item, chunk) pairs form
-// ONE sequence for the LDS-DMA look-ahead, so the next item's first two patch chunks stream in under this item's last products
-// and its epilogue.
 template <int EP>
-__global__ __launch_bounds__(512, 2) void wino4t_kernel(const W4TParams p) {
+__global__ __launch_bounds__(256, 2) void wino4t_kernel(const W4TParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const vbuf = smem + 2 * T_PATCH_B;
+    char* const vbuf = smem + T_PATCH_B;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grid = (int)gridDim.x;
-    const int first = (int)xcd_remap(blockIdx.x, gridDim.x);       // neighbouring items (channel blocks of one tile block) share an L2
+    const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);       // neighbouring items (channel blocks of one tile block) share an L2
+    const int kblk = (int)(bid % (uint32_t)p.tiles_k);
+    const int brow = (int)(bid / (uint32_t)p.tiles_k);           // tile block = row of the statistics
+    int blk = brow;
+    const int bx = blk % p.bw;
+    blk /= p.bw;
+    const int by = blk % p.bh;
+    const int n = blk / p.bh;
+    const int k0 = kblk * 64;
+    const int y0 = by * 8, x0 = bx * 32;            // first output pixel of the block
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
 
-    struct Item {
-        int n, y0, x0, k0, row;        // image, first output pixel, first output channel, tile block (= row of the statistics)
-    };
-    auto decode = [&](int item) {
-        Item it;
-        it.k0 = (item % p.tiles_k) * 64;
-        int blk = item / p.tiles_k;
-        it.row = blk;
-        it.x0 = (blk % p.bw) * 32;
-        blk /= p.bw;
-        it.y0 = (blk % p.bh) * 16;
-        it.n = blk / p.bh;
-        return it;
-    };
-
-    // ---- LDS-DMA pieces of this wave: piece = wave + 8 j covers patch slots 64 piece .. 64 piece + 63. The slot -> pixel
-    // arithmetic is redone per piece and chunk (a dozen integer instructions) rather than kept in six registers per lane: the
-    // accumulators leave none to spare ----
-    int d_item = first, d_chunk = 0, d_seq = 0;          // what the next issue fetches
-    Item d_it = decode(first < p.items ? first : 0);
+    // ---- LDS-DMA pieces of this wave: piece = wave + 4 j covers patch slots 64 piece .. 64 piece + 63 ----
+    int pc_off[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int L = (wave + 4 * j) * 64 + lane;
+        const int pl = L / T_PLANE_SLOTS, rem = L - pl * T_PLANE_SLOTS;
+        const int row = rem / T_QS, q = rem - row * T_QS;
+        const int v = q / 9, u = q - v * 9;
+        const int pcx = 4 * u + v;
+        const int iy = y0 - 1 + row, ix = x0 - 1 + pcx;
+        const bool ok = L < T_PATCH_SLOTS && q < 36 && pcx < 34 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        pc_off[j] = ok ? (((n * p.H + iy) * p.W + ix) * p.C + pl * 4) * 4 : T_OOB;
+    }
+    int d_chunk = 0;          // the chunk the next issue fetches
     auto issue = [&]() {
         if (T_EXP & 8) return;
-        const bool live = d_item < p.items;
-        char* const dstb = smem + (d_seq & 1) * T_PATCH_B;
+        const bool live = d_chunk < p.chunks;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int piece = wave + 8 * j;
-            char* const dst = piece < 43 ? dstb + piece * 1024 : smem + T_SCRATCH;
-            int ln = lane;
-            asm volatile("" : "+v"(ln));                // opaque: keeps this arithmetic here instead of hoisted into six register sets
-            const int L = piece * 64 + ln;
-            const int pl = (L * 6133) >> 22;             // L / 684 for L < 3072
-            const int rem = L - pl * T_PLANE_SLOTS;
-            const int row = (rem * 1725) >> 16;          // rem / 38 for rem < 684
-            const int q = rem - row * T_QS;
-            const int v = (q * 57) >> 9;                 // q / 9 for q < 38
-            const int pcx = 4 * (q - v * 9) + v;
-            const int iy = d_it.y0 - 1 + row, ix = d_it.x0 - 1 + pcx;
-            const bool ok = live && L < T_PATCH_SLOTS && q < 36 && pcx < 34 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const int off = (((d_it.n * p.H + iy) * p.W + ix) * p.C + pl * 4) * 4;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_ptr_t)dst, 16, ok ? off : T_OOB, d_chunk * 64, 0, 0);
-        }
-        d_seq += 1;
+        for (int j = 0; j < 6; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_ptr_t)(smem + (wave + 4 * j) * 1024), 16, live ? pc_off[j] : T_OOB,
+                                                     d_chunk * 64, 0, 0);
         d_chunk += 1;
-        if (d_chunk == p.chunks) {
-            d_chunk = 0;
-            d_item += grid;
-            if (d_item < p.items) d_it = decode(d_item);
-        }
     };
 
-    // ---- transform role: lane = (half, tile column, tile row); wave = (channel quad, component half) ----
-    const int t_half = lane & 1, t_tx = (lane >> 1) & 7, t_ty = (lane >> 4) & 3;
-    const int t_cq = wave & 3, t_lh = wave >> 2;
+    // ---- transform role: lane = (half, tile column, tile row, low bit of the channel quad); wave = (high bit, component half) ----
+    const int t_half = lane & 1, t_tx = (lane >> 1) & 7, t_ty = (lane >> 4) & 1;
+    const int t_cq = ((lane >> 5) & 1) | ((wave & 1) << 1), t_lh = wave >> 1;
     const int t_rd = t_cq * T_PLANE_B + (4 * t_ty * T_QS + t_tx) * 16 + t_half * 8;
-    char* const t_wr = vbuf + t_cq * 512 + (t_ty * 8 + t_tx) * 16 + t_half * 8;
+    char* const t_wr = vbuf + t_cq * 256 + (t_ty * 8 + t_tx) * 16 + t_half * 8;
 
-    // ---- product role: wave = (tile half tw, channel block kw); lane = (r, g) ----
+    // ---- product role: wave = channel block kw (16 channels), all 16 tiles; lane = (r, g) ----
     const int r15 = lane & 15, g = lane >> 4;
-    const int tw = wave & 1, kw = wave >> 1;
-    const char* const v_rd = vbuf + g * 512 + (16 * tw + r15) * 16;
+    const int kw = wave;
+    const char* const v_rd = vbuf + g * 256 + r15 * 16;
     // the filter fragments come through a buffer descriptor: one lane offset, the (chunk, component) offset is scalar
     const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, p.u_bytes, 0x00020000);
-    const int u_lane = ((16 * kw + r15) * 16 + 4 * g) * 4;       // + k0 * 64
+    const int u_voff = ((k0 + 16 * kw + r15) * 16 + 4 * g) * 4;
     const int u_xi = p.K * 64;                       // bytes per component
     const int u_chunk = 36 * u_xi;                   // bytes per chunk
+
+    f32x4 acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // filter fragments 2 T_D components (T_D pairs) ahead: a ring indexed by component % T_R - T_R divides 36, so the index runs
     // on across chunks, and exceeds the 2 T_D + 2 components in flight (everything is unrolled; the registers follow liveness)
     f32x4 fu[T_R];
-    auto load_u = [&](int voff, int chunk, int pair) {
+    if (T_EXP & 32) {
+#pragma unroll
+        for (int i = 0; i < T_R; ++i) asm volatile("" : "=v"(fu[i]));
+    }
+    auto load_u = [&](int chunk, int pair) {
+        if (T_EXP & 32) return;
         const int so = chunk * u_chunk + (2 * pair) * u_xi;
-        fu[(2 * pair) % T_R] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rU, voff, so, 0));
-        fu[(2 * pair + 1) % T_R] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rU, voff, so + u_xi, 0));
+        fu[(2 * pair) % T_R] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, so, 0));
+        fu[(2 * pair + 1) % T_R] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, so + u_xi, 0));
     };
     f32x4 fv[2][2];
+    if (T_EXP & 64) asm volatile("" : "=v"(fv[0][0]), "=v"(fv[0][1]), "=v"(fv[1][0]), "=v"(fv[1][1]));
     auto read_v = [&](int pair) {
-        fv[pair & 1][0] = *(const f32x4*)(v_rd + (2 * pair) * 2048);
-        fv[pair & 1][1] = *(const f32x4*)(v_rd + (2 * pair + 1) * 2048);
+        if (T_EXP & 64) return;
+        fv[pair & 1][0] = *(const f32x4*)(v_rd + (2 * pair) * 1024);
+        fv[pair & 1][1] = *(const f32x4*)(v_rd + (2 * pair + 1) * 1024);
     };
 
-    if (first >= p.items) return;
-    Item cur = decode(first);
-    int u_voff = u_lane + cur.k0 * 64;
+#if T_STAG
+    {
+        const bool late = T_STAG == 1 ? ((blockIdx.x >> 8) & 1) && blockIdx.x < 512 : (blockIdx.x & 1) && blockIdx.x < 512;
+        if (late) {
+#pragma unroll
+            for (int i = 0; i < T_STAG_N; ++i) __builtin_amdgcn_s_sleep(115);
+        }
+    }
+#endif
+    issue();
     if (!(T_EXP & 2)) {
 #pragma unroll
-        for (int pr = 0; pr < T_D; ++pr) load_u(u_voff, 0, pr);
+        for (int pr = 0; pr < T_D; ++pr) load_u(0, pr);
     }
-    issue();
-    issue();
-    int c_seq = 0;            // chunks consumed: the patch buffer of a chunk is its sequence number's parity
 
-    for (int item = first; item < p.items; item += grid) {
-        const bool has_next = item + grid < p.items;
-        const Item nxt = decode(has_next ? item + grid : item);
-        const int u_voff_next = u_lane + nxt.k0 * 64;
-        f32x4 acc[36];
+    for (int s = 0; s < p.chunks; ++s) {
+        // this chunk's pieces have landed: only the 2 T_D look-ahead fragment loads behind them may still fly (behind the first
+        // chunk that is implied: fragment loads issued behind the pieces have been consumed). Every wave is done with the
+        // products of chunk s - 1: V is free
+        T_WAIT_VM(2 * T_D);
+        T_BARRIER();
+        if (!(T_EXP & 1)) {
+            const char* prd = smem + t_rd;
+            if (t_lh == 0) t_transform<0>(prd, t_wr);
+            else t_transform<1>(prd, t_wr);
+        }
+        T_WAITCNT(63);                // lgkmcnt(0): this wave's V rows are written (vmcnt left alone)
+        T_BARRIER();                  // V is complete, the patch buffer is free
+        if (!(T_EXP & 2)) {
+            const int sn = s + 1 < p.chunks ? s + 1 : s;      // (the last chunk's look-ahead loads re-read its own fragments)
+            read_v(0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 36; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        for (int s = 0; s < p.chunks; ++s, ++c_seq) {
-            // Only the newest pieces (sequence number c_seq + 1) may still fly: this chunk's have landed. Behind the first chunk of a
-            // launch that is implied - the chunk's pieces are older than fragment loads (and epilogue loads) that have been consumed
-            // - and at the first chunk of a later item NOTHING is waited for: the epilogue's stores are still draining.
-            if (c_seq == 0) T_WAIT_VM(6);
-            else if (s != 0) T_WAIT_VM(6);
-            T_BARRIER();
-            if (!(T_EXP & 1)) {
-                const char* prd = smem + (c_seq & 1) * T_PATCH_B + t_rd;
-                if (t_lh == 0) t_transform<0>(prd, t_wr);
-                else t_transform<1>(prd, t_wr);
-            }
-            T_WAITCNT(63);                // lgkmcnt(0): this wave's V rows are written (vmcnt left alone)
-            T_BARRIER();
-            if (!(T_EXP & 2)) {
-                const bool last = s + 1 == p.chunks;
-                // (behind the last item the look-ahead loads re-read this chunk's own fragments)
-                const int voff_n = last ? u_voff_next : u_voff;
-                const int chunk_n = last ? (has_next ? 0 : s) : s + 1;
-                read_v(0);
+            for (int pr = 0; pr < 18; ++pr) {
+                // the fragment loads T_D pairs ahead (behind pair 17 - T_D: the next chunk's first pairs), the V fragments one pair
+                // ahead
+                if (pr + T_D < 18) load_u(s, pr + T_D);
+                else load_u(sn, pr + T_D - 18);
+                if (pr + 1 < 18) read_v(pr + 1);
+                const f32x4 ua = fu[(2 * pr) % T_R], ub = fu[(2 * pr + 1) % T_R];
+                const f32x4 va = fv[pr & 1][0], vb = fv[pr & 1][1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[2 * pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[j], va[j], acc[2 * pr], 0, 0, 0);
+                    acc[2 * pr + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[j], vb[j], acc[2 * pr + 1], 0, 0, 0);
+                }
+                // issue order of the pair: the loads slotted behind the first products (left to the compiler they sink to their uses)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (pr + 1 < 18) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int pr = 0; pr < 18; ++pr) {
-                    // the fragment loads T_D pairs ahead (behind pair 17 - T_D: the next chunk's first pairs), the V fragments one
-                    // pair ahead
-                    if (pr + T_D < 18) load_u(u_voff, s, pr + T_D);
-                    else load_u(voff_n, chunk_n, pr + T_D - 18);
-                    if (pr + 1 < 18) read_v(pr + 1);
-                    const f32x4 ua = fu[(2 * pr) % T_R], ub = fu[(2 * pr + 1) % T_R];
-                    const f32x4 va = fv[pr & 1][0], vb = fv[pr & 1][1];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[2 * pr] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[j], va[j], acc[2 * pr], 0, 0, 0);
-                        acc[2 * pr + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[j], vb[j], acc[2 * pr + 1], 0, 0, 0);
-                    }
-                    // issue order of the pair: the loads slotted behind the first products (left to the compiler they sink to
-                    // their uses)
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    if (pr + 1 < 18) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                    } else {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-                    }
+                if (pr == T_ISSUE && s + 1 < p.chunks) {
+                    issue();                 // the next chunk's pieces, into the buffer this chunk was transformed from
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // the chunk two ahead in the sequence, into the buffer this chunk was transformed from, behind every fragment load
-            // issued so far: the first load that waits for these pieces is consumed a whole transform and T_D pairs later
+        } else if (s + 1 < p.chunks) {
             issue();
         }
-        if (T_EXP & 4) {
+    }
+    // (no piece is in flight: the last chunk issued none; the look-ahead loads behind its last pairs are never consumed)
+    if (T_EXP & 4) {
 #pragma unroll
-            for (int i = 0; i < 36; ++i) asm volatile("" ::"v"(acc[i]));
-            cur = nxt;
-            u_voff = u_voff_next;
-            continue;
-        }
+        for (int i = 0; i < 36; ++i) asm volatile("" ::"v"(acc[i]));
+        return;
+    }
 
-        // ---- output transform in registers: Y = A^T M A, M[l][m] = acc[6 l + m] (4 output channels per lane) ----
-        f32x4 Y[16];
-        {
-            f32x4 Z[6][4];
+    // ---- output transform in registers: Y = A^T M A, M[l][m] = acc[6 l + m] (4 output channels per lane) ----
+    f32x4 Y[16];
+    {
+        f32x4 Z[6][4];
 #pragma unroll
-            for (int l = 0; l < 6; ++l)
+        for (int l = 0; l < 6; ++l)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                    bool fst = true;
+            for (int j = 0; j < 4; ++j) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                bool fst = true;
 #pragma unroll
-                    for (int m = 0; m < 6; ++m) {
-                        const float c = T_AT[j][m];
-                        if (c == 0.f) continue;
-                        if (fst) a = c == 1.f ? acc[6 * l + m] : acc[6 * l + m] * c;
-                        else if (c == 1.f) a += acc[6 * l + m];
-                        else if (c == -1.f) a -= acc[6 * l + m];
-                        else a = __builtin_elementwise_fma(f32x4{c, c, c, c}, acc[6 * l + m], a);
-                        fst = false;
-                    }
-                    Z[l][j] = a;
+                for (int m = 0; m < 6; ++m) {
+                    const float c = T_AT[j][m];
+                    if (c == 0.f) continue;
+                    if (fst) a = c == 1.f ? acc[6 * l + m] : acc[6 * l + m] * c;
+                    else if (c == 1.f) a += acc[6 * l + m];
+                    else if (c == -1.f) a -= acc[6 * l + m];
+                    else a = __builtin_elementwise_fma(f32x4{c, c, c, c}, acc[6 * l + m], a);
+                    fst = false;
                 }
+                Z[l][j] = a;
+            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                    bool fst = true;
+            for (int j = 0; j < 4; ++j) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                bool fst = true;
 #pragma unroll
-                    for (int l = 0; l < 6; ++l) {
-                        const float c = T_AT[i][l];
-                        if (c == 0.f) continue;
-                        if (fst) a = c == 1.f ? Z[l][j] : Z[l][j] * c;
-                        else if (c == 1.f) a += Z[l][j];
-                        else if (c == -1.f) a -= Z[l][j];
-                        else a = __builtin_elementwise_fma(f32x4{c, c, c, c}, Z[l][j], a);
-                        fst = false;
-                    }
-                    Y[4 * i + j] = a;
+                for (int l = 0; l < 6; ++l) {
+                    const float c = T_AT[i][l];
+                    if (c == 0.f) continue;
+                    if (fst) a = c == 1.f ? Z[l][j] : Z[l][j] * c;
+                    else if (c == 1.f) a += Z[l][j];
+                    else if (c == -1.f) a -= Z[l][j];
+                    else a = __builtin_elementwise_fma(f32x4{c, c, c, c}, Z[l][j], a);
+                    fst = false;
                 }
-        }
+                Y[4 * i + j] = a;
+            }
+    }
 
-        // ---- epilogue (wino4f.hip's): lane = (tile 16 tw + r15 of the block, channels k0 + 16 kw + 4 g .. + 3) ----
-        const int tl = 16 * tw + r15;
-        const int oy = cur.y0 + 4 * (tl >> 3), ox = cur.x0 + 4 * (tl & 7);
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const i32x4_t rsY = {(int)(unsigned)(unsigned long long)p.y, (int)(((unsigned long long)p.y >> 32) & 0xffffu), (int)p.y_bytes, 0x00020000};
-        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.add, 0, p.add ? p.y_bytes : 0u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rBX = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_x, 0, p.bs_x ? p.y_bytes : 0u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rBY = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_y, 0, p.bs_y ? p.y_bytes : 0u, 0x00020000);
-        const float floor_ = p.relu ? 0.f : -__builtin_inff();
-        const bool mask_y = p.bs_relu && p.bs_y, mask_x = p.bs_relu && !p.bs_y;
-        double ds[8];
-        {
-            const int kc = cur.k0 + 16 * kw + 4 * g;
-            const bool valid = oy < p.H && ox < p.W && kc < p.K;
+    // ---- epilogue (wino4f.hip's): lane = (tile r15 of the block, channels k0 + 16 kw + 4 g .. + 3) ----
+    const int oy = y0 + 4 * (r15 >> 3), ox = x0 + 4 * (r15 & 7);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const i32x4_t rsY = {(int)(unsigned)(unsigned long long)p.y, (int)(((unsigned long long)p.y >> 32) & 0xffffu), (int)p.y_bytes, 0x00020000};
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.add, 0, p.add ? p.y_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rBX = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_x, 0, p.bs_x ? p.y_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rBY = __builtin_amdgcn_make_buffer_rsrc((void*)p.bs_y, 0, p.bs_y ? p.y_bytes : 0u, 0x00020000);
+    const float floor_ = p.relu ? 0.f : -__builtin_inff();
+    const bool has_add = p.add != nullptr;          // (uniform: a pass without an add issues no loads and waits for none)
+    const bool mask_y = p.bs_relu && p.bs_y, mask_x = p.bs_relu && !p.bs_y;
+    double ds[8];
+    const int kc = k0 + 16 * kw + 4 * g;
+    const bool valid = oy < p.H && ox < p.W && kc < p.K;
+    {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) ds[c] = 0.0;
-            const int voff = valid ? (((cur.n * p.H + oy) * p.W + ox) * p.K + kc) * 4 : T_OOB;
-            const int kcs = valid ? kc : 0;
-            f32x4 b = z;
-            if (p.bias) b = *(const f32x4*)(p.bias + kcs);
-            f32x4 bmu = z, bis = z, bsc = z, bsh = z;
-            if (EP == 2) {
-                bmu = *(const f32x4*)(p.bs_mean + kcs);
-                bis = *(const f32x4*)(p.bs_invstd + kcs);
+        for (int c = 0; c < 8; ++c) ds[c] = 0.0;
+        const int voff = valid ? (((n * p.H + oy) * p.W + ox) * p.K + kc) * 4 : T_OOB;
+        const int voff_st = (T_EXP & 16) ? (valid ? (voff & 0xFFFFF) : T_OOB) : voff;
+        const int kcs = valid ? kc : 0;
+        f32x4 b = z;
+        if (p.bias) b = *(const f32x4*)(p.bias + kcs);
+        f32x4 bmu = z, bis = z, bsc = z, bsh = z;
+        if (EP == 2) {
+            bmu = *(const f32x4*)(p.bs_mean + kcs);
+            bis = *(const f32x4*)(p.bs_invstd + kcs);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    bsc[c] = (p.bs_gamma ? p.bs_gamma[kcs + c] : 1.f) * bis[c];
-                    bsh[c] = (p.bs_beta ? p.bs_beta[kcs + c] : 0.f) - bmu[c] * bsc[c];
+            for (int c = 0; c < 4; ++c) {
+                bsc[c] = (p.bs_gamma ? p.bs_gamma[kcs + c] : 1.f) * bis[c];
+                bsh[c] = (p.bs_beta ? p.bs_beta[kcs + c] : 0.f) - bmu[c] * bsc[c];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 ssum = z, ssq = z;          // the four values of an output row in fp32, doubles from there
+            f32x4 av[4], xv[4], yv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int soff = (i * p.W + j) * p.K * 4;
+                av[j] = z;
+                if (has_add) av[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, soff, 0));
+                if (EP == 2) {
+                    xv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rBX, voff, soff, 0));
+                    yv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rBY, voff, soff, 0));
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4 ssum = z, ssq = z;          // the four values of an output row in fp32, doubles from there
-                f32x4 av[4], xv[4], yv[4];
+            for (int j = 0; j < 4; ++j) {
+                const int soff = (i * p.W + j) * p.K * 4;
+                f32x4 o = (Y[4 * i + j] + b) + av[j];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int soff = (i * p.W + j) * p.K * 4;
-                    av[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, voff, soff, 0));
-                    if (EP == 2) {
-                        xv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rBX, voff, soff, 0));
-                        yv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rBY, voff, soff, 0));
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int soff = (i * p.W + j) * p.K * 4;
-                    f32x4 o = (Y[4 * i + j] + b) + av[j];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], floor_);
-                    t_store_b128(o, rsY, voff, soff);
-                    if (EP == 2) {
-                        f32x4 gq;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const float mk = mask_y ? yv[j][c] : (mask_x ? fmaf(xv[j][c], bsc[c], bsh[c]) : 1.f);
-                            gq[c] = mk > 0.f ? o[c] : 0.f;
-                            ssq[c] += gq[c] * ((xv[j][c] - bmu[c]) * bis[c]);
-                        }
-                        ssum += gq;
-                    } else if (EP == 1) {
-                        ssum += o;
-                        ssq += o * o;
-                    }
-                }
-                if (EP != 0 && valid) {
+                for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], floor_);
+                t_store_b128(o, rsY, voff_st, soff);
+                if (EP == 2) {
+                    f32x4 gq;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        ds[c] += (double)ssum[c];
-                        ds[4 + c] += (double)ssq[c];
+                        const float mk = mask_y ? yv[j][c] : (mask_x ? fmaf(xv[j][c], bsc[c], bsh[c]) : 1.f);
+                        gq[c] = mk > 0.f ? o[c] : 0.f;
+                        ssq[c] += gq[c] * ((xv[j][c] - bmu[c]) * bis[c]);
                     }
+                    ssum += gq;
+                } else if (EP == 1) {
+                    ssum += o;
+                    ssq += o * o;
                 }
             }
-        }
-        if (EP != 0) {
-            // over the 16 tiles of the wave (shuffles inside each group of 16 lanes), then over the two tile waves through LDS: the
-            // V buffer, free between the last products of this item and the next transform (the patch buffers are NOT: the next
-            // item's pieces are landing there). Raw barriers: the stores above and the pieces in flight are not waited for
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) ds[c] += __shfl_xor(ds[c], off, 64);
-            T_BARRIER();                                 // every wave has read its last V fragments
-            double* red = (double*)vbuf;                 // [tile wave][2][64 channels]
-            if (r15 == 0) {
+            if (EP != 0 && valid) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    red[(tw * 2 + 0) * 64 + 16 * kw + 4 * g + c] = ds[c];
-                    red[(tw * 2 + 1) * 64 + 16 * kw + 4 * g + c] = ds[4 + c];
+                    ds[c] += (double)ssum[c];
+                    ds[4 + c] += (double)ssq[c];
                 }
             }
-            T_WAITCNT(63);
-            T_BARRIER();
-            if (tid < 128) {
-                const int which = tid >> 6, ch = tid & 63;
-                const double a = red[(0 * 2 + which) * 64 + ch] + red[(1 * 2 + which) * 64 + ch];
-                if (cur.k0 + ch < p.K) p.stats[((long)cur.row * 2 + which) * p.K + cur.k0 + ch] = a;
-            }
-            // (the next transform's first V write lies behind the next top barrier, which every reader of `red` reaches after its read)
         }
-        cur = nxt;
-        u_voff = u_voff_next;
     }
-    __builtin_amdgcn_s_waitcnt(0);       // trailing (out-of-range) pieces and look-ahead loads
+    if (EP == 0) return;
+    // over the 16 tiles of the wave = the 16 lanes of a DPP row (row_ror 8, 4, 2, 1: every lane ends with the row's sum; the
+    // additions pair the same lanes as xor-shuffles would): the wave owns its 16 channels' column sums
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        ds[c] += t_row_ror<8>(ds[c]);
+        ds[c] += t_row_ror<4>(ds[c]);
+        ds[c] += t_row_ror<2>(ds[c]);
+        ds[c] += t_row_ror<1>(ds[c]);
+    }
+    if (r15 == 0 && kc < p.K) {
+        double* row = p.stats + (long)brow * 2 * p.K;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            row[kc + c] = ds[c];
+            row[p.K + kc + c] = ds[4 + c];
+        }
+    }
 }
 
 // U [36][K][C] (denet_conv_wino_filter, tile 4; K = output channels of the pass, C = its reduction) -> [C/16][36][K][16]
@@ -500,9 +499,9 @@ extern "C" int denet_conv_wino4t_ok(int N, int H, int W, int C, int K) {
             (long)N * H * W * C * 4 < 0x7FFFFFFFL && (long)N * H * W * K * 4 < 0x7FFFFFFFL && 36L * K * C * 4 < 0x7FFFFFFFL) ? 1 : 0;
 }
 
-// rows of partial statistics a launch writes: one per block of 4 x 8 tiles
+// rows of partial statistics a launch writes: one per block of 2 x 8 tiles
 extern "C" int denet_conv_wino4t_stats_rows(int N, int H, int W) {
-    return N * ((H + 15) / 16) * ((W + 31) / 32);
+    return N * ((H + 7) / 8) * ((W + 31) / 32);
 }
 
 extern "C" int denet_conv_wino4t_pack(const float* u, float* packed, int C, int K, hipStream_t stream) {
@@ -523,7 +522,7 @@ extern "C" int denet_conv_wino4t_sums(const float* x, const float* u_packed, con
     W4TParams p = {};
     p.x = x; p.U = u_packed; p.bias = bias; p.add = add; p.y = y;
     p.N = N; p.H = H; p.W = W; p.C = C; p.K = K;
-    p.bh = (H + 15) / 16; p.bw = (W + 31) / 32;
+    p.bh = (H + 7) / 8; p.bw = (W + 31) / 32;
     p.tiles_k = K / 64; p.chunks = C / 16; p.relu = relu;
     p.x_bytes = (unsigned)((size_t)N * H * W * C * 4);
     p.y_bytes = (unsigned)((size_t)N * H * W * K * 4);
@@ -548,28 +547,17 @@ extern "C" int denet_conv_wino4t_sums(const float* x, const float* u_packed, con
     static bool attr_done[3] = {};
     const kern_t fn = kerns[ep];
     if (!attr_done[ep]) {
-        const hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+        const hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         if (e != hipSuccess) {
             denet_set_error("conv_wino4t: hipFuncSetAttribute(%d B LDS): %s", T_LDS, hipGetErrorString(e));
             return -(int)e;
         }
         attr_done[ep] = true;
     }
-    // the LDS footprint allows one workgroup per CU: a persistent grid, work items strided over it
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-            denet_set_error("conv_wino4t: cannot query the device");
-            return DENET_ERR_ARG;
-        }
-        cus = prop.multiProcessorCount;
-    }
-    p.items = (int)(blocks * p.tiles_k);
-    const int grid = p.items < cus ? p.items : cus;
-    const int prof = denet_prof_begin(15, ep, 0, 0, stream);
-    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(512), T_LDS, stream, p);
+    // (experiments: DENET_W4T_LDS = LDS bytes requested per workgroup, e.g. 100000 leaves room for ONE workgroup per CU)
+    static const int lds_req = [] { const char* e = getenv("DENET_W4T_LDS"); const int v = e ? atoi(e) : 0; return v > T_LDS && v <= 163840 ? v : T_LDS; }();
+    const int prof = denet_prof_begin(16, ep, 0, 0, stream);
+    hipLaunchKernelGGL(fn, dim3((unsigned)(blocks * p.tiles_k)), dim3(256), lds_req, stream, p);
     denet_prof_end(prof, stream);
     DENET_CHECK_LAUNCH("conv_wino4t");
     return DENET_OK;

@@ -46,6 +46,8 @@ def kernel_symbol(kind, a, b, c):
         return "%s<%d>" % ({32: "wino4f_kernel_32", 64: "wino4f_kernel_64", 33: "wino4f_kernel_32x2", 34: "wino4f_kernel_32k"}[a], b)
     if kind == 15:
         return "wino4g_kernel<%d>" % c
+    if kind == 16:
+        return "wino4t_kernel<%d>" % a
     fixed = {11: "wino2f_wgrad_kernel", 12: "stem_fwd_kernel", 13: "stem_wgrad_kernel"}.get(kind)
     return fixed or "igemm_kernel<%d, %d, %d, 2, 2, %d>" % (kind, a, b, c)
 
@@ -596,7 +598,7 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
         # rows of partial sums: direct tiles of 128 pixels, the F(2x2) output transform, the fused 64-channel kernel (one
         # row per 16x16-pixel block) - whichever implementation runs, the buffer holds its rows
         rows = max((N * OH * OW + 127) // 128, (N * (OH // 2 + 1) * (OW // 2 + 1) * (K // 4) + 255) // 256,
-                   N * ((OH + 15) // 16) * ((OW + 15) // 16))
+                   N * ((OH + 15) // 16) * ((OW + 15) // 16), N * ((OH + 7) // 8) * ((OW + 31) // 32))
         st = cache.get("bn_stats_buf")
         if st is None or st.numel() < rows * 2 * K:
             st = cache["bn_stats_buf"] = torch.empty(rows * 2 * K, dtype=torch.float64, device="cuda")
@@ -660,7 +662,12 @@ _WINO = {}
 # gradient (64 -> 64 channels only).
 FUSED2 = 22
 WINO2F = int(os.environ.get("DENET_WINO2F", "7"))
-_WINO_GAIN = {2: 2.25, 4: 4.0, FUSED2: 2.25}      # direct multiplications / Winograd multiplications
+# A fourth: FUSED4, F(4x4,3x3) tile-parallel with BOTH transforms and the 36 products in one kernel (csrc/wino4t.hip): x -> y
+# only, like FUSED2, at 1.78 times fewer products. Forward pass and data gradient (DENET_WINO4T bits 0 / 1); reduction channels
+# a multiple of 16, written channels of 64, H and W multiples of 4. Chosen by the tuned file (or a policy), never by static_policy.
+FUSED4 = 44
+WINO4T = int(os.environ.get("DENET_WINO4T", "3"))
+_WINO_GAIN = {2: 2.25, 4: 4.0, FUSED2: 2.25, FUSED4: 4.0}      # direct multiplications / Winograd multiplications
 
 
 # POLICY: a callable (mode, geometry) -> tile that DECIDES the implementation of a pass that has no entry in _WINO yet (at the
@@ -694,12 +701,23 @@ def _decided(mode, g):
 def _tile_allowed(mode, tile):
     if tile == FUSED2:
         return WINOGRAD >= 2 and mode in (0, 1, 2) and bool((WINO2F >> mode) & 1)
+    if tile == FUSED4:
+        return WINOGRAD >= 4 and mode in (0, 1) and bool((WINO4T >> mode) & 1)
     return tile <= WINOGRAD
 
 
 def _filter_tile(tile):
     """the Winograd tile whose transformed filters the algorithm consumes"""
-    return 2 if tile == FUSED2 else tile
+    return 2 if tile == FUSED2 else (4 if tile == FUSED4 else tile)
+
+
+def conv_wino4t_ok(mode, g):
+    """geometry the tile-parallel fused F(4x4,3x3) kernel covers for the forward pass (mode 0) / the data gradient (1)"""
+    N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
+    if not (mode in (0, 1) and R == 3 and S == 3 and s_real == 3 and stride == 1 and pad == 1):
+        return False
+    red, out = (C, K) if mode == 0 else (K, C)
+    return bool(_L().denet_conv_wino4t_ok(N, H, W, red, out))
 
 
 def conv_wino2f_ok(mode, g):
@@ -745,6 +763,8 @@ def _wino_tile(mode, g, direct, wino):
         tiles = [t for t in (2, 4) if t <= WINOGRAD and conv_wino_ok(g, t)] if AUTOTUNE else []
         if AUTOTUNE and _tile_allowed(mode, FUSED2) and conv_wino2f_ok(mode, g):
             tiles.append(FUSED2)
+        if AUTOTUNE and _tile_allowed(mode, FUSED4) and conv_wino4t_ok(mode, g) and (g[3] if mode == 0 else g[4]) == 64:
+            tiles.append(FUSED4)         # (measured only where the fused F(2x2) kernel is the alternative: 64 reduction channels)
         if not tiles:
             use = 0
         elif PROFILE is not None:
@@ -754,7 +774,7 @@ def _wino_tile(mode, g, direct, wino):
             sws = WS.get("wgrad", WGRAD_WS_BYTES)
             best, use = 0.97 * _time_ms(direct), 0
             for t in tiles:
-                if t != FUSED2:                  # the batched products of the un-fused passes have configurations of their own
+                if t not in (FUSED2, FUSED4):    # the batched products of the un-fused passes have configurations of their own
                     ws = WS.get("wino", _L().denet_conv_wino_workspace_bytes(t, N, H, W, C, K))
                     check(_L().denet_conv_wino_tune(ptr(ws), ws.numel(), ptr(sws), sws.numel(), t, N, H, W, C, K, stream_ptr()),
                           "conv_wino_tune")
@@ -815,7 +835,10 @@ def wino_prefetch_filters(caches_and_weights, after=None):
                 if ent is None or ent[0] != tile:
                     K, _, _, C = w.shape
                     ent = c[("u", dgrad)] = [tile, torch.empty((ft + 2) * (ft + 2) * K * C, dtype=torch.float32, device="cuda"), False]
-                conv_wino_filter(w, ft, dgrad, out=ent[1])
+                if tile == FUSED4:
+                    conv_wino4t_filter(w, dgrad, out=ent[1])
+                else:
+                    conv_wino_filter(w, ft, dgrad, out=ent[1])
                 ent[2] = True
             ev = torch.cuda.Event()
             ev.record(_SIDE_FILTER)
@@ -915,6 +938,17 @@ def conv_wino_fwd(x, w, bias=None, add=None, out=None, tile=2, u=None, v_keep=No
         if st is not None:
             cache["bn_stats"] = _stats_result(st, rows.value, fin)
         return y
+    if tile == FUSED4:
+        import ctypes
+        if u is None:
+            u = conv_wino4t_filter(w, dgrad=False)
+        st, cache = stats if stats is not None and not relu else (None, None)
+        rows = ctypes.c_int(0)
+        check(_L().denet_conv_wino4t_sums(ptr(x), ptr(u), ptr(bias), ptr(add), ptr(y), int(relu), ptr(st), st.numel() * 8 if st is not None
+                                          else 0, ctypes.byref(rows), None, N, H, W, C, K, stream_ptr()), "conv_wino4t")
+        if st is not None:
+            cache["bn_stats"] = _stats_result(st, rows.value, None)
+        return y
     ws = _wino_ws(tile, N, H, W, C, K)
     if stats is not None and not relu:
         import ctypes
@@ -950,6 +984,16 @@ def conv_wino_dgrad(dy, w, add=None, out=None, tile=2, u=None, sums=None, cache=
                                               stream_ptr()), "conv_wino2f")
         if sums is not None:
             sums.done(sb, rows.value, fin)
+        return dx
+    if tile == FUSED4:
+        if u is None:
+            u = conv_wino4t_filter(w, dgrad=True)
+        sb = sums.buffer(cache, _L().denet_conv_wino4t_stats_rows(N, H, W), C) if sums is not None else None
+        check(_L().denet_conv_wino4t_sums(ptr(dy), ptr(u), None, ptr(add), ptr(dx), 0, ptr(sb), sb.numel() * 8 if sb is not None else 0,
+                                          ctypes.byref(rows), ctypes.byref(so) if so is not None else None, N, H, W, K, C,
+                                          stream_ptr()), "conv_wino4t")
+        if sums is not None:
+            sums.done(sb, rows.value, None)
         return dx
     ws = _wino_ws(tile, N, H, W, C, K)
     if sums is not None:
@@ -989,6 +1033,20 @@ def conv_wino_filter(w, tile, dgrad, out=None):
     u = out if out is not None else empty(nx, K, C)
     check(_L().denet_conv_wino_filter(ptr(w), ptr(u), tile, int(dgrad), C, K, stream_ptr()), "conv_wino_filter")
     return u
+
+
+def conv_wino4t_filter(w, dgrad, out=None):
+    """the F(4x4) transformed filters in the layout of the tile-parallel fused kernel, [red / 16][36][out][16] (red = the pass's
+    reduction channels: C forward, K for the data gradient): denet_conv_wino_filter (tile 4) + denet_conv_wino4t_pack"""
+    K, _, _, C = w.shape
+    # (the prefetch runs on a side stream beside passes that may transform filters themselves: a scratch buffer per stream kind)
+    name = "w4t_filter_side" if torch.cuda.current_stream() != torch.cuda.default_stream() else "w4t_filter"
+    u = WS.get(name, 36 * K * C * 4)[:36 * K * C * 4].view(torch.float32)
+    conv_wino_filter(w, 4, dgrad, out=u)
+    pk = out if out is not None else empty(36 * K * C)
+    red, outc = (K, C) if dgrad else (C, K)
+    check(_L().denet_conv_wino4t_pack(ptr(u), ptr(pk), red, outc, stream_ptr()), "conv_wino4t_pack")
+    return pk
 
 
 def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None, logical=None, cache=None, sums=None):

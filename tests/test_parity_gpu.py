@@ -262,7 +262,7 @@ def assert_kernels(table, batch, w4f=None, expect_w4f=None, expect_w4g=None):
     layer ran. expect_w4f(geom) / expect_w4g(geom) -> bool say where the fused F(4x4) product + output-transform kernel and
     the F(4x4) filter-gradient kernel must have run (None: the C side's default policy for this batch); w4f names the
     instantiation (32x2 / 32 / 64) when a test forces one."""
-    seen = {"wino4f": 0, "wino4g": 0, "wino2f": 0, "stem": 0}
+    seen = {"wino4f": 0, "wino4g": 0, "wino2f": 0, "wino4t": 0, "stem": 0}
     for r in table:
         g, fwd, bwd = r["geometry"], r["fwd"], r["bwd"]
         assert fwd, "layer %s (%s) launched no matrix kernel in the forward pass" % (r["layer"], g)
@@ -275,9 +275,14 @@ def assert_kernels(table, batch, w4f=None, expect_w4f=None, expect_w4g=None):
             continue
         c, k = _chan(g)
         if c == 64 and k == 64:
-            assert fwd == ["wino2f_ws_kernel<false>"], (r["layer"], g, fwd)
-            assert sorted(bwd) == ["wino2f_wgrad_kernel", "wino2f_ws_kernel<true>"], (r["layer"], g, bwd)
+            # the 64-channel stage: the fused F(2x2) kernels, or - where the tuned file says so (algorithm 44: the benchmark
+            # geometry) - the tile-parallel fused F(4x4) kernel for the forward pass / the data gradient (csrc/wino4t.hip);
+            # the filter gradient stays with the fused F(2x2) kernel
+            assert fwd in (["wino2f_ws_kernel<false>"], ["wino4t_kernel<1>"]), (r["layer"], g, fwd)
+            assert sorted(bwd) in (["wino2f_wgrad_kernel", "wino2f_ws_kernel<true>"], ["wino2f_wgrad_kernel", "wino4t_kernel<2>"],
+                                   ["wino2f_wgrad_kernel", "wino4t_kernel<0>"]), (r["layer"], g, bwd)
             seen["wino2f"] += 1
+            seen["wino4t"] += int(fwd[0].startswith("wino4t")) + int(any(x.startswith("wino4t") for x in bwd))
             continue
         T = batch * (_map(g) // 4) ** 2
         f4 = expect_w4f(g, T) if expect_w4f is not None else None
