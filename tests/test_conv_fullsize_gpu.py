@@ -120,10 +120,16 @@ def test_conv_passes_at_benchmark_geometry(hip, geom):
     saved = (ops.AUTOTUNE, dict(ops._WINO), set(ops._TUNED))
     res = {}
     try:
-        for label, tuned in (("direct", False), ("tuned", True)):
+        g0 = ops.conv_geom(x.shape, w.shape, stride, pad, s_real)
+        labels = [("direct", False), ("tuned", True)]
+        if C == 64 and ops.conv_wino4t_ok(0, g0) and ops.conv_wino4t_ok(1, g0):
+            labels.append(("fused4", True))        # what the committed file runs on the 64-channel stage: csrc/wino4t.hip (algorithm 44)
+        for label, tuned in labels:
             ops.AUTOTUNE = tuned
             ops._WINO.clear()
             ops._TUNED.clear()
+            if label == "fused4":
+                ops._WINO[(0, g0)] = ops._WINO[(1, g0)] = ops.FUSED4
             # "tuned": the algorithm of ops.static_policy (fused 64-channel / F(4x4) / F(2x2) wherever the geometry allows one - the
             # widest kernel coverage; nothing is timed) on the launch configurations of the committed file
             for rep in range(2):                                   # first call: decides and sets buffers up; second: the fixed choice alone
@@ -168,7 +174,7 @@ def test_conv_passes_at_benchmark_geometry(hip, geom):
             wino = ent["algo"][p]
             # direct kernels: fp32 FMA chains of <= 524 288 terms; Winograd F(4x4): transform constants up to 8 amplify the
             # rounding of the 36-point products (Lavin & Gray report ~1e-5 for F(4x4) in fp32)
-            bound = {0: 1e-5, 2: 2e-5, 4: 8e-5, 22: 1e-5}[wino]     # 22: ops.FUSED2, F(2x2) in one kernel
+            bound = {0: 1e-5, 2: 2e-5, 4: 8e-5, 22: 1e-5, 44: 8e-5}[wino]     # 22: ops.FUSED2, F(2x2) in one kernel; 44: ops.FUSED4, F(4x4) in one kernel
             assert mx <= bound, "%s %s %s (winograd tile %d): max-norm error %.2e > %.0e" % (name, label, p, wino, mx, bound)
             assert p999 <= 3 * bound, "%s %s %s: p99.9 element-wise error %.2e" % (name, label, p, p999)
             assert mx <= 1e-3 and p999 <= 1e-3                      # the north-star budget itself

@@ -242,6 +242,82 @@ def test_fused_winograd_f2_kernel(hip, case):
         ops._WINO.update(saved[1])
 
 
+@pytest.mark.parametrize("case", [(1, 8, 32, 64, 64), (2, 16, 64, 64, 64), (3, 12, 20, 64, 64), (2, 24, 40, 32, 128), (1, 16, 32, 128, 64),
+                                  (5, 64, 64, 64, 64), (2, 56, 56, 64, 64), (1, 4, 4, 16, 64)])
+def test_fused_winograd_f4_tile_parallel_kernel(hip, case):
+    """csrc/wino4t.hip through ops (algorithm ops.FUSED4: input transform, 36 products, output transform in one launch) against an
+    fp64 convolution: forward plain / with bias + add + batch-norm sums / with ReLU, and the data gradient with the accumulated add
+    and with the backward sums of a batch norm (both mask forms). (3,12,20) and (2,56,56): maps that are no multiple of the
+    8 x 32-pixel block (tiles masked, halo zero-filled); (2,24,40,32,128): two reduction chunks, two channel blocks; (1,16,32,128,64):
+    eight chunks; (1,4,4,16,64): one tile, one chunk. F(4x4) in fp32: <= 2.5e-5 max-norm measured at the benchmark sizes, 8e-5 asserted
+    like the other F(4x4) passes (tests/test_conv_fullsize_gpu.py)."""
+    import torch.nn.functional as Fn
+    from denet_amd import ops
+    N, H, W, C, K = case
+    gen = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, H, W, C, generator=gen).cuda()
+    w = (torch.randn(K, 3, 3, C, generator=gen) * (2.0 / (9 * C)) ** 0.5).cuda()
+    bias = torch.randn(K, generator=gen).cuda()
+    addt = torch.randn(N, H, W, K, generator=gen).cuda()
+    g = ops.conv_geom(x.shape, w.shape, 1, 1, None)
+    assert ops.conv_wino4t_ok(0, g) and ops.conv_wino4t_ok(1, g) == (C % 64 == 0 and K % 16 == 0)
+    saved = (ops.AUTOTUNE, dict(ops._WINO), set(ops._TUNED))
+    BOUND = 8e-5
+    try:
+        ops._WINO.clear()
+        ops._WINO[(0, g)] = ops.FUSED4
+        xd, wd = x.double().permute(0, 3, 1, 2).contiguous().requires_grad_(True), w.double().permute(0, 3, 1, 2)
+        ref = Fn.conv2d(xd, wd, None, padding=1)
+        r = ref.detach().permute(0, 2, 3, 1)
+        s = float(r.abs().max())
+        y = ops.conv_fwd(x, w, stride=1, pad=1)
+        assert float((y.double() - r).abs().max()) / s <= BOUND
+        cache = {"train": True}
+        y2 = ops.conv_fwd(x, w, bias=bias, add=addt, stride=1, pad=1, cache=cache, bn_stats=True)
+        assert cache["fwd_tile"] == ops.FUSED4
+        r2 = r + bias.double() + addt.double()
+        assert float((y2.double() - r2).abs().max()) / float(r2.abs().max()) <= BOUND
+        buf, rows = cache["bn_stats"]
+        assert rows == N * ((H + 7) // 8) * ((W + 31) // 32)
+        part = buf[:rows * 2 * K].view(rows, 2, K).sum(0)
+        yy = y2.double().reshape(-1, K)                    # the sums are those of what was STORED
+        assert float((part[0] - yy.sum(0)).abs().max() / yy.abs().sum(0).max()) <= 1e-6
+        assert float((part[1] - (yy * yy).sum(0)).abs().max() / (yy * yy).sum(0).max()) <= 1e-6
+        y3 = ops.conv_fwd(x, w, bias=bias, stride=1, pad=1, relu=True)
+        assert float((y3.double() - (r + bias.double()).clamp_min(0)).abs().max()) / s <= BOUND
+        if ops.conv_wino4t_ok(1, g):
+            ops._WINO[(1, g)] = ops.FUSED4
+            dy = torch.randn(N, H, W, K, generator=gen).cuda()
+            acc0 = torch.randn(N, H, W, C, generator=gen).cuda()
+            rdx = torch.autograd.grad(ref, xd, dy.double().permute(0, 3, 1, 2))[0].permute(0, 2, 3, 1) + acc0.double()
+            cache = {"train": True}
+            dx = ops.conv_dgrad(dy, w, tuple(x.shape), add=acc0, stride=1, pad=1, cache=cache)
+            assert cache["dgrad_tile"] == ops.FUSED4
+            assert float((dx.double() - rdx).abs().max()) / float(rdx.abs().max()) <= BOUND
+            # the backward sums of the batch norm whose output gradient dx is: sum(g), sum(g * xhat), g = dx masked by the ReLU
+            xb = torch.randn(N, H, W, C, generator=gen).cuda()
+            gam, bet = (torch.rand(C, generator=gen) + 0.5).cuda(), torch.randn(C, generator=gen).cuda()
+            mu = xb.reshape(-1, C).mean(0)
+            isd = 1.0 / (xb.reshape(-1, C).var(0, unbiased=False) + 1e-5).sqrt()
+            yb = torch.relu((xb - mu) * isd * gam + bet)
+            for with_y in (True, False):
+                bsum = ops.BnSums(xb, yb if with_y else None, gam, bet, mu, isd, True)
+                dx2 = ops.conv_dgrad(dy, w, tuple(x.shape), add=acc0, stride=1, pad=1, cache={"train": True}, sums=bsum)
+                assert torch.equal(dx2, dx)
+                assert bsum.partial is not None, "the pass did not write the backward sums"
+                sb, srows = bsum.partial[:2]
+                s2 = sb[:srows * 2 * C].view(srows, 2, C).sum(0)
+                yv = torch.relu(torch.addcmul(bet - mu * (gam * isd), xb, gam * isd)) if not with_y else yb
+                gq = torch.where(yv > 0, dx, torch.zeros_like(dx)).double().reshape(-1, C)
+                xh = ((xb - mu) * isd).double().reshape(-1, C)
+                assert float((s2[0] - gq.sum(0)).abs().max() / gq.abs().sum(0).max()) <= 1e-6
+                assert float((s2[1] - (gq * xh).sum(0)).abs().max() / (gq * xh).abs().sum(0).max()) <= 1e-6
+    finally:
+        ops.AUTOTUNE = saved[0]
+        ops._WINO.clear()
+        ops._WINO.update(saved[1])
+
+
 @pytest.mark.parametrize("case", [(2, 24, 24, 1536, 1024), (1, 24, 24, 768, 512), (3, 8, 12, 512, 128)])
 def test_opt_in_bf16_split_head_gemms(hip, case):
     """OPT-IN ops.HEAD_BF16X3 (csrc/gemm3b.hip): the head's 1x1 convolutions as 3-term bf16-split GEMMs - forward, data gradient

@@ -593,6 +593,9 @@ def test_denet34_skip_512_timed_batch_vs_oracle(hip):
     fused = lambda g, T: _map(g) in (64, 32)
     seen = assert_kernels(ka.table, B, expect_w4f=fused, expect_w4g=lambda g, T: True)
     assert seen["wino4f"] == 20 and seen["wino4g"] == 25 and seen["wino2f"] == 6 and seen["stem"] == 1, seen
+    # the 64-channel stage at this geometry: forward pass and data gradient of all six layers on the tile-parallel fused F(4x4)
+    # kernel (algorithm 44 of the committed file; DENET_WINO4T=0 would put the fused F(2x2) kernels back)
+    assert seen["wino4t"] == (12 if ops.WINO4T == 3 else seen["wino4t"]), seen
     for r in ka.table:      # 32-tile blocks everywhere: two 4-wave workgroups per CU where that fills the chip (the 64x64 maps, and the
         # data gradient of up1, whose 512 output channels give 512 workgroups), one 8-wave workgroup else
         if _is_3x3s1(r["geometry"]) and _chan(r["geometry"])[0] >= 128 and _map(r["geometry"]) in (64, 32):
