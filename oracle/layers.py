@@ -23,12 +23,49 @@ F32 = np.float32
 # convolution: denet/layer/convolution.py:55-89. Theano conv2d = TRUE convolution (filters flipped),
 # border 'half' = pad k//2, 'valid' = 0, 'full' = k-1, int n = n; output = ceil((in + 2p - k + 1)/s).
 # ---------------------------------------------------------------------------------------------------------
+_SCRATCH = {}
+_SCRATCH_CAP = []
+
+
+def _scratch_cap():
+    """bytes the reused work arrays may hold together: a quarter of the machine's memory, at most 24 GB"""
+    if not _SCRATCH_CAP:
+        try:
+            import psutil
+            total = psutil.virtual_memory().total
+        except Exception:
+            total = 16 << 30
+        _SCRATCH_CAP.append(min(24 << 30, total // 4))
+    return _SCRATCH_CAP[0]
+
+
+def _scratch(tag, shape, dtype):
+    """a reused work array (tag, shape, dtype): the im2col matrices of a 512x512 batch are gigabytes, and a fresh allocation of
+    that size is page-faulted in on every call - most of the oracle's time at the benchmark sizes. Only for temporaries that do
+    not outlive the call that asks for them."""
+    key = (tag, tuple(shape), np.dtype(dtype).str)
+    buf = _SCRATCH.get(key)
+    if buf is None:
+        if sum(b.nbytes for b in _SCRATCH.values()) + int(np.prod(shape)) * np.dtype(dtype).itemsize > _scratch_cap():
+            _SCRATCH.clear()
+        buf = _SCRATCH[key] = np.empty(shape, dtype=dtype)
+    return buf
+
+
 def _im2col(x, R, S, stride, pad):
     N, C, H, W = x.shape
     OH = (H + 2 * pad - R) // stride + 1
     OW = (W + 2 * pad - S) // stride + 1
-    xp = np.pad(x, ((0, 0), (0, 0), (pad, pad), (pad, pad))) if pad > 0 else x
-    cols = np.empty((N, C, R, S, OH, OW), dtype=x.dtype)
+    if pad > 0:
+        xp = _scratch("pad", (N, C, H + 2 * pad, W + 2 * pad), x.dtype)
+        xp[:, :, :pad] = 0
+        xp[:, :, pad + H:] = 0
+        xp[:, :, :, :pad] = 0
+        xp[:, :, :, pad + W:] = 0
+        xp[:, :, pad:pad + H, pad:pad + W] = x
+    else:
+        xp = x
+    cols = _scratch("cols", (N, C, R, S, OH, OW), x.dtype)
     for r in range(R):
         for s in range(S):
             cols[:, :, r, s] = xp[:, :, r:r + stride * OH:stride, s:s + stride * OW:stride]
@@ -68,7 +105,7 @@ def conv2d_grad(x, w, dy, stride=1, pad=0, need_dx=True):
     dx = None
     if need_dx:
         wf = w[:, :, ::-1, ::-1].reshape(K, C * R * S)
-        dcols = np.matmul(wf.T[None], dy2)
+        dcols = np.matmul(wf.T[None], dy2, out=_scratch("dcols", (N, C * R * S, OH * OW), np.result_type(wf, dy2)))
         dx = _col2im(dcols, x.shape, R, S, stride, pad, OH, OW)
     return dx, np.ascontiguousarray(dw), db
 
