@@ -176,7 +176,7 @@ constexpr float T_AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1
 
 #ifndef T_EXP
 #define T_EXP 0       // experiment builds (tools/exp/w4t_variants.sh -DT_EXP=bits): 1 no input transform, 2 no products, 4 no epilogue,
-                      // 8 no LDS-DMA, 16 stores into a 1 MB window, 32 no filter fragment loads, 64 no V fragment reads - wrong results, the time that is left tells what each phase costs
+                      // 8 no LDS-DMA, 16 stores into a 1 MB window, 32 no filter fragment loads, 64 no V fragment reads, 128 every second filter fragment pair only - wrong results, the time that is left tells what each phase costs
 #endif
 
 // EP: 0 = store only, 1 = + batch-norm column sums of what is stored, 2 = + backward sums of the batch norm in front
@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256, 2) void wino4t_kernel(const W4TParams p) {
     const char* const v_rd = vbuf + g * 256 + r15 * 16;
     // the filter fragments come through a buffer descriptor: one lane offset, the (chunk, component) offset is scalar
     const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, p.u_bytes, 0x00020000);
-    const int u_voff = ((k0 + 16 * kw + r15) * 16 + 4 * g) * 4;
+    // (T_EXP 256: waves 2, 3 fetch the fragments of waves 0, 1 - the same L1 requests, half of them L2 hits... or L1 hits)
+    const int u_voff = ((k0 + 16 * ((T_EXP & 256) ? (kw & 1) : kw) + r15) * 16 + 4 * g) * 4;
     const int u_xi = p.K * 64;                       // bytes per component
     const int u_chunk = 36 * u_xi;                   // bytes per chunk
 
@@ -251,6 +252,11 @@ __global__ __launch_bounds__(256, 2) void wino4t_kernel(const W4TParams p) {
     }
     auto load_u = [&](int chunk, int pair) {
         if (T_EXP & 32) return;
+        if ((T_EXP & 128) && (pair & 1)) {          // half the filter traffic: odd pairs reuse the fragments of the pair before
+            fu[(2 * pair) % T_R] = fu[(2 * pair - 2) % T_R];
+            fu[(2 * pair + 1) % T_R] = fu[(2 * pair - 1) % T_R];
+            return;
+        }
         const int so = chunk * u_chunk + (2 * pair) * u_xi;
         fu[(2 * pair) % T_R] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, so, 0));
         fu[(2 * pair + 1) % T_R] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, so + u_xi, 0));

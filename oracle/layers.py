@@ -25,6 +25,26 @@ F32 = np.float32
 # ---------------------------------------------------------------------------------------------------------
 _SCRATCH = {}
 _SCRATCH_CAP = []
+_POOL = []
+
+
+def _par(n, fn, min_bytes=0, nbytes=0):
+    """fn(lo, hi) over the images [0, n) in contiguous chunks on a thread pool (numpy releases the GIL inside array operations).
+    Every chunk computes exactly what the serial expression computes for its images - element-wise work and per-image copies
+    only, never a reduction across images: the results are bit-identical to the serial ones. At the benchmark sizes the oracle
+    spent most of its time in single-threaded element-wise passes over gigabyte tensors (tools/exp/oracle_profile.py)."""
+    import os
+    if n < 2 or nbytes < (8 << 20):
+        fn(0, n)
+        return
+    if not _POOL:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL.append(ThreadPoolExecutor(max_workers=max(1, min(16, (os.cpu_count() or 2) // 2))))
+    workers = _POOL[0]._max_workers
+    step = max(1, -(-n // workers))
+    futs = [_POOL[0].submit(fn, lo, min(n, lo + step)) for lo in range(0, n, step)]
+    for f in futs:
+        f.result()
 
 
 def _scratch_cap():
@@ -66,9 +86,16 @@ def _im2col(x, R, S, stride, pad):
     else:
         xp = x
     cols = _scratch("cols", (N, C, R, S, OH, OW), x.dtype)
-    for r in range(R):
-        for s in range(S):
-            cols[:, :, r, s] = xp[:, :, r:r + stride * OH:stride, s:s + stride * OW:stride]
+
+    c2 = cols.reshape(N * C, R, S, OH, OW)             # (a view: the work array is contiguous)
+    x2 = xp.reshape(N * C, xp.shape[2], xp.shape[3])   # images x channels as ONE axis: a single image still spreads over the pool
+
+    def fill(lo, hi):
+        for r in range(R):
+            for s in range(S):
+                c2[lo:hi, r, s] = x2[lo:hi, r:r + stride * OH:stride, s:s + stride * OW:stride]
+
+    _par(N * C, fill, nbytes=cols.nbytes)
     return cols.reshape(N, C * R * S, OH * OW), OH, OW
 
 
@@ -76,9 +103,16 @@ def _col2im(cols, x_shape, R, S, stride, pad, OH, OW):
     N, C, H, W = x_shape
     xp = np.zeros((N, C, H + 2 * pad, W + 2 * pad), dtype=cols.dtype)
     cols = cols.reshape(N, C, R, S, OH, OW)
-    for r in range(R):
-        for s in range(S):
-            xp[:, :, r:r + stride * OH:stride, s:s + stride * OW:stride] += cols[:, :, r, s]
+
+    c2 = cols.reshape(N * C, R, S, OH, OW)
+    x2 = xp.reshape(N * C, H + 2 * pad, W + 2 * pad)
+
+    def fold(lo, hi):
+        for r in range(R):
+            for s in range(S):
+                x2[lo:hi, r:r + stride * OH:stride, s:s + stride * OW:stride] += c2[lo:hi, r, s]
+
+    _par(N * C, fold, nbytes=cols.nbytes)
     return xp[:, :, pad:pad + H, pad:pad + W] if pad > 0 else xp
 
 
@@ -232,8 +266,18 @@ def bn_train(x, gamma, beta, eps=1e-5):
     mean = xd.mean(axis=(0, 2, 3))
     var = xd.var(axis=(0, 2, 3))
     invstd = 1.0 / np.sqrt(var + eps)
-    y = (xd - mean[None, :, None, None]) * invstd[None, :, None, None] * gamma[None, :, None, None] + beta[None, :, None, None]
-    return y.astype(F32), mean.astype(F32), invstd.astype(F32)
+    y = np.empty(x.shape, dtype=F32)
+
+    N, C = x.shape[0], x.shape[1]
+    rows = lambda v: np.tile(np.asarray(v), N)[:, None, None]           # per-channel values along the merged (image, channel) axis
+    x2, y2 = xd.reshape(N * C, x.shape[2], x.shape[3]), y.reshape(N * C, x.shape[2], x.shape[3])
+    m2, i2, g2, b2 = rows(mean), rows(invstd), rows(gamma), rows(beta)
+
+    def norm(lo, hi):
+        y2[lo:hi] = ((x2[lo:hi] - m2[lo:hi]) * i2[lo:hi] * g2[lo:hi] + b2[lo:hi]).astype(F32)
+
+    _par(N * C, norm, nbytes=xd.nbytes)
+    return y, mean.astype(F32), invstd.astype(F32)
 
 
 def bn_running_update(run_mean, run_stdinv, mean, invstd, momentum=0.9):
@@ -255,20 +299,56 @@ def bn_grad(x, dy, gamma, mean, invstd):
     """cuDNN BN backward with saved mean / invstd: returns dx, dgamma, dbeta"""
     xd, dyd = x.astype(np.float64), dy.astype(np.float64)
     m = x.shape[0] * x.shape[2] * x.shape[3]
-    xh = (xd - mean[None, :, None, None]) * invstd[None, :, None, None]
+    N, C, H, W = x.shape
+    rows = lambda v: np.tile(np.asarray(v), N)[:, None, None]           # per-channel values along the merged (image, channel) axis
+    xh = np.empty(xd.shape, dtype=np.float64)
+    prod = np.empty(xd.shape, dtype=np.float64)
+    x2, d2, h2, p2 = xd.reshape(N * C, H, W), dyd.reshape(N * C, H, W), xh.reshape(N * C, H, W), prod.reshape(N * C, H, W)
+    m2, i2 = rows(mean), rows(invstd)
+
+    def hat(lo, hi):
+        h2[lo:hi] = (x2[lo:hi] - m2[lo:hi]) * i2[lo:hi]
+        p2[lo:hi] = d2[lo:hi] * h2[lo:hi]
+
+    _par(N * C, hat, nbytes=xd.nbytes)
     dbeta = dyd.sum(axis=(0, 2, 3))
-    dgamma = (dyd * xh).sum(axis=(0, 2, 3))
-    dx = (gamma * invstd)[None, :, None, None] * (dyd - dbeta[None, :, None, None] / m - xh * dgamma[None, :, None, None] / m)
-    return dx.astype(F32), dgamma.astype(F32), dbeta.astype(F32)
+    dgamma = prod.sum(axis=(0, 2, 3))
+    dx = np.empty(x.shape, dtype=F32)
+    o2 = dx.reshape(N * C, H, W)
+    gi2, db2, dg2 = rows(gamma * invstd), rows(dbeta), rows(dgamma)
+
+    def grad(lo, hi):
+        o2[lo:hi] = (gi2[lo:hi] * (d2[lo:hi] - db2[lo:hi] / m - h2[lo:hi] * dg2[lo:hi] / m)).astype(F32)
+
+    _par(N * C, grad, nbytes=xd.nbytes)
+    return dx, dgamma.astype(F32), dbeta.astype(F32)
 
 
 def relu(x):
     """tensor.nnet.relu == 0.5*(x+|x|) (denet/layer/activation.py:31-34; batch_norm_relu.py:34-39)"""
-    return ((x + np.abs(x)) / F32(2)).astype(x.dtype)
+    if not x.flags.c_contiguous:
+        return ((x + np.abs(x)) / F32(2)).astype(x.dtype)
+    y = np.empty(x.shape, dtype=x.dtype)
+    xf, yf = x.reshape(-1), y.reshape(-1)
+
+    def act(lo, hi):
+        yf[lo:hi] = ((xf[lo:hi] + np.abs(xf[lo:hi])) / F32(2)).astype(x.dtype)
+
+    _par(xf.size, act, nbytes=x.nbytes)
+    return y
 
 
 def relu_grad(y, dy):
-    return np.where(y > 0, dy, 0).astype(dy.dtype)
+    if not (dy.flags.c_contiguous and y.flags.c_contiguous and y.shape == dy.shape):
+        return np.where(y > 0, dy, 0).astype(dy.dtype)
+    out = np.empty(dy.shape, dtype=dy.dtype)
+    yf, df, of = y.reshape(-1), dy.reshape(-1), out.reshape(-1)
+
+    def mask(lo, hi):
+        of[lo:hi] = np.where(yf[lo:hi] > 0, df[lo:hi], 0).astype(dy.dtype)
+
+    _par(df.size, mask, nbytes=dy.nbytes)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------
