@@ -69,6 +69,7 @@ struct W4TParams {
     int chunks;          // C / 16
     int relu;
     unsigned x_bytes, y_bytes, u_bytes;
+    unsigned long long* dbg;   // -DT_TRACE builds: s_memtime stamps of one workgroup per 64 (tools/exp/w4t_trace.py)
 };
 
 constexpr int T_OOB = (int)0xF0000000u;
@@ -174,6 +175,11 @@ __device__ __forceinline__ double t_row_ror(double v) {
 
 constexpr float T_AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
 
+#ifdef T_TRACE
+#define T_STAMP() if (p.dbg && (blockIdx.x & 63) == 0 && tid == 0 && dbg_n < 32) p.dbg[(blockIdx.x >> 6) * 32 + dbg_n++] = __builtin_amdgcn_s_memtime()
+#else
+#define T_STAMP()
+#endif
 #ifndef T_EXP
 #define T_EXP 0       // experiment builds (tools/exp/w4t_variants.sh -DT_EXP=bits): 1 no input transform, 2 no products, 4 no epilogue,
                       // 8 no LDS-DMA, 16 stores into a 1 MB window, 32 no filter fragment loads, 64 no V fragment reads, 128 every second filter fragment pair only - wrong results, the time that is left tells what each phase costs
@@ -278,6 +284,9 @@ __global__ __launch_bounds__(256, 2) void wino4t_kernel(const W4TParams p) {
         }
     }
 #endif
+    int dbg_n = 0;
+    (void)dbg_n;
+    T_STAMP();
     issue();
     if (!(T_EXP & 2)) {
 #pragma unroll
@@ -289,14 +298,18 @@ __global__ __launch_bounds__(256, 2) void wino4t_kernel(const W4TParams p) {
         // chunk that is implied: fragment loads issued behind the pieces have been consumed). Every wave is done with the
         // products of chunk s - 1: V is free
         T_WAIT_VM(2 * T_D);
+        T_STAMP();
         T_BARRIER();
+        T_STAMP();
         if (!(T_EXP & 1)) {
             const char* prd = smem + t_rd;
             if (t_lh == 0) t_transform<0>(prd, t_wr);
             else t_transform<1>(prd, t_wr);
         }
         T_WAITCNT(63);                // lgkmcnt(0): this wave's V rows are written (vmcnt left alone)
+        T_STAMP();
         T_BARRIER();                  // V is complete, the patch buffer is free
+        T_STAMP();
         if (!(T_EXP & 2)) {
             const int sn = s + 1 < p.chunks ? s + 1 : s;      // (the last chunk's look-ahead loads re-read its own fragments)
             read_v(0);
@@ -340,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void wino4t_kernel(const W4TParams p) {
         }
     }
     // (no piece is in flight: the last chunk issued none; the look-ahead loads behind its last pairs are never consumed)
+    T_STAMP();
     if (T_EXP & 4) {
 #pragma unroll
         for (int i = 0; i < 36; ++i) asm volatile("" ::"v"(acc[i]));
@@ -388,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void wino4t_kernel(const W4TParams p) {
             }
     }
 
+    T_STAMP();
     // ---- epilogue (wino4f.hip's): lane = (tile r15 of the block, channels k0 + 16 kw + 4 g .. + 3) ----
     const int oy = y0 + 4 * (r15 >> 3), ox = x0 + 4 * (r15 & 7);
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -463,6 +478,7 @@ __global__ __launch_bounds__(256, 2) void wino4t_kernel(const W4TParams p) {
             }
         }
     }
+    T_STAMP();
     if (EP == 0) return;
     // over the 16 tiles of the wave = the 16 lanes of a DPP row (row_ror 8, 4, 2, 1: every lane ends with the row's sum; the
     // additions pair the same lanes as xor-shuffles would): the wave owns its 16 channels' column sums
@@ -481,6 +497,7 @@ __global__ __launch_bounds__(256, 2) void wino4t_kernel(const W4TParams p) {
             row[p.K + kc + c] = ds[4 + c];
         }
     }
+    T_STAMP();
 }
 
 // U [36][K][C] (denet_conv_wino_filter, tile 4; K = output channels of the pass, C = its reduction) -> [C/16][36][K][16]
@@ -497,7 +514,13 @@ __global__ __launch_bounds__(256) void wino4t_pack_kernel(const float* __restric
     *(f32x4*)(P + idx * 4) = *(const f32x4*)(U + ((long)xi * K + k) * C + chunk * 16 + q * 4);
 }
 
+unsigned long long* g_w4t_dbg = nullptr;
+
 }  // namespace
+
+#ifdef T_TRACE
+extern "C" int denet_conv_wino4t_debug(unsigned long long* buf) { g_w4t_dbg = buf; return 0; }       // tools/exp/w4t_trace.py
+#endif
 
 // geometry the kernel covers: 3x3 stride 1 pad 1 (the caller's business), H and W multiples of 4, C a multiple of 16, K of 64
 extern "C" int denet_conv_wino4t_ok(int N, int H, int W, int C, int K) {
@@ -533,6 +556,7 @@ extern "C" int denet_conv_wino4t_sums(const float* x, const float* u_packed, con
     p.x_bytes = (unsigned)((size_t)N * H * W * C * 4);
     p.y_bytes = (unsigned)((size_t)N * H * W * K * 4);
     p.u_bytes = (unsigned)((size_t)36 * K * C * 4);
+    p.dbg = g_w4t_dbg;
     const long blocks = (long)N * p.bh * p.bw;
     int ep = 0;
     if (stats_partial) {

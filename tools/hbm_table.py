@@ -4,7 +4,7 @@ usage: python tools/hbm_table.py profiles/r04_c > profiles/r04_c_hbm_kernels.md"
 import json, re, sys
 tag = sys.argv[1]
 PEAK = 8000.0   # GB/s, /opt/skills/guides/MI355X_MICROARCH.md
-MATRIX = ("igemm_kernel", "wino4f_kernel", "wino4g_kernel", "wino2f_ws_kernel", "wino2f_wgrad_kernel", "stem_fwd_kernel",
+MATRIX = ("igemm_kernel", "wino4f_kernel", "wino4t_kernel", "wino4g_kernel", "wino2f_ws_kernel", "wino2f_wgrad_kernel", "stem_fwd_kernel",
           "stem_wgrad_kernel", "gemm3b")
 rows, leg = {}, False
 for line in open(tag + "_kernel_stats.md"):

@@ -7,7 +7,7 @@
 TAG=${1:-r02}
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
-CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-warm --no-split-bf16 --no-configs --no-dp-selftest --no-h2d --no-instep --no-audit"
+CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-warm --no-split-bf16 --no-configs --no-dp-selftest --no-h2d --no-instep --no-audit --no-inference"
 O=gpurun_out/${TAG}_prof
 rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace -d $O/kt -o kt -- $CMD > $O/kt.log 2>&1
