@@ -7,6 +7,7 @@ host layer (denet_amd) and compares with the CPU restatement on the same seeded 
     activations / costs / updated parameters within 1e-3 relative, RoI lists bit-identical
   * full-size (B=32, 512x512) size-independent properties: determinism, sortedness, idempotence, gather checksum
 """
+import os
 import random
 
 import numpy as np
@@ -49,6 +50,16 @@ def rel_close(a, b, rtol=1e-3, what="", atol=0.0, rtol_elem=None):
     rtol_elem = rtol if rtol_elem is None else rtol_elem
     assert q <= rtol_elem, "%s: element-wise p99.99 of |a-b| / (|b| + rms) = %.3e > %.1e (max-norm rel %.2e, rms %.3e)" % (
         what, q, rtol_elem, err / scale, rms)
+
+
+def _err_stats(a, b):
+    """(element-wise p99.99 of |a - b| / (|b| + rms(b)), max|a - b| / max|b|): the two figures rel_close asserts on"""
+    b = np.asarray(b, np.float64)
+    d = np.abs(np.asarray(a, np.float64) - b)
+    rms = float(np.sqrt(np.mean(b * b)))
+    stat = (d / (np.abs(b) + rms + 1e-30)).reshape(-1)
+    q = float(np.quantile(stat, 0.9999)) if stat.size >= 10000 else float(stat.max())
+    return q, float(d.max() / (np.abs(b).max() + 1e-12))
 
 
 def _rel_close_large(a, b, rtol, what, atol, rtol_elem):
@@ -1600,14 +1611,17 @@ def test_roi_clustering_device_path_vs_oracle(hip, sn_model):
 def test_denet101_wide_train_step_vs_oracle(hip, IMG):
     """BASELINE config 5 at reduced size: ResNet-101 bottleneck backbone, three skip scales (one through a plain
     SKIPSRC), SPLIT points, 48x48 = 2304 RoIs per image, joint-fitness + bounded-IoU head (papers/dss/denet101.sh).
-    IMG = 512 (the recipe's resolution, 128x128 corner map, 16x16 last-stage maps): FREE-RUNNING forward as well - every layer's
-    activation, the corner map and both costs against the oracle's own forward pass. What a free run of 101 layers at B = 1 can
-    show was measured layer by layer (tools/exp/d101_free.py, MI355X): the element-wise p99.99 grows by ~4 % per residual block -
-    3e-6 behind the stem, 3.3e-4 at layer 24, 9.6e-4 at layer 37, 3.5e-3 behind the last stage (batch statistics over 256 values),
-    4.2e-3 at the head's last layer; max-norm 1.0e-3 there - and it grows the SAME way with the direct fp32 kernels only
-    (DENET_WINOGRAD=0: 8.4e-4 / 3.1e-3 at layers 37 / 40): it is the distance between two fp32 evaluations of this depth (the
-    oracle's BLAS sums in another order), not a property of the Winograd passes. Asserted: costs 1e-3, every activation 2e-3
-    max-norm and 6e-3 element-wise, the first 24 layers at the north star's 1e-3 in both clauses; the op-by-op pass behind it
+    IMG = 512 (the recipe's resolution, 128x128 corner map, 16x16 last-stage maps): FREE-RUNNING forward as well, judged by an
+    fp64 ARBITER (round-5 verdict item 4): the same restatement evaluated in float64 (oracle/model.py: float64_arbiter) is the
+    reference, and the product (fp32 HIP kernels) and the fp32 oracle are both measured against it, layer by layer, in both
+    rel_close clauses. Measured on MI355X (tools/exp/d101_arbiter.py, 2026-09-30): the product's distance to fp64 is 1.07-1.37x the
+    fp32 oracle's at EVERY layer - 6.6e-7 vs 6.2e-7 behind the stem, 3.3e-4 vs 2.6e-4 (element-wise p99.99) at layer 24, 8.5e-4 vs
+    6.7e-4 at layer 37, 3.0e-3 vs 2.4e-3 behind the last stage (batch statistics over 256 values at B = 1), 3.7e-3 vs 2.9e-3 at
+    the head's last layer; max-norm 1.0e-3 vs 7.6e-4 there. Neither fp32 evaluation of a 101-layer network stays element-wise
+    within 1e-3 of the fp64 value beyond layer 37: that is fp32, not a kernel. Asserted, with no allowance of its own: costs 1e-3
+    against fp64; layers up to 37 and the corner map: the north star's 1e-3 in both clauses against fp64; every layer, both
+    clauses: the product no farther from fp64 than max(1e-3, 1.5 x the fp32 oracle's distance); max-norm <= 1.5e-3 everywhere.
+    The op-by-op pass behind it
     (every op on the product's own inputs) holds 2e-4 per op."""
     B = 1           # IMG = 512: the resolution of papers/dss/denet101.sh:19 (BASELINE config 5), 128x128 corner map
     model = zoo.denet101(B, "wide", IMG, class_num=80, seed=1,
@@ -1620,8 +1634,9 @@ def test_denet101_wide_train_step_vs_oracle(hip, IMG):
     dconv.omega.set_value(rng.normal(0, 0.05, dconv.omega.value.shape))
     _warm_corner_head(model, 4.0, 0.3)
     x, metas = zoo.synthetic_batch(B, IMG, seed=3)
-    om = OM.OracleModel(model.export_json(), B)
-    om_free = OM.OracleModel(model.export_json(), B) if IMG == 512 else None      # (the weights BEFORE the step)
+    json_before = model.export_json()                                             # (the weights BEFORE the step)
+    om = OM.OracleModel(json_before, B)
+    om_free = OM.OracleModel(json_before, B) if IMG == 512 else None
     model.build_train_func("nesterov")
     random.seed(9)
     cost, costs = model.train_step(x, metas, 0, 0, 0.05, [0.9], 1e-4)
@@ -1629,19 +1644,37 @@ def test_denet101_wide_train_step_vs_oracle(hip, IMG):
     assert len(roi_lists[0]) == 2304
     if IMG == 512:
         random.seed(9)
-        fcost, fcosts = om_free.train_step(x, metas, 0, 0.05, 0.9, 1e-4, "nesterov", sample_override=roi_lists)
-        assert abs(cost - fcost) <= 1e-3 * abs(fcost), (cost, fcost)
-        for c, oc in zip(costs, fcosts):
-            assert abs(c - oc) <= 1e-3 * max(abs(oc), 1e-6), (costs, fcosts)
-        ELEMENTWISE.clear()
-        for i, a in _product_acts(model).items():
-            deep = i > 24
-            rel_close(a, om_free.acts[i], 2e-3 if deep else 1e-3, "activation L%d %s" % (i, model.layers[i].type_name),
-                      rtol_elem=6e-3 if deep else 1e-3)
-        rel_close(by_type("denet-corner").corner_pr.cpu().numpy(), om_free.corner_pr, 2e-3, "corner_pr", rtol_elem=6e-3)
-        print("DeNet-101 wide 512x512 free-running: element-wise p99.99 / max-norm:",
-              {k: ("%.2e" % v[1], "%.2e" % v[0]) for k, v in ELEMENTWISE.items()})
-        del om_free
+        fcost, fcosts = om_free.forward_costs(x, metas, sample_override=roi_lists)          # the fp32 oracle, forward only
+        with OM.float64_arbiter():
+            om64 = OM.OracleModel(json_before, B)
+            random.seed(9)
+            acost, acosts = om64.forward_costs(x, metas, sample_override=roi_lists)         # the arbiter
+        assert np.array_equal(om_free.taps[0], om64.taps[0]) and np.array_equal(om_free.taps[1], om64.taps[1])
+        assert abs(cost - acost) <= 1e-3 * abs(acost), (cost, acost)
+        for c, oc in zip(costs, acosts):
+            assert abs(c - oc) <= 1e-3 * max(abs(oc), 1e-6), (costs, acosts)
+        table = {}
+        acts = _product_acts(model)
+        acts["corner_pr"] = by_type("denet-corner").corner_pr.cpu().numpy()
+        for i, a in acts.items():
+            ref64 = om64.corner_pr if i == "corner_pr" else om64.acts[i]
+            ref32 = om_free.corner_pr if i == "corner_pr" else om_free.acts[i]
+            p, o = _err_stats(a, ref64), _err_stats(ref32, ref64)
+            what = "corner_pr" if i == "corner_pr" else "L%d %s" % (i, model.layers[i].type_name)
+            table[what] = {"product_vs_fp64": p, "oracle32_vs_fp64": o}
+            for clause, pv, ov in (("element-wise p99.99", p[0], o[0]), ("max-norm", p[1], o[1])):
+                assert pv <= max(1e-3, 1.5 * ov), "%s %s: product %.2e from fp64, the fp32 oracle %.2e" % (what, clause, pv, ov)
+            assert p[1] <= 1.5e-3, (what, p)
+            if i == "corner_pr" or i <= 37:
+                assert p[0] <= 1e-3 and p[1] <= 1e-3, "%s: %.2e / %.2e against fp64 (north star: 1e-3)" % (what, p[0], p[1])
+        worst = max(table.items(), key=lambda kv: kv[1]["product_vs_fp64"][0])
+        print("DeNet-101 wide 512x512 free-running vs the fp64 arbiter, worst layer:", worst)
+        out = os.environ.get("D101_ARBITER_REPORT_PATH")
+        if out:
+            import json
+            with open(out, "w") as f:
+                json.dump({"test": "test_denet101_wide_train_step_vs_oracle[512]", "columns": "element-wise p99.99, max-norm", "layers": table}, f, indent=1)
+        del om_free, om64
     ocost, ocosts = _forced_step_check(model, om, x, metas, 0, 0.05, 0.9, 1e-4, "nesterov", roi_lists)
     assert abs(cost - ocost) <= 1e-4 * abs(ocost), (cost, ocost)
     ys, xs = om.taps
