@@ -173,6 +173,10 @@ def _inference_batch(B, steps, res):
         ent = {}
         if B == 1:
             ent["oracle_check"] = _inference_check(model, dnd, dns, dnc, x, r, params)
+            # the checker kept the host busy and the device idle for a second or two (power state, BLAS threads winding down):
+            # a few untimed calls before the clock starts (without them the first leg read 6.5 ms per call against 2.4 alone)
+            for _ in range(10):
+                dnd.get_detections(model, xd, metas, params)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -227,7 +231,9 @@ def _inference_check(model, dnd, dns, dnc, x, results, params):
     o_det, o_fit, o_box = OL.detect_outputs(om.detect_out.v, om.sample_bbox, C, bool(dnd.use_jointfit), t0)
     n = int(counts[0])
     d = det_pr.cpu().numpy().reshape(1, sn, sn, C + 1).transpose(0, 3, 1, 2).reshape(C + 1, -1)[:, :n]
-    derr = float(numpy.abs(d - o_det.reshape(C + 1, -1)[:, :n]).max()) if n else 0.0
+    # (the tolerance of tests/test_inference_gpu.py: |product - oracle| <= 1e-3 + 1e-3 |oracle| on the class log-probabilities)
+    o_d = o_det.reshape(C + 1, -1)[:, :n]
+    derr = float((numpy.abs(d - o_d) / (1e-3 + 1e-3 * numpy.abs(o_d))).max()) if n else 0.0
     # threshold + NMS: exact on the product's decoded arrays (oracle/build_samples.cc restates denet_detect.cc:99-173)
     S, C1 = sn * sn, C + 1
     det = numpy.ascontiguousarray(det_pr.cpu().numpy().reshape(1, sn, sn, C1).transpose(0, 3, 1, 2), dtype=numpy.float32)
@@ -247,10 +253,11 @@ def _inference_check(model, dnd, dns, dnc, x, results, params):
     for (pr, cls, box), rr in zip(dets, ref):
         if cls != int(rr[1]) or not numpy.array_equal(numpy.array(box, numpy.float32), rr[2:]) or abs(pr - rr[0]) > 2e-6 * rr[0]:
             raise AssertionError("inference check: a detection differs from the oracle's NMS on the same decoded arrays")
-    if cerr > 1e-3 or derr > 2e-3:
-        raise AssertionError("inference check: corner map %.2e / class log-probabilities %.2e off the oracle's test-mode forward" % (cerr, derr))
+    if cerr > 1e-3 or derr > 1.0:
+        raise AssertionError("inference check: corner map %.2e (bound 1e-3) / class log-probabilities %.2f of their tolerance off the "
+                             "oracle's test-mode forward" % (cerr, derr))
     return {"rois": n, "detections": len(dets), "roi_lists_equal_oracle_proposal": True, "nms_equal_oracle": True,
-            "corner_map_max_rel_err_vs_oracle": float("%.2e" % cerr), "class_logprob_max_abs_err_vs_oracle": float("%.2e" % derr)}
+            "corner_map_max_rel_err_vs_oracle": float("%.2e" % cerr), "class_logprob_max_err_in_units_of_tolerance_1e-3_abs_plus_1e-3_rel": float("%.3f" % derr)}
 
 
 def self_launch(n):

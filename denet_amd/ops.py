@@ -618,6 +618,13 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
     # the implementation is fixed on the first call; the timed candidates scribble over `y`, so the call always ends
     # with a launch of the chosen one (run-to-run determinism)
     tile = _wino_tile(0, g, direct, lambda t: conv_wino_fwd(x, w, bias, add, out=y, tile=t, relu=relu))
+    # INFERENCE (no filter gradient will want the transformed input of this pass, the batch norms are folded into plain tensors):
+    # the tuned file may name another algorithm for the forward pass alone - mode 3 entries (the tile-parallel fused F(4x4) kernel
+    # on the many-channel layers, where training keeps the component-walk kernel because its V feeds the filter gradient)
+    if cache is not None and not cache.get("train") and (3, g) in _WINO and _tile_allowed(0, _WINO[(3, g)]):
+        t3 = _WINO[(3, g)]
+        if (t3 == FUSED4 and conv_wino4t_ok(0, g)) or (t3 in (2, 4) and conv_wino_ok(g, t3)) or t3 == 0:
+            tile = t3
     if tile:
         if PROFILE is not None:
             PROFILE.add(_conv_flops(g, logical) / _WINO_GAIN[tile])     # the FLOPs its batched GEMM really executes
@@ -629,7 +636,8 @@ def conv_fwd(x, w, bias=None, add=None, stride=1, pad=0, s_real=None, out=None, 
                 # inference: the filters do not change between calls - transform them once per weights version
                 ent = cache.get("u_test")
                 if ent is None or ent[0] != tile or ent[2] != WEIGHTS_VERSION or ent[3] != w.data_ptr():
-                    ent = cache["u_test"] = (tile, conv_wino_filter(w, _filter_tile(tile), dgrad=False), WEIGHTS_VERSION, w.data_ptr())
+                    uf = conv_wino4t_filter(w, dgrad=False) if tile == FUSED4 else conv_wino_filter(w, _filter_tile(tile), dgrad=False)
+                    ent = cache["u_test"] = (tile, uf, WEIGHTS_VERSION, w.data_ptr())
                 u = ent[1]
             # the filter gradient of this layer uses the same transformed input when it runs with the same tile
             if cache.get("train") and _decided(2, g) == tile:
@@ -702,7 +710,7 @@ def _tile_allowed(mode, tile):
     if tile == FUSED2:
         return WINOGRAD >= 2 and mode in (0, 1, 2) and bool((WINO2F >> mode) & 1)
     if tile == FUSED4:
-        return WINOGRAD >= 4 and mode in (0, 1) and bool((WINO4T >> mode) & 1)
+        return WINOGRAD >= 4 and mode in (0, 1, 3) and bool((WINO4T >> (mode & 1)) & 1)       # (mode 3: the inference forward pass)
     return tile <= WINOGRAD
 
 

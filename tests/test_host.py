@@ -296,7 +296,7 @@ def test_committed_launch_configurations_are_consistent():
     seen = set()
     n_fused = 0
     for mode, g, tile in d["winograd"]:
-        assert mode in (0, 1, 2) and len(g) == 12 and tile in (0, 2, 4, 22, 44)
+        assert mode in (0, 1, 2, 3) and len(g) == 12 and tile in (0, 2, 4, 22, 44)       # mode 3: the inference forward pass
         assert (mode, tuple(g)) not in seen
         seen.add((mode, tuple(g)))
         N, H, W, C, K, R, S, s_real, stride, pad, OH, OW = g
@@ -308,14 +308,15 @@ def test_committed_launch_configurations_are_consistent():
             assert ops.conv_wino_ok(tuple(g), tile)
         if tile == 22:                                  # csrc/wino2f.hip: denet_conv_wino2f_ok / _wgrad_ok
             n_fused += 1
+            assert mode != 3
             ci, co = (C, K) if mode == 0 else (K, C)
             assert H % 2 == 0 and W % 2 == 0 and ci == 64 and co % 64 == 0
             if mode == 2:
                 assert C == 64 and K == 64
         if tile == 44:                                  # csrc/wino4t.hip: denet_conv_wino4t_ok (forward / data gradient only)
             n_fused += 1
-            red, out = (C, K) if mode == 0 else (K, C)
-            assert mode in (0, 1) and H % 4 == 0 and W % 4 == 0 and red % 16 == 0 and out % 64 == 0
+            red, out = (K, C) if mode == 1 else (C, K)
+            assert mode in (0, 1, 3) and H % 4 == 0 and W % 4 == 0 and red % 16 == 0 and out % 64 == 0
     assert n_fused >= 3                                 # the 64-channel stage of the benchmark configuration, all three passes
 
 

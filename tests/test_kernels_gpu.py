@@ -243,13 +243,13 @@ def test_fused_winograd_f2_kernel(hip, case):
 
 
 @pytest.mark.parametrize("case", [(1, 8, 32, 64, 64), (2, 16, 64, 64, 64), (3, 12, 20, 64, 64), (2, 24, 40, 32, 128), (1, 16, 32, 128, 64),
-                                  (5, 64, 64, 64, 64), (2, 56, 56, 64, 64), (1, 4, 4, 16, 64)])
+                                  (5, 64, 64, 64, 64), (2, 56, 56, 64, 64), (1, 4, 4, 32, 64)])
 def test_fused_winograd_f4_tile_parallel_kernel(hip, case):
     """csrc/wino4t.hip through ops (algorithm ops.FUSED4: input transform, 36 products, output transform in one launch) against an
     fp64 convolution: forward plain / with bias + add + batch-norm sums / with ReLU, and the data gradient with the accumulated add
     and with the backward sums of a batch norm (both mask forms). (3,12,20) and (2,56,56): maps that are no multiple of the
     8 x 32-pixel block (tiles masked, halo zero-filled); (2,24,40,32,128): two reduction chunks, two channel blocks; (1,16,32,128,64):
-    eight chunks; (1,4,4,16,64): one tile, one chunk. F(4x4) in fp32: <= 2.5e-5 max-norm measured at the benchmark sizes, 8e-5 asserted
+    eight chunks; (1,4,4,32,64): one tile. F(4x4) in fp32: <= 2.5e-5 max-norm measured at the benchmark sizes, 8e-5 asserted
     like the other F(4x4) passes (tests/test_conv_fullsize_gpu.py)."""
     import torch.nn.functional as Fn
     from denet_amd import ops
@@ -285,6 +285,22 @@ def test_fused_winograd_f4_tile_parallel_kernel(hip, case):
         assert float((part[1] - (yy * yy).sum(0)).abs().max() / (yy * yy).sum(0).max()) <= 1e-6
         y3 = ops.conv_fwd(x, w, bias=bias, stride=1, pad=1, relu=True)
         assert float((y3.double() - (r + bias.double()).clamp_min(0)).abs().max()) / s <= BOUND
+        # the inference form: a layer cache without "train" keeps the packed filters per weights version (twice: the cached ones)
+        icache = {}
+        for _ in range(2):
+            y4 = ops.conv_fwd(x, w, bias=bias, stride=1, pad=1, relu=True, cache=icache)
+            assert torch.equal(y4, y3) and icache["fwd_tile"] == ops.FUSED4
+        # ... and a mode-3 entry of the tuned file overrides the training decision for the inference forward pass only
+        ops._WINO[(0, g)] = 0
+        ops._WINO[(3, g)] = ops.FUSED4
+        icache = {}
+        y5 = ops.conv_fwd(x, w, bias=bias, stride=1, pad=1, relu=True, cache=icache)
+        assert torch.equal(y5, y3) and icache["fwd_tile"] == ops.FUSED4
+        tcache = {"train": True}
+        ops.conv_fwd(x, w, bias=bias, stride=1, pad=1, relu=True, cache=tcache)
+        assert tcache["fwd_tile"] == 0
+        ops._WINO[(0, g)] = ops.FUSED4
+        del ops._WINO[(3, g)]
         if ops.conv_wino4t_ok(1, g):
             ops._WINO[(1, g)] = ops.FUSED4
             dy = torch.randn(N, H, W, K, generator=gen).cuda()
