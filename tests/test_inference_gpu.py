@@ -288,6 +288,60 @@ def test_inference_bn_folding_matches_unfolded(hip):
     assert float(np.abs(outs[0][0]).max()) > 0
 
 
+def test_inference_forward_at_the_batch_of_the_tuned_file(hip):
+    """B = 32, 512x512 - the geometry at which the committed tuned file decides the algorithms, including its MODE 3 entries (the
+    inference forward pass alone: the tile-parallel fused F(4x4) kernel, csrc/wino4t.hip, on the 128 / 256-channel layers, where
+    training keeps the component-walk kernel) and algorithm 44 on the 64-channel stage. The test-mode forward with those decisions
+    against the same forward with the tile-parallel kernel switched off (DENET_WINO4T = 0: fused F(2x2) / component-walk F(4x4)
+    kernels): corner map and class logits agree to 2e-4 of their scale, the per-layer audit shows the kernels really differ."""
+    from denet_amd import ops
+    from denet_amd.model import audit
+    from tests.test_parity_gpu import _warm_corner_head
+    B = 32
+    model = zoo.denet34(B, "skip", 512, class_num=80, seed=1)
+    _warm_corner_head(model, 4.0, 0.3)
+    rng = np.random.RandomState(3)
+    dnd = [l for l in model.layers if l.type_name == "denet-detect"][0]
+    dnc = [l for l in model.layers if l.type_name == "denet-corner"][0]
+    dnd.layers[0].omega.set_value(rng.normal(0, 0.02, dnd.layers[0].omega.value.shape))
+    x, metas = zoo.synthetic_batch(B, 512, 80, seed=1)
+    xd = torch.from_numpy(x).cuda()
+    ops._load_tuned_once()
+    saved = (ops.WINO4T, dict(ops._WINO))
+    outs, kernels = [], []
+    try:
+        for on in (True, False):
+            if not on:
+                ops.WINO4T = 0
+                for k in [k for k, v in ops._WINO.items() if v == ops.FUSED4]:
+                    del ops._WINO[k]                       # (what load_tuned does with entries the switches exclude: decided afresh)
+            for l in model_cnn_walk(model):
+                l.__dict__.pop("_plan", None)
+            with audit.KernelAudit(model) as ka:
+                model.forward(xd, None, train=False)
+                torch.cuda.synchronize()
+            kernels.append({g: tuple(e["fwd"]) for g, e in ka.summary().items()})
+            dns = [l for l in model.layers if l.type_name == "denet-sparse"][0]
+            outs.append((dnc.corner_pr.cpu().numpy().copy(), dnc.conv.output.data.float().cpu().numpy().copy(),
+                         dnd.conv.output.data.float().cpu().numpy().copy(), [list(l) for l in dns.sample_bbox_list]))
+    finally:
+        ops.WINO4T = saved[0]
+        ops._WINO.clear()
+        ops._WINO.update(saved[1])
+    used = [g for g, k in kernels[0].items() if any(n.startswith("wino4t_kernel") for n in k)]
+    assert len(used) >= 5, kernels[0]                      # the 64-channel stage + the four mode-3 geometries
+    assert not any(n.startswith("wino4t_kernel") for k in kernels[1].values() for n in k)
+    # corner map and the corner layer's convolution output (corner logits + the sampling features): everything the backbone feeds
+    # the detector with; the head's logits row by row only where both runs proposed the same RoI lists (the proposal ranks by
+    # scores that differ in the last bits between the two kernel sets)
+    for a, b in zip(outs[0][:2], outs[1][:2]):
+        scale = float(np.abs(b).max())
+        assert float(np.abs(a - b).max()) <= 2e-4 * scale, (float(np.abs(a - b).max()), scale)
+    if outs[0][3] == outs[1][3]:
+        a, b = outs[0][2], outs[1][2]
+        assert float(np.abs(a - b).max()) <= 2e-4 * float(np.abs(b).max())
+
+
 def model_cnn_walk(model):
     from denet_amd.model.model_cnn import walk_layers
     return walk_layers(model.layers)
