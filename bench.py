@@ -850,7 +850,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_inference:
         try:
-            del model
+            model = None                      # (another leg may have dropped it already: not `del`)
             torch.cuda.empty_cache()
             out["inference"] = inference_leg(max(5, min(args.steps, 20)))
         except Exception as exc:          # an extra leg must never cost the headline line

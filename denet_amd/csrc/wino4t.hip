@@ -29,7 +29,7 @@
 //       ds_read_b128 reads lane r + 16 g at g * 256 + r * 16.
 // vmcnt discipline: LDS-DMA pieces and U fragment loads share one in-order counter, so a fragment load issued behind a piece
 // cannot be consumed before the piece has landed. The next chunk's pieces are issued after component pair T_ISSUE of this
-// chunk's products: the fragment loads behind them are consumed four pairs later at the earliest, and the consumption of the
+// chunk's products: the fragment loads behind them are consumed T_D (three) pairs later at the earliest, and the consumption of the
 // last ones implies that the pieces have landed when the next transform starts.
 #include "common.h"
 #include "bn_final.h"
@@ -88,7 +88,7 @@ constexpr int T_LDS = T_PATCH_B + T_V_B;          // 61 440: two workgroups per 
 #define T_STAG_N 1
 #endif
 #ifndef T_D_
-#define T_D_ 4
+#define T_D_ 3
 #endif
 #ifndef T_ISSUE_
 #define T_ISSUE_ 9
