@@ -1047,9 +1047,8 @@ def conv_wino4t_filter(w, dgrad, out=None):
     """the F(4x4) transformed filters in the layout of the tile-parallel fused kernel, [red / 16][36][out][16] (red = the pass's
     reduction channels: C forward, K for the data gradient): denet_conv_wino_filter (tile 4) + denet_conv_wino4t_pack"""
     K, _, _, C = w.shape
-    # (the prefetch runs on a side stream beside passes that may transform filters themselves: a scratch buffer per stream kind)
-    name = "w4t_filter_side" if torch.cuda.current_stream() != torch.cuda.default_stream() else "w4t_filter"
-    u = WS.get(name, 36 * K * C * 4)[:36 * K * C * 4].view(torch.float32)
+    # (the prefetch runs on a side stream beside passes that may transform filters themselves: a scratch buffer per stream)
+    u = WS.get("w4t_filter_%x" % torch.cuda.current_stream().cuda_stream, 36 * K * C * 4)[:36 * K * C * 4].view(torch.float32)
     conv_wino_filter(w, 4, dgrad, out=u)
     pk = out if out is not None else empty(36 * K * C)
     red, outc = (K, C) if dgrad else (C, K)
