@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libdenet_hip.so")
 
-SOURCES = ["runtime.hip", "igemm.hip", "bn.hip", "pool.hip", "elementwise.hip", "dss.hip", "samples.hip", "detect.hip", "winograd.hip", "wino2f.hip", "wino4f.hip", "wino4t.hip", "wino4g.hip", "stem.hip", "gemm3b.hip",
+SOURCES = ["runtime.hip", "igemm.hip", "bn.hip", "pool.hip", "elementwise.hip", "dss.hip", "samples.hip", "detect.hip", "winograd.hip", "wino2f.hip", "wino4f.hip", "wino4t.hip", "dgrad_s2.hip", "wino4g.hip", "stem.hip", "gemm3b.hip",
            "augment.hip", "image.hip"]
 # files whose integer results must not depend on FMA contraction
 NO_CONTRACT = {"dss.hip", "samples.hip", "detect.hip", "augment.hip", "image.hip"}

@@ -97,6 +97,10 @@ SIGNATURES = {
     "denet_conv_dgrad_1x1t": (I, [P] * 6 + [Z, P] + [I] * 5 + [P]),
     "denet_conv_dgrad_t": (I, [P] * 6 + [Z, P] + [I] * 12 + [P]),
     "denet_conv_wino2f_sums": (I, [P] * 5 + [I, P, Z, P, P] + [I] * 5 + [P]),
+    "denet_conv_dgrad_s2_ok": (I, [I] * 5),
+    "denet_conv_dgrad_s2_stats_rows": (I, [I] * 3),
+    "denet_conv_dgrad_s2_pack": (I, [P, P, I, I, P]),
+    "denet_conv_dgrad_s2": (I, [P] * 6 + [Z, P] + [I] * 5 + [P]),
     "denet_conv_wino4t_ok": (I, [I] * 5),
     "denet_conv_wino4t_stats_rows": (I, [I] * 3),
     "denet_conv_wino4t_pack": (I, [P, P, I, I, P]),

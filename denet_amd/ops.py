@@ -48,6 +48,8 @@ def kernel_symbol(kind, a, b, c):
         return "wino4g_kernel<%d>" % c
     if kind == 16:
         return "wino4t_kernel<%d>" % a
+    if kind == 17:
+        return "dgrad_s2_kernel<%d>" % a
     fixed = {11: "wino2f_wgrad_kernel", 12: "stem_fwd_kernel", 13: "stem_wgrad_kernel"}.get(kind)
     return fixed or "igemm_kernel<%d, %d, %d, 2, 2, %d>" % (kind, a, b, c)
 
@@ -803,6 +805,24 @@ def _cached_u(cache, dgrad, tile):
     return ent[1]
 
 
+def _cached_ws2(cache):
+    """packed filter of a 3x3 stride-2 layer's data gradient prepared ahead by wino_prefetch_filters (None: the caller packs)"""
+    ent = cache.get("ws2") if cache is not None else None
+    if ent is None or not ent[1]:
+        return None
+    wait_upload(cache.get("ws2_event"))
+    ent[1] = False                            # valid for one step: the solver changes the weights
+    return ent[0]
+
+
+def conv_dgrad_s2_pack(w, out=None):
+    """w [K][3][3][C] -> [K/16][9][C][16] for denet_conv_dgrad_s2"""
+    K, _, _, C = w.shape
+    pk = out if out is not None else empty(9 * K * C)
+    check(_L().denet_conv_dgrad_s2_pack(ptr(w), ptr(pk), C, K, stream_ptr()), "conv_dgrad_s2_pack")
+    return pk
+
+
 def _cached_wt(cache):
     """transposed filter of a large 1x1 layer prepared ahead by wino_prefetch_filters (None: the caller transposes)"""
     ent = cache.get("wt") if cache is not None else None
@@ -819,7 +839,8 @@ def wino_prefetch_filters(caches_and_weights, after=None):
     global _SIDE_FILTER
     todo = [(c, w) for c, w in caches_and_weights if c.get("fwd_tile") or c.get("dgrad_tile")]
     tr = [(c, w) for c, w in caches_and_weights if c.get("dgrad_1x1t") or c.get("dgrad_t")]
-    if not todo and not tr:
+    s2 = [(c, w) for c, w in caches_and_weights if c.get("dgrad_s2")]
+    if not todo and not tr and not s2:
         return
     if _SIDE_FILTER is None:
         init_streams()
@@ -870,6 +891,18 @@ def wino_prefetch_filters(caches_and_weights, after=None):
             ev.record(_SIDE_FILTER)
             for c, _ in tr:
                 c["wt_event"] = ev
+        if s2:
+            # the packed filters of the 3x3 stride-2 layers' data gradients (conv_dgrad -> csrc/dgrad_s2.hip)
+            for c, w in s2:
+                ent = c.get("ws2")
+                if ent is None or ent[0].numel() != w.numel():
+                    ent = c["ws2"] = [torch.empty(w.numel(), dtype=torch.float32, device="cuda"), False]
+                conv_dgrad_s2_pack(w, out=ent[0])
+                ent[1] = True
+            ev = torch.cuda.Event()
+            ev.record(_SIDE_FILTER)
+            for c, _ in s2:
+                c["ws2_event"] = ev
 
 
 _SIDE_FILTER = None
@@ -889,6 +922,9 @@ DGRAD_1X1T_GFLOP = float(os.environ.get("DENET_DGRAD_1X1T_GFLOP", "100"))
 # the head layers 517 -> 538 / 267 -> 306 us - what holds these launches back is not the filter's fragment reads (short reductions
 # of 4-16 chunks per parity class, the strided gather of dy), so the default stays the k-major mode
 DGRAD_T = os.environ.get("DENET_DGRAD_T", "0") != "0"
+# the 3x3 stride-2 data gradients with the four parity classes of input pixels in one workgroup (csrc/dgrad_s2.hip); 0: the
+# implicit-GEMM kernel, one problem per class
+DGRAD_S2 = os.environ.get("DENET_DGRAD_S2", "1") != "0"
 
 
 class wgrad_stream:
@@ -1091,6 +1127,31 @@ def conv_dgrad(dy, w, x_shape, add=None, stride=1, pad=0, s_real=None, out=None,
                   "conv_dgrad_1x1t")
         if sb is not None:
             sums.done(sb, rows.value, fin)
+        return dx
+    if DGRAD_S2 and g[5] == 3 and g[6] == 3 and g[7] == 3 and g[8] == 2 and g[9] == 1 and \
+            _L().denet_conv_dgrad_s2_ok(g[0], g[1], g[2], g[3], g[4]):
+        # a 3x3 stride-2 layer (the first convolution of a ResNet stage): the four parity classes of input pixels in one
+        # workgroup (csrc/dgrad_s2.hip); the packed filter comes from the side stream when a training step prepared it
+        import ctypes
+        N, H, W, C, K = g[0], g[1], g[2], g[3], g[4]
+        wp = _cached_ws2(cache)
+        if wp is None:
+            wp = conv_dgrad_s2_pack(w)
+        if cache is not None:
+            cache["dgrad_tile"] = 0
+            cache["dgrad_s2"] = True
+        if PROFILE is not None:
+            PROFILE.add(_conv_flops(g, logical))
+        rows = ctypes.c_int(0)
+        sb = so = None
+        if sums is not None and (int(BWD_SUMS) & 2):
+            sb = sums.buffer(cache, _L().denet_conv_dgrad_s2_stats_rows(N, H, W), C)
+            so = sums.c_struct()
+        check(_L().denet_conv_dgrad_s2(ptr(dy), ptr(wp), ptr(add), ptr(dx), ctypes.byref(so) if so is not None else None, ptr(sb),
+                                       sb.numel() * 8 if sb is not None else 0, ctypes.byref(rows), N, H, W, C, K, stream_ptr()),
+              "conv_dgrad_s2")
+        if sb is not None:
+            sums.done(sb, rows.value, None)
         return dx
     _tune_first(1, g, dy, w, None, add, dx, None)
 

@@ -13,6 +13,7 @@ SWITCHES = {
     "DENET_WINOGRAD": ("4", "kernels", "largest Winograd tile allowed for the 3x3 stride-1 layers (0: direct only, 2: F(2x2) only)"),
     "DENET_WINO_RAGGED": ("1", "kernels", "Winograd on maps that are no multiple of the tile (ceil tiles; 0: multiples only)"),
     "DENET_WINO2F": ("7", "kernels", "fused F(2x2) kernels of the 64-channel layers: bit 0 forward, 1 data gradient, 2 filter gradient"),
+    "DENET_DGRAD_S2": ("1", "kernels", "3x3 stride-2 data gradients: the four parity classes in one workgroup (csrc/dgrad_s2.hip; 0: implicit GEMM per class)"),
     "DENET_WINO4T": ("3", "kernels", "tile-parallel fully fused F(4x4) kernel (csrc/wino4t.hip) where the tuned file names it: bit 0 forward, 1 data gradient"),
     "DENET_W4T_LDS": ("0", "kernels", "experiment: LDS bytes a wino4t workgroup requests (100000: one workgroup per CU)"),
     "DENET_WINO4F": ("1", "kernels", "fused F(4x4) product + output-transform kernel (0: un-fused component GEMMs + transform)"),

@@ -248,6 +248,17 @@ int denet_conv_dgrad_sums(const float* dy, const float* w, const float* add, flo
 int denet_conv_dgrad_t(const float* dy, const float* wt, const float* add, float* dx, const denet_bn_link* sums_of,
                        double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int C, int K, int R, int S,
                        int S_real, int stride, int pad, int OH, int OW, hipStream_t stream);
+/* The data gradient of a 3x3 STRIDE-2 pad-1 convolution (the first convolution of a ResNet stage: convolution.py:80-83 under
+ * tensor.grad, model_cnn.py:318 -> cuDNN bwd-data) with the four parity classes of input pixels in one workgroup (csrc/dgrad_s2.hip):
+ * x [N,H,W,C] -> y [N,H/2,W/2,K], even H and W, C and K multiples of 64. w_packed = denet_conv_dgrad_s2_pack(w [K][3][3][C]) =
+ * [K/16][9][C][16]. add / sums_of / stats_partial / stats_rows as denet_conv_dgrad_sums (rows = denet_conv_dgrad_s2_stats_rows: one
+ * per block of 8 x 8 output positions), or null. Same sums as denet_conv_dgrad in another order (not bit-identical to it). */
+int denet_conv_dgrad_s2_ok(int N, int H, int W, int C, int K);
+int denet_conv_dgrad_s2_stats_rows(int N, int H, int W);
+int denet_conv_dgrad_s2_pack(const float* w, float* packed, int C, int K, hipStream_t stream);
+int denet_conv_dgrad_s2(const float* dy, const float* w_packed, const float* add, float* dx, const denet_bn_link* sums_of,
+                        double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int C, int K,
+                        hipStream_t stream);
 int denet_conv_dgrad_1x1t(const float* dy, const float* wt, const float* add, float* dx, const denet_bn_link* sums_of,
                           double* stats_partial, size_t stats_bytes, int* stats_rows, int N, int H, int W, int C, int K,
                           hipStream_t stream);

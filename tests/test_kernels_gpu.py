@@ -334,6 +334,67 @@ def test_fused_winograd_f4_tile_parallel_kernel(hip, case):
         ops._WINO.update(saved[1])
 
 
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 64), (3, 32, 48, 64, 128), (2, 20, 12, 128, 64), (1, 64, 64, 128, 256), (2, 2, 2, 64, 64),
+                                  (1, 34, 18, 64, 192)])
+def test_stride2_data_gradient_with_the_parity_classes_in_one_workgroup(hip, case):
+    """csrc/dgrad_s2.hip through ops.conv_dgrad (3x3 stride 2 pad 1) against fp64 autograd and against the implicit-GEMM kernel
+    (DENET_DGRAD_S2 = 0): plain, with the accumulated add, with the backward sums of a batch norm (both ReLU-mask forms).
+    (2,20,12), (1,34,18): output maps that are no multiple of the 8 x 8-position block (positions masked, the dy halo beyond the map
+    zero-filled); (3,32,48,64,128) / (1,64,64,128,256): two / four reduction chunks; (1,34,18,64,192): three; (2,2,2): one position.
+    Exact fp32 FMA chains: <= 1e-5 max-norm like the direct kernels."""
+    import torch.nn.functional as Fn
+    from denet_amd import ops
+    N, H, W, C, K = case
+    gen = torch.Generator().manual_seed(sum(case))
+    w = (torch.randn(K, 3, 3, C, generator=gen) * (2.0 / (9 * C)) ** 0.5).cuda()
+    dy = torch.randn(N, H // 2, W // 2, K, generator=gen).cuda()
+    acc0 = torch.randn(N, H, W, C, generator=gen).cuda()
+    xd = torch.zeros(N, C, H, W, dtype=torch.float64, requires_grad=True)
+    y = Fn.conv2d(xd, w.double().cpu().permute(0, 3, 1, 2), None, stride=2, padding=1)
+    ref = torch.autograd.grad(y, xd, dy.double().cpu().permute(0, 3, 1, 2))[0].permute(0, 2, 3, 1).cuda()
+    g = ops.conv_geom((N, H, W, C), w.shape, 2, 1, None)
+    saved = (ops.DGRAD_S2, ops.AUTOTUNE, dict(ops._WINO), set(ops._TUNED))
+    try:
+        ops._load_tuned_once()
+        ops.DGRAD_S2 = True
+        cache = {"train": True}
+        with ops.LaunchTrace() as lt:
+            dx = ops.conv_dgrad(dy, w, (N, H, W, C), stride=2, pad=1, cache=cache)
+        assert cache.get("dgrad_s2") and any(n.startswith("dgrad_s2_kernel") for n in lt.symbols), lt.symbols
+        assert float((dx.double() - ref).abs().max() / ref.abs().max()) <= 1e-5
+        dx1 = ops.conv_dgrad(dy, w, (N, H, W, C), add=acc0, stride=2, pad=1)
+        r1 = ref + acc0.double()
+        assert float((dx1.double() - r1).abs().max() / r1.abs().max()) <= 1e-5
+        ops.DGRAD_S2 = False
+        dxi = ops.conv_dgrad(dy, w, (N, H, W, C), add=acc0, stride=2, pad=1)
+        ops.DGRAD_S2 = True
+        assert float((dx1 - dxi).abs().max() / dxi.abs().max()) <= 5e-6
+        xb = torch.randn(N, H, W, C, generator=gen).cuda()
+        gam, bet = (torch.rand(C, generator=gen) + 0.5).cuda(), torch.randn(C, generator=gen).cuda()
+        mu = xb.reshape(-1, C).mean(0)
+        isd = 1.0 / (xb.reshape(-1, C).var(0, unbiased=False) + 1e-5).sqrt()
+        yb = torch.relu((xb - mu) * isd * gam + bet)
+        for with_y in (True, False):
+            bsum = ops.BnSums(xb, yb if with_y else None, gam, bet, mu, isd, True)
+            dx2 = ops.conv_dgrad(dy, w, (N, H, W, C), add=acc0, stride=2, pad=1, cache={"train": True}, sums=bsum)
+            assert torch.equal(dx2, dx1)
+            assert bsum.partial is not None
+            sb, rows = bsum.partial[:2]
+            assert rows == N * ((H // 2 + 7) // 8) * ((W // 2 + 7) // 8)
+            s2 = sb[:rows * 2 * C].view(rows, 2, C).sum(0)
+            yv = yb if with_y else torch.relu(torch.addcmul(bet - mu * (gam * isd), xb, gam * isd))
+            gq = torch.where(yv > 0, dx1, torch.zeros_like(dx1)).double().reshape(-1, C)
+            xh = ((xb - mu) * isd).double().reshape(-1, C)
+            assert float((s2[0] - gq.sum(0)).abs().max() / gq.abs().sum(0).max()) <= 1e-6
+            assert float((s2[1] - (gq * xh).sum(0)).abs().max() / (gq * xh).abs().sum(0).max()) <= 1e-6
+    finally:
+        ops.DGRAD_S2, ops.AUTOTUNE = saved[0], saved[1]
+        ops._WINO.clear()
+        ops._WINO.update(saved[2])
+        ops._TUNED.clear()
+        ops._TUNED.update(saved[3])
+
+
 @pytest.mark.parametrize("case", [(2, 24, 24, 1536, 1024), (1, 24, 24, 768, 512), (3, 8, 12, 512, 128)])
 def test_opt_in_bf16_split_head_gemms(hip, case):
     """OPT-IN ops.HEAD_BF16X3 (csrc/gemm3b.hip): the head's 1x1 convolutions as 3-term bf16-split GEMMs - forward, data gradient

@@ -282,7 +282,9 @@ def assert_kernels(table, batch, w4f=None, expect_w4f=None, expect_w4g=None):
             seen["stem"] += 1
             continue
         if not _is_3x3s1(g):
-            assert all(k.startswith("igemm_kernel<") for k in fwd + bwd), (r["layer"], g, fwd, bwd)
+            # (the 3x3 stride-2 layers' data gradients: csrc/dgrad_s2.hip, the four parity classes in one workgroup)
+            assert all(k.startswith("igemm_kernel<") or (k.startswith("dgrad_s2_kernel<") and " 3x3/2" in g) for k in fwd + bwd), (
+                r["layer"], g, fwd, bwd)
             continue
         c, k = _chan(g)
         if c == 64 and k == 64:
