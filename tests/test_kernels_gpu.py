@@ -844,11 +844,12 @@ def test_data_gradient_over_the_transposed_filter_is_bit_identical(hip, case):
     x = (torch.randn(N, H, W, C, generator=g) * 1.5 + 0.3).cuda()
     gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
     y, sm, si = ops.bn_fwd_train(x, gamma, beta, torch.zeros(C).cuda(), torch.ones(C).cuda(), relu=True)
-    saved = (ops.DGRAD_T, ops.BWD_SUMS, dict(ops._WINO), ops.DGRAD_1X1T_GFLOP, ops.POLICY)
+    saved = (ops.DGRAD_T, ops.BWD_SUMS, dict(ops._WINO), ops.DGRAD_1X1T_GFLOP, ops.POLICY, ops.DGRAD_S2)
     out = {}
     try:
         ops.BWD_SUMS = 3
         ops.DGRAD_1X1T_GFLOP = 0.0
+        ops.DGRAD_S2 = False                         # (the subject is the implicit-GEMM kernel's two filter layouts, also at stride 2)
         ops.POLICY = lambda mode, geom: 0            # the direct kernels (no Winograd pass, nothing measured)
         for mode in ("plain", "transposed", "prepared"):
             ops.DGRAD_T = mode != "plain"
@@ -870,7 +871,7 @@ def test_data_gradient_over_the_transposed_filter_is_bit_identical(hip, case):
             else:
                 out[mode] = (dx.clone(),)
     finally:
-        ops.DGRAD_T, ops.BWD_SUMS, ops.DGRAD_1X1T_GFLOP, ops.POLICY = saved[0], saved[1], saved[3], saved[4]
+        ops.DGRAD_T, ops.BWD_SUMS, ops.DGRAD_1X1T_GFLOP, ops.POLICY, ops.DGRAD_S2 = saved[0], saved[1], saved[3], saved[4], saved[5]
         ops._WINO.clear()
         ops._WINO.update(saved[2])
     for mode in ("transposed", "prepared"):
